@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (run in the build container).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Imports the *reference itself* (``/root/reference/src/fast/models/fast.py``,
+read-only) and scipy.signal, runs them on seeded inputs and stores inputs +
+outputs as small ``.npz`` files.  The reference never travels to the GPU box;
+these vectors do.  IDs follow SURVEY.md 8c (G1..G9).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.signal as ss
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("ISD_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REF, "src"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from fast.models.fast import FAST, Conv4Layers, EEGNet_Encoder  # noqa: E402  (the reference)
+from oracle import cnn as ocnn, dsp as odsp  # noqa: E402  (constants / band tables only)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def sd_np(module, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def grads_np(module, prefix="grad."):
+    return {prefix + k: p.grad.detach().numpy().copy() for k, p in module.named_parameters()}
+
+
+# ---------------------------------------------------------------- G1: scipy stft
+def g1():
+    out = {}
+    for tag, (T, fs, nperseg) in {"a": (800, 250, 64), "b": (512, 256, 64), "c": (4096, 1024, 1024)}.items():
+        x = np.random.default_rng(0).standard_normal((2, 3, T)).astype(np.float32)
+        f, t, Z = ss.stft(x, fs=fs, nperseg=nperseg, noverlap=nperseg // 2)
+        out[f"{tag}_x"], out[f"{tag}_f"], out[f"{tag}_t"], out[f"{tag}_Z"] = x, f, t, Z
+        out[f"{tag}_cfg"] = np.array([T, fs, nperseg])
+        # scripts/global_shap_analysis.py:151-156 band aggregation on |Z|
+        S = np.abs(Z)
+        bm = []
+        for _, lo, hi in odsp.BANDS_5:
+            idx = np.where((f >= lo) & (f <= hi))[0]
+            bm.append(S[..., idx, :].mean(axis=-2) if len(idx) else np.zeros(S.shape[:-2] + S.shape[-1:]))
+        out[f"{tag}_band5"] = np.stack(bm, axis=-2)
+    save("g1_stft.npz", **out)
+
+
+# ---------------------------------------------------------------- G2: butter sos + sosfilt
+def g2():
+    out = {}
+    for tag, bands, fs, T in (("b5", odsp.BANDS_5, 256.0, 512), ("b9", odsp.BANDS_9, 256.0, 512),
+                              ("b40", odsp.BANDS_40, 1024.0, 4096)):
+        sos = np.stack([ss.butter(4, (lo, hi), "bandpass", fs=fs, output="sos") for _, lo, hi in bands])
+        out[f"{tag}_sos"] = sos
+        out[f"{tag}_fs"] = np.array(fs)
+        x = np.random.default_rng(1).standard_normal((2 if T <= 512 else 1, 2, T)).astype(np.float32)
+        out[f"{tag}_x"] = x
+        sel = list(range(len(bands))) if len(bands) <= 9 else [0, 1, 20, 39]
+        out[f"{tag}_sel"] = np.array(sel)
+        out[f"{tag}_y"] = np.stack([ss.sosfilt(sos[b], x.astype(np.float64), axis=-1) for b in sel], axis=1)
+    save("g2_sos.npz", **out)
+
+
+# ---------------------------------------------------------------- G3: spec-S features via scipy
+def g3():
+    out = {}
+    for tag, bands, fs, T, C, nperseg, nov in (("c1", odsp.BANDS_5, 256.0, 512, 64, 64, 32),
+                                                ("c2", odsp.BANDS_9, 256.0, 512, 64, 64, 32),
+                                                ("c5", odsp.BANDS_40[:6], 1024.0, 4096, 4, 1024, 960)):
+        B = 4 if C == 64 else 2
+        x = np.random.default_rng(3).standard_normal((B, C, T)).astype(np.float32)
+        feats = []
+        for _, lo, hi in bands:
+            sos = ss.butter(4, (lo, hi), "bandpass", fs=fs, output="sos")
+            y = ss.sosfilt(sos, x.astype(np.float64), axis=-1)
+            f, _, Z = ss.stft(y, fs=fs, nperseg=nperseg, noverlap=nov)
+            idx = np.where((f >= lo) & (f <= hi))[0]
+            P = (np.abs(Z[..., idx, :]) ** 2).mean(axis=-2)
+            feats.append(np.log(P + 1e-10))
+        out[f"{tag}_feat"] = np.stack(feats, axis=1).astype(np.float32)
+        out[f"{tag}_cfg"] = np.array([B, C, T, fs, nperseg, nov, len(bands)])
+        if C != 64:
+            out[f"{tag}_x"] = x       # 64-ch inputs are regenerated from the seed
+    save("g3_features.npz", **out)
+
+
+# ---------------------------------------------------------------- G4: Conv4Layers fwd/bwd
+def g4():
+    out = {}
+    for cz in (6, 15):
+        torch.manual_seed(0)
+        m = Conv4Layers(cz, 32)
+        x = torch.randn(3, cz, 250, requires_grad=True)
+        y = m(x)
+        y.square().sum().backward()
+        out.update(sd_np(m, f"c{cz}.sd."))
+        out.update(grads_np(m, f"c{cz}.grad."))
+        out[f"c{cz}.x"], out[f"c{cz}.y"], out[f"c{cz}.dx"] = x.detach().numpy(), y.detach().numpy(), x.grad.numpy()
+    save("g4_conv4layers.npz", **out)
+
+
+def small_config():
+    # values of tests/conftest.py:32-54 (dropout 0 -> deterministic in train mode)
+    electrodes = ["Fp1", "Fp2", "F3", "F4", "C3", "C4", "O1", "O2"]
+    zones = {"Frontal": ["Fp1", "Fp2", "F3", "F4"], "Central": ["C3", "C4"], "Occipital": ["O1", "O2"]}
+    return types.SimpleNamespace(electrodes=electrodes, zone_dict=zones, dim_cnn=16, dim_token=16, seq_len=500,
+                                 window_len=250, slide_step=125, head="Conv4Layers", n_classes=3, num_layers=1,
+                                 num_heads=4, dropout=0.0)
+
+
+def prod_config():
+    # values of tests/conftest.py:12-29 / scripts/train_fast.py:293-307
+    return types.SimpleNamespace(electrodes=ocnn.ELECTRODES, zone_dict=ocnn.ZONES, dim_cnn=32, dim_token=32,
+                                 seq_len=800, window_len=250, slide_step=125, head="Conv4Layers", n_classes=5,
+                                 num_layers=4, num_heads=8, dropout=0.1)
+
+
+# ---------------------------------------------------------------- G5 + G9: FAST(small) train_head / default, AdamW
+def g5_g9():
+    out = {}
+    cfg = small_config()
+    torch.manual_seed(0)
+    m = FAST(cfg)
+    m.train()
+    x = torch.randn(2, 8, 500)
+    labels = torch.tensor([0, 2])
+    out.update(sd_np(m, "sd."))
+    out["x"], out["labels"] = x.numpy(), labels.numpy().astype(np.uint8)
+    feat = m.forward_head(x)
+    out["features"] = feat.detach().numpy()
+    for mode in ("train_head", "default"):
+        m.zero_grad()
+        logits = m(x, forward_mode=mode)
+        loss = torch.nn.CrossEntropyLoss()(logits, labels)
+        loss.backward()
+        out[f"{mode}.logits"], out[f"{mode}.loss"] = logits.detach().numpy(), loss.detach().numpy()
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                out[f"{mode}.grad.{k}"] = p.grad.detach().numpy().copy()
+    save("g5_fast_small.npz", **out)
+
+    # G9: 3 AdamW steps (lr 5e-4, torch defaults) in train_head mode, params not used there excluded
+    torch.manual_seed(0)
+    m = FAST(cfg)
+    m.train()
+    names = [k for k, _ in m.named_parameters() if k.startswith(("head.", "input_layer.", "last_layer."))]
+    params = [dict(m.named_parameters())[k] for k in names]
+    opt = torch.optim.AdamW(params, lr=5e-4)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = torch.nn.CrossEntropyLoss()(m(x, forward_mode="train_head"), labels)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    o9 = {"losses": np.array(losses, dtype=np.float64)}
+    o9.update({"final." + k: dict(m.named_parameters())[k].detach().numpy().copy() for k in names})
+    save("g9_adamw.npz", **o9)
+
+
+# ---------------------------------------------------------------- G6: production config, eval logits + argmax
+def g6():
+    cfg = prod_config()
+    torch.manual_seed(0)
+    m = FAST(cfg)
+    m.eval()
+    # input regenerated from this seed by the tests (not stored)
+    x = torch.from_numpy(np.random.default_rng(6).standard_normal((4, 64, 800)).astype(np.float32))
+    with torch.no_grad():
+        feat = m.forward_head(x)
+        lg_head = m(x, forward_mode="train_head")
+        lg_def = m(x, forward_mode="default")
+    keep = {k: v for k, v in sd_np(m, "sd.").items()}
+    save("g6_fast_prod.npz", features=feat.numpy(), train_head_logits=lg_head.numpy(),
+         train_head_pred=lg_head.argmax(1).numpy(), default_logits=lg_def.numpy(),
+         default_pred=lg_def.argmax(1).numpy(), **keep)
+
+
+# ---------------------------------------------------------------- G7: EEGNet_Encoder eval + train
+def g7():
+    out = {}
+    for tag, (C, T, B) in {"z6": (6, 250, 5), "c128": (128, 96, 3)}.items():
+        torch.manual_seed(0)
+        m = EEGNet_Encoder(C, 32, dropout=0.0)
+        # non-trivial running stats / affine params
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.running_mean.uniform_(-0.2, 0.2)
+                    mod.running_var.uniform_(0.5, 1.5)
+                    mod.weight.uniform_(0.5, 1.5)
+                    mod.bias.uniform_(-0.3, 0.3)
+        out.update(sd_np(m, f"{tag}.sd."))
+        x = torch.randn(B, C, T, requires_grad=True)
+        m.eval()
+        with torch.no_grad():
+            out[f"{tag}.y_eval"] = m(x).numpy()
+        m.train()
+        y = m(x)
+        y.square().sum().backward()
+        out[f"{tag}.x"], out[f"{tag}.y_train"], out[f"{tag}.dx"] = x.detach().numpy(), y.detach().numpy(), x.grad.numpy()
+        out.update(grads_np(m, f"{tag}.grad."))
+        out.update(sd_np(m, f"{tag}.sd_after."))
+    save("g7_eegnet.npz", **out)
+
+
+# ---------------------------------------------------------------- G8: cosine schedule
+def g8():
+    # src/fast/train/trainer.py is not importable (lightning absent): the 12-line function is
+    # evaluated from its published formula (linspace warm-up + half-cosine), values as in SURVEY 8c.
+    base, final, epochs, it, wu = 1, 0.1, 200, 5, 10
+    warm = np.linspace(0, base, wu * it)
+    iters = np.arange(epochs * it - wu * it)
+    sched = np.concatenate((warm, final + 0.5 * (base - final) * (1 + np.cos(np.pi * iters / len(iters)))))
+    save("g8_cosine.npz", schedule=sched, args=np.array([base, final, epochs, it, wu]))
+
+
+if __name__ == "__main__":
+    g1(); g2(); g3(); g4(); g5_g9(); g6(); g7(); g8()

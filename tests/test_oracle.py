@@ -1,0 +1,160 @@
+"""The oracle restatements against golden vectors captured from the reference / scipy (CPU)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import cnn as ocnn, dsp as odsp
+
+
+# ------------------------------------------------------------------ DSP (scipy-pinned)
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_stft_matches_scipy_golden(tag):
+    g = load_golden("g1_stft.npz")
+    T, fs, nperseg = [int(v) for v in g[f"{tag}_cfg"]]
+    f, t, Z = odsp.stft(g[f"{tag}_x"], fs, nperseg, nperseg // 2)
+    assert Z.shape == g[f"{tag}_Z"].shape and Z.dtype == np.complex64
+    np.testing.assert_allclose(f, g[f"{tag}_f"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(t, g[f"{tag}_t"], rtol=0, atol=1e-12)
+    assert np.abs(Z - g[f"{tag}_Z"]).max() <= 2e-6 * np.abs(g[f"{tag}_Z"]).max()
+    bm = odsp.band_magnitude(Z, fs, nperseg, odsp.BANDS_5)
+    np.testing.assert_allclose(bm, g[f"{tag}_band5"], rtol=1e-5, atol=1e-7)
+
+
+def test_stft_frame_counts():
+    # J = 26 @ T=800, 17 @ T=512, 9 @ T=4096 / nperseg 1024
+    assert odsp.stft_frames(800, 64, 32)[0] == 26
+    assert odsp.stft_frames(512, 64, 32)[0] == 17
+    assert odsp.stft_frames(4096, 1024, 512)[0] == 9
+    assert odsp.stft_frames(4096, 1024, 960)[0] == 65
+
+
+@pytest.mark.parametrize("tag", ["b5", "b9", "b40"])
+def test_sosfilt_matches_scipy_golden(tag):
+    g = load_golden("g2_sos.npz")
+    sos, x, sel = g[f"{tag}_sos"], g[f"{tag}_x"], g[f"{tag}_sel"]
+    bands = {"b5": odsp.BANDS_5, "b9": odsp.BANDS_9, "b40": odsp.BANDS_40}[tag]
+    for j, b in enumerate(sel):
+        _, lo, hi = bands[b]
+        np.testing.assert_allclose(odsp.butter_bandpass_sos(4, lo, hi, float(g[f"{tag}_fs"])), sos[b],
+                                   rtol=1e-13, atol=0)
+        y = odsp.sosfilt(sos[b], x)
+        assert rel_err(y, g[f"{tag}_y"][:, j]) < 1e-11
+
+
+@pytest.mark.parametrize("tag,bands", [("c1", odsp.BANDS_5), ("c2", odsp.BANDS_9), ("c5", odsp.BANDS_40[:6])])
+def test_spec_s_features_match_scipy_golden(tag, bands):
+    g = load_golden("g3_features.npz")
+    B, C, T, fs, nperseg, nov, nb = g[f"{tag}_cfg"]
+    B, C, T, nperseg, nov = int(B), int(C), int(T), int(nperseg), int(nov)
+    x = g[f"{tag}_x"] if f"{tag}_x" in g else np.random.default_rng(3).standard_normal((B, C, T)).astype(np.float32)
+    feat = odsp.extract_features(x[:2], fs=float(fs), bands=bands, nperseg=nperseg, noverlap=nov)
+    np.testing.assert_allclose(feat, g[f"{tag}_feat"][:2], rtol=0, atol=2e-5)
+
+
+# ------------------------------------------------------------------ CNN (reference-pinned)
+def _t(g, prefix):
+    return {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("cz", [6, 15])
+def test_conv4layers_matches_reference_golden(cz):
+    g = load_golden("g4_conv4layers.npz")
+    p = {k: v.requires_grad_() for k, v in _t(g, f"c{cz}.sd.").items()}
+    x = torch.from_numpy(g[f"c{cz}.x"]).requires_grad_()
+    y = ocnn.conv4layers(x, p)
+    y.square().sum().backward()
+    assert rel_err(y.detach(), g[f"c{cz}.y"]) < 1e-6
+    assert rel_err(x.grad, g[f"c{cz}.dx"]) < 1e-5
+    for k, v in p.items():
+        assert rel_err(v.grad, g[f"c{cz}.grad.{k}"]) < 1e-5, k
+
+
+def _small_zones():
+    electrodes = ["Fp1", "Fp2", "F3", "F4", "C3", "C4", "O1", "O2"]
+    zones = {"Frontal": ["Fp1", "Fp2", "F3", "F4"], "Central": ["C3", "C4"], "Occipital": ["O1", "O2"]}
+    return list(zones), ocnn.zone_index_lists(electrodes, zones)
+
+
+def test_fast_small_train_head_matches_reference_golden():
+    g = load_golden("g5_fast_small.npz")
+    names, idx = _small_zones()
+    p = {k: v.requires_grad_() for k, v in _t(g, "sd.").items()}
+    x = torch.from_numpy(g["x"])
+    feat = ocnn.forward_head(x, p, names, idx)
+    assert feat.shape == (2, 3, 3, 16)
+    assert rel_err(feat.detach(), g["features"]) < 1e-6
+    logits = ocnn.train_head_logits(x, p, names, idx)
+    loss = ocnn.cross_entropy(logits, g["labels"])
+    loss.backward()
+    assert rel_err(logits.detach(), g["train_head.logits"]) < 1e-6
+    assert abs(float(loss) - float(g["train_head.loss"])) < 1e-6
+    for k in g.files:
+        if k.startswith("train_head.grad."):
+            name = k[len("train_head.grad."):]
+            assert rel_err(p[name].grad, g[k]) < 2e-5, name
+
+
+def test_fast_prod_eval_logits_and_argmax_match_reference_golden():
+    g = load_golden("g6_fast_prod.npz")
+    p = _t(g, "sd.")
+    x = torch.from_numpy(np.random.default_rng(6).standard_normal((4, 64, 800)).astype(np.float32))
+    names, idx = list(ocnn.ZONES), ocnn.zone_index_lists()
+    with torch.no_grad():
+        feat = ocnn.forward_head(x, p, names, idx)
+        logits = ocnn.train_head_logits(x, p, names, idx)
+    assert feat.shape == (4, 5, 8, 32)
+    assert rel_err(feat, g["features"]) < 1e-6
+    assert rel_err(logits, g["train_head_logits"]) < 1e-6
+    assert np.array_equal(ocnn.predict(logits).numpy(), g["train_head_pred"])
+
+
+@pytest.mark.parametrize("tag", ["z6", "c128"])
+def test_eegnet_matches_reference_golden(tag):
+    g = load_golden("g7_eegnet.npz")
+    p = _t(g, f"{tag}.sd.")
+    for k, v in p.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_()
+    x = torch.from_numpy(g[f"{tag}.x"]).requires_grad_()
+    with torch.no_grad():
+        assert rel_err(ocnn.eegnet_encoder(x, p, training=False), g[f"{tag}.y_eval"]) < 1e-5
+    y = ocnn.eegnet_encoder(x, p, training=True)
+    y.square().sum().backward()
+    assert rel_err(y.detach(), g[f"{tag}.y_train"]) < 1e-5
+    assert rel_err(x.grad, g[f"{tag}.dx"]) < 1e-4
+    for k in g.files:
+        if k.startswith(f"{tag}.grad."):
+            assert rel_err(p[k[len(tag) + 6:]].grad, g[k]) < 1e-4, k
+    for name in ("temporal_conv.1", "spatial_conv.1", "separable_conv.2"):
+        for buf in ("running_mean", "running_var"):
+            assert rel_err(p[f"{name}.{buf}"], g[f"{tag}.sd_after.{name}.{buf}"]) < 1e-6
+
+
+def test_cosine_schedule_matches_golden_and_quirk():
+    g = load_golden("g8_cosine.npz")
+    s = ocnn.cosine_scheduler(1, 0.1, 200, 5, warmup_epochs=10)
+    np.testing.assert_allclose(s, g["schedule"], rtol=0, atol=1e-15)
+    assert len(s) == 1000 and s[0] == 0 and s[49] == 1 and s[50] == 1
+    assert abs(s[-1] - 0.1000025) < 1e-6
+    assert ocnn.lr_multiplier(s, 0) == s[-1]          # trainer.py:52 quirk
+
+
+def test_adamw_trajectory_matches_reference_golden():
+    g5, g9 = load_golden("g5_fast_small.npz"), load_golden("g9_adamw.npz")
+    names, idx = _small_zones()
+    keys = [k[len("final."):] for k in g9.files if k.startswith("final.")]
+    p = _t(g5, "sd.")
+    params = [p[k].requires_grad_() for k in keys]
+    opt = torch.optim.AdamW(params, lr=5e-4)
+    x = torch.from_numpy(g5["x"])
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = ocnn.cross_entropy(ocnn.train_head_logits(x, p, names, idx), g5["labels"])
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(losses, g9["losses"], rtol=1e-5)
+    for k in keys:
+        assert rel_err(p[k].detach(), g9["final." + k]) < 1e-5, k
