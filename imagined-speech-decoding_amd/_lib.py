@@ -1,0 +1,83 @@
+"""ctypes binding of libisd_hip.so (the C ABI of include/isd_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails the
+product raises.  Build it with ``python -m isd_amd.build`` (or
+``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+ISD_OK = 0
+ISD_ERR_INVALID, ISD_ERR_UNSUPPORTED, ISD_ERR_HIP, ISD_ERR_NO_DEVICE = -1, -2, -3, -4
+FB_F32, FB_F64, FB_AUTO = 0, 1, 2
+BP_MAGNITUDE, BP_POWER, BP_LOGPOWER = 0, 1, 2
+
+
+class IsdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libisd_hip error {code}: {msg}")
+        self.code = code
+
+
+class IsdUnsupported(IsdError):
+    pass
+
+
+_p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_pi, _pd = C.POINTER(C.c_int), C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol include/isd_hip.h declares
+SIGNATURES = {
+    "isd_abi_version": (_i, []),
+    "isd_last_error": (C.c_char_p, []),
+    "isd_device_count": (_i, []),
+    "isd_fb_plan_create": (_i, [C.POINTER(_p), _i, _i, _pd, _pd, _i]),
+    "isd_fb_plan_destroy": (_i, [_p]),
+    "isd_fb_plan_precision": (_i, [_p]),
+    "isd_fb_forward": (_i, [_p, _p, _p, _i64, _i64, _i64, _p]),
+    "isd_stft_plan_create": (_i, [C.POINTER(_p), _i, _i, _i]),
+    "isd_stft_plan_destroy": (_i, [_p]),
+    "isd_stft_plan_frames": (_i, [_p]),
+    "isd_stft_plan_bins": (_i, [_p]),
+    "isd_stft_forward": (_i, [_p, _p, _p, _i64, _p]),
+    "isd_stft_bandpower": (_i, [_p, _p, _p, _i64, _i64, _i, _i, _pi, _pi, _i, _f, _p]),
+    "isd_features_fused": (_i, [_p, _p, _p, _p, _i64, _i64, _pi, _pi, _i, _f, _p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "There is no CPU fallback for the product path.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)           # AttributeError if the header and the .so disagree
+            fn.restype, fn.argtypes = res, args
+        if h.isd_abi_version() != 1:
+            raise ImportError(f"{LIB_PATH}: ABI version {h.isd_abi_version()} != 1; rebuild")
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != ISD_OK:
+        msg = lib().isd_last_error().decode("utf-8", "replace")
+        raise (IsdUnsupported if rc == ISD_ERR_UNSUPPORTED else IsdError)(rc, msg)
+    return rc
+
+
+def int_array(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def double_array(vals):
+    return (C.c_double * len(vals))(*[float(v) for v in vals])

@@ -1,0 +1,67 @@
+// Shared host/device helpers for libisd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/isd_hip.h"
+
+namespace isd {
+
+void set_error(const char* fmt, ...);
+
+#define ISD_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      isd::set_error(__VA_ARGS__);               \
+      return ISD_ERR_INVALID;                    \
+    }                                            \
+  } while (0)
+
+#define ISD_HIP_TRY(expr)                                                         \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      isd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                     __FILE__, __LINE__);                                         \
+      return ISD_ERR_HIP;                                                         \
+    }                                                                             \
+  } while (0)
+
+// checks the launch that was just enqueued (no host sync)
+#define ISD_LAUNCH_CHECK() ISD_HIP_TRY(hipGetLastError())
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------ device side
+#if defined(__HIPCC__)
+
+// DPP row shift right by N inside each 16-lane row; lanes with no source get 0.
+template <int N>
+__device__ __forceinline__ float row_shr(float v) {
+  int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xf, 0xf, false);
+  return __int_as_float(r);
+}
+template <int N>
+__device__ __forceinline__ double row_shr(double v) {
+  long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x110 + N, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x110 + N, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// DPP row shift left by N (lane i reads lane i+N of its 16-lane row; 0 past the end).
+template <int N>
+__device__ __forceinline__ float row_shl(float v) {
+  int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, false);
+  return __int_as_float(r);
+}
+// value of lane `src` (wave-uniform index) broadcast to every lane
+__device__ __forceinline__ double read_lane(double v, int src) {
+  long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src);
+  int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+#endif  // __HIPCC__
+}  // namespace isd

@@ -1,0 +1,501 @@
+// Filterbank: per-band Butterworth SOS cascade as a chunked linear-recurrence scan.
+//
+// Replaces scipy `sosfilt(butter(..., 'sos'), x, axis=-1)` (spec S steps 1-2; the
+// reference's only band-pass is notebooks/svm_baseline.ipynb:238).
+//
+// Mapping (CDNA4, wave64): a 16-lane DPP row owns one 512-sample segment of one
+// (trial, channel) row; each lane owns a contiguous 32-sample chunk in registers.
+// Per band and per biquad section:
+//   1. in-chunk DF2T recursion from zero state            (3 VALU ops / sample)
+//   2. inclusive scan of the chunk-end states over the 16 lanes with the constant
+//      2x2 transition matrix M = A^32 (Kogge-Stone over DPP row_shr, fp64)
+//   3. zero-input correction  y[n] += h1[n]*s1_in + h2[n]*s2_in   (2 FMA / sample)
+// Global traffic is coalesced float4; the chunk<->coalesced transposition goes
+// through a padded LDS tile (stride 36 floats: conflict-free ds_read_b128).
+// Rows longer than 512 samples chain 2 or 4 rows-of-16-lanes (and loop) with the
+// group transition matrix P = M^16 and per-lane powers Q_i = M^i.
+#include "common.h"
+#include "stft_plan.h"
+#include <math.h>
+#include <vector>
+#include <string.h>
+
+namespace isd {
+
+constexpr int kL = 32;          // samples per lane
+constexpr int kSeg = 16 * kL;   // samples per 16-lane group
+constexpr int kPad = kL + 4;    // LDS chunk stride (floats)
+constexpr int kMaxSec = 8;
+
+struct FbSec {                  // constants of one (band, section); wave-uniform -> SMEM loads
+  double Mp[4][4];              // M^(1,2,4,8), row-major 2x2, M = A^32
+  double P[4];                  // M^16
+  double a1d, a2d;
+  double hd[kL][2];             // zero-input response seen at the output: row 0 of A^n
+  float a1f, a2f;
+  float hf[kL][2];
+};
+
+struct FbBand {
+  double gd;
+  float gf;
+  float pad;
+};
+
+}  // namespace isd
+
+struct isd_fb_plan {
+  int n_bands, n_sections, precision;
+  isd::FbSec* d_sec;   // [n_bands][n_sections]
+  isd::FbBand* d_band; // [n_bands]
+  double* d_Q;         // [n_bands][n_sections][16][4]  per-lane M^i
+};
+
+namespace isd {
+
+template <typename T> struct Sel;
+template <> struct Sel<float> {
+  static __device__ __forceinline__ float a1(const FbSec& s) { return s.a1f; }
+  static __device__ __forceinline__ float a2(const FbSec& s) { return s.a2f; }
+  static __device__ __forceinline__ float h(const FbSec& s, int n, int j) { return s.hf[n][j]; }
+  static __device__ __forceinline__ float g(const FbBand& b) { return b.gf; }
+};
+template <> struct Sel<double> {
+  static __device__ __forceinline__ double a1(const FbSec& s) { return s.a1d; }
+  static __device__ __forceinline__ double a2(const FbSec& s) { return s.a2d; }
+  static __device__ __forceinline__ double h(const FbSec& s, int n, int j) { return s.hd[n][j]; }
+  static __device__ __forceinline__ double g(const FbBand& b) { return b.gd; }
+};
+
+template <int D>
+__device__ __forceinline__ void scan_step(double& e1, double& e2, const double* M) {
+  double p1 = row_shr<D>(e1), p2 = row_shr<D>(e2);
+  e1 = fma(M[0], p1, fma(M[1], p2, e1));
+  e2 = fma(M[2], p1, fma(M[3], p2, e2));
+}
+
+// One biquad section over the lane's chunk, including the cross-chunk state fix-up.
+// `cin1/cin2` : incoming state of the wave's first group of this row (GPR==4 loop carry).
+// Returns the outgoing carry (only meaningful for GPR == 4).
+template <typename TL, int GPR>
+__device__ __forceinline__ void section(TL (&v)[kL], const FbSec& sc, const double* __restrict__ Qsec,
+                                        int lane, double& c1, double& c2) {
+  const TL a1 = Sel<TL>::a1(sc), a2 = Sel<TL>::a2(sc);
+  TL s1 = 0, s2 = 0;
+#pragma unroll
+  for (int n = 0; n < kL; ++n) {
+    TL x = v[n];
+    TL y = x + s1;
+    s1 = fma(-a1, y, s2);
+    s2 = fma(-a2, y, -x);
+    v[n] = y;
+  }
+  double e1 = (double)s1, e2 = (double)s2;
+  scan_step<1>(e1, e2, sc.Mp[0]);
+  scan_step<2>(e1, e2, sc.Mp[1]);
+  scan_step<4>(e1, e2, sc.Mp[2]);
+  scan_step<8>(e1, e2, sc.Mp[3]);
+  double i1 = row_shr<1>(e1), i2 = row_shr<1>(e2);   // exclusive; lane 0 of each row -> 0
+  if (GPR > 1) {
+    // group totals (wave-uniform) and the serial chain over the 4 groups of the wave
+    double E1[4], E2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      E1[g] = read_lane(e1, 16 * g + 15);
+      E2[g] = read_lane(e2, 16 * g + 15);
+    }
+    double C1[4], C2[4];
+    C1[0] = (GPR == 4) ? c1 : 0.0;
+    C2[0] = (GPR == 4) ? c2 : 0.0;
+#pragma unroll
+    for (int g = 1; g < 4; ++g) {
+      if (g % GPR == 0) {
+        C1[g] = 0.0;
+        C2[g] = 0.0;
+      } else {
+        C1[g] = fma(sc.P[0], C1[g - 1], fma(sc.P[1], C2[g - 1], E1[g - 1]));
+        C2[g] = fma(sc.P[2], C1[g - 1], fma(sc.P[3], C2[g - 1], E2[g - 1]));
+      }
+    }
+    if (GPR == 4) {
+      c1 = fma(sc.P[0], C1[3], fma(sc.P[1], C2[3], E1[3]));
+      c2 = fma(sc.P[2], C1[3], fma(sc.P[3], C2[3], E2[3]));
+    }
+    const int q = lane >> 4;
+    double m1 = q == 0 ? C1[0] : q == 1 ? C1[1] : q == 2 ? C1[2] : C1[3];
+    double m2 = q == 0 ? C2[0] : q == 1 ? C2[1] : q == 2 ? C2[2] : C2[3];
+    const double* Q = Qsec + (lane & 15) * 4;         // M^i of this lane
+    i1 = fma(Q[0], m1, fma(Q[1], m2, i1));
+    i2 = fma(Q[2], m1, fma(Q[3], m2, i2));
+  }
+  const TL t1 = (TL)i1, t2 = (TL)i2;
+#pragma unroll
+  for (int n = 0; n < kL; ++n) v[n] = fma(Sel<TL>::h(sc, n, 0), t1, fma(Sel<TL>::h(sc, n, 1), t2, v[n]));
+}
+
+// Cooperative (whole wave) coalesced load of the 4 groups' 512-sample segments into the
+// padded chunk-major LDS tile.  seg_base[g] < 0 marks an absent group.
+__device__ __forceinline__ void tile_load(float* tile, const float* __restrict__ x, int lane,
+                                          const int64_t (&gbase)[4], const int (&gt0)[4], int T, bool vec) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = (k * 64 + lane) * 4;              // element inside the 512-sample segment
+      const int t = gt0[g] + e;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gbase[g] >= 0) {
+        const float* p = x + gbase[g] + t;
+        if (vec && t + 3 < T) {
+          val = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (t + 0 < T) val.x = p[0];
+          if (t + 1 < T) val.y = p[1];
+          if (t + 2 < T) val.z = p[2];
+          if (t + 3 < T) val.w = p[3];
+        }
+      }
+      *reinterpret_cast<float4*>(tile + (g * 16 + (e >> 5)) * kPad + (e & 31)) = val;
+    }
+  }
+}
+
+__device__ __forceinline__ void tile_store(const float* tile, float* __restrict__ y, int lane,
+                                           const int64_t (&gbase)[4], const int (&gt0)[4], int T, bool vec) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = (k * 64 + lane) * 4;
+      const int t = gt0[g] + e;
+      if (gbase[g] < 0 || t >= T) continue;
+      const float4 val = *reinterpret_cast<const float4*>(tile + (g * 16 + (e >> 5)) * kPad + (e & 31));
+      float* p = y + gbase[g] + t;
+      if (vec && t + 3 < T) {
+        *reinterpret_cast<float4*>(p) = val;
+      } else {
+        p[0] = val.x;
+        if (t + 1 < T) p[1] = val.y;
+        if (t + 2 < T) p[2] = val.z;
+        if (t + 3 < T) p[3] = val.w;
+      }
+    }
+  }
+}
+
+// One wave per workgroup.  GPR = 16-lane groups per row (1: T<=512, 2: T<=1024, 4: any T).
+template <typename TL, int GPR>
+__global__ __launch_bounds__(64) void fb_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
+                                                const double* __restrict__ Qtab, const float* __restrict__ x,
+                                                float* __restrict__ y, int64_t R, int C, int T, int nb, int ns,
+                                                int vec) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* tile = reinterpret_cast<float*>(smem_raw);                       // [4][16][kPad]
+  double* carry = reinterpret_cast<double*>(smem_raw + 4 * 16 * kPad * 4); // [nb][ns][2]  (GPR == 4)
+  const int lane = threadIdx.x;
+  constexpr int RPW = 4 / GPR;                                            // rows per wave
+  const int64_t row0 = (int64_t)blockIdx.x * RPW;
+  const int n_iter = (GPR == 4) ? (T + 4 * kSeg - 1) / (4 * kSeg) : 1;
+
+  if (GPR == 4) {
+    for (int j = lane; j < nb * ns * 2; j += 64) carry[j] = 0.0;
+  }
+
+  for (int it = 0; it < n_iter; ++it) {
+    int64_t xbase[4];
+    int gt0[4];
+    int64_t rowg[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t r = row0 + g / GPR;
+      rowg[g] = r;
+      gt0[g] = (it * GPR + g % GPR) * kSeg;
+      xbase[g] = (r < R && gt0[g] < T) ? r * (int64_t)T : -1;
+    }
+    __syncthreads();
+    tile_load(tile, x, lane, xbase, gt0, T, vec != 0);
+    __syncthreads();
+    float xs[kL];
+    {
+      const float* src = tile + lane * kPad;          // (q*16 + i) == lane
+#pragma unroll
+      for (int n = 0; n < kL; n += 4) {
+        float4 f = *reinterpret_cast<const float4*>(src + n);
+        xs[n] = f.x; xs[n + 1] = f.y; xs[n + 2] = f.z; xs[n + 3] = f.w;
+      }
+    }
+    for (int b = 0; b < nb; ++b) {
+      TL v[kL];
+      const TL g = Sel<TL>::g(bands[b]);
+#pragma unroll
+      for (int n = 0; n < kL; ++n) v[n] = (TL)xs[n] * g;
+      for (int s = 0; s < ns; ++s) {
+        const int bs = b * ns + s;
+        double c1 = 0.0, c2 = 0.0;
+        if (GPR == 4) { c1 = carry[bs * 2]; c2 = carry[bs * 2 + 1]; }
+        section<TL, GPR>(v, secs[bs], Qtab + (int64_t)bs * 64, lane, c1, c2);
+        if (GPR == 4 && n_iter > 1) {
+          if (lane == 0) { carry[bs * 2] = c1; carry[bs * 2 + 1] = c2; }
+        }
+      }
+      __syncthreads();                                // previous tile_store reads are done
+      {
+        float* dst = tile + lane * kPad;
+#pragma unroll
+        for (int n = 0; n < kL; n += 4)
+          *reinterpret_cast<float4*>(dst + n) = make_float4((float)v[n], (float)v[n + 1], (float)v[n + 2], (float)v[n + 3]);
+      }
+      __syncthreads();
+      int64_t ybase[4];
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        if (xbase[gq] < 0) { ybase[gq] = -1; continue; }
+        const int64_t r = rowg[gq];
+        const int64_t bt = r / C, ch = r - bt * C;
+        ybase[gq] = ((bt * nb + b) * C + ch) * (int64_t)T;
+      }
+      tile_store(tile, y, lane, ybase, gt0, T, vec != 0);
+    }
+  }
+}
+
+struct FusedBands {
+  int klo[kMaxBands];
+  int khi[kMaxBands];
+};
+
+// Fused spec-S extractor for T <= 512, nperseg 64 / hop 32: after the cascade each lane
+// holds chunk i of its row; STFT frame j is chunk j-1 (window first half) followed by
+// chunk j (second half), so every lane forms two partial windowed DFT sums per bin and
+// one DPP row_shr joins neighbours.  Only the band's own bins are evaluated.
+template <typename TL>
+__global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
+                                                   const float2* __restrict__ dft, const float* __restrict__ x,
+                                                   float* __restrict__ feat, int64_t R, int C, int T, int nb, int ns,
+                                                   int J, float scale2, FusedBands fbnd, int mode, float eps,
+                                                   int vec) {
+  __shared__ __attribute__((aligned(16))) float tile[4 * 16 * kPad];
+  const int lane = threadIdx.x;
+  const int i = lane & 15;
+  const int64_t row0 = (int64_t)blockIdx.x * 4;
+  int64_t xbase[4];
+  int gt0[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    gt0[g] = 0;
+    xbase[g] = (row0 + g < R) ? (row0 + g) * (int64_t)T : -1;
+  }
+  tile_load(tile, x, lane, xbase, gt0, T, vec != 0);
+  __syncthreads();
+  float xs[kL];
+  {
+    const float* src = tile + lane * kPad;
+#pragma unroll
+    for (int n = 0; n < kL; n += 4) {
+      float4 f = *reinterpret_cast<const float4*>(src + n);
+      xs[n] = f.x; xs[n + 1] = f.y; xs[n + 2] = f.z; xs[n + 3] = f.w;
+    }
+  }
+  const int64_t row = row0 + (lane >> 4);
+  const int64_t bt = row / C;
+  const int ch = (int)(row - bt * C);
+  for (int b = 0; b < nb; ++b) {
+    TL v[kL];
+    const TL g = Sel<TL>::g(bands[b]);
+#pragma unroll
+    for (int n = 0; n < kL; ++n) v[n] = (TL)xs[n] * g;
+    for (int s = 0; s < ns; ++s) {
+      double c1 = 0.0, c2 = 0.0;
+      section<TL, 1>(v, secs[b * ns + s], nullptr, lane, c1, c2);
+    }
+    float vf[kL];
+#pragma unroll
+    for (int n = 0; n < kL; ++n) vf[n] = (float)v[n];
+    const int klo = fbnd.klo[b], khi = fbnd.khi[b];
+    float acc = 0.f, acc16 = 0.f;
+    for (int k = klo; k <= khi; ++k) {
+      const float2* __restrict__ tb = dft + k * 64;
+      float p1r = 0.f, p1i = 0.f, p2r = 0.f, p2i = 0.f;
+#pragma unroll
+      for (int n = 0; n < kL; ++n) {
+        const float2 ca = tb[n], cb = tb[kL + n];
+        p1r = fmaf(vf[n], ca.x, p1r);
+        p1i = fmaf(vf[n], ca.y, p1i);
+        p2r = fmaf(vf[n], cb.x, p2r);
+        p2i = fmaf(vf[n], cb.y, p2i);
+      }
+      const float zr = p2r + row_shr<1>(p1r), zi = p2i + row_shr<1>(p1i);
+      const float pw = (zr * zr + zi * zi) * scale2;
+      const float pw16 = (p1r * p1r + p1i * p1i) * scale2;
+      acc += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw) : pw;
+      acc16 += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw16) : pw16;
+    }
+    const float inv = khi >= klo ? 1.f / (float)(khi - klo + 1) : 0.f;
+    float r = acc * inv, r16 = acc16 * inv;
+    if (mode == ISD_BP_LOGPOWER) { r = logf(r + eps); r16 = logf(r16 + eps); }
+    if (row < R) {
+      float* o = feat + ((bt * nb + b) * C + ch) * (int64_t)J;
+      if (i < J) o[i] = r;
+      if (i == 15 && J == 17) o[16] = r16;
+    }
+  }
+}
+
+static void mat2_mul(const double* a, const double* b, double* o) {
+  double r[4] = {a[0] * b[0] + a[1] * b[2], a[0] * b[1] + a[1] * b[3], a[2] * b[0] + a[3] * b[2],
+                 a[2] * b[1] + a[3] * b[3]};
+  memcpy(o, r, sizeof(r));
+}
+
+}  // namespace isd
+
+using namespace isd;
+
+extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections, const double* a12,
+                                  const double* gain, int precision) {
+  ISD_CHECK_ARG(out && a12 && gain, "isd_fb_plan_create: null argument");
+  ISD_CHECK_ARG(n_bands >= 1 && n_bands <= 4096, "isd_fb_plan_create: n_bands=%d out of range", n_bands);
+  ISD_CHECK_ARG(n_sections >= 1 && n_sections <= kMaxSec, "isd_fb_plan_create: n_sections=%d not in [1,%d]",
+                n_sections, kMaxSec);
+  ISD_CHECK_ARG(precision == ISD_FB_F32 || precision == ISD_FB_F64 || precision == ISD_FB_AUTO,
+                "isd_fb_plan_create: bad precision %d", precision);
+  const int n = n_bands * n_sections;
+  std::vector<FbSec> secs(n);
+  std::vector<FbBand> bands(n_bands);
+  std::vector<double> Q((size_t)n * 64);
+  double worst = 0.0;
+  for (int b = 0; b < n_bands; ++b) {
+    bands[b].gd = gain[b];
+    bands[b].gf = (float)gain[b];
+    bands[b].pad = 0.f;
+    for (int s = 0; s < n_sections; ++s) {
+      const int bs = b * n_sections + s;
+      const double a1 = a12[bs * 2], a2 = a12[bs * 2 + 1];
+      // stability (poles strictly inside the unit circle)
+      ISD_CHECK_ARG(a2 < 1.0 && a2 > -1.0 && fabs(a1) < 1.0 + a2,
+                    "isd_fb_plan_create: band %d section %d is not stable (a1=%g a2=%g)", b, s, a1, a2);
+      FbSec& sc = secs[bs];
+      const double A[4] = {-a1, 1.0, -a2, 0.0};
+      double An[4] = {1, 0, 0, 1};
+      for (int k = 0; k < kL; ++k) {              // h[n] = row 0 of A^n ; afterwards An = A^32
+        sc.hd[k][0] = An[0];
+        sc.hd[k][1] = An[1];
+        sc.hf[k][0] = (float)An[0];
+        sc.hf[k][1] = (float)An[1];
+        mat2_mul(A, An, An);
+      }
+      double Mk[4];
+      memcpy(Mk, An, sizeof(Mk));
+      double Qi[4] = {1, 0, 0, 1};
+      for (int i = 0; i < 16; ++i) {              // Q_i = M^i
+        memcpy(&Q[(size_t)bs * 64 + i * 4], Qi, sizeof(Qi));
+        mat2_mul(Mk, Qi, Qi);
+      }
+      memcpy(sc.P, Qi, sizeof(Qi));               // M^16
+      for (int k = 0; k < 4; ++k) {               // M^(1,2,4,8)
+        memcpy(sc.Mp[k], Mk, sizeof(Mk));
+        mat2_mul(Mk, Mk, Mk);
+      }
+      sc.a1d = a1; sc.a2d = a2; sc.a1f = (float)a1; sc.a2f = (float)a2;
+      // fp32 round-off amplification of a resonator ~ 1 / ((1-r) sin(theta))
+      if (a2 > 0.0) {
+        const double r = sqrt(a2);
+        double c = -a1 / (2.0 * r);
+        c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+        const double st = sqrt(1.0 - c * c);
+        const double g = 1.0 / ((1.0 - r) * (st > 1e-9 ? st : 1e-9));
+        if (g > worst) worst = g;
+      }
+    }
+  }
+  if (precision == ISD_FB_AUTO) precision = worst > 2000.0 ? ISD_FB_F64 : ISD_FB_F32;
+  isd_fb_plan* p = new isd_fb_plan();
+  p->n_bands = n_bands; p->n_sections = n_sections; p->precision = precision;
+  p->d_sec = nullptr; p->d_band = nullptr; p->d_Q = nullptr;
+  hipError_t e = hipMalloc(&p->d_sec, sizeof(FbSec) * n);
+  if (e == hipSuccess) e = hipMalloc(&p->d_band, sizeof(FbBand) * n_bands);
+  if (e == hipSuccess) e = hipMalloc(&p->d_Q, sizeof(double) * Q.size());
+  if (e == hipSuccess) e = hipMemcpy(p->d_sec, secs.data(), sizeof(FbSec) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->d_band, bands.data(), sizeof(FbBand) * n_bands, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->d_Q, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_error("isd_fb_plan_create: %s", hipGetErrorString(e));
+    isd_fb_plan_destroy(p);
+    return e == hipErrorNoDevice ? ISD_ERR_NO_DEVICE : ISD_ERR_HIP;
+  }
+  *out = p;
+  return ISD_OK;
+}
+
+extern "C" int isd_fb_plan_destroy(isd_fb_plan* p) {
+  if (!p) return ISD_OK;
+  if (p->d_sec) (void)hipFree(p->d_sec);
+  if (p->d_band) (void)hipFree(p->d_band);
+  if (p->d_Q) (void)hipFree(p->d_Q);
+  delete p;
+  return ISD_OK;
+}
+
+extern "C" int isd_fb_plan_precision(const isd_fb_plan* p) { return p ? p->precision : ISD_ERR_INVALID; }
+
+template <typename TL, int GPR>
+static int fb_launch(const isd_fb_plan* p, const float* x, float* y, int64_t R, int C, int T, hipStream_t st) {
+  const int64_t items = cdiv(R, 4 / GPR);
+  ISD_CHECK_ARG(items <= 0x7fffffffLL, "isd_fb_forward: too many rows (%lld)", (long long)R);
+  const size_t lds = 4 * 16 * kPad * 4 + (GPR == 4 ? (size_t)p->n_bands * p->n_sections * 2 * 8 : 0);
+  ISD_CHECK_ARG(lds <= 64 * 1024, "isd_fb_forward: n_bands*n_sections too large for the carry tile");
+  const int vec = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  hipLaunchKernelGGL((fb_kernel<TL, GPR>), dim3((unsigned)items), dim3(64), lds, st, p->d_sec, p->d_band, p->d_Q, x,
+                     y, R, C, T, p->n_bands, p->n_sections, vec);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+extern "C" int isd_fb_forward(const isd_fb_plan* p, const float* x, float* y, int64_t B, int64_t C, int64_t T,
+                              void* stream) {
+  ISD_CHECK_ARG(p && x && y, "isd_fb_forward: null argument");
+  ISD_CHECK_ARG(B >= 0 && C >= 1 && T >= 1 && T <= (1 << 24) && C <= (1 << 20), "isd_fb_forward: bad shape B=%lld C=%lld T=%lld",
+                (long long)B, (long long)C, (long long)T);
+  if (B == 0) return ISD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t R = B * C;
+  const bool f64 = p->precision == ISD_FB_F64;
+  if (T <= kSeg) return f64 ? fb_launch<double, 1>(p, x, y, R, (int)C, (int)T, st) : fb_launch<float, 1>(p, x, y, R, (int)C, (int)T, st);
+  if (T <= 2 * kSeg) return f64 ? fb_launch<double, 2>(p, x, y, R, (int)C, (int)T, st) : fb_launch<float, 2>(p, x, y, R, (int)C, (int)T, st);
+  return f64 ? fb_launch<double, 4>(p, x, y, R, (int)C, (int)T, st) : fb_launch<float, 4>(p, x, y, R, (int)C, (int)T, st);
+}
+
+template <typename TL>
+static int fused_launch(const isd_fb_plan* fb, const isd_stft_plan* st, const float* x, float* feat, int64_t R, int C,
+                        const FusedBands& fbnd, int mode, float eps, hipStream_t stream) {
+  const int64_t items = cdiv(R, 4);
+  ISD_CHECK_ARG(items <= 0x7fffffffLL, "isd_features_fused: too many rows (%lld)", (long long)R);
+  const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  hipLaunchKernelGGL((fused_kernel<TL>), dim3((unsigned)items), dim3(64), 0, stream, fb->d_sec, fb->d_band, st->d_dft,
+                     x, feat, R, C, st->T, fb->n_bands, fb->n_sections, st->J, st->scale * st->scale, fbnd, mode, eps,
+                     vec);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st, const float* x, float* feat,
+                                  int64_t B, int64_t C, const int* klo, const int* khi, int mode, float eps,
+                                  void* stream) {
+  ISD_CHECK_ARG(fb && st && x && feat, "isd_features_fused: null argument");
+  ISD_CHECK_ARG(B >= 0 && C >= 1 && C <= (1 << 20), "isd_features_fused: bad shape B=%lld C=%lld", (long long)B,
+                (long long)C);
+  ISD_CHECK_ARG(mode >= ISD_BP_MAGNITUDE && mode <= ISD_BP_LOGPOWER, "isd_features_fused: bad mode %d", mode);
+  if (!(st->n == 64 && st->hop == 32 && st->T <= kSeg && st->d_dft)) {
+    set_error("isd_features_fused: needs nperseg=64, noverlap=32, T<=512 (got nperseg=%d hop=%d T=%d)", st->n,
+              st->hop, st->T);
+    return ISD_ERR_UNSUPPORTED;
+  }
+  FusedBands fbnd = {};
+  int rc = fill_band_args(st, fb->n_bands, klo, khi, fbnd.klo, fbnd.khi, "isd_features_fused");
+  if (rc) return rc;
+  if (B == 0) return ISD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  return fb->precision == ISD_FB_F64 ? fused_launch<double>(fb, st, x, feat, B * C, (int)C, fbnd, mode, eps, s)
+                                     : fused_launch<float>(fb, st, x, feat, B * C, (int)C, fbnd, mode, eps, s);
+}

@@ -1,0 +1,229 @@
+// STFT (scipy-legacy defaults) and band aggregation.
+//
+// Replaces scipy.signal.stft(sig, fs, nperseg=64, noverlap=32) at
+// scripts/global_shap_analysis.py:132 and the band means of :151-156.
+//
+// Generic path: radix-2 FFT in LDS, twiddles and window staged in LDS, several frames
+// per 256-thread workgroup.  The epilogue either writes the one-sided complex spectrum
+// in scipy's [row][bin][frame] layout or reduces it to band magnitude / power / log-power.
+// (The headline 64/32 configuration is normally served by the fused kernel in fb.hip,
+// which never materialises the filtered signals.)
+#include "common.h"
+#include "stft_plan.h"
+#include <math.h>
+#include <vector>
+
+namespace isd {
+
+struct BandArgs {
+  int klo[kMaxBands];
+  int khi[kMaxBands];
+};
+
+__device__ __forceinline__ unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
+
+// mode_out: 0 complex spectrum, 1 band reduction
+template <int MODE_OUT>
+__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                   const float* __restrict__ win, const float2* __restrict__ tw,
+                                                   int64_t n_frames_total, int T, int n, int log2n, int hop, int J,
+                                                   int tpf, float scale, int C, int nbi, int nb, BandArgs ba,
+                                                   int bp_mode, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int fpb = 256 / tpf;                        // frames per block
+  float2* buf = reinterpret_cast<float2*>(smem_raw);                 // [fpb][n]
+  float2* stw = buf + (size_t)fpb * n;                                // [n/2]
+  float* swin = reinterpret_cast<float*>(stw + n / 2);                // [n]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n / 2; i += 256) stw[i] = tw[i];
+  for (int i = tid; i < n; i += 256) swin[i] = win[i];
+  __syncthreads();
+
+  const int fl = tid / tpf;                         // local frame
+  const int tl = tid - fl * tpf;                    // thread inside the frame
+  const int64_t fid = (int64_t)blockIdx.x * fpb + fl;
+  const bool live = fid < n_frames_total;
+  const int64_t row = live ? fid / J : 0;
+  const int j = live ? (int)(fid - row * J) : 0;
+  float2* fb = buf + (size_t)fl * n;
+  const int half = n / 2;
+
+  // windowed load in bit-reversed order (zero extension by n/2 on both sides + zero padding)
+  for (int idx = tl; idx < n; idx += tpf) {
+    const int pos = j * hop + idx - half;
+    float v = 0.f;
+    if (live && pos >= 0 && pos < T) v = x[row * (int64_t)T + pos] * swin[idx];
+    fb[bitrev((unsigned)idx, log2n)] = make_float2(v, 0.f);
+  }
+  __syncthreads();
+  for (int s = 0; s < log2n; ++s) {
+    const int hs = 1 << s;
+    const int tstride = half >> s;                  // twiddle stride n / (2*hs)
+    for (int t = tl; t < half; t += tpf) {
+      const int k = t & (hs - 1);
+      const int i0 = ((t >> s) << (s + 1)) + k;
+      const int i1 = i0 + hs;
+      const float2 w = stw[k * tstride];
+      const float2 a = fb[i0], b = fb[i1];
+      const float2 bw = make_float2(b.x * w.x - b.y * w.y, b.x * w.y + b.y * w.x);
+      fb[i0] = make_float2(a.x + bw.x, a.y + bw.y);
+      fb[i1] = make_float2(a.x - bw.x, a.y - bw.y);
+    }
+    __syncthreads();
+  }
+  if (!live) return;
+  if (MODE_OUT == 0) {
+    const int nfreq = half + 1;
+    float2* Z = reinterpret_cast<float2*>(out);
+    for (int k = tl; k < nfreq; k += tpf) {
+      const float2 v = fb[k];
+      Z[(row * nfreq + k) * (int64_t)J + j] = make_float2(v.x * scale, v.y * scale);
+    }
+  } else {
+    // row = (b * nbi + bi) * C + c
+    const int64_t bc = row / C;
+    const int c = (int)(row - bc * C);
+    const int bi = (int)(bc % nbi);
+    const int64_t bt = bc / nbi;
+    const int b_first = (nbi == 1) ? 0 : bi;
+    const int b_count = (nbi == 1) ? nb : 1;
+    for (int q = tl; q < b_count; q += tpf) {
+      const int b = b_first + q;
+      const int klo = ba.klo[b], khi = ba.khi[b];
+      float acc = 0.f;
+      for (int k = klo; k <= khi; ++k) {
+        const float2 v = fb[k];
+        const float p = (v.x * v.x + v.y * v.y) * (scale * scale);
+        acc += (bp_mode == ISD_BP_MAGNITUDE) ? sqrtf(p) : p;
+      }
+      float r = khi >= klo ? acc / (float)(khi - klo + 1) : 0.f;
+      if (bp_mode == ISD_BP_LOGPOWER) r = logf(r + eps);
+      out[((bt * nb + b) * C + c) * (int64_t)J + j] = r;
+    }
+  }
+}
+
+}  // namespace isd
+
+using namespace isd;
+
+extern "C" int isd_stft_plan_create(isd_stft_plan** out, int T, int nperseg, int noverlap) {
+  ISD_CHECK_ARG(out, "isd_stft_plan_create: null argument");
+  ISD_CHECK_ARG(T >= 1 && T <= (1 << 24), "isd_stft_plan_create: T=%d out of range", T);
+  ISD_CHECK_ARG(nperseg >= 8 && nperseg <= 4096 && (nperseg & (nperseg - 1)) == 0,
+                "isd_stft_plan_create: nperseg=%d must be a power of two in [8,4096]", nperseg);
+  ISD_CHECK_ARG(noverlap >= 0 && noverlap < nperseg, "isd_stft_plan_create: noverlap=%d not in [0,%d)", noverlap,
+                nperseg);
+  isd_stft_plan* p = new isd_stft_plan();
+  p->T = T; p->n = nperseg; p->hop = nperseg - noverlap;
+  p->log2n = 0;
+  while ((1 << p->log2n) < nperseg) ++p->log2n;
+  int L = T + 2 * (nperseg / 2);
+  const int rem = (L - nperseg) % p->hop;
+  const int pad = ((p->hop - rem) % p->hop) % nperseg;   // scipy: (-(L-nperseg) % nstep) % nperseg
+  L += pad;
+  p->J = (L - nperseg) / p->hop + 1;
+  std::vector<float> win(nperseg);
+  std::vector<float2> tw(nperseg / 2);
+  double wsum = 0.0;
+  for (int i = 0; i < nperseg; ++i) {
+    win[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / nperseg));   // periodic Hann, rounded to f32 like scipy
+    wsum += (double)win[i];
+  }
+  p->scale = (float)(1.0 / wsum);
+  for (int i = 0; i < nperseg / 2; ++i)
+    tw[i] = make_float2((float)cos(2.0 * M_PI * i / nperseg), (float)(-sin(2.0 * M_PI * i / nperseg)));
+  // direct-DFT table for the fused 64/32 kernel: tab[k][n] = w[n] * exp(-2 pi i k n / 64)
+  std::vector<float2> dft;
+  if (nperseg == 64) {
+    dft.resize(33 * 64);
+    for (int k = 0; k <= 32; ++k)
+      for (int i = 0; i < 64; ++i) {
+        const double ph = 2.0 * M_PI * ((k * i) % 64) / 64.0;
+        dft[k * 64 + i] = make_float2((float)((double)win[i] * cos(ph)), (float)(-(double)win[i] * sin(ph)));
+      }
+  }
+  p->d_win = nullptr; p->d_tw = nullptr; p->d_dft = nullptr;
+  hipError_t e = hipMalloc(&p->d_win, sizeof(float) * nperseg);
+  if (e == hipSuccess) e = hipMalloc(&p->d_tw, sizeof(float2) * (nperseg / 2));
+  if (e == hipSuccess) e = hipMemcpy(p->d_win, win.data(), sizeof(float) * nperseg, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * (nperseg / 2), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !dft.empty()) {
+    e = hipMalloc(&p->d_dft, sizeof(float2) * dft.size());
+    if (e == hipSuccess) e = hipMemcpy(p->d_dft, dft.data(), sizeof(float2) * dft.size(), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    set_error("isd_stft_plan_create: %s", hipGetErrorString(e));
+    isd_stft_plan_destroy(p);
+    return e == hipErrorNoDevice ? ISD_ERR_NO_DEVICE : ISD_ERR_HIP;
+  }
+  *out = p;
+  return ISD_OK;
+}
+
+extern "C" int isd_stft_plan_destroy(isd_stft_plan* p) {
+  if (!p) return ISD_OK;
+  if (p->d_win) (void)hipFree(p->d_win);
+  if (p->d_tw) (void)hipFree(p->d_tw);
+  if (p->d_dft) (void)hipFree(p->d_dft);
+  delete p;
+  return ISD_OK;
+}
+
+extern "C" int isd_stft_plan_frames(const isd_stft_plan* p) { return p ? p->J : ISD_ERR_INVALID; }
+extern "C" int isd_stft_plan_bins(const isd_stft_plan* p) { return p ? p->n / 2 + 1 : ISD_ERR_INVALID; }
+
+static int stft_launch(const isd_stft_plan* p, int mode_out, const float* x, float* out, int64_t R, int C, int nbi,
+                       int nb, const BandArgs& ba, int bp_mode, float eps, hipStream_t st) {
+  const int tpf = p->n / 2 < 256 ? p->n / 2 : 256;
+  const int fpb = 256 / tpf;
+  const int64_t frames = R * p->J;
+  const int64_t blocks = cdiv(frames, fpb);
+  ISD_CHECK_ARG(blocks <= 0x7fffffffLL, "stft: too many frames (%lld)", (long long)frames);
+  const size_t lds = sizeof(float2) * ((size_t)fpb * p->n + p->n / 2) + sizeof(float) * p->n;
+  if (mode_out == 0)
+    hipLaunchKernelGGL((stft_kernel<0>), dim3((unsigned)blocks), dim3(256), lds, st, x, out, p->d_win, p->d_tw, frames,
+                       p->T, p->n, p->log2n, p->hop, p->J, tpf, p->scale, C, nbi, nb, ba, bp_mode, eps);
+  else
+    hipLaunchKernelGGL((stft_kernel<1>), dim3((unsigned)blocks), dim3(256), lds, st, x, out, p->d_win, p->d_tw, frames,
+                       p->T, p->n, p->log2n, p->hop, p->J, tpf, p->scale, C, nbi, nb, ba, bp_mode, eps);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+extern "C" int isd_stft_forward(const isd_stft_plan* p, const float* x, float* Z, int64_t R, void* stream) {
+  ISD_CHECK_ARG(p && x && Z, "isd_stft_forward: null argument");
+  ISD_CHECK_ARG(R >= 0, "isd_stft_forward: R=%lld", (long long)R);
+  if (R == 0) return ISD_OK;
+  BandArgs ba = {};
+  return stft_launch(p, 0, x, Z, R, 1, 1, 1, ba, 0, 0.f, (hipStream_t)stream);
+}
+
+int isd::fill_band_args(const isd_stft_plan* p, int n_bands, const int* klo, const int* khi, int* oklo, int* okhi,
+                        const char* who) {
+  ISD_CHECK_ARG(n_bands >= 1 && n_bands <= kMaxBands, "%s: n_bands=%d not in [1,%d]", who, n_bands, kMaxBands);
+  ISD_CHECK_ARG(klo && khi, "%s: null band table", who);
+  for (int b = 0; b < n_bands; ++b) {
+    ISD_CHECK_ARG(khi[b] < klo[b] || (klo[b] >= 0 && khi[b] <= p->n / 2), "%s: band %d bins [%d,%d] outside [0,%d]",
+                  who, b, klo[b], khi[b], p->n / 2);
+    oklo[b] = klo[b];
+    okhi[b] = khi[b];
+  }
+  return ISD_OK;
+}
+
+extern "C" int isd_stft_bandpower(const isd_stft_plan* p, const float* y, float* feat, int64_t B, int64_t C,
+                                  int n_bands_in, int n_bands, const int* klo, const int* khi, int mode, float eps,
+                                  void* stream) {
+  ISD_CHECK_ARG(p && y && feat, "isd_stft_bandpower: null argument");
+  ISD_CHECK_ARG(B >= 0 && C >= 1 && C <= (1 << 20), "isd_stft_bandpower: bad shape B=%lld C=%lld", (long long)B,
+                (long long)C);
+  ISD_CHECK_ARG(n_bands_in == 1 || n_bands_in == n_bands, "isd_stft_bandpower: n_bands_in must be 1 or n_bands");
+  ISD_CHECK_ARG(mode >= ISD_BP_MAGNITUDE && mode <= ISD_BP_LOGPOWER, "isd_stft_bandpower: bad mode %d", mode);
+  BandArgs ba = {};
+  int rc = fill_band_args(p, n_bands, klo, khi, ba.klo, ba.khi, "isd_stft_bandpower");
+  if (rc) return rc;
+  if (B == 0) return ISD_OK;
+  return stft_launch(p, 1, y, feat, B * n_bands_in * C, (int)C, n_bands_in, n_bands, ba, mode, eps,
+                     (hipStream_t)stream);
+}

@@ -1,0 +1,17 @@
+// STFT plan shared by stft.hip (generic FFT path) and fb.hip (fused 64/32 direct-DFT path).
+#pragma once
+#include "common.h"
+
+struct isd_stft_plan {
+  int T, n, hop, log2n, J;
+  float scale;          // 1 / sum(window)  (scipy scaling='spectrum')
+  float* d_win;         // [n] periodic Hann
+  float2* d_tw;         // [n/2] exp(-2 pi i k / n)
+  float2* d_dft;        // n == 64 only: [33][64] w[n] * exp(-2 pi i k n / 64)
+};
+
+namespace isd {
+constexpr int kMaxBands = 64;
+int fill_band_args(const isd_stft_plan* p, int n_bands, const int* klo, const int* khi, int* oklo, int* okhi,
+                   const char* who);
+}  // namespace isd

@@ -1,0 +1,193 @@
+"""Feature extraction front end: ``extract_features(trials)`` (spec S).
+
+Host side of the filterbank -> STFT -> log band power path.  The arithmetic
+runs in libisd_hip.so (csrc/fb.hip, csrc/stft.hip); this module designs the
+filters, owns the plans and passes raw device pointers.  Reference anchors:
+scripts/global_shap_analysis.py:132-156 (STFT + band means) and
+notebooks/svm_baseline.ipynb:238 (band-pass in front of the classifier).
+"""
+import ctypes as C
+import functools
+
+import numpy as np
+import torch
+
+from . import _lib
+from .constants import BANDS_9, band_edges
+from .filter_design import filterbank_tables
+
+_PREC = {"f32": _lib.FB_F32, "f64": _lib.FB_F64, "auto": _lib.FB_AUTO}
+_MODE = {"magnitude": _lib.BP_MAGNITUDE, "power": _lib.BP_POWER, "logpower": _lib.BP_LOGPOWER}
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise TypeError(f"{name} must be a contiguous float32 CUDA tensor")
+
+
+def band_bins(fs, nperseg, bands):
+    """Inclusive rfft-bin range [klo, khi] per band (global_shap_analysis.py:153); (1, 0) if empty."""
+    f = np.fft.rfftfreq(nperseg, 1.0 / fs)
+    out = []
+    for lo, hi in band_edges(bands):
+        k = np.where((f >= lo) & (f <= hi))[0]
+        out.append((int(k[0]), int(k[-1])) if len(k) else (1, 0))
+    return out
+
+
+class Filterbank:
+    """Butterworth band-pass filterbank plan (``butter(order, band, 'bandpass', fs, 'sos')`` + ``sosfilt``)."""
+
+    def __init__(self, bands, fs, order=4, precision="auto"):
+        self.bands = band_edges(bands)
+        self.fs, self.order = float(fs), int(order)
+        a12, gain = filterbank_tables(self.bands, self.fs, self.order)
+        self.a12, self.gain = a12, gain
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().isd_fb_plan_create(C.byref(self._h), len(self.bands), self.order,
+                                                 _lib.double_array(a12.ravel()), _lib.double_array(gain),
+                                                 _PREC[precision]))
+        self.precision = "f64" if _lib.lib().isd_fb_plan_precision(self._h) == _lib.FB_F64 else "f32"
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().isd_fb_plan_destroy(h)
+            except Exception:
+                pass
+
+    @property
+    def n_bands(self):
+        return len(self.bands)
+
+    def forward(self, x, out=None):
+        """x f32 CUDA [B, C, T] -> y f32 CUDA [B, n_bands, C, T] (causal, zero initial state)."""
+        _require_cuda(x, "x")
+        B, Cc, T = x.shape
+        if out is None:
+            out = torch.empty((B, self.n_bands, Cc, T), dtype=torch.float32, device=x.device)
+        else:
+            _require_cuda(out, "out")
+            assert out.shape == (B, self.n_bands, Cc, T)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_fb_forward(self._h, x.data_ptr(), out.data_ptr(), B, Cc, T, _stream_ptr()))
+        return out
+
+
+class Stft:
+    """scipy-legacy STFT plan (periodic Hann, zero boundary, padded, one-sided, 'spectrum' scaling)."""
+
+    def __init__(self, T, nperseg=64, noverlap=None):
+        self.T, self.nperseg = int(T), int(nperseg)
+        self.noverlap = self.nperseg // 2 if noverlap is None else int(noverlap)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().isd_stft_plan_create(C.byref(self._h), self.T, self.nperseg, self.noverlap))
+        self.n_frames = _lib.lib().isd_stft_plan_frames(self._h)
+        self.n_bins = _lib.lib().isd_stft_plan_bins(self._h)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().isd_stft_plan_destroy(h)
+            except Exception:
+                pass
+
+    def forward(self, x):
+        """x f32 CUDA [..., T] -> complex64 CUDA [..., n_bins, n_frames] (scipy's Zxx layout)."""
+        _require_cuda(x, "x")
+        assert x.shape[-1] == self.T
+        R = x.numel() // self.T
+        Z = torch.empty(tuple(x.shape[:-1]) + (self.n_bins, self.n_frames, 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_stft_forward(self._h, x.data_ptr(), Z.data_ptr(), R, _stream_ptr()))
+        return torch.view_as_complex(Z)
+
+    def bandpower(self, y, bins, mode="logpower", eps=1e-10, shared_signal=False, out=None):
+        """y f32 CUDA [B, nb, C, T] (or [B, 1, C, T] with shared_signal) -> [B, nb, C, J]."""
+        _require_cuda(y, "y")
+        B, nbi, Cc, T = y.shape
+        nb = len(bins)
+        assert T == self.T and (nbi == nb or (shared_signal and nbi == 1))
+        if out is None:
+            out = torch.empty((B, nb, Cc, self.n_frames), dtype=torch.float32, device=y.device)
+        klo, khi = _lib.int_array([b[0] for b in bins]), _lib.int_array([b[1] for b in bins])
+        with torch.cuda.device(y.device):
+            _lib.check(_lib.lib().isd_stft_bandpower(self._h, y.data_ptr(), out.data_ptr(), B, Cc, nbi, nb, klo, khi,
+                                                     _MODE[mode], float(eps), _stream_ptr()))
+        return out
+
+
+class FeatureExtractor:
+    """Spec-S pipeline bound to one (T, fs, bands, order, nperseg, noverlap) configuration."""
+
+    def __init__(self, T, fs, bands=BANDS_9, order=4, nperseg=64, noverlap=None, eps=1e-10, precision="auto",
+                 mode="logpower"):
+        self.fb = Filterbank(bands, fs, order, precision)
+        self.stft = Stft(T, nperseg, noverlap)
+        self.bins = band_bins(fs, nperseg, bands)
+        self.eps, self.mode = float(eps), mode
+        self._klo = _lib.int_array([b[0] for b in self.bins])
+        self._khi = _lib.int_array([b[1] for b in self.bins])
+        self.can_fuse = self.stft.nperseg == 64 and self.stft.noverlap == 32 and T <= 512
+
+    @property
+    def n_bands(self):
+        return self.fb.n_bands
+
+    @property
+    def n_frames(self):
+        return self.stft.n_frames
+
+    def __call__(self, x, fused=None, out=None):
+        """x f32 CUDA [B, C, T] -> f32 CUDA [B, n_bands, C, J]."""
+        _require_cuda(x, "trials")
+        B, Cc, T = x.shape
+        if T != self.stft.T:
+            raise ValueError(f"extractor was planned for T={self.stft.T}, got T={T}")
+        if fused is None:
+            fused = self.can_fuse
+        if out is None:
+            out = torch.empty((B, self.n_bands, Cc, self.n_frames), dtype=torch.float32, device=x.device)
+        if fused:
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().isd_features_fused(self.fb._h, self.stft._h, x.data_ptr(), out.data_ptr(), B, Cc,
+                                                         self._klo, self._khi, _MODE[self.mode], self.eps,
+                                                         _stream_ptr()))
+            return out
+        y = self.fb.forward(x)
+        return self.stft.bandpower(y, self.bins, self.mode, self.eps, out=out)
+
+
+@functools.lru_cache(maxsize=32)
+def _cached_extractor(T, fs, bands, order, nperseg, noverlap, eps, precision, device_index):
+    with torch.cuda.device(device_index):
+        return FeatureExtractor(T, fs, bands, order, nperseg, noverlap, eps, precision)
+
+
+def extract_features(trials, *, fs=256.0, bands=BANDS_9, order=4, nperseg=64, noverlap=None, eps=1e-10,
+                     precision="auto", fused=None, device=None):
+    """Spec S: trials f32 [B, C, T] -> log band power f32 [B, n_bands, C, J].
+
+    ``trials`` may be a CUDA tensor (used in place, result stays on the device)
+    or a NumPy array / CPU tensor (copied to ``device`` and the result copied
+    back as NumPy).  There is no CPU implementation behind this function.
+    """
+    as_numpy = not (isinstance(trials, torch.Tensor) and trials.is_cuda)
+    if as_numpy:
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        x = torch.as_tensor(np.ascontiguousarray(trials, dtype=np.float32)).to(dev)
+    else:
+        x = trials.contiguous().float()
+    if x.dim() != 3:
+        raise ValueError("trials must be [batch, channels, time]")
+    bands_key = tuple((float(lo), float(hi)) for lo, hi in band_edges(bands))
+    fx = _cached_extractor(int(x.shape[-1]), float(fs), bands_key, int(order), int(nperseg),
+                           None if noverlap is None else int(noverlap), float(eps), precision, x.device.index or 0)
+    out = fx(x, fused=fused)
+    return out.cpu().numpy() if as_numpy else out
