@@ -311,6 +311,10 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
     float vf[kL];
 #pragma unroll
     for (int n = 0; n < kL; ++n) vf[n] = (float)v[n];
+    if (T < kSeg) {                                   // the STFT sees y[0..T) then zeros, not the filter's ringing
+#pragma unroll
+      for (int n = 0; n < kL; ++n) vf[n] = (i * kL + n < T) ? vf[n] : 0.f;
+    }
     const int klo = fbnd.klo[b], khi = fbnd.khi[b];
     float acc = 0.f, acc16 = 0.f;
     for (int k = klo; k <= khi; ++k) {
@@ -454,10 +458,11 @@ static int fb_launch(const isd_fb_plan* p, const float* x, float* y, int64_t R, 
 
 extern "C" int isd_fb_forward(const isd_fb_plan* p, const float* x, float* y, int64_t B, int64_t C, int64_t T,
                               void* stream) {
-  ISD_CHECK_ARG(p && x && y, "isd_fb_forward: null argument");
+  ISD_CHECK_ARG(p, "isd_fb_forward: null plan");
   ISD_CHECK_ARG(B >= 0 && C >= 1 && T >= 1 && T <= (1 << 24) && C <= (1 << 20), "isd_fb_forward: bad shape B=%lld C=%lld T=%lld",
                 (long long)B, (long long)C, (long long)T);
   if (B == 0) return ISD_OK;
+  ISD_CHECK_ARG(x && y, "isd_fb_forward: null argument");
   hipStream_t st = (hipStream_t)stream;
   const int64_t R = B * C;
   const bool f64 = p->precision == ISD_FB_F64;
@@ -482,7 +487,8 @@ static int fused_launch(const isd_fb_plan* fb, const isd_stft_plan* st, const fl
 extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st, const float* x, float* feat,
                                   int64_t B, int64_t C, const int* klo, const int* khi, int mode, float eps,
                                   void* stream) {
-  ISD_CHECK_ARG(fb && st && x && feat, "isd_features_fused: null argument");
+  ISD_CHECK_ARG(fb && st, "isd_features_fused: null plan");
+  ISD_CHECK_ARG(B == 0 || (x && feat), "isd_features_fused: null argument");
   ISD_CHECK_ARG(B >= 0 && C >= 1 && C <= (1 << 20), "isd_features_fused: bad shape B=%lld C=%lld", (long long)B,
                 (long long)C);
   ISD_CHECK_ARG(mode >= ISD_BP_MAGNITUDE && mode <= ISD_BP_LOGPOWER, "isd_features_fused: bad mode %d", mode);

@@ -192,7 +192,7 @@ static int stft_launch(const isd_stft_plan* p, int mode_out, const float* x, flo
 }
 
 extern "C" int isd_stft_forward(const isd_stft_plan* p, const float* x, float* Z, int64_t R, void* stream) {
-  ISD_CHECK_ARG(p && x && Z, "isd_stft_forward: null argument");
+  ISD_CHECK_ARG(p && (R == 0 || (x && Z)), "isd_stft_forward: null argument");
   ISD_CHECK_ARG(R >= 0, "isd_stft_forward: R=%lld", (long long)R);
   if (R == 0) return ISD_OK;
   BandArgs ba = {};
@@ -215,7 +215,7 @@ int isd::fill_band_args(const isd_stft_plan* p, int n_bands, const int* klo, con
 extern "C" int isd_stft_bandpower(const isd_stft_plan* p, const float* y, float* feat, int64_t B, int64_t C,
                                   int n_bands_in, int n_bands, const int* klo, const int* khi, int mode, float eps,
                                   void* stream) {
-  ISD_CHECK_ARG(p && y && feat, "isd_stft_bandpower: null argument");
+  ISD_CHECK_ARG(p && (B == 0 || (y && feat)), "isd_stft_bandpower: null argument");
   ISD_CHECK_ARG(B >= 0 && C >= 1 && C <= (1 << 20), "isd_stft_bandpower: bad shape B=%lld C=%lld", (long long)B,
                 (long long)C);
   ISD_CHECK_ARG(n_bands_in == 1 || n_bands_in == n_bands, "isd_stft_bandpower: n_bands_in must be 1 or n_bands");
