@@ -44,6 +44,18 @@ SIGNATURES = {
     "isd_stft_forward": (_i, [_p, _p, _p, _i64, _p]),
     "isd_stft_bandpower": (_i, [_p, _p, _p, _i64, _i64, _i, _i, _pi, _pi, _i, _f, _p]),
     "isd_features_fused": (_i, [_p, _p, _p, _p, _i64, _i64, _pi, _pi, _i, _f, _p]),
+    "isd_conv4_plan_create": (_i, [C.POINTER(_p), _i, _i, _pi, _pi, _i, _i, _i, _i]),
+    "isd_conv4_plan_destroy": (_i, [_p]),
+    "isd_conv4_param_count": (_i64, [_p]),
+    "isd_conv4_param_offset": (_i64, [_p, _i, _i]),
+    "isd_conv4_windows": (_i, [_p, _i64]),
+    "isd_conv4_workspace_bytes": (_i64, [_p, _i64, _i64]),
+    "isd_conv4_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
+    "isd_conv4_backward": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
+    "isd_linear_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
+    "isd_linear_workspace_bytes": (_i64, [_i64, _i, _i]),
+    "isd_linear_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
+    "isd_softmax_ce": (_i, [_p, _p, _i, _p, _p, _p, _p, _i64, _i, _i, _f, _p]),
 }
 
 _lib = None

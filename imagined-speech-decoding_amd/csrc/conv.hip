@@ -1,0 +1,765 @@
+// Zone-wise Conv4Layers stack (reference: src/fast/models/fast.py:103-119 `Conv4Layers`,
+// :199-210 `Head`, :242-252 `FAST.forward_head`) forward + backward on gfx950.
+//
+//   cnn1 (1->F, 1x5, bias, valid) and cnn2 (F->F, Cz x 1) have no nonlinearity between
+//   them, so they are applied as ONE (Cz x 5)-tap convolution with
+//       Weff[g,c,k] = sum_f W2[g,f,c] W1[f,k],   beff[g] = sum_{f,c} W2[g,f,c] b1[f];
+//   the [B',F,Cz,246] cnn1 activation (32x the input) is never formed.  The backward
+//   pass produces dWeff/dbeff and chains them to cnn1.weight / cnn1.bias / cnn2.weight.
+//   cnn3, cnn4: F->F, 5 taps, zero pad 2.  Then exact-erf GELU and the mean over time.
+//
+// All convolutions are GEMM-shaped (K = 5*Cin) and run on v_mfma_f32_16x16x4_f32
+// (exact fp32 FMA chains).  M = output filters (16-row tiles), N = 16 time steps,
+// K = 4 input channels per MFMA, one MFMA per tap.  Sliding windows and the zone
+// gather are index arithmetic on the raw trial tensor; nothing is copied.
+#include "common.h"
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+namespace isd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTaps = 5;
+constexpr int kCK = 32;          // input channels staged per chunk
+constexpr int kMaxZones = 64;
+
+struct ZoneDesc {
+  int cin;          // channels of this zone (Cz)
+  int idx_off;      // offset into the channel-index table
+  int64_t p_off;    // offset of the zone's parameters in the flat parameter block
+  int64_t eff_off;  // offset of Weff frag block (fwd) in the weight workspace
+  int64_t wg_off;   // offset of the zone's dWeff block [F][Cz+1][5] in the wgrad result
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight preparation.  "frag order": block (cg, k, gt) holds, for lane l,
+//   W[gt*16 + (l&15)][4*cg + (l>>4)][k]   (zero beyond Cin)   -> one coalesced A-fragment load.
+// ---------------------------------------------------------------------------------------
+__global__ void prep_fused_kernel(const float* __restrict__ params, const ZoneDesc* __restrict__ zones,
+                                  float* __restrict__ wfrag, float* __restrict__ beff, int F) {
+  const int z = blockIdx.y;
+  const ZoneDesc zd = zones[z];
+  const int GT = F / 16;
+  const int ncg = (zd.cin + 3) / 4;
+  const float* W1 = params + zd.p_off;                 // [F][5]
+  const float* b1 = W1 + F * kTaps;                    // [F]
+  const float* W2 = b1 + F;                            // [F][F][Cz]
+  const int total = ncg * kTaps * GT * 64;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + F; e += gridDim.x * blockDim.x) {
+    if (e < total) {
+      const int lane = e & 63;
+      const int blk = e >> 6;
+      const int gt = blk % GT;
+      const int k = (blk / GT) % kTaps;
+      const int cg = blk / (GT * kTaps);
+      const int g = gt * 16 + (lane & 15);
+      const int c = cg * 4 + (lane >> 4);
+      float acc = 0.f;
+      if (c < zd.cin)
+        for (int f = 0; f < F; ++f) acc = fmaf(W2[(g * F + f) * zd.cin + c], W1[f * kTaps + k], acc);
+      wfrag[zd.eff_off + e] = acc;
+    } else {
+      const int g = e - total;
+      float acc = 0.f;
+      for (int f = 0; f < F; ++f) {
+        float s = 0.f;
+        for (int c = 0; c < zd.cin; ++c) s += W2[(g * F + f) * zd.cin + c];
+        acc = fmaf(s, b1[f], acc);
+      }
+      beff[z * F + g] = acc;
+    }
+  }
+}
+
+// cnn3 / cnn4 weights [F][F][5] -> frag order, forward and transposed+flipped (dgrad) copies.
+__global__ void prep_conv_kernel(const float* __restrict__ params, const ZoneDesc* __restrict__ zones,
+                                 float* __restrict__ wf, float* __restrict__ wt, int F, int layer, int64_t zstride) {
+  const int z = blockIdx.y;
+  const ZoneDesc zd = zones[z];
+  const int GT = F / 16;
+  const int ncg = F / 4;
+  const float* W = params + zd.p_off + F * kTaps + F + (int64_t)F * F * zd.cin + (int64_t)layer * F * F * kTaps;
+  const int total = ncg * kTaps * GT * 64;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int lane = e & 63;
+    const int blk = e >> 6;
+    const int gt = blk % GT;
+    const int k = (blk / GT) % kTaps;
+    const int cg = blk / (GT * kTaps);
+    const int g = gt * 16 + (lane & 15);
+    const int c = cg * 4 + (lane >> 4);
+    wf[z * zstride + e] = W[(g * F + c) * kTaps + k];
+    wt[z * zstride + e] = W[(c * F + g) * kTaps + (kTaps - 1 - k)];   // dIn[g] <- dOut[c], flipped taps
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Forward convolution (also used as dgrad with transposed weights).
+// ---------------------------------------------------------------------------------------
+struct ConvArgs {
+  const float* in;
+  float* out;
+  const float* wfrag;        // frag-ordered weights (per-zone offset from ZoneDesc or z*wz_stride)
+  const float* bias;         // [Z][F] or null
+  const ZoneDesc* zones;
+  const int* chan_idx;
+  int64_t wz_stride;         // MODE 1: per-zone stride of wfrag
+  int64_t items;             // B' = B * N
+  int Z, F, Tin, Tout, pad, TT, IPW, RS;
+  int Ctot, Tx, N, S;        // MODE 0 only
+};
+
+// MODE 0: input gathered from the raw trials  x[b][chan_idx[c]][n*S + t]   (item = b*N + n)
+// MODE 1: input is an activation tensor      in[((item*Z + z)*F + c)*Tin + t]
+template <int MODE>
+__global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int z = blockIdx.y;
+  const ZoneDesc zd = a.zones[z];
+  const int cin = (MODE == 0) ? zd.cin : a.F;
+  const int GT = a.F / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t item0 = (int64_t)blockIdx.x * a.IPW;
+  const int n_items = (int)((a.items - item0) < a.IPW ? (a.items - item0) : a.IPW);
+  const int n_ct = n_items * a.TT;
+  float* in_tile = smem;                                  // [IPW][kCK][RS]
+  float* w_tile = smem + a.IPW * kCK * a.RS;              // [kCK/4][5][GT][64]
+  const float* wbase = a.wfrag + ((MODE == 0) ? zd.eff_off : (int64_t)z * a.wz_stride);
+  const int n_chunks = (cin + kCK - 1) / kCK;
+
+  for (int base = 0; base < n_ct; base += 16) {
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) acc[j][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int t_ii[4], t_t0[4];
+    bool t_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ct = base + wave * 4 + j;
+      t_ok[j] = ct < n_ct;
+      const int ctc = t_ok[j] ? ct : 0;
+      t_ii[j] = ctc / a.TT;
+      t_t0[j] = (ctc - t_ii[j] * a.TT) * 16;
+    }
+    for (int ch = 0; ch < n_chunks; ++ch) {
+      const int c_lo = ch * kCK;
+      const int ckc = (cin - c_lo) < kCK ? (cin - c_lo) : kCK;
+      const int ckc4 = (ckc + 3) & ~3;
+      __syncthreads();
+      // stage the input rows (zero padded on both sides and up to RS)
+      const int rows = n_items * ckc4;
+      for (int e = threadIdx.x; e < rows * a.RS; e += 256) {
+        const int r = e / a.RS, tp = e - r * a.RS;
+        const int ii = r / ckc4, cc = r - ii * ckc4;
+        const int t = tp - a.pad;
+        float v = 0.f;
+        if (cc < ckc && t >= 0 && t < a.Tin) {
+          const int64_t item = item0 + ii;
+          if (MODE == 0) {
+            const int64_t b = item / a.N;
+            const int n = (int)(item - b * a.N);
+            const int chn = a.chan_idx[zd.idx_off + c_lo + cc];
+            v = a.in[(b * a.Ctot + chn) * (int64_t)a.Tx + (int64_t)n * a.S + t];
+          } else {
+            v = a.in[((item * a.Z + z) * a.F + c_lo + cc) * (int64_t)a.Tin + t];
+          }
+        }
+        in_tile[(ii * kCK + cc) * a.RS + tp] = v;
+      }
+      // stage this chunk's weight fragments (contiguous)
+      const int wlen = (ckc4 / 4) * kTaps * GT * 64;
+      const float* wsrc = wbase + (int64_t)ch * (kCK / 4) * kTaps * GT * 64;
+      for (int e = threadIdx.x; e < wlen; e += 256) w_tile[e] = wsrc[e];
+      __syncthreads();
+      for (int cg = 0; cg < ckc4 / 4; ++cg) {
+        const int crow = cg * 4 + (lane >> 4);
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) {
+          float af[2];
+          af[0] = w_tile[((cg * kTaps + k) * GT + 0) * 64 + lane];
+          af[1] = (GT > 1) ? w_tile[((cg * kTaps + k) * GT + 1) * 64 + lane] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float bf = in_tile[(t_ii[j] * kCK + crow) * a.RS + t_t0[j] + k + (lane & 15)];
+            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf, acc[j][0], 0, 0, 0);
+            if (GT > 1) acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf, acc[j][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // epilogue: D[row g = 4*(lane>>4)+r][col t = lane&15]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!t_ok[j]) continue;
+      const int64_t item = item0 + t_ii[j];
+      const int t = t_t0[j] + (lane & 15);
+      if (t >= a.Tout) continue;
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt) {
+        if (gt >= GT) break;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int g = gt * 16 + 4 * (lane >> 4) + r;
+          float v = acc[j][gt][r];
+          if (a.bias) v += a.bias[z * a.F + g];
+          a.out[((item * a.Z + z) * a.F + g) * (int64_t)a.Tout + t] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// GELU + mean over time (fast.py:117-118) and its backward (in place on the activation).
+// one 16-lane row per (item, zone, filter) row of length T
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gelu_mean_fwd_kernel(const float* __restrict__ a, float* __restrict__ feat,
+                                                            int64_t rows, int T) {
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int i = threadIdx.x & 15;
+  float s = 0.f;
+  if (row < rows) {
+    const float* p = a + row * T;
+    for (int t = i; t < T; t += 16) s += gelu_f(p[t]);
+  }
+  s += row_shr<8>(s);   // lanes >= 8 accumulate lanes - 8 ... finish with a butterfly via shifts
+  s += row_shr<4>(s);
+  s += row_shr<2>(s);
+  s += row_shr<1>(s);
+  if (row < rows && i == 15) feat[row] = s / (float)T;
+}
+
+__global__ __launch_bounds__(256) void gelu_mean_bwd_kernel(float* __restrict__ a, const float* __restrict__ dfeat,
+                                                            int64_t rows, int T) {
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int i = threadIdx.x & 15;
+  if (row >= rows) return;
+  const float g = dfeat[row] / (float)T;
+  float* p = a + row * T;
+  for (int t = i; t < T; t += 16) p[t] = g * gelu_grad_f(p[t]);
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight gradient: dW[g][c][k] = sum_{item,t} dOut[item][g][t] * In[item][c][t + k - pad].
+// M = g, N = c (16 per wave), K = t (4 per MFMA); 5 accumulators per (g-tile) for the taps.
+// MODE 0 appends a virtual all-ones channel (index cin) whose tap-0 column is dbias.
+// Each workgroup reduces a contiguous range of items and writes one partial slab.
+// ---------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* dout;         // [items][Z][F][Tout]
+  const float* in;           // MODE 0: raw trials, MODE 1: [items][Z][F][Tin]
+  float* part;               // [n_wg * n_grp][slab_size]
+  const ZoneDesc* zones;
+  const int* chan_idx;
+  int64_t items, slab_size;
+  int64_t wz_stride;         // MODE 1: per-zone stride inside a slab
+  int items_per_wg, IPS;     // items per workgroup, items per LDS stage
+  int CW;                    // input channels staged per workgroup (16, 32, 48 or 64)
+  int Z, F, Tin, Tout, pad, RSo, RSi;
+  int Ctot, Tx, N, S;
+};
+
+// Wave roles: with n_ct = CW/16 channel tiles and GT filter tiles, roles = n_ct*GT.
+//   roles <= 4 : a wave owns ONE (c-tile, g-tile); the 4/roles wave groups split the items
+//                and write separate slabs (summed by reduce_slabs_kernel);
+//   roles == 8 : a wave owns one c-tile and both g-tiles.
+template <int MODE>
+__global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int z = blockIdx.y;
+  const ZoneDesc zd = a.zones[z];
+  const int cin = (MODE == 0) ? zd.cin + 1 : a.F;          // + ones channel (dbias)
+  const int c_base = blockIdx.z * a.CW;
+  if (c_base >= cin) return;
+  const int GT = a.F / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_ct = a.CW / 16;
+  const int roles = n_ct * GT;
+  const bool both = roles > 4;
+  const int n_grp = both ? 1 : 4 / roles;
+  const int ct = both ? wave : wave % n_ct;
+  const int gsel = both ? 0 : (wave / n_ct) % GT;
+  const int grp = both ? 0 : wave / roles;
+  const int c_tile = c_base + ct * 16;
+  const bool wave_live = c_tile < cin && grp < n_grp;
+  float* do_tile = smem;                                    // [IPS][F][RSo]
+  float* in_tile = smem + a.IPS * a.F * a.RSo;              // [IPS][CW][RSi]
+  const int64_t i_lo = (int64_t)blockIdx.x * a.items_per_wg;
+  const int64_t i_hi = (i_lo + a.items_per_wg) < a.items ? (i_lo + a.items_per_wg) : a.items;
+  const int Tk = (a.Tout + 3) & ~3;                         // K extent (zero filled)
+
+  f32x4 acc0[kTaps], acc1[kTaps];
+#pragma unroll
+  for (int k = 0; k < kTaps; ++k) {
+    acc0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int64_t is = i_lo; is < i_hi; is += a.IPS) {
+    const int n_it = (int)((i_hi - is) < a.IPS ? (i_hi - is) : a.IPS);
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_it * a.F * a.RSo; e += 256) {
+      const int r = e / a.RSo, t = e - r * a.RSo;
+      const int ii = r / a.F, g = r - ii * a.F;
+      float v = 0.f;
+      if (t < a.Tout) v = a.dout[(((is + ii) * a.Z + z) * a.F + g) * (int64_t)a.Tout + t];
+      do_tile[e] = v;
+    }
+    for (int e = threadIdx.x; e < n_it * a.CW * a.RSi; e += 256) {
+      const int r = e / a.RSi, tp = e - r * a.RSi;
+      const int ii = r / a.CW, cc = r - ii * a.CW;
+      const int c = c_base + cc;
+      const int t = tp - a.pad;
+      float v = 0.f;
+      if (c < cin && t >= 0 && t < a.Tin) {
+        const int64_t item = is + ii;
+        if (MODE == 0) {
+          if (c == cin - 1) {
+            v = (t < a.Tout) ? 1.f : 0.f;
+          } else {
+            const int64_t b = item / a.N;
+            const int n = (int)(item - b * a.N);
+            v = a.in[(b * a.Ctot + a.chan_idx[zd.idx_off + c]) * (int64_t)a.Tx + (int64_t)n * a.S + t];
+          }
+        } else {
+          v = a.in[((item * a.Z + z) * a.F + c) * (int64_t)a.Tin + t];
+        }
+      }
+      in_tile[e] = v;
+    }
+    __syncthreads();
+    if (wave_live) {
+      for (int ii = grp; ii < n_it; ii += n_grp) {
+        const float* dro = do_tile + (ii * a.F + gsel * 16 + (lane & 15)) * a.RSo + (lane >> 4);
+        const float* iro = in_tile + (ii * a.CW + ct * 16 + (lane & 15)) * a.RSi + (lane >> 4);
+        for (int t0 = 0; t0 < Tk; t0 += 4) {
+          const float a0 = dro[t0];
+          const float a1 = both ? dro[16 * a.RSo + t0] : 0.f;
+#pragma unroll
+          for (int k = 0; k < kTaps; ++k) {
+            const float bf = iro[t0 + k];
+            acc0[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc0[k], 0, 0, 0);
+            if (both) acc1[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc1[k], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (!wave_live) return;
+  float* slab = a.part + ((int64_t)blockIdx.x * n_grp + grp) * a.slab_size +
+                ((MODE == 0) ? zd.wg_off : (int64_t)z * a.wz_stride);
+  const int c = c_tile + (lane & 15);
+  if (c < cin) {
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int g = gsel * 16 + 4 * (lane >> 4) + r;
+        slab[((int64_t)g * cin + c) * kTaps + k] = acc0[k][r];
+        if (both) slab[((int64_t)(g + 16) * cin + c) * kTaps + k] = acc1[k][r];
+      }
+  }
+}
+
+// sum the per-workgroup slabs: out[e] = sum_s part[s][e]
+__global__ void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int n_slabs) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < n_slabs; ++k) s += part[(int64_t)k * n + e];
+    out[e] = s;
+  }
+}
+
+// Chain dWeff / dbeff back to cnn1.weight, cnn1.bias, cnn2.weight (one block per zone).
+//   dW2[g,f,c] = sum_k dWeff[g,c,k] W1[f,k] + dbeff[g] b1[f]
+//   dW1[f,k]   = sum_{g,c} dWeff[g,c,k] W2[g,f,c]
+//   db1[f]     = sum_g dbeff[g] sum_c W2[g,f,c]
+__global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict__ params,
+                                                        const ZoneDesc* __restrict__ zones,
+                                                        const float* __restrict__ dweff, float* __restrict__ dparams,
+                                                        int F) {
+  const ZoneDesc zd = zones[blockIdx.x];
+  const int cz = zd.cin, cin1 = cz + 1;
+  const float* W1 = params + zd.p_off;
+  const float* b1 = W1 + F * kTaps;
+  const float* W2 = b1 + F;
+  const float* dWe = dweff + zd.wg_off;                 // [F][cz+1][5]; channel cz, tap 0 = dbeff
+  float* dW1 = dparams + zd.p_off;
+  float* db1 = dW1 + F * kTaps;
+  float* dW2 = db1 + F;
+  for (int e = threadIdx.x; e < F * F * cz; e += 256) {
+    const int c = e % cz, f = (e / cz) % F, g = e / (cz * F);
+    float s = dWe[(g * cin1 + cz) * kTaps] * b1[f];
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) s = fmaf(dWe[(g * cin1 + c) * kTaps + k], W1[f * kTaps + k], s);
+    dW2[e] = s;
+  }
+  for (int e = threadIdx.x; e < F * kTaps + F; e += 256) {
+    float s = 0.f;
+    if (e < F * kTaps) {
+      const int f = e / kTaps, k = e - f * kTaps;
+      for (int g = 0; g < F; ++g)
+        for (int c = 0; c < cz; ++c) s = fmaf(dWe[(g * cin1 + c) * kTaps + k], W2[(g * F + f) * cz + c], s);
+      dW1[e] = s;
+    } else {
+      const int f = e - F * kTaps;
+      for (int g = 0; g < F; ++g) {
+        float w = 0.f;
+        for (int c = 0; c < cz; ++c) w += W2[(g * F + f) * cz + c];
+        s = fmaf(dWe[(g * cin1 + cz) * kTaps], w, s);
+      }
+      db1[f] = s;
+    }
+  }
+}
+
+}  // namespace isd
+
+using namespace isd;
+
+struct isd_conv4_plan {
+  int Ctot, Z, F, n_layers, W, S;
+  int cz[kMaxZones];
+  int64_t p_off[kMaxZones];
+  int64_t n_params;
+  int64_t eff_size;        // floats of all fused frag blocks
+  int64_t conv_zstride;    // floats of one zone's cnn3/cnn4 frag block
+  int64_t wg_size;         // floats of all dWeff blocks
+  int max_cz;
+  ZoneDesc* d_zones;
+  int* d_idx;
+};
+
+static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int isd_conv4_plan_create(isd_conv4_plan** out, int c_total, int n_zones, const int* zone_sizes,
+                                     const int* zone_channels, int feature_dim, int n_layers, int window_len,
+                                     int slide_step) {
+  ISD_CHECK_ARG(out && zone_sizes && zone_channels, "isd_conv4_plan_create: null argument");
+  ISD_CHECK_ARG(n_zones >= 1 && n_zones <= kMaxZones, "isd_conv4_plan_create: n_zones=%d not in [1,%d]", n_zones,
+                kMaxZones);
+  ISD_CHECK_ARG(feature_dim == 16 || feature_dim == 32, "isd_conv4_plan_create: feature_dim=%d must be 16 or 32",
+                feature_dim);
+  ISD_CHECK_ARG(n_layers == 2 || n_layers == 4, "isd_conv4_plan_create: n_layers must be 2 or 4");
+  ISD_CHECK_ARG(window_len >= kTaps && slide_step >= 1, "isd_conv4_plan_create: window_len=%d slide_step=%d",
+                window_len, slide_step);
+  isd_conv4_plan* p = new isd_conv4_plan();
+  p->Ctot = c_total; p->Z = n_zones; p->F = feature_dim; p->n_layers = n_layers; p->W = window_len; p->S = slide_step;
+  p->d_zones = nullptr; p->d_idx = nullptr;
+  const int F = feature_dim, GT = F / 16;
+  std::vector<ZoneDesc> zd(n_zones);
+  std::vector<int> idx;
+  int64_t po = 0, eo = 0, wo = 0;
+  p->max_cz = 0;
+  for (int z = 0; z < n_zones; ++z) {
+    const int cz = zone_sizes[z];
+    if (cz < 1 || cz > 4096) { delete p; set_error("isd_conv4_plan_create: zone %d has %d channels", z, cz); return ISD_ERR_INVALID; }
+    for (int c = 0; c < cz; ++c) {
+      const int ch = zone_channels[idx.size()];
+      if (ch < 0 || ch >= c_total) { delete p; set_error("isd_conv4_plan_create: channel index %d outside [0,%d)", ch, c_total); return ISD_ERR_INVALID; }
+      idx.push_back(ch);
+    }
+    p->cz[z] = cz;
+    p->p_off[z] = po;
+    if (cz > p->max_cz) p->max_cz = cz;
+    zd[z].cin = cz;
+    zd[z].idx_off = (int)idx.size() - cz;
+    zd[z].p_off = po;
+    zd[z].eff_off = eo;
+    zd[z].wg_off = wo;
+    po += (int64_t)F * kTaps + F + (int64_t)F * F * cz + (n_layers == 4 ? 2LL * F * F * kTaps : 0);
+    eo += (int64_t)align_up(cz, kCK) / 4 * kTaps * GT * 64;   // chunk-aligned so chunk offsets are uniform
+    wo += (int64_t)F * (cz + 1) * kTaps;
+  }
+  p->n_params = po; p->eff_size = eo; p->wg_size = wo;
+  p->conv_zstride = (int64_t)(F / 4) * kTaps * GT * 64;
+  hipError_t e = hipMalloc(&p->d_zones, sizeof(ZoneDesc) * n_zones);
+  if (e == hipSuccess) e = hipMalloc(&p->d_idx, sizeof(int) * idx.size());
+  if (e == hipSuccess) e = hipMemcpy(p->d_zones, zd.data(), sizeof(ZoneDesc) * n_zones, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->d_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_error("isd_conv4_plan_create: %s", hipGetErrorString(e));
+    isd_conv4_plan_destroy(p);
+    return e == hipErrorNoDevice ? ISD_ERR_NO_DEVICE : ISD_ERR_HIP;
+  }
+  *out = p;
+  return ISD_OK;
+}
+
+extern "C" int isd_conv4_plan_destroy(isd_conv4_plan* p) {
+  if (!p) return ISD_OK;
+  if (p->d_zones) (void)hipFree(p->d_zones);
+  if (p->d_idx) (void)hipFree(p->d_idx);
+  delete p;
+  return ISD_OK;
+}
+
+extern "C" int64_t isd_conv4_param_count(const isd_conv4_plan* p) { return p ? p->n_params : ISD_ERR_INVALID; }
+
+extern "C" int64_t isd_conv4_param_offset(const isd_conv4_plan* p, int zone, int which) {
+  if (!p || zone < 0 || zone >= p->Z || which < 0 || which > 4 || (which > 2 && p->n_layers != 4)) return ISD_ERR_INVALID;
+  const int64_t F = p->F;
+  const int64_t offs[5] = {0, F * kTaps, F * kTaps + F, F * kTaps + F + F * F * p->cz[zone],
+                           F * kTaps + F + F * F * p->cz[zone] + F * F * kTaps};
+  return p->p_off[zone] + offs[which];
+}
+
+extern "C" int isd_conv4_windows(const isd_conv4_plan* p, int64_t T) {
+  if (!p || T < p->W) return ISD_ERR_INVALID;
+  return (int)((T - p->W) / p->S + 1);
+}
+
+namespace {
+struct Geo {           // derived sizes for one call
+  int N, T1, TT, IPW, RS_a, RS_b;
+  int64_t items, act;  // act = floats of one activation tensor
+  // workspace layout (floats)
+  int64_t o_eff, o_beff, o_w3, o_w3t, o_w4, o_w4t, o_a2, o_a3, o_a4, o_s, o_wg, o_wg34, o_part, total;
+  int ipw0, ipw1, ns0, ns1, cw0, cw1, grp0, grp1;   // wgrad: items per wg, slabs (incl. wave groups), channels per wg
+  int64_t slab0, slab1;
+};
+
+int row_stride_fwd(int need) {           // conflict-free B-fragment reads: stride == 16 (mod 32) when it matters
+  if (need <= 32) return need | 1;
+  int rs = need;
+  while (rs % 32 != 16) ++rs;
+  return rs;
+}
+int row_stride_wgrad(int need) {         // lanes (l&15) walk rows: stride == 2 (mod 32) is conflict free
+  int rs = need;
+  while (rs % 32 != 2) ++rs;
+  return rs;
+}
+
+int make_geo(const isd_conv4_plan* p, int64_t B, int64_t T, Geo& g) {
+  ISD_CHECK_ARG(T >= p->W, "conv4: T=%lld shorter than window_len=%d", (long long)T, p->W);
+  g.N = (int)((T - p->W) / p->S + 1);
+  g.T1 = p->W - (kTaps - 1);
+  g.TT = (g.T1 + 15) / 16;
+  g.IPW = g.TT >= 16 ? 1 : 16 / g.TT;
+  g.items = B * g.N;
+  g.act = g.items * p->Z * p->F * g.T1;
+  g.RS_a = row_stride_fwd(16 * g.TT + kTaps - 1 > p->W ? 16 * g.TT + kTaps - 1 : p->W);
+  g.RS_b = row_stride_fwd(16 * g.TT + kTaps - 1);
+  {   // keep the staged tile (input rows + one weight chunk) inside 64 KiB of LDS
+    const int64_t wfl = (int64_t)(kCK / 4) * kTaps * (p->F / 16) * 64;
+    const int64_t per_item = (int64_t)kCK * (g.RS_a > g.RS_b ? g.RS_a : g.RS_b);
+    const int64_t fit = (64 * 1024 / 4 - wfl) / per_item;
+    ISD_CHECK_ARG(fit >= 1, "conv4: window_len=%d is too long for the LDS tile", p->W);
+    if (g.IPW > fit) g.IPW = (int)fit;
+  }
+  int64_t o = 0;
+  g.o_eff = o;  o += align_up(p->eff_size, 64);
+  g.o_beff = o; o += align_up((int64_t)p->Z * p->F, 64);
+  const int64_t cw = align_up(p->conv_zstride * p->Z, 64);
+  g.o_w3 = o; o += cw; g.o_w3t = o; o += cw; g.o_w4 = o; o += cw; g.o_w4t = o; o += cw;
+  g.o_a2 = o; o += align_up(g.act, 64);
+  g.o_a3 = o; o += align_up(g.act, 64);
+  g.o_a4 = o; o += align_up(g.act, 64);
+  g.o_s = o;  o += align_up(g.act, 64);
+  g.o_wg = o; o += align_up(p->wg_size, 64);
+  g.slab1 = (int64_t)p->Z * p->F * p->F * kTaps;
+  g.o_wg34 = o; o += align_up(g.slab1, 64);
+  // wgrad slabs: ~2048 workgroups over (item ranges) x zones x channel groups
+  const int GT = p->F / 16;
+  auto plan_wg = [&](int cin_max, int& cw, int& ipw, int& ns, int& grp) {
+    cw = cin_max >= 64 ? 64 : (int)align_up(cin_max, 16);
+    const int roles = (cw / 16) * GT;
+    grp = roles > 4 ? 1 : 4 / roles;
+    const int zg = (cin_max + cw - 1) / cw;
+    int64_t want = 2048 / ((int64_t)p->Z * zg);
+    if (want < 1) want = 1;
+    const int64_t it = g.items > 0 ? g.items : 1;
+    if (want > it) want = it;
+    ipw = (int)cdiv(it, want);
+    ns = (int)cdiv(it, ipw) * grp;
+  };
+  plan_wg(p->max_cz + 1, g.cw0, g.ipw0, g.ns0, g.grp0);
+  plan_wg(p->F, g.cw1, g.ipw1, g.ns1, g.grp1);
+  g.slab0 = p->wg_size;
+  const int64_t pa = (int64_t)g.ns0 * g.slab0, pb = (p->n_layers == 4) ? (int64_t)g.ns1 * g.slab1 : 0;
+  g.o_part = o; o += align_up(pa > pb ? pa : pb, 64);
+  g.total = o;
+  return ISD_OK;
+}
+}  // namespace
+
+extern "C" int64_t isd_conv4_workspace_bytes(const isd_conv4_plan* p, int64_t B, int64_t T) {
+  if (!p || B < 0) return ISD_ERR_INVALID;
+  Geo g;
+  if (make_geo(p, B, T, g)) return ISD_ERR_INVALID;
+  return g.total * 4;
+}
+
+static int launch_conv(int mode, const ConvArgs& a, int n_zones, hipStream_t st) {
+  const int64_t blocks = cdiv(a.items, a.IPW);
+  ISD_CHECK_ARG(blocks <= 0x7fffffffLL, "conv4: too many items");
+  const int GT = a.F / 16;
+  const size_t lds = sizeof(float) * ((size_t)a.IPW * kCK * a.RS + (size_t)(kCK / 4) * kTaps * GT * 64);
+  ISD_CHECK_ARG(lds <= 64 * 1024, "conv4: LDS tile of %zu bytes exceeds 64 KiB (window too long)", lds);
+  if (mode == 0)
+    hipLaunchKernelGGL((conv5_fwd_kernel<0>), dim3((unsigned)blocks, n_zones), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((conv5_fwd_kernel<1>), dim3((unsigned)blocks, n_zones), dim3(256), lds, st, a);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const float* params, float* feat,
+                                 void* workspace, int64_t B, int64_t T, void* stream) {
+  ISD_CHECK_ARG(p, "isd_conv4_forward: null plan");
+  ISD_CHECK_ARG(B >= 0, "isd_conv4_forward: B=%lld", (long long)B);
+  Geo g;
+  int rc = make_geo(p, B, T, g);
+  if (rc) return rc;
+  if (B == 0) return ISD_OK;
+  ISD_CHECK_ARG(x && params && feat && workspace, "isd_conv4_forward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int F = p->F;
+  hipLaunchKernelGGL(prep_fused_kernel, dim3(8, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_eff,
+                     ws + g.o_beff, F);
+  ISD_LAUNCH_CHECK();
+  if (p->n_layers == 4) {
+    hipLaunchKernelGGL(prep_conv_kernel, dim3(4, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_w3,
+                       ws + g.o_w3t, F, 0, p->conv_zstride);
+    hipLaunchKernelGGL(prep_conv_kernel, dim3(4, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_w4,
+                       ws + g.o_w4t, F, 1, p->conv_zstride);
+    ISD_LAUNCH_CHECK();
+  }
+  ConvArgs a = {};
+  a.zones = p->d_zones; a.chan_idx = p->d_idx; a.items = g.items; a.Z = p->Z; a.F = F;
+  a.TT = g.TT; a.IPW = g.IPW; a.Tout = g.T1;
+  a.Ctot = p->Ctot; a.Tx = (int)T; a.N = g.N; a.S = p->S;
+  // cnn1 o cnn2
+  a.in = x; a.out = ws + g.o_a2; a.wfrag = ws + g.o_eff; a.bias = ws + g.o_beff; a.Tin = p->W; a.pad = 0; a.RS = g.RS_a;
+  rc = launch_conv(0, a, p->Z, st);
+  if (rc) return rc;
+  const float* last = ws + g.o_a2;
+  if (p->n_layers == 4) {
+    a.bias = nullptr; a.Tin = g.T1; a.pad = 2; a.RS = g.RS_b; a.wz_stride = p->conv_zstride;
+    a.in = ws + g.o_a2; a.out = ws + g.o_a3; a.wfrag = ws + g.o_w3;
+    rc = launch_conv(1, a, p->Z, st);
+    if (rc) return rc;
+    a.in = ws + g.o_a3; a.out = ws + g.o_a4; a.wfrag = ws + g.o_w4;
+    rc = launch_conv(1, a, p->Z, st);
+    if (rc) return rc;
+    last = ws + g.o_a4;
+  }
+  const int64_t rows = g.items * p->Z * F;
+  hipLaunchKernelGGL(gelu_mean_fwd_kernel, dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, last, feat, rows,
+                     g.T1);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+static int launch_wgrad(int mode, WgradArgs& a, int n_zones, int cin_max, hipStream_t st) {
+  const int64_t per_item = (int64_t)a.F * a.RSo + (int64_t)a.CW * a.RSi;
+  int ips = (int)((96 * 1024 / 4) / per_item);
+  ISD_CHECK_ARG(ips >= 1, "conv4 wgrad: window too long for the LDS tile");
+  if (ips > 16) ips = 16;
+  if (ips > a.items_per_wg) ips = a.items_per_wg;
+  a.IPS = ips;
+  const size_t lds = sizeof(float) * (size_t)ips * per_item;
+  const int64_t wgs = cdiv(a.items, a.items_per_wg);
+  const int zgroups = (cin_max + a.CW - 1) / a.CW;
+  if (mode == 0) {
+    if (lds > 48 * 1024)
+      ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((conv5_wgrad_kernel<0>), dim3((unsigned)wgs, n_zones, zgroups), dim3(256), lds, st, a);
+  } else {
+    if (lds > 48 * 1024)
+      ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((conv5_wgrad_kernel<1>), dim3((unsigned)wgs, n_zones, zgroups), dim3(256), lds, st, a);
+  }
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+// cnn3 / cnn4 gradient in natural [F][F][5] layout -> flat gradient block
+__global__ void scatter_conv_grad_kernel(const float* __restrict__ wg, const isd::ZoneDesc* __restrict__ zones,
+                                         float* __restrict__ dparams, int F, int layer) {
+  const int z = blockIdx.y;
+  const isd::ZoneDesc zd = zones[z];
+  const int n = F * F * isd::kTaps;
+  float* dst = dparams + zd.p_off + F * isd::kTaps + F + (int64_t)F * F * zd.cin + (int64_t)layer * n;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) dst[e] = wg[(int64_t)z * n + e];
+}
+
+extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const float* params, const float* dfeat,
+                                  float* dparams, void* workspace, int64_t B, int64_t T, void* stream) {
+  ISD_CHECK_ARG(p, "isd_conv4_backward: null plan");
+  ISD_CHECK_ARG(B >= 0, "isd_conv4_backward: B=%lld", (long long)B);
+  Geo g;
+  int rc = make_geo(p, B, T, g);
+  if (rc) return rc;
+  ISD_CHECK_ARG(dparams, "isd_conv4_backward: null dparams");
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    ISD_HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * p->n_params, st));
+    return ISD_OK;
+  }
+  ISD_CHECK_ARG(x && params && dfeat && workspace, "isd_conv4_backward: null argument");
+  float* ws = (float*)workspace;
+  const int F = p->F;
+  const int64_t rows = g.items * p->Z * F;
+  float* top = ws + (p->n_layers == 4 ? g.o_a4 : g.o_a2);        // activation that fed GELU
+  hipLaunchKernelGGL(gelu_mean_bwd_kernel, dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, top, dfeat, rows,
+                     g.T1);
+  ISD_LAUNCH_CHECK();
+  WgradArgs w = {};
+  w.zones = p->d_zones; w.chan_idx = p->d_idx; w.items = g.items;
+  w.Z = p->Z; w.F = F; w.Tout = g.T1; w.part = ws + g.o_part;
+  w.Ctot = p->Ctot; w.Tx = (int)T; w.N = g.N; w.S = p->S;
+  ConvArgs a = {};
+  a.zones = p->d_zones; a.chan_idx = p->d_idx; a.items = g.items; a.Z = p->Z; a.F = F;
+  a.TT = g.TT; a.IPW = g.IPW; a.Tout = g.T1; a.Tin = g.T1; a.pad = 2; a.RS = g.RS_b; a.wz_stride = p->conv_zstride;
+  a.Ctot = p->Ctot; a.Tx = (int)T; a.N = g.N; a.S = p->S;
+  const float* g2 = top;                                          // gradient w.r.t. the cnn2 output
+  if (p->n_layers == 4) {
+    const int RSo = row_stride_wgrad(((g.T1 + 3) & ~3));
+    const int RSi = row_stride_wgrad(((g.T1 + 3) & ~3) + kTaps - 1);
+    // cnn4: dW4 = wgrad(G4, A3); G3 = dgrad(G4)
+    w.dout = ws + g.o_a4; w.in = ws + g.o_a3; w.Tin = g.T1; w.pad = 2; w.RSo = RSo; w.RSi = RSi;
+    w.slab_size = g.slab1; w.wz_stride = (int64_t)F * F * kTaps; w.items_per_wg = g.ipw1; w.CW = g.cw1;
+    rc = launch_wgrad(1, w, p->Z, F, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(64), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg34, g.slab1, g.ns1);
+    hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 1);
+    ISD_LAUNCH_CHECK();
+    a.in = ws + g.o_a4; a.out = ws + g.o_s; a.wfrag = ws + g.o_w4t;
+    rc = launch_conv(1, a, p->Z, st);
+    if (rc) return rc;
+    // cnn3: dW3 = wgrad(G3, A2); G2 = dgrad(G3) (into the A4 buffer, free now)
+    w.dout = ws + g.o_s; w.in = ws + g.o_a2;
+    rc = launch_wgrad(1, w, p->Z, F, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(64), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg34, g.slab1, g.ns1);
+    hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 0);
+    ISD_LAUNCH_CHECK();
+    a.in = ws + g.o_s; a.out = ws + g.o_a4; a.wfrag = ws + g.o_w3t;
+    rc = launch_conv(1, a, p->Z, st);
+    if (rc) return rc;
+    g2 = ws + g.o_a4;
+  }
+  // cnn1 o cnn2: dWeff (+ dbeff in the ones channel), then chain to W1, b1, W2
+  w.dout = g2; w.in = x; w.Tin = p->W; w.pad = 0;
+  w.RSo = row_stride_wgrad((g.T1 + 3) & ~3);
+  w.RSi = row_stride_wgrad(((g.T1 + 3) & ~3) + kTaps - 1 > p->W ? ((g.T1 + 3) & ~3) + kTaps - 1 : p->W);
+  w.slab_size = g.slab0; w.wz_stride = 0; w.items_per_wg = g.ipw0; w.CW = g.cw0;
+  rc = launch_wgrad(0, w, p->Z, p->max_cz + 1, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(64), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg, g.slab0, g.ns0);
+  hipLaunchKernelGGL(fused_bwd_kernel, dim3(p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_wg, dparams, F);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}

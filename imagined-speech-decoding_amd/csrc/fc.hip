@@ -1,0 +1,275 @@
+// Dense head and loss (reference: FAST.input_layer / last_layer / 'train_head' branch,
+// src/fast/models/fast.py:235,239,273-278; nn.CrossEntropyLoss at src/fast/train/trainer.py:37,59;
+// argmax predict at trainer.py:89).
+//
+// The linear layers run on v_mfma_f32_16x16x4_f32: M = output features (A = weight rows),
+// N = 16 samples per wave (B = activation rows), K = input features in steps of 4, so the
+// accumulator of a lane is 4 consecutive output features of one sample -> float4 stores.
+#include "common.h"
+#include <math.h>
+
+namespace isd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kKC = 64;      // K chunk staged in LDS
+constexpr int kRS = kKC + 2; // row stride: lanes (l&15) walk rows, == 2 (mod 32) is conflict free
+
+__device__ __forceinline__ float gelu1(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu1_grad(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+// y[m][o] = act( sum_i x[m][i] * W(o,i) + bias[o] ),  W(o,i) = w[o*so + i*si]
+// grid: (ceil(M/64), ceil(Nout/64)); block 256 = 4 waves x 16 samples; up to 4 output tiles per wave.
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         float* __restrict__ pre, int64_t M, int K, int Nout,
+                                                         int64_t so, int64_t si, int act) {
+  __shared__ float xs[64 * kRS];
+  __shared__ float wsm[64 * kRS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int o0 = blockIdx.y * 64;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += kKC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * kKC; e += 256) {
+      const int r = e / kKC, c = e - r * kKC;
+      const int64_t m = m0 + r;
+      const int k = k0 + c;
+      xs[r * kRS + c] = (m < M && k < K) ? x[m * K + k] : 0.f;
+      const int o = o0 + r;
+      wsm[r * kRS + c] = (o < Nout && k < K) ? w[o * so + k * si] : 0.f;
+    }
+    __syncthreads();
+    const float* xr = xs + (wave * 16 + (lane & 15)) * kRS + (lane >> 4);
+    const float* wr = wsm + (lane & 15) * kRS + (lane >> 4);
+#pragma unroll 4
+    for (int kk = 0; kk < kKC; kk += 4) {
+      const float bf = xr[kk];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (o0 + t * 16 < Nout) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t * 16 * kRS + kk], bf, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  const int64_t m = m0 + wave * 16 + (lane & 15);
+  if (m >= M) return;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = o0 + t * 16 + 4 * (lane >> 4) + r;
+      if (o < Nout) {
+        float v = acc[t][r] + (bias ? bias[o] : 0.f);
+        if (pre) pre[m * Nout + o] = v;
+        y[m * Nout + o] = act ? gelu1(v) : v;
+      }
+    }
+  }
+}
+
+// dpre = dy * gelu'(pre)   (act) or a plain copy
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dpre,
+                               int64_t n, int act) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    dpre[e] = act ? dy[e] * gelu1_grad(pre[e]) : dy[e];
+}
+
+// dW[o][i] = sum_m dpre[m][o] * x[m][i];  column i == K is the bias gradient (x == 1).
+// M = o (A = dpre^T), N = i (16 per wave), K = samples.  grid: (slabs, ceil((K+1)/64)); partial slabs.
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ x,
+                                                           float* __restrict__ part, int64_t M, int K, int Nout,
+                                                           int m_per_wg) {
+  __shared__ float ds[64 * 80];   // [64 samples][Nout<=64], stride 80 == 16 (mod 32)
+  __shared__ float xs[64 * 80];   // [64 samples][64 inputs]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 64;
+  const int64_t m_lo = (int64_t)blockIdx.x * m_per_wg;
+  const int64_t m_hi = (m_lo + m_per_wg) < M ? (m_lo + m_per_wg) : M;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int64_t ms = m_lo; ms < m_hi; ms += 64) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      const int64_t m = ms + r;
+      const bool ok = m < m_hi;
+      ds[r * 80 + c] = (ok && c < Nout) ? dpre[m * Nout + c] : 0.f;
+      const int i = i0 + c;
+      xs[r * 80 + c] = !ok ? 0.f : (i < K ? x[m * K + i] : (i == K ? 1.f : 0.f));
+    }
+    __syncthreads();
+    const float* ar = ds + (lane >> 4) * 80 + (lane & 15);
+    const float* br = xs + (lane >> 4) * 80 + wave * 16 + (lane & 15);
+#pragma unroll 4
+    for (int mm = 0; mm < 64; mm += 4) {
+      const float bf = br[mm * 80];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t * 16 < Nout) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[mm * 80 + t * 16], bf, acc[t], 0, 0, 0);
+    }
+  }
+  const int i = i0 + wave * 16 + (lane & 15);
+  if (i > K) return;
+  float* slab = part + (int64_t)blockIdx.x * Nout * (K + 1);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = t * 16 + 4 * (lane >> 4) + r;
+      if (o < Nout) slab[(int64_t)o * (K + 1) + i] = acc[t][r];
+    }
+}
+
+__global__ void linear_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                           float* __restrict__ db, int K, int Nout, int n_slabs) {
+  const int n = Nout * (K + 1);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < n_slabs; ++k) s += part[(int64_t)k * n + e];
+    const int o = e / (K + 1), i = e - o * (K + 1);
+    if (i < K) dw[o * K + i] = s;
+    else if (db) db[o] = s;
+  }
+}
+
+// Mean over tokens, softmax cross-entropy (mean over the global batch), gradient and argmax.
+// One workgroup: the tensors are tiny ([B][n_tok][n_cls], n_cls <= 32) and the loss sum stays deterministic.
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ lt, const void* __restrict__ labels,
+                                                         int label_bytes, float* __restrict__ lmean,
+                                                         float* __restrict__ loss, float* __restrict__ dlt,
+                                                         int64_t* __restrict__ pred, int64_t B, int n_tok, int n_cls,
+                                                         float grad_scale) {
+  __shared__ float red[256];
+  float lsum = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += 256) {
+    float v[32];
+    float mx = -INFINITY;
+    int am = 0;
+    for (int c = 0; c < n_cls; ++c) {
+      float s = 0.f;
+      for (int n = 0; n < n_tok; ++n) s += lt[(b * n_tok + n) * n_cls + c];
+      s /= (float)n_tok;
+      v[c] = s;
+      if (lmean) lmean[b * n_cls + c] = s;
+      if (s > mx) { mx = s; am = c; }          // strict '>' keeps the lowest index on ties (torch.argmax)
+    }
+    if (pred) pred[b] = am;
+    if (labels) {
+      float se = 0.f;
+      for (int c = 0; c < n_cls; ++c) se += expf(v[c] - mx);
+      const float lse = mx + logf(se);
+      const int64_t yb = label_bytes == 1 ? (int64_t)((const unsigned char*)labels)[b] : ((const int64_t*)labels)[b];
+      lsum += lse - v[yb];
+      if (dlt) {
+        for (int c = 0; c < n_cls; ++c) {
+          const float g = (expf(v[c] - lse) - (c == yb ? 1.f : 0.f)) * grad_scale / (float)n_tok;
+          for (int n = 0; n < n_tok; ++n) dlt[(b * n_tok + n) * n_cls + c] = g;
+        }
+      }
+    }
+  }
+  if (loss) {
+    red[threadIdx.x] = lsum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0] * grad_scale;
+  }
+}
+
+}  // namespace isd
+
+using namespace isd;
+
+static int launch_linear(const float* x, const float* w, const float* bias, float* y, float* pre, int64_t M, int K,
+                         int Nout, int64_t so, int64_t si, int act, hipStream_t st) {
+  const int64_t gx = cdiv(M, 64);
+  ISD_CHECK_ARG(gx <= 0x7fffffffLL, "linear: M too large");
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)gx, (unsigned)cdiv(Nout, 64)), dim3(256), 0, st, x, w, bias, y,
+                     pre, M, K, Nout, so, si, act);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+extern "C" int isd_linear_forward(const float* x, const float* w, const float* bias, float* y, float* pre, int64_t M,
+                                  int K, int N, int act, void* stream) {
+  ISD_CHECK_ARG(M >= 0 && K >= 1 && N >= 1 && K <= (1 << 20) && N <= (1 << 20), "isd_linear_forward: bad shape M=%lld K=%d N=%d",
+                (long long)M, K, N);
+  ISD_CHECK_ARG(act == 0 || act == 1, "isd_linear_forward: act must be 0 (none) or 1 (gelu)");
+  if (M == 0) return ISD_OK;
+  ISD_CHECK_ARG(x && w && y, "isd_linear_forward: null argument");
+  return launch_linear(x, w, bias, y, pre, M, K, N, K, 1, act, (hipStream_t)stream);
+}
+
+static int wgrad_slabs(int64_t M, int* m_per_wg) {
+  int64_t want = 256;
+  int64_t per = cdiv(cdiv(M, want), 64) * 64;
+  if (per < 64) per = 64;
+  *m_per_wg = (int)per;
+  return (int)cdiv(M, per);
+}
+
+extern "C" int64_t isd_linear_workspace_bytes(int64_t M, int K, int N) {
+  if (M < 0 || K < 1 || N < 1) return ISD_ERR_INVALID;
+  int mp;
+  const int slabs = wgrad_slabs(M > 0 ? M : 1, &mp);
+  return 4 * (M * N + (int64_t)slabs * N * (K + 1)) + 256;
+}
+
+extern "C" int isd_linear_backward(const float* x, const float* w, const float* dy, const float* pre, float* dx,
+                                   float* dw, float* db, void* workspace, int64_t M, int K, int N, int act,
+                                   void* stream) {
+  ISD_CHECK_ARG(M >= 0 && K >= 1 && N >= 1, "isd_linear_backward: bad shape");
+  ISD_CHECK_ARG(N <= 64, "isd_linear_backward: N=%d > 64 output features is not supported", N);
+  ISD_CHECK_ARG(act == 0 || (act == 1 && pre), "isd_linear_backward: gelu needs the saved pre-activation");
+  ISD_CHECK_ARG(dw, "isd_linear_backward: null dw");
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    ISD_HIP_TRY(hipMemsetAsync(dw, 0, sizeof(float) * N * K, st));
+    if (db) ISD_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * N, st));
+    return ISD_OK;
+  }
+  ISD_CHECK_ARG(x && w && dy && workspace, "isd_linear_backward: null argument");
+  float* dpre = (float*)workspace;
+  float* part = dpre + ((M * N + 63) / 64) * 64;
+  const float* dsrc = dy;
+  if (act) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(cdiv(M * N, 256) < 4096 ? cdiv(M * N, 256) : 4096)), dim3(256), 0,
+                       st, dy, pre, dpre, M * N, act);
+    ISD_LAUNCH_CHECK();
+    dsrc = dpre;
+  }
+  if (dx) {   // dx[m][i] = sum_o dpre[m][o] W[o][i]  ==  linear with W'(out=i, in=o) = w[o*K + i]
+    int rc = launch_linear(dsrc, w, nullptr, dx, nullptr, M, N, K, 1, K, 0, st);
+    if (rc) return rc;
+  }
+  int mp;
+  const int slabs = wgrad_slabs(M, &mp);
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(slabs, (unsigned)cdiv(K + 1, 64)), dim3(256), 0, st, dsrc, x, part, M, K,
+                     N, mp);
+  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)cdiv((int64_t)N * (K + 1), 256)), dim3(256), 0, st, part,
+                     dw, db, K, N, slabs);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+extern "C" int isd_softmax_ce(const float* logits_tok, const void* labels, int label_bytes, float* logits_mean,
+                              float* loss, float* dlogits_tok, int64_t* pred, int64_t B, int n_tok, int n_cls,
+                              float grad_scale, void* stream) {
+  ISD_CHECK_ARG(B >= 0 && n_tok >= 1 && n_cls >= 1 && n_cls <= 32, "isd_softmax_ce: bad shape B=%lld n_tok=%d n_cls=%d",
+                (long long)B, n_tok, n_cls);
+  ISD_CHECK_ARG(!labels || label_bytes == 1 || label_bytes == 8, "isd_softmax_ce: labels must be uint8 or int64");
+  ISD_CHECK_ARG(B == 0 || logits_tok, "isd_softmax_ce: null logits");
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits_tok, labels, label_bytes,
+                     logits_mean, labels ? loss : nullptr, labels ? dlogits_tok : nullptr, pred, B, n_tok, n_cls,
+                     grad_scale);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}

@@ -1,0 +1,418 @@
+"""torch.nn-compatible front end of the HIP CNN / FC-head / loss kernels.
+
+Mirrors the reference's module surface for the hot path
+(src/fast/models/fast.py): ``Conv4Layers(channels, dim)`` with the head
+contract ``Head_cls(n_zone_channels, feature_dim)`` -> ``encoder(x[B',Cz,T]) ->
+[B', feature_dim]`` (fast.py:203-210), ``Head(head, electrodes, zone_dict,
+feature_dim)``, and ``FAST(config)`` in ``forward_mode='train_head'``
+(fast.py:273-278).  Parameter names and shapes equal the reference's
+state_dict, so its checkpoints load.  All arithmetic runs in libisd_hip.so; the
+autograd bridge passes ``tensor.data_ptr()`` through ctypes.  PyTorch holds the
+parameters (one flat block, aliased by the named nn.Parameters) and runs the
+optimizer.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .constants import ELECTRODES, ZONES
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise TypeError(f"{name} must be a float32 CUDA tensor (the product has no CPU path)")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------- plans
+class ConvStackPlan:
+    """isd_conv4_plan wrapper: static geometry of a zone-wise Conv4Layers stack."""
+
+    def __init__(self, c_total, zone_idx, feature_dim, n_layers, window_len, slide_step):
+        self.c_total, self.zone_idx = int(c_total), [list(map(int, z)) for z in zone_idx]
+        self.F, self.n_layers = int(feature_dim), int(n_layers)
+        self.window_len, self.slide_step = int(window_len), int(slide_step)
+        self._h = C.c_void_p()
+        sizes = [len(z) for z in self.zone_idx]
+        flat = [c for z in self.zone_idx for c in z]
+        _lib.check(_lib.lib().isd_conv4_plan_create(C.byref(self._h), self.c_total, len(sizes), _lib.int_array(sizes),
+                                                    _lib.int_array(flat), self.F, self.n_layers, self.window_len,
+                                                    self.slide_step))
+        self.n_params = int(_lib.lib().isd_conv4_param_count(self._h))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().isd_conv4_plan_destroy(h)
+            except Exception:
+                pass
+
+    @property
+    def n_zones(self):
+        return len(self.zone_idx)
+
+    def offset(self, zone, which):
+        return int(_lib.lib().isd_conv4_param_offset(self._h, zone, which))
+
+    def windows(self, T):
+        n = _lib.lib().isd_conv4_windows(self._h, int(T))
+        if n < 1:
+            raise ValueError(f"T={T} is shorter than window_len={self.window_len}")
+        return n
+
+    def workspace(self, B, T, device):
+        nbytes = int(_lib.lib().isd_conv4_workspace_bytes(self._h, int(B), int(T)))
+        if nbytes < 0:
+            raise ValueError("bad conv stack geometry")
+        return torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=device)
+
+
+# ----------------------------------------------------------------------------- autograd bridge
+class _ConvStackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flat, plan):
+        x, flat = _f32c(x, "x"), _f32c(flat, "params")
+        B, Ct, T = x.shape
+        if Ct != plan.c_total:
+            raise ValueError(f"expected {plan.c_total} channels, got {Ct}")
+        N = plan.windows(T)
+        feat = torch.empty((B * N, plan.n_zones, plan.F), dtype=torch.float32, device=x.device)
+        ws = plan.workspace(B, T, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_conv4_forward(plan._h, x.data_ptr(), flat.data_ptr(), feat.data_ptr(),
+                                                    ws.data_ptr(), B, T, _stream()))
+        ctx.plan, ctx.ws = plan, ws
+        ctx.save_for_backward(x, flat)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        x, flat = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient w.r.t. the EEG input is not provided by the HIP conv stack yet")
+        B, _, T = x.shape
+        dflat = torch.empty_like(flat)
+        dfeat = _f32c(dfeat, "dfeat")
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_conv4_backward(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dfeat.data_ptr(),
+                                                     dflat.data_ptr(), ctx.ws.data_ptr(), B, T, _stream()))
+        ctx.ws = None
+        return None, dflat, None
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x, w = _f32c(x, "x"), _f32c(w, "weight")
+        b = None if b is None else _f32c(b, "bias")
+        K = x.shape[-1]
+        N = w.shape[0]
+        M = x.numel() // K
+        y = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+        pre = torch.empty_like(y) if act else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_linear_forward(x.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(),
+                                                     y.data_ptr(), 0 if pre is None else pre.data_ptr(), M, K, N,
+                                                     int(act), _stream()))
+        ctx.act, ctx.has_bias = int(act), b is not None
+        ctx.save_for_backward(x, w, pre)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, pre = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        K, N = x.shape[-1], w.shape[0]
+        M = x.numel() // K
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        ws = torch.empty(max(int(_lib.lib().isd_linear_workspace_bytes(M, K, N)) // 4, 1), dtype=torch.float32,
+                         device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_linear_backward(x.data_ptr(), w.data_ptr(), dy.data_ptr(),
+                                                      0 if pre is None else pre.data_ptr(),
+                                                      0 if dx is None else dx.data_ptr(), dw.data_ptr(),
+                                                      0 if db is None else db.data_ptr(), ws.data_ptr(), M, K, N,
+                                                      ctx.act, _stream()))
+        return dx, dw, db, None
+
+
+class _SoftmaxCEFn(torch.autograd.Function):
+    """loss = CrossEntropyLoss()(logits_tok.mean(1), y) * (B / global_batch)."""
+
+    @staticmethod
+    def forward(ctx, logits_tok, labels, grad_scale):
+        lt = _f32c(logits_tok, "logits")
+        B, n_tok, n_cls = lt.shape
+        labels = labels.contiguous()
+        if labels.dtype not in (torch.uint8, torch.int64):
+            labels = labels.long()
+        loss = torch.empty((), dtype=torch.float32, device=lt.device)
+        dlt = torch.empty_like(lt)
+        with torch.cuda.device(lt.device):
+            _lib.check(_lib.lib().isd_softmax_ce(lt.data_ptr(), labels.data_ptr(), labels.element_size(), 0,
+                                                 loss.data_ptr(), dlt.data_ptr(), 0, B, n_tok, n_cls,
+                                                 float(grad_scale), _stream()))
+        ctx.save_for_backward(dlt)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlt,) = ctx.saved_tensors
+        return dlt * g, None, None
+
+
+def linear(x, weight, bias=None, act=False):
+    return _LinearFn.apply(x, weight, bias, act)
+
+
+def token_mean_cross_entropy(logits_tok, labels, global_batch=None):
+    """CE of the token-mean logits (fast.py:277 + trainer.py:59).  logits_tok [B, n_tok, n_cls]."""
+    if logits_tok.dim() == 2:
+        logits_tok = logits_tok.unsqueeze(1)
+    B = logits_tok.shape[0]
+    return _SoftmaxCEFn.apply(logits_tok, labels, 1.0 / float(global_batch or B))
+
+
+def token_mean_predict(logits_tok):
+    """-> (mean logits [B, n_cls], argmax int64 [B]); ties -> lowest index (trainer.py:89)."""
+    if logits_tok.dim() == 2:
+        logits_tok = logits_tok.unsqueeze(1)
+    lt = _f32c(logits_tok.detach(), "logits")
+    B, n_tok, n_cls = lt.shape
+    lm = torch.empty((B, n_cls), dtype=torch.float32, device=lt.device)
+    pred = torch.empty((B,), dtype=torch.int64, device=lt.device)
+    with torch.cuda.device(lt.device):
+        _lib.check(_lib.lib().isd_softmax_ce(lt.data_ptr(), 0, 0, lm.data_ptr(), 0, 0, pred.data_ptr(), B, n_tok,
+                                             n_cls, 1.0, _stream()))
+    return lm, pred
+
+
+# ----------------------------------------------------------------------------- modules
+def _conv_init_(t, fan_in, gen=None):
+    """nn.Conv2d / nn.Linear default: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))."""
+    bound = 1.0 / math.sqrt(fan_in)
+    with torch.no_grad():
+        t.uniform_(-bound, bound, generator=gen)
+
+
+class _Conv4Params(nn.Module):
+    """Parameter holder with the reference's Conv4Layers names/shapes (fast.py:106-109)."""
+
+    def __init__(self, channels, dim, n_layers=4):
+        super().__init__()
+        self.channels, self.dim, self.n_layers = channels, dim, n_layers
+        self.cnn1 = nn.Conv2d(1, dim, (1, 5), bias=True)
+        self.cnn2 = nn.Conv2d(dim, dim, (channels, 1), padding=0, bias=False)
+        if n_layers == 4:
+            self.cnn3 = nn.Conv2d(dim, dim, (1, 5), padding=(0, 2), bias=False)
+            self.cnn4 = nn.Conv2d(dim, dim, (1, 5), padding=(0, 2), bias=False)
+
+    def ordered(self):
+        ps = [self.cnn1.weight, self.cnn1.bias, self.cnn2.weight]
+        if self.n_layers == 4:
+            ps += [self.cnn3.weight, self.cnn4.weight]
+        return ps
+
+
+class _FlatParamMixin:
+    """Keeps a list of nn.Parameters packed, in order, in one contiguous flat buffer.
+
+    The C ABI takes one parameter block; data-parallel training all-reduces one
+    gradient block.  Parameters stay ordinary named leaves (state_dict works);
+    their storage is re-packed lazily if someone moved them (``.cuda()``, ``load_state_dict``
+    keeps aliasing because it copies in place).
+    """
+
+    def _ordered_params(self):
+        raise NotImplementedError
+
+    def flat_params(self):
+        ps = self._ordered_params()
+        flat = getattr(self, "_flat", None)
+        ok = flat is not None and flat.device == ps[0].device
+        if ok:
+            ptr = flat.data_ptr()
+            for p in ps:
+                if p.data_ptr() != ptr or not p.is_contiguous():
+                    ok = False
+                    break
+                ptr += p.numel() * 4
+        if not ok:
+            flat = torch.cat([p.detach().reshape(-1).float() for p in ps]).contiguous()
+            off = 0
+            for p in ps:
+                p.data = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            self._flat = flat
+            self._flat_grad = None
+        return self._flat
+
+    def flat_grads(self):
+        """One flat gradient buffer aliased by every ``p.grad`` (allocated on first use)."""
+        flat = self.flat_params()
+        g = getattr(self, "_flat_grad", None)
+        if g is None or g.device != flat.device:
+            g = torch.zeros_like(flat)
+            off = 0
+            for p in self._ordered_params():
+                p.grad = g[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            self._flat_grad = g
+        return g
+
+
+class Conv4Layers(_Conv4Params, _FlatParamMixin):
+    """Drop-in for the reference's ``Conv4Layers(channels, dim=32)`` (fast.py:103-119).
+
+    ``forward(x[B', channels, T]) -> [B', dim]``; honours the head contract
+    ``Head_cls(n_zone_channels, feature_dim)`` of fast.py:203-210.
+    """
+
+    def __init__(self, channels, dim=32, n_layers=4):
+        super().__init__(channels, dim, n_layers)
+        self._plans = {}
+
+    def _ordered_params(self):
+        return self.ordered()
+
+    def _plan(self, T):
+        pl = self._plans.get(T)
+        if pl is None:
+            pl = ConvStackPlan(self.channels, [list(range(self.channels))], self.dim, self.n_layers, T, 1)
+            self._plans[T] = pl
+        return pl
+
+    def forward(self, x):
+        if x.dim() != 3:
+            raise ValueError("expected [batch, channels, time]")
+        flat = self.flat_params()
+        theta = torch.cat([p.reshape(-1) for p in self.ordered()]) if torch.is_grad_enabled() else flat
+        return _ConvStackFn.apply(x, theta, self._plan(x.shape[-1])).squeeze(1)
+
+
+class Head(nn.Module, _FlatParamMixin):
+    """Drop-in for the reference's ``Head(head, electrodes, zone_dict, feature_dim)`` (fast.py:199-210).
+
+    All zones run in one launch per layer; ``forward(x[B', C, T]) -> [B', Z, F]``.
+    ``forward_windows(x[B, C, T], window_len, slide_step)`` additionally folds the
+    sliding windows of ``FAST.forward_head`` into the kernels' index arithmetic.
+    """
+
+    def __init__(self, head, electrodes, zone_dict, feature_dim):
+        super().__init__()
+        if head != "Conv4Layers":
+            raise NotImplementedError(f"head '{head}' is not provided by the HIP path yet (Conv4Layers is)")
+        self.electrodes = list(electrodes)
+        self.index_dict = {}
+        self.encoders = nn.ModuleDict()
+        for area, ch_names in zone_dict.items():
+            self.index_dict[area] = torch.tensor([self.electrodes.index(ch) for ch in ch_names])
+            self.encoders[area] = _Conv4Params(len(ch_names), feature_dim)
+        self.feature_dim = feature_dim
+        self._plans = {}
+
+    def _ordered_params(self):
+        return [p for enc in self.encoders.values() for p in enc.ordered()]
+
+    def _plan(self, window_len, slide_step):
+        key = (window_len, slide_step)
+        pl = self._plans.get(key)
+        if pl is None:
+            pl = ConvStackPlan(len(self.electrodes), [v.tolist() for v in self.index_dict.values()], self.feature_dim,
+                               4, window_len, slide_step)
+            self._plans[key] = pl
+        return pl
+
+    def _theta(self):
+        flat = self.flat_params()
+        if torch.is_grad_enabled():
+            return torch.cat([p.reshape(-1) for p in self._ordered_params()])
+        return flat
+
+    def forward_windows(self, x, window_len, slide_step):
+        """x [B, C, T] -> [B*N, Z, F] with N sliding windows per trial (fast.py:247-251)."""
+        return _ConvStackFn.apply(x, self._theta(), self._plan(int(window_len), int(slide_step)))
+
+    def forward(self, x):
+        return _ConvStackFn.apply(x, self._theta(), self._plan(int(x.shape[-1]), 1))
+
+
+class FAST(nn.Module):
+    """The reference's ``FAST(config)`` restricted to the CNN + FC-head path (``forward_mode='train_head'``).
+
+    Parameter names equal the reference's (``head.encoders.<Zone>.cnn1.weight``, ``input_layer.0.weight``,
+    ``last_layer.weight`` ...), so ``load_state_dict(reference_state_dict, strict=False)`` works.
+    The transformer tail (``forward_mode='default'``) is listed as "next" in SURVEY.md 8(f).
+    """
+    name = "FAST"
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.n_tokens = (config.seq_len - config.window_len) // config.slide_step + 1
+        self.head = Head(config.head, config.electrodes, config.zone_dict, config.dim_cnn)
+        self.input_layer = nn.Sequential(nn.Linear(config.dim_cnn * len(config.zone_dict), config.dim_token), nn.GELU())
+        self.last_layer = nn.Linear(config.dim_token, config.n_classes)
+
+    def forward_head(self, x, step_override=None):
+        step = self.config.slide_step if step_override is None else step_override
+        B = x.shape[0]
+        feat = self.head.forward_windows(x, self.config.window_len, step)
+        return feat.view(B, -1, feat.shape[1], feat.shape[2])          # [B, N, Z, F]
+
+    def batched_forward_head(self, x, step, batch_size):
+        return torch.cat([self.forward_head(mb, step) for mb in torch.split(x, batch_size, dim=0)], dim=0)
+
+    def token_logits(self, x):
+        feat = self.forward_head(x)
+        B, N, Z, Fd = feat.shape
+        tok = linear(feat.reshape(B, N, Z * Fd), self.input_layer[0].weight, self.input_layer[0].bias, act=True)
+        return linear(tok, self.last_layer.weight, self.last_layer.bias)   # [B, N, n_classes]
+
+    def forward(self, x, forward_mode="train_head"):
+        if forward_mode == "train_head":
+            lt = self.token_logits(x)
+            if torch.is_grad_enabled():
+                return lt.mean(dim=1)
+            return token_mean_predict(lt)[0]
+        if forward_mode in ("default", "train_transformer"):
+            raise NotImplementedError("the transformer tail is not part of the HIP hot path yet (SURVEY.md 8f)")
+        raise NotImplementedError
+
+
+class FeatureCNN(nn.Module):
+    """Build-defined classifier over spec-S features: ``Conv4Layers(nb*C, F)`` through the
+    unmodified head contract, then ``Linear(F, n_classes)``.  ``n_layers=2`` is BASELINE config 1's 2-layer CNN."""
+
+    def __init__(self, in_channels, feature_dim=32, n_classes=5, n_layers=4):
+        super().__init__()
+        self.cnn = Conv4Layers(in_channels, feature_dim, n_layers)
+        self.fc = nn.Linear(feature_dim, n_classes)
+
+    def token_logits(self, feats):
+        B = feats.shape[0]
+        h = self.cnn(feats.reshape(B, -1, feats.shape[-1]))
+        return linear(h, self.fc.weight, self.fc.bias).unsqueeze(1)      # [B, 1, n_classes]
+
+    def forward(self, feats):
+        return self.token_logits(feats).squeeze(1)
+
+
+def fast_config(electrodes=None, zone_dict=None, **kw):
+    """Attribute bag with the reference's production values (scripts/train_fast.py:293-307)."""
+    import types
+    d = dict(electrodes=ELECTRODES if electrodes is None else electrodes, zone_dict=ZONES if zone_dict is None else zone_dict,
+             dim_cnn=32, dim_token=32, seq_len=800, window_len=250, slide_step=125, head="Conv4Layers", n_classes=5,
+             num_layers=4, num_heads=8, dropout=0.1)
+    d.update(kw)
+    return types.SimpleNamespace(**d)

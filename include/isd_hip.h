@@ -108,6 +108,70 @@ int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st, const flo
                        float* feat, int64_t B, int64_t C, const int* klo, const int* khi,
                        int mode, float eps, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Zone-wise Conv4Layers stack over sliding windows: the reference's
+ *   FAST.forward_head   src/fast/models/fast.py:242-252  (unfold window_len / slide_step)
+ *   Head.forward        src/fast/models/fast.py:209-210  (zone gather, one encoder per zone, stack)
+ *   Conv4Layers.forward src/fast/models/fast.py:111-119  (cnn1..cnn4, exact GELU, mean over time)
+ * x [B][c_total][T] f32 -> feat [B*N][n_zones][F] f32 (== the reference's [B, N, Z, F]),
+ * N = (T - window_len) / slide_step + 1.  The spec-S feature classifier uses the same
+ * entry points with one zone of nb*C "channels" and window_len == T == J.
+ *
+ * Parameters live in ONE flat f32 block (so that data-parallel training
+ * all-reduces a single bucket): per zone, in the reference's state_dict order,
+ *   cnn1.weight [F,1,1,5] | cnn1.bias [F] | cnn2.weight [F,F,Cz,1] | cnn3.weight [F,F,1,5] | cnn4.weight [F,F,1,5]
+ * (n_layers == 2 drops cnn3/cnn4: the build-defined "2-layer CNN" of BASELINE config 1).
+ * ---------------------------------------------------------------------- */
+typedef struct isd_conv4_plan isd_conv4_plan;
+
+/* zone_sizes: host [n_zones]; zone_channels: host, concatenated channel indices (Head.index_dict, fast.py:206) */
+int isd_conv4_plan_create(isd_conv4_plan** out, int c_total, int n_zones, const int* zone_sizes,
+                          const int* zone_channels, int feature_dim, int n_layers, int window_len,
+                          int slide_step);
+int isd_conv4_plan_destroy(isd_conv4_plan* plan);
+int64_t isd_conv4_param_count(const isd_conv4_plan* plan);
+/* which: 0 cnn1.weight, 1 cnn1.bias, 2 cnn2.weight, 3 cnn3.weight, 4 cnn4.weight -> offset in floats */
+int64_t isd_conv4_param_offset(const isd_conv4_plan* plan, int zone, int which);
+int isd_conv4_windows(const isd_conv4_plan* plan, int64_t T);
+int64_t isd_conv4_workspace_bytes(const isd_conv4_plan* plan, int64_t B, int64_t T);
+
+/* forward keeps the activations the backward needs inside `workspace` (caller-owned,
+ * isd_conv4_workspace_bytes bytes); backward must see the same x, params and workspace.
+ * dparams: flat gradient block, same layout as params, overwritten. */
+int isd_conv4_forward(const isd_conv4_plan* plan, const float* x, const float* params, float* feat,
+                      void* workspace, int64_t B, int64_t T, void* stream);
+int isd_conv4_backward(const isd_conv4_plan* plan, const float* x, const float* params,
+                       const float* dfeat, float* dparams, void* workspace, int64_t B, int64_t T,
+                       void* stream);
+
+/* ------------------------------------------------------------------------
+ * Dense head on the matrix cores (fp32-in MFMA).  nn.Linear semantics:
+ *   y[M][N] = act(x[M][K] . w[N][K]^T + bias[N]),  act: 0 none, 1 exact-erf GELU.
+ * Replaces FAST.input_layer (Linear 256->32 + GELU, fast.py:235) and
+ * FAST.last_layer (Linear 32->5, fast.py:239) as used at fast.py:276-277.
+ * `pre` (nullable) receives the pre-activation, which backward needs when act == 1.
+ * ---------------------------------------------------------------------- */
+int isd_linear_forward(const float* x, const float* w, const float* bias, float* y, float* pre,
+                       int64_t M, int K, int N, int act, void* stream);
+int64_t isd_linear_workspace_bytes(int64_t M, int K, int N);
+/* dx nullable; db nullable; N <= 64 */
+int isd_linear_backward(const float* x, const float* w, const float* dy, const float* pre, float* dx,
+                        float* dw, float* db, void* workspace, int64_t M, int K, int N, int act,
+                        void* stream);
+
+/* ------------------------------------------------------------------------
+ * Token mean + softmax cross-entropy + argmax:
+ *   logits = logits_tok.mean(dim=1)                         fast.py:277
+ *   loss   = nn.CrossEntropyLoss()(logits, y)               trainer.py:37,59  (mean; uint8 or int64 labels)
+ *   pred   = argmax(logits, dim=1), ties -> lowest index    trainer.py:89
+ * logits_tok [B][n_tok][n_cls]; grad_scale = 1 / global batch size (1/B on one GPU);
+ * loss receives grad_scale * sum_b CE_b; dlogits_tok gets d loss / d logits_tok.
+ * labels == NULL: inference (no loss / gradient).  Any output pointer may be NULL.
+ * ---------------------------------------------------------------------- */
+int isd_softmax_ce(const float* logits_tok, const void* labels, int label_bytes, float* logits_mean,
+                   float* loss, float* dlogits_tok, int64_t* pred, int64_t B, int n_tok, int n_cls,
+                   float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,201 @@
+"""GPU parity: HIP Conv4Layers stack / FC head / softmax-CE (through the C ABI) vs the oracle and
+the golden vectors captured from the reference model."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import cnn as ocnn
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4      # north star: logits/features within 1e-4 rel fp32
+
+
+@pytest.fixture(scope="module")
+def inn():
+    import isd_amd.nn as m
+    assert torch.cuda.is_available()
+    return m
+
+
+def _sd(g, prefix):
+    return {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+
+
+# ------------------------------------------------------------------ Conv4Layers (G4, from the reference)
+@pytest.mark.parametrize("cz", [6, 15])
+def test_conv4layers_matches_reference_golden(inn, cz):
+    g = load_golden("g4_conv4layers.npz")
+    m = inn.Conv4Layers(cz, 32).cuda()
+    m.load_state_dict(_sd(g, f"c{cz}.sd."))
+    x = torch.from_numpy(g[f"c{cz}.x"]).cuda()
+    y = m(x)
+    assert y.shape == (3, 32)
+    assert rel_err(y.detach().cpu(), g[f"c{cz}.y"]) < TOL
+    y.square().sum().backward()
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad.cpu(), g[f"c{cz}.grad.{k}"]) < TOL, k
+
+
+@pytest.mark.parametrize("channels,T,dim,n_layers,B", [(4, 250, 16, 4, 5), (40, 64, 32, 4, 3), (70, 21, 32, 2, 9),
+                                                      (576, 17, 32, 4, 20), (3, 300, 32, 4, 2), (1, 9, 16, 2, 1)])
+def test_conv4layers_vs_oracle_shapes(inn, channels, T, dim, n_layers, B):
+    p = ocnn.init_conv4_params(channels, dim, seed=channels + T, n_layers=n_layers)
+    m = inn.Conv4Layers(channels, dim, n_layers).cuda()
+    m.load_state_dict(p)
+    x = torch.randn(B, channels, T, generator=torch.Generator().manual_seed(1))
+    w = torch.randn(B, dim, generator=torch.Generator().manual_seed(2))
+    y = m(x.cuda())
+    (y * w.cuda()).sum().backward()
+    pr = {k: v.clone().double().requires_grad_() for k, v in p.items()}
+    yr = ocnn.conv4layers(x.double(), pr, n_layers=n_layers)
+    (yr * w.double()).sum().backward()
+    assert rel_err(y.detach().cpu(), yr.detach()) < TOL
+    for k, q in m.named_parameters():
+        assert rel_err(q.grad.cpu(), pr[k].grad) < TOL, k
+
+
+# ------------------------------------------------------------------ FAST train_head (G5 / G6, from the reference)
+def _small_cfg(inn):
+    electrodes = ["Fp1", "Fp2", "F3", "F4", "C3", "C4", "O1", "O2"]
+    zones = {"Frontal": ["Fp1", "Fp2", "F3", "F4"], "Central": ["C3", "C4"], "Occipital": ["O1", "O2"]}
+    return inn.fast_config(electrodes, zones, dim_cnn=16, dim_token=16, seq_len=500, n_classes=3, num_layers=1,
+                           num_heads=4, dropout=0.0)
+
+
+def test_fast_small_train_head_matches_reference_golden(inn):
+    g = load_golden("g5_fast_small.npz")
+    m = inn.FAST(_small_cfg(inn)).cuda()
+    missing, unexpected = m.load_state_dict(_sd(g, "sd."), strict=False)
+    assert not missing, missing                              # every parameter of the hot path is provided
+    assert all(k.startswith(("transformer.", "pos_embedding", "cls_token")) for k in unexpected)
+    assert m.n_tokens == 3
+    x = torch.from_numpy(g["x"]).cuda()
+    feat = m.forward_head(x)
+    assert feat.shape == (2, 3, 3, 16)
+    assert rel_err(feat.detach().cpu(), g["features"]) < TOL
+    lt = m.token_logits(x)
+    loss = inn.token_mean_cross_entropy(lt, torch.from_numpy(g["labels"]).cuda())
+    loss.backward()
+    assert rel_err(m(x).detach().cpu(), g["train_head.logits"]) < TOL
+    assert abs(float(loss) - float(g["train_head.loss"])) < 1e-5
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad.cpu(), g[f"train_head.grad.{k}"]) < 2e-4, k
+
+
+def test_fast_prod_eval_logits_bitexact_argmax(inn):
+    g = load_golden("g6_fast_prod.npz")
+    m = inn.FAST(inn.fast_config()).cuda().eval()
+    missing, _ = m.load_state_dict(_sd(g, "sd."), strict=False)
+    assert not missing
+    x = torch.from_numpy(np.random.default_rng(6).standard_normal((4, 64, 800)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        feat = m.forward_head(x)
+        logits = m(x)
+        lm, pred = inn.token_mean_predict(m.token_logits(x))
+    assert feat.shape == (4, 5, 8, 32)
+    assert rel_err(feat.cpu(), g["features"]) < TOL
+    assert rel_err(logits.cpu(), g["train_head_logits"]) < TOL
+    assert np.array_equal(pred.cpu().numpy(), g["train_head_pred"])       # class indices bit-exact
+    assert pred.dtype == torch.int64
+    with pytest.raises(NotImplementedError):
+        m(x, forward_mode="nonexistent")
+
+
+def test_head_matches_oracle_on_reference_zones(inn):
+    # Head contract: [B', 64, 250] -> [B', 8, 32], zone order = dict order
+    g = load_golden("g6_fast_prod.npz")
+    sd = {k[len("head."):]: v for k, v in _sd(g, "sd.").items() if k.startswith("head.")}
+    import isd_amd
+    h = inn.Head("Conv4Layers", isd_amd.ELECTRODES, isd_amd.ZONES, 32).cuda()
+    h.load_state_dict(sd)
+    x = torch.randn(3, 64, 250, generator=torch.Generator().manual_seed(3))
+    y = h(x.cuda())
+    p = {"head." + k: v for k, v in sd.items()}
+    ref = ocnn.head_forward(x, p, list(ocnn.ZONES), ocnn.zone_index_lists())
+    assert y.shape == (3, 8, 32)
+    assert rel_err(y.detach().cpu(), ref) < TOL
+    assert [v.tolist() for v in h.index_dict.values()] == ocnn.zone_index_lists()
+
+
+# ------------------------------------------------------------------ FC head and loss
+@pytest.mark.parametrize("M,K,N,act", [(37, 256, 32, True), (4096 * 3, 256, 32, True), (100, 32, 5, False),
+                                       (1, 7, 3, False), (130, 70, 64, True)])
+def test_linear_forward_backward_vs_torch(inn, M, K, N, act):
+    gen = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen)
+    dy = torch.randn(M, N, generator=gen)
+    xr, wr, br = (t.clone().double().requires_grad_() for t in (x, w, b))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr = torch.nn.functional.gelu(yr) if act else yr
+    (yr * dy.double()).sum().backward()
+    xg, wg, bg = (t.clone().cuda().requires_grad_() for t in (x, w, b))
+    y = inn.linear(xg, wg, bg, act=act)
+    (y * dy.cuda()).sum().backward()
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-5
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-5
+    assert rel_err(wg.grad.cpu(), wr.grad) < 1e-5
+    assert rel_err(bg.grad.cpu(), br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,n_tok,n_cls,dtype", [(2, 3, 3, torch.uint8), (4096, 1, 5, torch.int64), (300, 5, 5, torch.uint8)])
+def test_softmax_ce_argmax_vs_torch(inn, B, n_tok, n_cls, dtype):
+    gen = torch.Generator().manual_seed(B)
+    lt = torch.randn(B, n_tok, n_cls, generator=gen)
+    lt[0] = 0.25                                              # all-equal row: argmax tie -> index 0
+    y = torch.randint(0, n_cls, (B,), generator=gen).to(dtype)
+    ltr = lt.clone().double().requires_grad_()
+    lr = ocnn.cross_entropy(ltr.mean(1), y)
+    lr.backward()
+    ltg = lt.clone().cuda().requires_grad_()
+    loss = inn.token_mean_cross_entropy(ltg, y.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(lr)) < 1e-5
+    assert rel_err(ltg.grad.cpu(), ltr.grad) < 1e-5
+    lm, pred = inn.token_mean_predict(lt.cuda())
+    assert rel_err(lm.cpu(), lt.mean(1)) < 1e-6
+    assert np.array_equal(pred.cpu().numpy(), ocnn.predict(lm.cpu()).numpy())
+    assert int(pred[0]) == 0
+
+
+# ------------------------------------------------------------------ feature classifier
+@pytest.mark.parametrize("n_layers", [2, 4])
+def test_feature_cnn_vs_oracle(inn, n_layers):
+    nbC, J, B = 9 * 8, 17, 6
+    m = inn.FeatureCNN(nbC, 32, 5, n_layers).cuda()
+    p = {k: v.detach().cpu().clone().double().requires_grad_() for k, v in m.state_dict().items()}
+    feats = torch.randn(B, 9, 8, J, generator=torch.Generator().manual_seed(4))
+    y = torch.tensor([0, 1, 2, 3, 4, 1], dtype=torch.uint8)
+    loss = inn.token_mean_cross_entropy(m.token_logits(feats.cuda()), y.cuda())
+    loss.backward()
+    lr = ocnn.cross_entropy(ocnn.feature_cnn_logits(feats.double(), p, n_layers), y)
+    lr.backward()
+    assert abs(float(loss) - float(lr)) < 1e-5
+    for k, q in m.named_parameters():
+        assert rel_err(q.grad.cpu(), p[k].grad) < TOL, k
+
+
+def test_full_size_feature_cnn_gradient_is_mean_of_shards(inn):
+    # BASELINE config 2 size: [4096, 9*64, 17]; property: grad(full batch) == mean of the two half-batch grads
+    torch.manual_seed(0)
+    m = inn.FeatureCNN(576, 32, 5).cuda()
+    feats = torch.randn(4096, 9, 64, 17, device="cuda")
+    y = torch.randint(0, 5, (4096,), device="cuda")
+
+    def grads(sl):
+        m.zero_grad(set_to_none=True)
+        inn.token_mean_cross_entropy(m.token_logits(feats[sl]), y[sl]).backward()
+        return torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    full = grads(slice(0, 4096))
+    half = 0.5 * (grads(slice(0, 2048)) + grads(slice(2048, 4096)))
+    assert torch.isfinite(full).all()
+    assert float((full - half).abs().max() / full.abs().max()) < 1e-4
+    # and a 16-trial slice against the oracle
+    p = {k: v.detach().cpu().clone().double().requires_grad_() for k, v in m.state_dict().items()}
+    ocnn.cross_entropy(ocnn.feature_cnn_logits(feats[:16].cpu().double(), p), y[:16].cpu()).backward()
+    got = grads(slice(0, 16))
+    ref = torch.cat([p[k].grad.reshape(-1) for k, _ in m.named_parameters()])
+    assert rel_err(got.cpu(), ref) < TOL
