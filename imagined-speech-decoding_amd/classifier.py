@@ -1,0 +1,409 @@
+"""Estimators with the sklearn protocol the reference uses for ``[trials, channels, time]`` arrays
+(``clf.fit(X, y)`` / ``clf.predict(X)``, notebooks/svm_baseline.ipynb:307,316), trained the way the
+reference trains FAST (src/fast/train/trainer.py): CrossEntropyLoss, AdamW(lr 5e-4), per-step cosine
+multiplier with 10 warm-up epochs and the ``[global_step - 1]`` indexing quirk (trainer.py:15-27,38,48-54).
+
+The step itself bypasses autograd: feature kernels -> conv stack -> FC head -> softmax-CE -> backward
+kernels write straight into ONE flat gradient block, which data-parallel training all-reduces once
+(RCCL over xGMI through ``torch.distributed``), followed by one AdamW step on the flat parameter.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .constants import BANDS_9, CLASSES, ELECTRODES, ZONES
+from .features import FeatureExtractor
+from .nn import FAST, FeatureCNN, _FlatParamMixin, _stream, fast_config, token_mean_predict
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0):
+    """Per-step multiplier table (src/fast/train/trainer.py:15-27): linear warm-up then half cosine."""
+    total = epochs * niter_per_ep
+    warm_iters = warmup_epochs * niter_per_ep
+    warm = np.linspace(start_warmup_value, base_value, warm_iters) if warmup_epochs > 0 else np.array([])
+    n = total - warm_iters
+    sched = final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * np.arange(n) / n))
+    sched = np.concatenate((warm, sched))
+    assert len(sched) == total
+    return sched
+
+
+def lr_multiplier(table, global_step):
+    """LambdaLR of trainer.py:52 evaluates ``table[global_step - 1]``: step 0 reads the LAST entry."""
+    return float(table[(global_step - 1) % len(table)])
+
+
+# ----------------------------------------------------------------------------- flat-parameter models
+class _FlatModel(nn.Module, _FlatParamMixin):
+    """A model whose parameters are packed in one block: [conv stack | dense layers]."""
+
+    def _dense_layers(self):
+        raise NotImplementedError
+
+    def _conv(self):
+        raise NotImplementedError
+
+    def _ordered_params(self):
+        ps = list(self._conv()._ordered_params())
+        for lin in self._dense_layers():
+            ps += [lin.weight, lin.bias]
+        return ps
+
+
+class _FeatureModel(_FlatModel):
+    def __init__(self, in_channels, feature_dim, n_classes, n_layers):
+        super().__init__()
+        self.net = FeatureCNN(in_channels, feature_dim, n_classes, n_layers)
+
+    def _conv(self):
+        return self.net.cnn
+
+    def _dense_layers(self):
+        return [self.net.fc]
+
+    def conv_plan(self, x):
+        return self.net.cnn._plan(x.shape[-1])
+
+    hidden_act = ()
+
+
+class _FastModel(_FlatModel):
+    def __init__(self, config):
+        super().__init__()
+        self.net = FAST(config)
+
+    def _conv(self):
+        return self.net.head
+
+    def _dense_layers(self):
+        return [self.net.input_layer[0], self.net.last_layer]
+
+    def conv_plan(self, x):
+        c = self.net.config
+        return self.net.head._plan(c.window_len, c.slide_step)
+
+    hidden_act = (True,)
+
+
+class HotPath:
+    """Autograd-free forward/backward of  conv stack -> [Linear+GELU] -> Linear -> token-mean CE.
+
+    Gradients land in ``model.flat_grads()`` in the order of ``model.flat_params()``.
+    """
+
+    def __init__(self, model):
+        self.model = model
+        self._ws = {}
+
+    def _buf(self, key, numel, device):
+        t = self._ws.get(key)
+        if t is None or t.numel() < numel or t.device != device:
+            t = torch.empty(max(int(numel), 1), dtype=torch.float32, device=device)
+            self._ws[key] = t
+        return t
+
+    def _layout(self):
+        m = self.model
+        flat = m.flat_params()
+        n_conv = sum(p.numel() for p in m._conv()._ordered_params())
+        offs, o = [], n_conv
+        for lin in m._dense_layers():
+            offs.append((o, o + lin.weight.numel(), lin.out_features, lin.in_features))
+            o += lin.weight.numel() + lin.bias.numel()
+        return flat, n_conv, offs
+
+    def forward(self, x, labels=None, global_batch=None, want_grad=False):
+        """x f32 CUDA [B, C, T] -> dict(loss, logits, pred); with labels and want_grad also fills the gradients."""
+        m, L = self.model, _lib.lib()
+        flat, n_conv, offs = self._layout()
+        gflat = m.flat_grads() if want_grad else None
+        plan = m.conv_plan(x)
+        B, _, T = x.shape
+        N = plan.windows(T)
+        dev, st = x.device, _stream()
+        fp, f4 = flat.data_ptr(), 4
+        ws_bytes = int(L.isd_conv4_workspace_bytes(plan._h, B, T))
+        ws = self._buf("conv", ws_bytes // 4, dev)
+        feat = self._buf("feat", B * N * plan.n_zones * plan.F, dev)
+        _lib.check(L.isd_conv4_forward(plan._h, x.data_ptr(), fp, feat.data_ptr(), ws.data_ptr(), B, T, st))
+        # dense layers
+        acts, pres = [feat], []
+        M, K = B * N, plan.n_zones * plan.F
+        n_lin = len(offs)
+        for i, (wo, bo, nout, nin) in enumerate(offs):
+            assert nin == K
+            act = 1 if i < n_lin - 1 else 0
+            y = self._buf(f"y{i}", M * nout, dev)
+            pre = self._buf(f"pre{i}", M * nout, dev) if act else None
+            _lib.check(L.isd_linear_forward(acts[-1].data_ptr(), fp + wo * f4, fp + bo * f4, y.data_ptr(),
+                                            0 if pre is None else pre.data_ptr(), M, K, nout, act, st))
+            acts.append(y)
+            pres.append(pre)
+            K = nout
+        n_cls = K
+        logits = torch.empty((B, n_cls), dtype=torch.float32, device=dev)
+        pred = torch.empty((B,), dtype=torch.int64, device=dev)
+        out = {"logits": logits, "pred": pred}
+        if labels is None:
+            _lib.check(L.isd_softmax_ce(acts[-1].data_ptr(), 0, 0, logits.data_ptr(), 0, 0, pred.data_ptr(), B, N,
+                                        n_cls, 1.0, st))
+            return out
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dlt = self._buf("dlt", M * n_cls, dev)
+        scale = 1.0 / float(global_batch or B)
+        _lib.check(L.isd_softmax_ce(acts[-1].data_ptr(), labels.data_ptr(), labels.element_size(), logits.data_ptr(),
+                                    loss.data_ptr(), dlt.data_ptr() if want_grad else 0, pred.data_ptr(), B, N, n_cls,
+                                    scale, st))
+        out["loss"] = loss
+        if not want_grad:
+            return out
+        gp = gflat.data_ptr()
+        dy = dlt
+        for i in range(n_lin - 1, -1, -1):
+            wo, bo, nout, nin = offs[i]
+            act = 1 if i < n_lin - 1 else 0
+            dx = self._buf(f"dx{i}", M * nin, dev)
+            lws = self._buf(f"lws{i}", int(L.isd_linear_workspace_bytes(M, nin, nout)) // 4 + 64, dev)
+            _lib.check(L.isd_linear_backward(acts[i].data_ptr(), fp + wo * f4, dy.data_ptr(),
+                                             0 if pres[i] is None else pres[i].data_ptr(), dx.data_ptr(),
+                                             gp + wo * f4, gp + bo * f4, lws.data_ptr(), M, nin, nout, act, st))
+            dy = dx
+        _lib.check(L.isd_conv4_backward(plan._h, x.data_ptr(), fp, dy.data_ptr(), gp, ws.data_ptr(), B, T, st))
+        return out
+
+
+# ----------------------------------------------------------------------------- data parallel helper
+class GradientBucket:
+    """One flat gradient all-reduce per step.  With ``torch.distributed`` initialised
+    (backend 'nccl' == RCCL on ROCm, 'gloo' on CPU) the bucket is summed over ranks; the loss kernel
+    already divided by the GLOBAL batch, so the sum is the global-mean gradient."""
+
+    def __init__(self, process_group=None):
+        import torch.distributed as dist
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.group = process_group
+
+    @property
+    def world_size(self):
+        return self.dist.get_world_size(self.group) if self.dist else 1
+
+    @property
+    def rank(self):
+        return self.dist.get_rank(self.group) if self.dist else 0
+
+    def all_reduce_(self, flat_grad, extra=None):
+        if self.dist is None or self.world_size == 1:
+            return
+        self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM, group=self.group)
+        if extra is not None:
+            self.dist.all_reduce(extra, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def broadcast_(self, flat_params, src=0):
+        if self.dist is not None and self.world_size > 1:
+            self.dist.broadcast(flat_params, src=src, group=self.group)
+
+    def shard(self, n):
+        """Contiguous shard [lo, hi) of n items owned by this rank (equal shards, remainder to the first ranks)."""
+        w, r = self.world_size, self.rank
+        base, rem = divmod(n, w)
+        lo = r * base + min(r, rem)
+        return lo, lo + base + (1 if r < rem else 0)
+
+
+class Trainer:
+    """AdamW(lr 5e-4, wd 1e-2, torch defaults) on the flat parameter + the reference's per-step schedule."""
+
+    def __init__(self, model, lr=5e-4, weight_decay=1e-2, schedule=None, bucket=None):
+        self.model, self.path = model, HotPath(model)
+        self.bucket = bucket or GradientBucket()
+        flat = model.flat_params()
+        self.flat = nn.Parameter(flat)                     # aliases the block every named parameter lives in
+        self.flat.grad = model.flat_grads()
+        self.base_lr = lr
+        try:
+            self.opt = torch.optim.AdamW([self.flat], lr=lr, weight_decay=weight_decay, fused=True)
+        except (RuntimeError, TypeError):
+            self.opt = torch.optim.AdamW([self.flat], lr=lr, weight_decay=weight_decay)
+        self.schedule = schedule
+        self.global_step = 0
+        self.bucket.broadcast_(flat)
+
+    def step(self, x, labels, global_batch=None):
+        """One optimisation step on a device-resident batch.  Returns the (local share of the) loss tensor."""
+        out = self.path.forward(x, labels, global_batch=global_batch, want_grad=True)
+        self.bucket.all_reduce_(self.flat.grad)
+        if self.schedule is not None:
+            lr = self.base_lr * lr_multiplier(self.schedule, self.global_step)
+            for g in self.opt.param_groups:
+                g["lr"] = lr
+        self.opt.step()
+        self.global_step += 1
+        return out
+
+
+# ----------------------------------------------------------------------------- estimators
+def _to_device(X, device):
+    if isinstance(X, torch.Tensor):
+        return X.to(device=device, dtype=torch.float32).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(X, dtype=np.float32)).to(device)
+
+
+class _Estimator:
+    classes_ = np.arange(len(CLASSES))
+    class_names_ = list(CLASSES)
+
+    def __init__(self, max_epochs=200, batch_size=64, lr=5e-4, weight_decay=1e-2, warmup_epochs=10, seed=42,
+                 device=None, shuffle=True, verbose=False):
+        self.max_epochs, self.batch_size, self.lr, self.weight_decay = max_epochs, batch_size, lr, weight_decay
+        self.warmup_epochs, self.seed, self.shuffle, self.verbose = warmup_epochs, seed, shuffle, verbose
+        self.device = device
+        self.model_ = None
+        self.trainer_ = None
+        self.history_ = []
+
+    def _device(self):
+        if self.device is not None:
+            return torch.device(self.device)
+        if not torch.cuda.is_available():
+            raise RuntimeError("isd_amd classifiers need an MI355X GPU: there is no CPU fallback")
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def _build(self, X):
+        raise NotImplementedError
+
+    def _inputs(self, xb):
+        return xb
+
+    def _ensure_model(self, X):
+        if self.model_ is None:
+            torch.manual_seed(self.seed)
+            self.model_ = self._build(X).to(self._device())
+        return self.model_
+
+    def fit(self, X, y):
+        """X [n, C, T] (ndarray or CUDA tensor), y int [n] in label order CLASSES.  Returns self."""
+        dev = self._device()
+        X = _to_device(X, dev)
+        y = torch.as_tensor(np.asarray(y.cpu() if isinstance(y, torch.Tensor) else y)).to(dev)
+        if y.dtype not in (torch.uint8, torch.int64):
+            y = y.long()
+        n = X.shape[0]
+        if n != y.shape[0]:
+            raise ValueError("X and y disagree on the number of trials")
+        model = self._ensure_model(X)
+        bs = min(self.batch_size, n)
+        iters = (n + bs - 1) // bs
+        warm = min(self.warmup_epochs, max(self.max_epochs - 1, 0))
+        table = cosine_scheduler(1, 0.1, self.max_epochs, iters, warmup_epochs=warm)
+        self.trainer_ = Trainer(model, self.lr, self.weight_decay, schedule=table)
+        gen = torch.Generator(device="cpu").manual_seed(self.seed)
+        for ep in range(self.max_epochs):
+            order = torch.randperm(n, generator=gen).to(dev) if self.shuffle else torch.arange(n, device=dev)
+            tot, cnt = 0.0, 0
+            for i in range(iters):
+                idx = order[i * bs:(i + 1) * bs]
+                xb, yb = self._inputs(X[idx].contiguous()), y[idx].contiguous()
+                out = self.trainer_.step(xb, yb)
+                if self.verbose or ep == self.max_epochs - 1:
+                    tot += float(out["loss"]) * len(idx)
+                    cnt += len(idx)
+            if cnt:
+                self.history_.append(tot / cnt)
+                if self.verbose:
+                    print(f"epoch {ep + 1}/{self.max_epochs} loss {tot / cnt:.4f}")
+        return self
+
+    def decision_function(self, X, batch_size=4096):
+        """Logits [n, n_classes] as a NumPy array."""
+        dev = self._device()
+        model = self._ensure_model(X if isinstance(X, torch.Tensor) else np.asarray(X))
+        path = self.trainer_.path if self.trainer_ is not None else HotPath(model)
+        outs = []
+        for i in range(0, len(X), batch_size):
+            xb = self._inputs(_to_device(X[i:i + batch_size], dev))
+            outs.append(path.forward(xb)["logits"].clone())
+        return torch.cat(outs).cpu().numpy() if outs else np.zeros((0, len(CLASSES)), np.float32)
+
+    def predict(self, X, batch_size=4096):
+        """Class indices int64 [n] (argmax, ties -> lowest index; order = CLASSES)."""
+        dev = self._device()
+        model = self._ensure_model(X if isinstance(X, torch.Tensor) else np.asarray(X))
+        path = self.trainer_.path if self.trainer_ is not None else HotPath(model)
+        outs = []
+        for i in range(0, len(X), batch_size):
+            xb = self._inputs(_to_device(X[i:i + batch_size], dev))
+            outs.append(path.forward(xb)["pred"].clone())
+        return torch.cat(outs).cpu().numpy() if outs else np.zeros((0,), np.int64)
+
+    def score(self, X, y):
+        return float((self.predict(X) == np.asarray(y)).mean())
+
+
+class FilterbankCNNClassifier(_Estimator):
+    """extract_features (Butterworth filterbank -> STFT -> log band power) -> 4-layer CNN -> Linear.
+
+    BASELINE config 2: 9 bands, nperseg 64 / noverlap 32, Conv4Layers(nb*C, 32) + Linear(32, 5).
+    ``n_layers=2`` with the 5-band set is config 1.
+    """
+
+    def __init__(self, fs=256.0, bands=BANDS_9, order=4, nperseg=64, noverlap=None, eps=1e-10, feature_dim=32,
+                 n_classes=5, n_layers=4, fused=None, **kw):
+        super().__init__(**kw)
+        self.fs, self.bands, self.order = fs, bands, order
+        self.nperseg, self.noverlap, self.eps = nperseg, noverlap, eps
+        self.feature_dim, self.n_classes, self.n_layers, self.fused = feature_dim, n_classes, n_layers, fused
+        self.extractor_ = None
+
+    def _extractor(self, T):
+        if self.extractor_ is None or self.extractor_.stft.T != T:
+            self.extractor_ = FeatureExtractor(T, self.fs, self.bands, self.order, self.nperseg, self.noverlap,
+                                               self.eps)
+        return self.extractor_
+
+    def extract_features(self, trials):
+        """trials f32 CUDA [B, C, T] -> [B, nb, C, J] (same as the module-level ``extract_features``)."""
+        return self._extractor(trials.shape[-1])(trials, fused=self.fused)
+
+    def _build(self, X):
+        fx = self._extractor(X.shape[-1])
+        return _FeatureModel(fx.n_bands * X.shape[1], self.feature_dim, self.n_classes, self.n_layers)
+
+    def _inputs(self, xb):
+        f = self.extract_features(xb)
+        return f.view(f.shape[0], -1, f.shape[-1])
+
+
+class FASTHeadClassifier(_Estimator):
+    """The reference's FAST in ``forward_mode='train_head'`` on raw EEG: zone-wise Conv4Layers over sliding
+    windows -> Linear(256, 32) + GELU -> Linear(32, 5) -> mean over windows (fast.py:273-278)."""
+
+    def __init__(self, config=None, **kw):
+        super().__init__(**kw)
+        self.config = config
+
+    def _build(self, X):
+        cfg = self.config or fast_config(ELECTRODES, ZONES, seq_len=int(X.shape[-1]))
+        return _FastModel(cfg)
+
+    def load_reference_state_dict(self, sd, X_like=None):
+        """Load a reference FAST state_dict (keys ``head.encoders...``, ``input_layer.0...``, ``last_layer...``)."""
+        if self.model_ is None:
+            self.model_ = _FastModel(self.config or fast_config()).to(self._device())
+        missing, unexpected = self.model_.net.load_state_dict(sd, strict=False)
+        if missing:
+            raise KeyError(f"state_dict lacks hot-path parameters: {missing}")
+        return unexpected
+
+
+def smoke_classifier():
+    """Tiny end-to-end step on cuda:0 (used by __graft_entry__.smoke)."""
+    torch.manual_seed(0)
+    x = torch.randn(8, 64, 512, device="cuda")
+    y = torch.randint(0, 5, (8,), device="cuda")
+    clf = FilterbankCNNClassifier(max_epochs=2, batch_size=8)
+    clf.fit(x, y)
+    p = clf.predict(x)
+    assert p.shape == (8,) and np.isfinite(clf.history_[-1])

@@ -42,8 +42,11 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // Weight preparation.  "frag order": block (cg, k, gt) holds, for lane l,
 //   W[gt*16 + (l&15)][4*cg + (l>>4)][k]   (zero beyond Cin)   -> one coalesced A-fragment load.
 // ---------------------------------------------------------------------------------------
-__global__ void prep_fused_kernel(const float* __restrict__ params, const ZoneDesc* __restrict__ zones,
-                                  float* __restrict__ wfrag, float* __restrict__ beff, int F) {
+__global__ __launch_bounds__(256) void prep_fused_kernel(const float* __restrict__ params,
+                                                         const ZoneDesc* __restrict__ zones,
+                                                         float* __restrict__ wfrag, float* __restrict__ beff, int F,
+                                                         int nbw) {
+  __shared__ float red[256];
   const int z = blockIdx.y;
   const ZoneDesc zd = zones[z];
   const int GT = F / 16;
@@ -52,30 +55,33 @@ __global__ void prep_fused_kernel(const float* __restrict__ params, const ZoneDe
   const float* b1 = W1 + F * kTaps;                    // [F]
   const float* W2 = b1 + F;                            // [F][F][Cz]
   const int total = ncg * kTaps * GT * 64;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + F; e += gridDim.x * blockDim.x) {
-    if (e < total) {
-      const int lane = e & 63;
-      const int blk = e >> 6;
-      const int gt = blk % GT;
-      const int k = (blk / GT) % kTaps;
-      const int cg = blk / (GT * kTaps);
-      const int g = gt * 16 + (lane & 15);
-      const int c = cg * 4 + (lane >> 4);
-      float acc = 0.f;
-      if (c < zd.cin)
-        for (int f = 0; f < F; ++f) acc = fmaf(W2[(g * F + f) * zd.cin + c], W1[f * kTaps + k], acc);
-      wfrag[zd.eff_off + e] = acc;
-    } else {
-      const int g = e - total;
-      float acc = 0.f;
-      for (int f = 0; f < F; ++f) {
-        float s = 0.f;
-        for (int c = 0; c < zd.cin; ++c) s += W2[(g * F + f) * zd.cin + c];
-        acc = fmaf(s, b1[f], acc);
-      }
-      beff[z * F + g] = acc;
-    }
+  if ((int)blockIdx.x < nbw) {                         // one thread per fragment element
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int lane = e & 63;
+    const int blk = e >> 6;
+    const int gt = blk % GT;
+    const int k = (blk / GT) % kTaps;
+    const int cg = blk / (GT * kTaps);
+    const int g = gt * 16 + (lane & 15);
+    const int c = cg * 4 + (lane >> 4);
+    float acc = 0.f;
+    if (c < zd.cin)
+      for (int f = 0; f < F; ++f) acc = fmaf(W2[(g * F + f) * zd.cin + c], W1[f * kTaps + k], acc);
+    wfrag[zd.eff_off + e] = acc;
+    return;
   }
+  const int g = blockIdx.x - nbw;                      // one block per beff[g]
+  if (g >= F) return;
+  float s = 0.f;
+  for (int e = threadIdx.x; e < F * zd.cin; e += 256) s = fmaf(W2[(int64_t)g * F * zd.cin + e], b1[e / zd.cin], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) beff[z * F + g] = red[0];
 }
 
 // cnn3 / cnn4 weights [F][F][5] -> frag order, forward and transposed+flipped (dgrad) copies.
@@ -113,11 +119,15 @@ struct ConvArgs {
   int64_t wz_stride;         // MODE 1: per-zone stride of wfrag
   int64_t items;             // B' = B * N
   int Z, F, Tin, Tout, pad, TT, IPW, RS;
+  int lin;                   // 1: a chunk's rows are one contiguous block in global memory and RS == Tin
   int Ctot, Tx, N, S;        // MODE 0 only
 };
 
 // MODE 0: input gathered from the raw trials  x[b][chan_idx[c]][n*S + t]   (item = b*N + n)
 // MODE 1: input is an activation tensor      in[((item*Z + z)*F + c)*Tin + t]
+// LDS rows are unpadded copies of the source rows (stride RS >= Tin); zero padding, the ragged last
+// time tile and the channel round-up are handled by masking the B fragment, so staging moves only
+// real data (float4 when the block is contiguous and aligned).
 template <int MODE>
 __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -129,10 +139,11 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
   const int64_t item0 = (int64_t)blockIdx.x * a.IPW;
   const int n_items = (int)((a.items - item0) < a.IPW ? (a.items - item0) : a.IPW);
   const int n_ct = n_items * a.TT;
-  float* in_tile = smem;                                  // [IPW][kCK][RS]
-  float* w_tile = smem + a.IPW * kCK * a.RS;              // [kCK/4][5][GT][64]
+  float* in_tile = smem;                                   // [IPW][kCK][RS]
+  float* w_tile = smem + ((a.IPW * kCK * a.RS + 3) & ~3);  // [kCK/4][5][GT][64], 16-byte aligned
   const float* wbase = a.wfrag + ((MODE == 0) ? zd.eff_off : (int64_t)z * a.wz_stride);
   const int n_chunks = (cin + kCK - 1) / kCK;
+  const int q = lane >> 4, jl = lane & 15;
 
   for (int base = 0; base < n_ct; base += 16) {
     f32x4 acc[4][2];
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
     bool t_ok[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int ct = base + wave * 4 + j;
+      const int ct = base + j * 4 + wave;                  // round-robin: few tiles still use every wave
       t_ok[j] = ct < n_ct;
       const int ctc = t_ok[j] ? ct : 0;
       t_ii[j] = ctc / a.TT;
@@ -155,33 +166,52 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
       const int ckc = (cin - c_lo) < kCK ? (cin - c_lo) : kCK;
       const int ckc4 = (ckc + 3) & ~3;
       __syncthreads();
-      // stage the input rows (zero padded on both sides and up to RS)
-      const int rows = n_items * ckc4;
-      for (int e = threadIdx.x; e < rows * a.RS; e += 256) {
-        const int r = e / a.RS, tp = e - r * a.RS;
-        const int ii = r / ckc4, cc = r - ii * ckc4;
-        const int t = tp - a.pad;
-        float v = 0.f;
-        if (cc < ckc && t >= 0 && t < a.Tin) {
+      if (a.lin) {
+        // one contiguous block of ckc*Tin floats per item
+        const int cnt = ckc * a.Tin;
+        for (int ii = wave; ii < n_items; ii += 4) {
           const int64_t item = item0 + ii;
+          const float* src = (MODE == 0)
+                                 ? a.in + (item * a.Ctot + a.chan_idx[zd.idx_off + c_lo]) * (int64_t)a.Tx
+                                 : a.in + ((item * a.Z + z) * a.F + c_lo) * (int64_t)a.Tin;
+          float* dst = in_tile + ii * kCK * a.RS;
+          if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(dst);
+            for (int e = lane; e < (cnt >> 2); e += 64) d4[e] = s4[e];
+          } else {
+            for (int e = lane; e < cnt; e += 64) dst[e] = src[e];
+          }
+        }
+      } else {
+        // one wave per row, lanes along time (coalesced 256-byte segments)
+        const int rows = n_items * ckc;
+        for (int r = wave; r < rows; r += 4) {
+          const int ii = r / ckc, cc = r - ii * ckc;
+          const int64_t item = item0 + ii;
+          const float* src;
           if (MODE == 0) {
             const int64_t b = item / a.N;
             const int n = (int)(item - b * a.N);
-            const int chn = a.chan_idx[zd.idx_off + c_lo + cc];
-            v = a.in[(b * a.Ctot + chn) * (int64_t)a.Tx + (int64_t)n * a.S + t];
+            src = a.in + (b * a.Ctot + a.chan_idx[zd.idx_off + c_lo + cc]) * (int64_t)a.Tx + (int64_t)n * a.S;
           } else {
-            v = a.in[((item * a.Z + z) * a.F + c_lo + cc) * (int64_t)a.Tin + t];
+            src = a.in + ((item * a.Z + z) * a.F + c_lo + cc) * (int64_t)a.Tin;
           }
+          float* dst = in_tile + (ii * kCK + cc) * a.RS;
+          for (int t = lane; t < a.Tin; t += 64) dst[t] = src[t];
         }
-        in_tile[(ii * kCK + cc) * a.RS + tp] = v;
       }
-      // stage this chunk's weight fragments (contiguous)
-      const int wlen = (ckc4 / 4) * kTaps * GT * 64;
-      const float* wsrc = wbase + (int64_t)ch * (kCK / 4) * kTaps * GT * 64;
-      for (int e = threadIdx.x; e < wlen; e += 256) w_tile[e] = wsrc[e];
+      {
+        const int wlen4 = (ckc4 / 4) * kTaps * GT * 16;
+        const float4* wsrc = reinterpret_cast<const float4*>(wbase + (int64_t)ch * (kCK / 4) * kTaps * GT * 64);
+        float4* wdst = reinterpret_cast<float4*>(w_tile);
+        for (int e = threadIdx.x; e < wlen4; e += 256) wdst[e] = wsrc[e];
+      }
       __syncthreads();
       for (int cg = 0; cg < ckc4 / 4; ++cg) {
-        const int crow = cg * 4 + (lane >> 4);
+        const int crow = cg * 4 + q;
+        const bool c_ok = crow < ckc;
+        const int crow_c = c_ok ? crow : 0;
 #pragma unroll
         for (int k = 0; k < kTaps; ++k) {
           float af[2];
@@ -189,7 +219,11 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
           af[1] = (GT > 1) ? w_tile[((cg * kTaps + k) * GT + 1) * 64 + lane] : 0.f;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float bf = in_tile[(t_ii[j] * kCK + crow) * a.RS + t_t0[j] + k + (lane & 15)];
+            const int idx = t_t0[j] + jl + k - a.pad;
+            const bool ok = c_ok && idx >= 0 && idx < a.Tin;
+            const int idc = idx < 0 ? 0 : (idx >= a.Tin ? a.Tin - 1 : idx);
+            float bf = in_tile[(t_ii[j] * kCK + crow_c) * a.RS + idc];
+            bf = ok ? bf : 0.f;
             acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf, acc[j][0], 0, 0, 0);
             if (GT > 1) acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf, acc[j][1], 0, 0, 0);
           }
@@ -201,14 +235,14 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
     for (int j = 0; j < 4; ++j) {
       if (!t_ok[j]) continue;
       const int64_t item = item0 + t_ii[j];
-      const int t = t_t0[j] + (lane & 15);
+      const int t = t_t0[j] + jl;
       if (t >= a.Tout) continue;
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) {
         if (gt >= GT) break;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int g = gt * 16 + 4 * (lane >> 4) + r;
+          const int g = gt * 16 + 4 * q + r;
           float v = acc[j][gt][r];
           if (a.bias) v += a.bias[z * a.F + g];
           a.out[((item * a.Z + z) * a.F + g) * (int64_t)a.Tout + t] = v;
@@ -264,6 +298,7 @@ struct WgradArgs {
   int64_t wz_stride;         // MODE 1: per-zone stride inside a slab
   int items_per_wg, IPS;     // items per workgroup, items per LDS stage
   int CW;                    // input channels staged per workgroup (16, 32, 48 or 64)
+  int lin;                   // 1: the CW rows of an item are one contiguous block and RSi == Tin
   int Z, F, Tin, Tout, pad, RSo, RSi;
   int Ctot, Tx, N, S;
 };
@@ -272,6 +307,7 @@ struct WgradArgs {
 //   roles <= 4 : a wave owns ONE (c-tile, g-tile); the 4/roles wave groups split the items
 //                and write separate slabs (summed by reduce_slabs_kernel);
 //   roles == 8 : a wave owns one c-tile and both g-tiles.
+// LDS rows are unpadded copies (RSo >= Tout, RSi >= Tin); range / padding handled by masks.
 template <int MODE>
 __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -282,6 +318,7 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
   if (c_base >= cin) return;
   const int GT = a.F / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, jl = lane & 15;
   const int n_ct = a.CW / 16;
   const int roles = n_ct * GT;
   const bool both = roles > 4;
@@ -291,11 +328,16 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
   const int grp = both ? 0 : wave / roles;
   const int c_tile = c_base + ct * 16;
   const bool wave_live = c_tile < cin && grp < n_grp;
+  const int n_real = (MODE == 0) ? cin - 1 : cin;           // channels that exist in memory
+  const int do_sz = (a.IPS * a.F * a.RSo + 3) & ~3;
   float* do_tile = smem;                                    // [IPS][F][RSo]
-  float* in_tile = smem + a.IPS * a.F * a.RSo;              // [IPS][CW][RSi]
+  float* in_tile = smem + do_sz;                            // [IPS][CW][RSi]
   const int64_t i_lo = (int64_t)blockIdx.x * a.items_per_wg;
   const int64_t i_hi = (i_lo + a.items_per_wg) < a.items ? (i_lo + a.items_per_wg) : a.items;
-  const int Tk = (a.Tout + 3) & ~3;                         // K extent (zero filled)
+  const int Tk = (a.Tout + 3) & ~3;
+  const int c_mine = c_tile + jl;                           // channel of this lane's B column
+  const bool c_real = c_mine < n_real;
+  const bool c_ones = (MODE == 0) && c_mine == cin - 1;
 
   f32x4 acc0[kTaps], acc1[kTaps];
 #pragma unroll
@@ -303,50 +345,85 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
     acc0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  const int cw_real = (n_real - c_base) < a.CW ? (n_real - c_base) : a.CW;   // real rows to stage (may be <= 0)
 
   for (int64_t is = i_lo; is < i_hi; is += a.IPS) {
     const int n_it = (int)((i_hi - is) < a.IPS ? (i_hi - is) : a.IPS);
     __syncthreads();
-    for (int e = threadIdx.x; e < n_it * a.F * a.RSo; e += 256) {
-      const int r = e / a.RSo, t = e - r * a.RSo;
-      const int ii = r / a.F, g = r - ii * a.F;
-      float v = 0.f;
-      if (t < a.Tout) v = a.dout[(((is + ii) * a.Z + z) * a.F + g) * (int64_t)a.Tout + t];
-      do_tile[e] = v;
-    }
-    for (int e = threadIdx.x; e < n_it * a.CW * a.RSi; e += 256) {
-      const int r = e / a.RSi, tp = e - r * a.RSi;
-      const int ii = r / a.CW, cc = r - ii * a.CW;
-      const int c = c_base + cc;
-      const int t = tp - a.pad;
-      float v = 0.f;
-      if (c < cin && t >= 0 && t < a.Tin) {
-        const int64_t item = is + ii;
-        if (MODE == 0) {
-          if (c == cin - 1) {
-            v = (t < a.Tout) ? 1.f : 0.f;
-          } else {
-            const int64_t b = item / a.N;
-            const int n = (int)(item - b * a.N);
-            v = a.in[(b * a.Ctot + a.chan_idx[zd.idx_off + c]) * (int64_t)a.Tx + (int64_t)n * a.S + t];
-          }
+    // dOut: [F][Tout] of an item is contiguous
+    {
+      const int cnt = a.F * a.Tout;
+      for (int ii = wave; ii < n_it; ii += 4) {
+        const float* src = a.dout + ((is + ii) * a.Z + z) * (int64_t)cnt;
+        float* dst = do_tile + ii * a.F * a.RSo;
+        if (a.RSo == a.Tout && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
+          const float4* s4 = reinterpret_cast<const float4*>(src);
+          float4* d4 = reinterpret_cast<float4*>(dst);
+          for (int e = lane; e < (cnt >> 2); e += 64) d4[e] = s4[e];
+        } else if (a.RSo == a.Tout) {
+          for (int e = lane; e < cnt; e += 64) dst[e] = src[e];
         } else {
-          v = a.in[((item * a.Z + z) * a.F + c) * (int64_t)a.Tin + t];
+          for (int g = 0; g < a.F; ++g)
+            for (int t = lane; t < a.Tout; t += 64) dst[g * a.RSo + t] = src[g * a.Tout + t];
         }
       }
-      in_tile[e] = v;
+    }
+    if (cw_real > 0) {
+      if (a.lin) {
+        const int cnt = cw_real * a.Tin;
+        for (int ii = wave; ii < n_it; ii += 4) {
+          const int64_t item = is + ii;
+          const float* src = (MODE == 0)
+                                 ? a.in + (item * a.Ctot + a.chan_idx[zd.idx_off + c_base]) * (int64_t)a.Tx
+                                 : a.in + ((item * a.Z + z) * a.F + c_base) * (int64_t)a.Tin;
+          float* dst = in_tile + ii * a.CW * a.RSi;
+          if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(dst);
+            for (int e = lane; e < (cnt >> 2); e += 64) d4[e] = s4[e];
+          } else {
+            for (int e = lane; e < cnt; e += 64) dst[e] = src[e];
+          }
+        }
+      } else {
+        const int rows = n_it * cw_real;
+        for (int r = wave; r < rows; r += 4) {
+          const int ii = r / cw_real, cc = r - ii * cw_real;
+          const int64_t item = is + ii;
+          const float* src;
+          if (MODE == 0) {
+            const int64_t b = item / a.N;
+            const int n = (int)(item - b * a.N);
+            src = a.in + (b * a.Ctot + a.chan_idx[zd.idx_off + c_base + cc]) * (int64_t)a.Tx + (int64_t)n * a.S;
+          } else {
+            src = a.in + ((item * a.Z + z) * a.F + c_base + cc) * (int64_t)a.Tin;
+          }
+          float* dst = in_tile + (ii * a.CW + cc) * a.RSi;
+          for (int t = lane; t < a.Tin; t += 64) dst[t] = src[t];
+        }
+      }
     }
     __syncthreads();
     if (wave_live) {
+      const int row_b = c_real ? (ct * 16 + jl) : 0;
       for (int ii = grp; ii < n_it; ii += n_grp) {
-        const float* dro = do_tile + (ii * a.F + gsel * 16 + (lane & 15)) * a.RSo + (lane >> 4);
-        const float* iro = in_tile + (ii * a.CW + ct * 16 + (lane & 15)) * a.RSi + (lane >> 4);
+        const float* dro = do_tile + (ii * a.F + gsel * 16 + jl) * a.RSo;
+        const float* iro = in_tile + (ii * a.CW + row_b) * a.RSi;
         for (int t0 = 0; t0 < Tk; t0 += 4) {
-          const float a0 = dro[t0];
-          const float a1 = both ? dro[16 * a.RSo + t0] : 0.f;
+          const int ta = t0 + q;
+          const bool a_ok = ta < a.Tout;
+          const int tac = a_ok ? ta : 0;
+          float a0 = dro[tac];
+          float a1 = both ? dro[16 * a.RSo + tac] : 0.f;
+          a0 = a_ok ? a0 : 0.f;
+          a1 = a_ok ? a1 : 0.f;
 #pragma unroll
           for (int k = 0; k < kTaps; ++k) {
-            const float bf = iro[t0 + k];
+            const int idx = ta + k - a.pad;
+            const bool in_rng = idx >= 0 && idx < a.Tin;
+            const int idc = in_rng ? idx : 0;
+            float bf = iro[idc];
+            bf = (c_real && in_rng) ? bf : ((c_ones && idx >= 0 && idx < a.Tout) ? 1.f : 0.f);
             acc0[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc0[k], 0, 0, 0);
             if (both) acc1[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc1[k], 0, 0, 0);
           }
@@ -357,37 +434,49 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
   if (!wave_live) return;
   float* slab = a.part + ((int64_t)blockIdx.x * n_grp + grp) * a.slab_size +
                 ((MODE == 0) ? zd.wg_off : (int64_t)z * a.wz_stride);
-  const int c = c_tile + (lane & 15);
-  if (c < cin) {
+  if (c_mine < cin) {
 #pragma unroll
     for (int k = 0; k < kTaps; ++k)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int g = gsel * 16 + 4 * (lane >> 4) + r;
-        slab[((int64_t)g * cin + c) * kTaps + k] = acc0[k][r];
-        if (both) slab[((int64_t)(g + 16) * cin + c) * kTaps + k] = acc1[k][r];
+        const int g = gsel * 16 + 4 * q + r;
+        slab[((int64_t)g * cin + c_mine) * kTaps + k] = acc0[k][r];
+        if (both) slab[((int64_t)(g + 16) * cin + c_mine) * kTaps + k] = acc1[k][r];
       }
   }
 }
 
-// sum the per-workgroup slabs: out[e] = sum_s part[s][e]
-__global__ void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int n_slabs) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < n_slabs; ++k) s += part[(int64_t)k * n + e];
-    out[e] = s;
+// sum the per-workgroup slabs: out[e] = sum_s part[s][e].  Block = 64 elements x 4 slab groups
+// (coalesced 256-B rows, 4 independent load streams per element, LDS combine).
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                           int64_t n, int n_slabs) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < n) {
+    int k = grp;
+    for (; k + 4 < n_slabs; k += 8) {
+      s0 += part[(int64_t)k * n + e];
+      s1 += part[(int64_t)(k + 4) * n + e];
+    }
+    if (k < n_slabs) s0 += part[(int64_t)k * n + e];
   }
+  red[grp][lane] = s0 + s1;
+  __syncthreads();
+  if (grp == 0 && e < n) out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-// Chain dWeff / dbeff back to cnn1.weight, cnn1.bias, cnn2.weight (one block per zone).
-//   dW2[g,f,c] = sum_k dWeff[g,c,k] W1[f,k] + dbeff[g] b1[f]
-//   dW1[f,k]   = sum_{g,c} dWeff[g,c,k] W2[g,f,c]
-//   db1[f]     = sum_g dbeff[g] sum_c W2[g,f,c]
+// Chain dWeff / dbeff back to cnn1.weight, cnn1.bias, cnn2.weight.  grid = (blocks, zones):
+//   blocks [0, nb2)          : dW2[g,f,c] = sum_k dWeff[g,c,k] W1[f,k] + dbeff[g] b1[f]      (one thread per element)
+//   blocks [nb2, nb2 + 5F)   : dW1[f,k]   = sum_{g,c} dWeff[g,c,k] W2[g,f,c]                 (one block per output)
+//   blocks [nb2 + 5F, +F)    : db1[f]     = sum_g dbeff[g] sum_c W2[g,f,c]
 __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict__ params,
                                                         const ZoneDesc* __restrict__ zones,
                                                         const float* __restrict__ dweff, float* __restrict__ dparams,
-                                                        int F) {
-  const ZoneDesc zd = zones[blockIdx.x];
+                                                        int F, int nb2) {
+  __shared__ float red[256];
+  const ZoneDesc zd = zones[blockIdx.y];
   const int cz = zd.cin, cin1 = cz + 1;
   const float* W1 = params + zd.p_off;
   const float* b1 = W1 + F * kTaps;
@@ -396,29 +485,42 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
   float* dW1 = dparams + zd.p_off;
   float* db1 = dW1 + F * kTaps;
   float* dW2 = db1 + F;
-  for (int e = threadIdx.x; e < F * F * cz; e += 256) {
+  const int blk = blockIdx.x;
+  if (blk < nb2) {
+    const int e = blk * 256 + threadIdx.x;
+    if (e >= F * F * cz) return;
     const int c = e % cz, f = (e / cz) % F, g = e / (cz * F);
     float s = dWe[(g * cin1 + cz) * kTaps] * b1[f];
 #pragma unroll
     for (int k = 0; k < kTaps; ++k) s = fmaf(dWe[(g * cin1 + c) * kTaps + k], W1[f * kTaps + k], s);
     dW2[e] = s;
+    return;
   }
-  for (int e = threadIdx.x; e < F * kTaps + F; e += 256) {
-    float s = 0.f;
-    if (e < F * kTaps) {
-      const int f = e / kTaps, k = e - f * kTaps;
-      for (int g = 0; g < F; ++g)
-        for (int c = 0; c < cz; ++c) s = fmaf(dWe[(g * cin1 + c) * kTaps + k], W2[(g * F + f) * cz + c], s);
-      dW1[e] = s;
-    } else {
-      const int f = e - F * kTaps;
-      for (int g = 0; g < F; ++g) {
-        float w = 0.f;
-        for (int c = 0; c < cz; ++c) w += W2[(g * F + f) * cz + c];
-        s = fmaf(dWe[(g * cin1 + cz) * kTaps], w, s);
-      }
-      db1[f] = s;
+  const int o = blk - nb2;                              // output index: [0, 5F) -> dW1, [5F, 6F) -> db1
+  if (o >= F * kTaps + F) return;
+  float s = 0.f;
+  if (o < F * kTaps) {
+    const int f = o / kTaps, k = o - f * kTaps;
+    for (int e = threadIdx.x; e < F * cz; e += 256) {
+      const int g = e / cz, c = e - g * cz;
+      s = fmaf(dWe[(g * cin1 + c) * kTaps + k], W2[(g * F + f) * cz + c], s);
     }
+  } else {
+    const int f = o - F * kTaps;
+    for (int e = threadIdx.x; e < F * cz; e += 256) {
+      const int g = e / cz, c = e - g * cz;
+      s = fmaf(dWe[(g * cin1 + cz) * kTaps], W2[(g * F + f) * cz + c], s);
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (o < F * kTaps) dW1[o] = red[0];
+    else db1[o - F * kTaps] = red[0];
   }
 }
 
@@ -435,11 +537,17 @@ struct isd_conv4_plan {
   int64_t conv_zstride;    // floats of one zone's cnn3/cnn4 frag block
   int64_t wg_size;         // floats of all dWeff blocks
   int max_cz;
+  int contiguous;          // every zone's channel list is consecutive -> rows of a zone are adjacent in memory
   ZoneDesc* d_zones;
   int* d_idx;
 };
 
 static inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+static inline int row_threads(int row_len) {   // power of two in [16, 256] covering a staged row
+  int tw = 16;
+  while (tw < row_len && tw < 256) tw <<= 1;
+  return tw;
+}
 
 extern "C" int isd_conv4_plan_create(isd_conv4_plan** out, int c_total, int n_zones, const int* zone_sizes,
                                      const int* zone_channels, int feature_dim, int n_layers, int window_len,
@@ -481,6 +589,10 @@ extern "C" int isd_conv4_plan_create(isd_conv4_plan** out, int c_total, int n_zo
     wo += (int64_t)F * (cz + 1) * kTaps;
   }
   p->n_params = po; p->eff_size = eo; p->wg_size = wo;
+  p->contiguous = 1;
+  for (int z = 0; z < n_zones; ++z)
+    for (int c = 1; c < zone_sizes[z]; ++c)
+      if (idx[zd[z].idx_off + c] != idx[zd[z].idx_off + c - 1] + 1) p->contiguous = 0;
   p->conv_zstride = (int64_t)(F / 4) * kTaps * GT * 64;
   hipError_t e = hipMalloc(&p->d_zones, sizeof(ZoneDesc) * n_zones);
   if (e == hipSuccess) e = hipMalloc(&p->d_idx, sizeof(int) * idx.size());
@@ -520,7 +632,7 @@ extern "C" int isd_conv4_windows(const isd_conv4_plan* p, int64_t T) {
 
 namespace {
 struct Geo {           // derived sizes for one call
-  int N, T1, TT, IPW, RS_a, RS_b;
+  int N, T1, TT, IPW, RS_a, RS_b, lin0;
   int64_t items, act;  // act = floats of one activation tensor
   // workspace layout (floats)
   int64_t o_eff, o_beff, o_w3, o_w3t, o_w4, o_w4t, o_a2, o_a3, o_a4, o_s, o_wg, o_wg34, o_part, total;
@@ -528,15 +640,10 @@ struct Geo {           // derived sizes for one call
   int64_t slab0, slab1;
 };
 
-int row_stride_fwd(int need) {           // conflict-free B-fragment reads: stride == 16 (mod 32) when it matters
+int row_stride_fwd(int need) {           // unpadded rows; B-fragment reads touch 4 rows x 16 consecutive t
   if (need <= 32) return need | 1;
   int rs = need;
   while (rs % 32 != 16) ++rs;
-  return rs;
-}
-int row_stride_wgrad(int need) {         // lanes (l&15) walk rows: stride == 2 (mod 32) is conflict free
-  int rs = need;
-  while (rs % 32 != 2) ++rs;
   return rs;
 }
 
@@ -548,14 +655,23 @@ int make_geo(const isd_conv4_plan* p, int64_t B, int64_t T, Geo& g) {
   g.IPW = g.TT >= 16 ? 1 : 16 / g.TT;
   g.items = B * g.N;
   g.act = g.items * p->Z * p->F * g.T1;
-  g.RS_a = row_stride_fwd(16 * g.TT + kTaps - 1 > p->W ? 16 * g.TT + kTaps - 1 : p->W);
-  g.RS_b = row_stride_fwd(16 * g.TT + kTaps - 1);
+  // MODE 0 rows: one contiguous block per (item, chunk) when the zones are contiguous channel ranges and the
+  // window is the whole row; otherwise gathered rows with a bank-friendly stride.  MODE 1 rows are always contiguous.
+  g.lin0 = (p->contiguous && g.N == 1 && T == p->W) ? 1 : 0;
+  g.RS_a = g.lin0 ? p->W : row_stride_fwd(p->W);
+  g.RS_b = g.T1;
   {   // keep the staged tile (input rows + one weight chunk) inside 64 KiB of LDS
     const int64_t wfl = (int64_t)(kCK / 4) * kTaps * (p->F / 16) * 64;
     const int64_t per_item = (int64_t)kCK * (g.RS_a > g.RS_b ? g.RS_a : g.RS_b);
     const int64_t fit = (64 * 1024 / 4 - wfl) / per_item;
     ISD_CHECK_ARG(fit >= 1, "conv4: window_len=%d is too long for the LDS tile", p->W);
     if (g.IPW > fit) g.IPW = (int)fit;
+    // enough workgroups to co-schedule ~4 per CU (staging of one overlaps the MFMA phase of another)
+    const int64_t occ = (g.items * p->Z) / 1024;
+    int min_ipw = (4 + g.TT - 1) / g.TT;                         // at least one column tile per wave
+    if (min_ipw < 1) min_ipw = 1;
+    int64_t want = occ < min_ipw ? min_ipw : occ;
+    if (g.IPW > want) g.IPW = (int)want;
   }
   int64_t o = 0;
   g.o_eff = o;  o += align_up(p->eff_size, 64);
@@ -604,7 +720,7 @@ static int launch_conv(int mode, const ConvArgs& a, int n_zones, hipStream_t st)
   const int64_t blocks = cdiv(a.items, a.IPW);
   ISD_CHECK_ARG(blocks <= 0x7fffffffLL, "conv4: too many items");
   const int GT = a.F / 16;
-  const size_t lds = sizeof(float) * ((size_t)a.IPW * kCK * a.RS + (size_t)(kCK / 4) * kTaps * GT * 64);
+  const size_t lds = sizeof(float) * ((((size_t)a.IPW * kCK * a.RS + 3) & ~(size_t)3) + (size_t)(kCK / 4) * kTaps * GT * 64);
   ISD_CHECK_ARG(lds <= 64 * 1024, "conv4: LDS tile of %zu bytes exceeds 64 KiB (window too long)", lds);
   if (mode == 0)
     hipLaunchKernelGGL((conv5_fwd_kernel<0>), dim3((unsigned)blocks, n_zones), dim3(256), lds, st, a);
@@ -626,9 +742,12 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const int F = p->F;
-  hipLaunchKernelGGL(prep_fused_kernel, dim3(8, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_eff,
-                     ws + g.o_beff, F);
-  ISD_LAUNCH_CHECK();
+  {
+    const int nbw = (int)cdiv(((int64_t)(p->max_cz + 3) / 4) * kTaps * (F / 16) * 64, 256);
+    hipLaunchKernelGGL(prep_fused_kernel, dim3(nbw + F, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_eff,
+                       ws + g.o_beff, F, nbw);
+    ISD_LAUNCH_CHECK();
+  }
   if (p->n_layers == 4) {
     hipLaunchKernelGGL(prep_conv_kernel, dim3(4, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_w3,
                        ws + g.o_w3t, F, 0, p->conv_zstride);
@@ -642,11 +761,12 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
   a.Ctot = p->Ctot; a.Tx = (int)T; a.N = g.N; a.S = p->S;
   // cnn1 o cnn2
   a.in = x; a.out = ws + g.o_a2; a.wfrag = ws + g.o_eff; a.bias = ws + g.o_beff; a.Tin = p->W; a.pad = 0; a.RS = g.RS_a;
+  a.lin = g.lin0;
   rc = launch_conv(0, a, p->Z, st);
   if (rc) return rc;
   const float* last = ws + g.o_a2;
   if (p->n_layers == 4) {
-    a.bias = nullptr; a.Tin = g.T1; a.pad = 2; a.RS = g.RS_b; a.wz_stride = p->conv_zstride;
+    a.bias = nullptr; a.Tin = g.T1; a.pad = 2; a.RS = g.RS_b; a.wz_stride = p->conv_zstride; a.lin = 1;
     a.in = ws + g.o_a2; a.out = ws + g.o_a3; a.wfrag = ws + g.o_w3;
     rc = launch_conv(1, a, p->Z, st);
     if (rc) return rc;
@@ -664,12 +784,14 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
 
 static int launch_wgrad(int mode, WgradArgs& a, int n_zones, int cin_max, hipStream_t st) {
   const int64_t per_item = (int64_t)a.F * a.RSo + (int64_t)a.CW * a.RSi;
-  int ips = (int)((96 * 1024 / 4) / per_item);
+  int ips = (int)((96 * 1024 / 4 - 4) / per_item);
   ISD_CHECK_ARG(ips >= 1, "conv4 wgrad: window too long for the LDS tile");
+  const int ips_occ = (int)((32 * 1024 / 4) / per_item);      // prefer <= 32 KiB so several workgroups share a CU
+  if (ips_occ >= 1 && ips > ips_occ) ips = ips_occ;
   if (ips > 16) ips = 16;
   if (ips > a.items_per_wg) ips = a.items_per_wg;
   a.IPS = ips;
-  const size_t lds = sizeof(float) * (size_t)ips * per_item;
+  const size_t lds = sizeof(float) * ((size_t)ips * per_item + 4);
   const int64_t wgs = cdiv(a.items, a.items_per_wg);
   const int zgroups = (cin_max + a.CW - 1) / a.CW;
   if (mode == 0) {
@@ -723,17 +845,15 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
   ConvArgs a = {};
   a.zones = p->d_zones; a.chan_idx = p->d_idx; a.items = g.items; a.Z = p->Z; a.F = F;
   a.TT = g.TT; a.IPW = g.IPW; a.Tout = g.T1; a.Tin = g.T1; a.pad = 2; a.RS = g.RS_b; a.wz_stride = p->conv_zstride;
+  a.lin = 1;
   a.Ctot = p->Ctot; a.Tx = (int)T; a.N = g.N; a.S = p->S;
   const float* g2 = top;                                          // gradient w.r.t. the cnn2 output
   if (p->n_layers == 4) {
-    const int RSo = row_stride_wgrad(((g.T1 + 3) & ~3));
-    const int RSi = row_stride_wgrad(((g.T1 + 3) & ~3) + kTaps - 1);
-    // cnn4: dW4 = wgrad(G4, A3); G3 = dgrad(G4)
-    w.dout = ws + g.o_a4; w.in = ws + g.o_a3; w.Tin = g.T1; w.pad = 2; w.RSo = RSo; w.RSi = RSi;
+    w.dout = ws + g.o_a4; w.in = ws + g.o_a3; w.Tin = g.T1; w.pad = 2; w.RSo = g.T1; w.RSi = g.T1; w.lin = 1;
     w.slab_size = g.slab1; w.wz_stride = (int64_t)F * F * kTaps; w.items_per_wg = g.ipw1; w.CW = g.cw1;
     rc = launch_wgrad(1, w, p->Z, F, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(64), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg34, g.slab1, g.ns1);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdiv(g.slab1, 64)), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg34, g.slab1, g.ns1);
     hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 1);
     ISD_LAUNCH_CHECK();
     a.in = ws + g.o_a4; a.out = ws + g.o_s; a.wfrag = ws + g.o_w4t;
@@ -743,7 +863,7 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
     w.dout = ws + g.o_s; w.in = ws + g.o_a2;
     rc = launch_wgrad(1, w, p->Z, F, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(64), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg34, g.slab1, g.ns1);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdiv(g.slab1, 64)), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg34, g.slab1, g.ns1);
     hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 0);
     ISD_LAUNCH_CHECK();
     a.in = ws + g.o_s; a.out = ws + g.o_a4; a.wfrag = ws + g.o_w3t;
@@ -753,13 +873,17 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
   }
   // cnn1 o cnn2: dWeff (+ dbeff in the ones channel), then chain to W1, b1, W2
   w.dout = g2; w.in = x; w.Tin = p->W; w.pad = 0;
-  w.RSo = row_stride_wgrad((g.T1 + 3) & ~3);
-  w.RSi = row_stride_wgrad(((g.T1 + 3) & ~3) + kTaps - 1 > p->W ? ((g.T1 + 3) & ~3) + kTaps - 1 : p->W);
+  w.RSo = g.T1; w.lin = g.lin0;
+  w.RSi = g.lin0 ? p->W : (p->W | 1);
   w.slab_size = g.slab0; w.wz_stride = 0; w.items_per_wg = g.ipw0; w.CW = g.cw0;
   rc = launch_wgrad(0, w, p->Z, p->max_cz + 1, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(64), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg, g.slab0, g.ns0);
-  hipLaunchKernelGGL(fused_bwd_kernel, dim3(p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_wg, dparams, F);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdiv(g.slab0, 64)), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg, g.slab0, g.ns0);
+  {
+    const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
+    hipLaunchKernelGGL(fused_bwd_kernel, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,
+                       ws + g.o_wg, dparams, F, nb2);
+  }
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }

@@ -236,38 +236,42 @@ class _FlatParamMixin:
     def _ordered_params(self):
         raise NotImplementedError
 
+    @staticmethod
+    def _as_flat(ps):
+        """A flat tensor over ``ps`` if they already sit back to back in one storage, else None."""
+        base = ps[0]
+        st = base.untyped_storage()
+        off = base.storage_offset()
+        pos = off
+        for p in ps:
+            if (p.dtype != torch.float32 or not p.is_contiguous() or p.storage_offset() != pos
+                    or p.untyped_storage().data_ptr() != st.data_ptr()):
+                return None
+            pos += p.numel()
+        return torch.empty(0, dtype=torch.float32, device=base.device).set_(st, off, (pos - off,))
+
     def flat_params(self):
         ps = self._ordered_params()
-        flat = getattr(self, "_flat", None)
-        ok = flat is not None and flat.device == ps[0].device
-        if ok:
-            ptr = flat.data_ptr()
-            for p in ps:
-                if p.data_ptr() != ptr or not p.is_contiguous():
-                    ok = False
-                    break
-                ptr += p.numel() * 4
-        if not ok:
+        flat = self._as_flat([p.data for p in ps])
+        if flat is None:
             flat = torch.cat([p.detach().reshape(-1).float() for p in ps]).contiguous()
             off = 0
             for p in ps:
                 p.data = flat[off:off + p.numel()].view(p.shape)
                 off += p.numel()
-            self._flat = flat
-            self._flat_grad = None
-        return self._flat
+        return flat
 
     def flat_grads(self):
-        """One flat gradient buffer aliased by every ``p.grad`` (allocated on first use)."""
+        """One flat gradient buffer aliased by every ``p.grad`` (allocated when the grads are not packed yet)."""
         flat = self.flat_params()
-        g = getattr(self, "_flat_grad", None)
+        ps = self._ordered_params()
+        g = self._as_flat([p.grad for p in ps]) if all(p.grad is not None for p in ps) else None
         if g is None or g.device != flat.device:
             g = torch.zeros_like(flat)
             off = 0
-            for p in self._ordered_params():
+            for p in ps:
                 p.grad = g[off:off + p.numel()].view(p.shape)
                 off += p.numel()
-            self._flat_grad = g
         return g
 
 

@@ -1,0 +1,107 @@
+"""GPU: estimators (fit/predict), the autograd-free hot path vs the autograd modules, optimizer wiring."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import cnn as ocnn, dsp as odsp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def isd():
+    import isd_amd
+    assert torch.cuda.is_available()
+    return isd_amd
+
+
+def test_hot_path_equals_autograd_modules(isd):
+    from isd_amd.classifier import _FeatureModel
+    import isd_amd.nn as inn
+    torch.manual_seed(0)
+    m = _FeatureModel(9 * 8, 32, 5, 4).cuda()
+    feats = torch.randn(10, 72, 17, device="cuda")
+    y = torch.randint(0, 5, (10,), device="cuda")
+    out = isd.HotPath(m).forward(feats, y, want_grad=True)
+    g_manual = m.flat_grads().clone()
+    m.zero_grad(set_to_none=True)
+    loss = inn.token_mean_cross_entropy(m.net.token_logits(feats.view(10, 9, 8, 17)), y)
+    loss.backward()
+    g_auto = torch.cat([p.grad.reshape(-1) for p in m._ordered_params()])
+    assert abs(float(out["loss"]) - float(loss)) < 1e-6
+    assert rel_err(g_manual.cpu(), g_auto.cpu()) < 1e-6
+    assert np.array_equal(out["pred"].cpu().numpy(), out["logits"].argmax(1).cpu().numpy())
+
+
+def test_fast_adamw_trajectory_matches_reference_golden(isd):
+    """G9: three AdamW steps of FAST(small_config) train_head through Trainer == the reference's losses/params."""
+    from isd_amd.classifier import _FastModel
+    import isd_amd.nn as inn
+    g5, g9 = load_golden("g5_fast_small.npz"), load_golden("g9_adamw.npz")
+    electrodes = ["Fp1", "Fp2", "F3", "F4", "C3", "C4", "O1", "O2"]
+    zones = {"Frontal": ["Fp1", "Fp2", "F3", "F4"], "Central": ["C3", "C4"], "Occipital": ["O1", "O2"]}
+    cfg = inn.fast_config(electrodes, zones, dim_cnn=16, dim_token=16, seq_len=500, n_classes=3)
+    m = _FastModel(cfg).cuda()
+    sd = {k[3:]: torch.from_numpy(g5[k]) for k in g5.files if k.startswith("sd.")}
+    assert not m.net.load_state_dict(sd, strict=False)[0]
+    tr = isd.Trainer(m, lr=5e-4, weight_decay=1e-2, schedule=None)
+    x = torch.from_numpy(g5["x"]).cuda()
+    y = torch.from_numpy(g5["labels"]).cuda()
+    losses = [float(tr.step(x, y)["loss"]) for _ in range(3)]
+    np.testing.assert_allclose(losses, g9["losses"], rtol=2e-5)
+    for k, p in m.net.named_parameters():
+        assert rel_err(p.detach().cpu(), g9["final." + k]) < 2e-5, k
+
+
+def test_fast_head_classifier_reference_checkpoint_predicts_bitexact(isd):
+    g = load_golden("g6_fast_prod.npz")
+    clf = isd.FASTHeadClassifier()
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    clf.load_reference_state_dict(sd)
+    X = np.random.default_rng(6).standard_normal((4, 64, 800)).astype(np.float32)
+    pred = clf.predict(X)
+    assert pred.dtype == np.int64 and np.array_equal(pred, g["train_head_pred"])
+    assert rel_err(clf.decision_function(X), g["train_head_logits"]) < 1e-4
+
+
+def test_filterbank_cnn_classifier_learns_and_matches_cpu_path_accuracy(isd):
+    """Synthetic task of SURVEY 8d (class-dependent tone): the HIP pipeline learns it, and its accuracy equals
+    the oracle pipeline's (same init, same batches) within 0.1 %."""
+    X, y = odsp.synth_trials(256, 64, 512, 256.0, seed=0)
+    clf = isd.FilterbankCNNClassifier(max_epochs=40, batch_size=64, warmup_epochs=2, seed=1, shuffle=False)
+    clf.fit(X, y)
+    acc = clf.score(X, y)
+    assert acc > 0.9, acc
+    assert clf.predict(X[:7]).shape == (7,)
+    # oracle-side replay: same initial parameters, same schedule, same batch order
+    torch.manual_seed(1)
+    from isd_amd.classifier import _FeatureModel
+    ref_model = _FeatureModel(9 * 64, 32, 5, 4)
+    p = {k[len("net."):]: v.detach().clone().requires_grad_() for k, v in ref_model.state_dict().items()}
+    feats = torch.from_numpy(odsp.extract_features(X, fs=256.0, bands=odsp.BANDS_9))
+    opt = torch.optim.AdamW(list(p.values()), lr=5e-4)
+    table = ocnn.cosine_scheduler(1, 0.1, 40, 4, warmup_epochs=2)
+    step = 0
+    yt = torch.from_numpy(y)
+    for ep in range(40):
+        for i in range(4):
+            for gr in opt.param_groups:
+                gr["lr"] = 5e-4 * ocnn.lr_multiplier(table, step)
+            opt.zero_grad()
+            sl = slice(i * 64, (i + 1) * 64)
+            ocnn.cross_entropy(ocnn.feature_cnn_logits(feats[sl], p), yt[sl]).backward()
+            opt.step()
+            step += 1
+    with torch.no_grad():
+        acc_ref = float((ocnn.predict(ocnn.feature_cnn_logits(feats, p)).numpy() == y).mean())
+    assert abs(acc - acc_ref) <= 0.001 + 1e-9, (acc, acc_ref)
+
+
+def test_estimator_accepts_device_tensors_and_uint8_labels(isd):
+    x = torch.randn(16, 64, 512, device="cuda")
+    y = torch.randint(0, 5, (16,), dtype=torch.uint8)
+    clf = isd.FilterbankCNNClassifier(max_epochs=1, batch_size=8, n_layers=2, bands=isd.BANDS_5)
+    assert clf.fit(x, y) is clf
+    assert clf.predict(x).shape == (16,)
+    assert clf.extractor_.fb.precision == "f64"
