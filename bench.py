@@ -48,7 +48,8 @@ def synth_trials(B, C, T, fs, seed):
 def cpu_baseline(C, T, fs, n_trials=128, steps=3):
     """The oracle (CPU restatement of the same pipeline) timed on this box's host cores, bounded sample."""
     from oracle import cnn as ocnn, dsp as odsp
-    threads = os.cpu_count() or 1
+    # the GPU box grants a 16-CPU share per GPU (cpu_count reports the whole host)
+    threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(threads)
     X, y = synth_trials(n_trials, C, T, fs, seed=123)
     p = ocnn.init_conv4_params(9 * C, 32, prefix="cnn.", seed=0)
@@ -180,7 +181,8 @@ def main():
         tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tf):
             try:
-                roof["traffic"] = json.load(open(tf)).get(roof["kernel"].split(" ")[0])
+                ent = json.load(open(tf)).get(roof["kernel"].split(" ")[0])
+                roof["traffic"] = ent["bytes_per_launch"] if ent and B == 4096 else None
             except Exception:
                 pass
         line = {

@@ -55,7 +55,8 @@ SIGNATURES = {
     "isd_linear_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "isd_linear_workspace_bytes": (_i64, [_i64, _i, _i]),
     "isd_linear_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
-    "isd_softmax_ce": (_i, [_p, _p, _i, _p, _p, _p, _p, _i64, _i, _i, _f, _p]),
+    "isd_softmax_ce_workspace_bytes": (_i64, [_i64]),
+    "isd_softmax_ce": (_i, [_p, _p, _i, _p, _p, _p, _p, _i64, _i, _i, _f, _p, _p]),
 }
 
 _lib = None

@@ -149,14 +149,15 @@ class HotPath:
         out = {"logits": logits, "pred": pred}
         if labels is None:
             _lib.check(L.isd_softmax_ce(acts[-1].data_ptr(), 0, 0, logits.data_ptr(), 0, 0, pred.data_ptr(), B, N,
-                                        n_cls, 1.0, st))
+                                        n_cls, 1.0, 0, st))
             return out
         loss = torch.empty((), dtype=torch.float32, device=dev)
         dlt = self._buf("dlt", M * n_cls, dev)
         scale = 1.0 / float(global_batch or B)
+        cws = self._buf("cews", int(L.isd_softmax_ce_workspace_bytes(B)) // 4 + 1, dev)
         _lib.check(L.isd_softmax_ce(acts[-1].data_ptr(), labels.data_ptr(), labels.element_size(), logits.data_ptr(),
                                     loss.data_ptr(), dlt.data_ptr() if want_grad else 0, pred.data_ptr(), B, N, n_cls,
-                                    scale, st))
+                                    scale, cws.data_ptr(), st))
         out["loss"] = loss
         if not want_grad:
             return out
@@ -220,13 +221,23 @@ class Trainer:
         self.model, self.path = model, HotPath(model)
         self.bucket = bucket or GradientBucket()
         flat = model.flat_params()
-        self.flat = nn.Parameter(flat)                     # aliases the block every named parameter lives in
-        self.flat.grad = model.flat_grads()
+        gflat = model.flat_grads()
+        self.flat, self.flat_grad = flat, gflat
+        # The optimizer sees the flat block as ~64 equal views (AdamW is elementwise with uniform
+        # hyper-parameters, so this equals per-tensor AdamW); more views = more blocks in torch's
+        # fused multi-tensor kernel than one 100k-element tensor would get.
+        n = flat.numel()
+        step = max(1024, -(-n // 64))
+        self.chunks = []
+        for lo in range(0, n, step):
+            p = nn.Parameter(flat[lo:lo + step])
+            p.grad = gflat[lo:lo + step]
+            self.chunks.append(p)
         self.base_lr = lr
         try:
-            self.opt = torch.optim.AdamW([self.flat], lr=lr, weight_decay=weight_decay, fused=True)
+            self.opt = torch.optim.AdamW(self.chunks, lr=lr, weight_decay=weight_decay, fused=True)
         except (RuntimeError, TypeError):
-            self.opt = torch.optim.AdamW([self.flat], lr=lr, weight_decay=weight_decay)
+            self.opt = torch.optim.AdamW(self.chunks, lr=lr, weight_decay=weight_decay)
         self.schedule = schedule
         self.global_step = 0
         self.bucket.broadcast_(flat)
@@ -234,7 +245,7 @@ class Trainer:
     def step(self, x, labels, global_batch=None):
         """One optimisation step on a device-resident batch.  Returns the (local share of the) loss tensor."""
         out = self.path.forward(x, labels, global_batch=global_batch, want_grad=True)
-        self.bucket.all_reduce_(self.flat.grad)
+        self.bucket.all_reduce_(self.flat_grad)
         if self.schedule is not None:
             lr = self.base_lr * lr_multiplier(self.schedule, self.global_step)
             for g in self.opt.param_groups:

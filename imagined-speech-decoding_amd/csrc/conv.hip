@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
           af[1] = (GT > 1) ? w_tile[((cg * kTaps + k) * GT + 1) * 64 + lane] : 0.f;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
+            if (!t_ok[j]) continue;                          // wave-uniform: unused tile slots issue nothing
             const int idx = t_t0[j] + jl + k - a.pad;
             const bool ok = c_ok && idx >= 0 && idx < a.Tin;
             const int idc = idx < 0 ? 0 : (idx >= a.Tin ? a.Tin - 1 : idx);
@@ -667,7 +668,7 @@ int make_geo(const isd_conv4_plan* p, int64_t B, int64_t T, Geo& g) {
     ISD_CHECK_ARG(fit >= 1, "conv4: window_len=%d is too long for the LDS tile", p->W);
     if (g.IPW > fit) g.IPW = (int)fit;
     // enough workgroups to co-schedule ~4 per CU (staging of one overlaps the MFMA phase of another)
-    const int64_t occ = (g.items * p->Z) / 1024;
+    const int64_t occ = (g.items * p->Z) / 512;
     int min_ipw = (4 + g.TT - 1) / g.TT;                         // at least one column tile per wave
     if (min_ipw < 1) min_ipw = 1;
     int64_t want = occ < min_ipw ? min_ipw : occ;
@@ -685,14 +686,14 @@ int make_geo(const isd_conv4_plan* p, int64_t B, int64_t T, Geo& g) {
   g.o_wg = o; o += align_up(p->wg_size, 64);
   g.slab1 = (int64_t)p->Z * p->F * p->F * kTaps;
   g.o_wg34 = o; o += align_up(g.slab1, 64);
-  // wgrad slabs: ~2048 workgroups over (item ranges) x zones x channel groups
+  // wgrad slabs: ~1024 workgroups over (item ranges) x zones x channel groups
   const int GT = p->F / 16;
   auto plan_wg = [&](int cin_max, int& cw, int& ipw, int& ns, int& grp) {
     cw = cin_max >= 64 ? 64 : (int)align_up(cin_max, 16);
     const int roles = (cw / 16) * GT;
     grp = roles > 4 ? 1 : 4 / roles;
     const int zg = (cin_max + cw - 1) / cw;
-    int64_t want = 2048 / ((int64_t)p->Z * zg);
+    int64_t want = 1024 / ((int64_t)p->Z * zg);
     if (want < 1) want = 1;
     const int64_t it = g.items > 0 ? g.items : 1;
     if (want > it) want = it;

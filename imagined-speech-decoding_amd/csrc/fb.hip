@@ -19,6 +19,7 @@
 #include <math.h>
 #include <vector>
 #include <string.h>
+#include <type_traits>
 
 namespace isd {
 
@@ -53,14 +54,46 @@ struct isd_fb_plan {
 
 namespace isd {
 
-template <typename T> struct Sel;
-template <> struct Sel<float> {
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Value types: float (one row per lane group), double (fp64 FMA issues at the same rate as unpacked
+// fp32 on gfx950), and f2 = TWO rows packed in a register pair so the cascade runs on
+// v_pk_fma_f32 / v_pk_add_f32.  Measured at cfg2 (tools/ubench/valu_rate.hip: v_fma_f32 70 TF,
+// v_pk_fma_f32 119 TF, v_fma_f64 62 TF) the packed variant halves the cascade's instruction count
+// but its 64 extra VGPRs cost a wave per SIMD and it ran slower (2.10 vs 1.49 ms), so the dispatch
+// uses float / double; f2 is kept for the kernels that can afford the registers.
+template <typename VT> struct VOps;
+template <> struct VOps<float> {
+  using S = float;
+  static constexpr int NR = 1;
+  static __device__ __forceinline__ float splat(float s) { return s; }
+  static __device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+  static __device__ __forceinline__ float get(float v, int) { return v; }
+  static __device__ __forceinline__ void set(float& v, int, float s) { v = s; }
   static __device__ __forceinline__ float a1(const FbSec& s) { return s.a1f; }
   static __device__ __forceinline__ float a2(const FbSec& s) { return s.a2f; }
   static __device__ __forceinline__ float h(const FbSec& s, int n, int j) { return s.hf[n][j]; }
   static __device__ __forceinline__ float g(const FbBand& b) { return b.gf; }
 };
-template <> struct Sel<double> {
+template <> struct VOps<f2> {
+  using S = float;
+  static constexpr int NR = 2;
+  static __device__ __forceinline__ f2 splat(float s) { return (f2){s, s}; }
+  static __device__ __forceinline__ f2 fma_(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+  static __device__ __forceinline__ float get(f2 v, int r) { return r ? v.y : v.x; }
+  static __device__ __forceinline__ void set(f2& v, int r, float s) { if (r) v.y = s; else v.x = s; }
+  static __device__ __forceinline__ float a1(const FbSec& s) { return s.a1f; }
+  static __device__ __forceinline__ float a2(const FbSec& s) { return s.a2f; }
+  static __device__ __forceinline__ float h(const FbSec& s, int n, int j) { return s.hf[n][j]; }
+  static __device__ __forceinline__ float g(const FbBand& b) { return b.gf; }
+};
+template <> struct VOps<double> {
+  using S = double;
+  static constexpr int NR = 1;
+  static __device__ __forceinline__ double splat(double s) { return s; }
+  static __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
+  static __device__ __forceinline__ double get(double v, int) { return v; }
+  static __device__ __forceinline__ void set(double& v, int, double s) { v = s; }
   static __device__ __forceinline__ double a1(const FbSec& s) { return s.a1d; }
   static __device__ __forceinline__ double a2(const FbSec& s) { return s.a2d; }
   static __device__ __forceinline__ double h(const FbSec& s, int n, int j) { return s.hd[n][j]; }
@@ -74,67 +107,78 @@ __device__ __forceinline__ void scan_step(double& e1, double& e2, const double* 
   e2 = fma(M[2], p1, fma(M[3], p2, e2));
 }
 
-// One biquad section over the lane's chunk, including the cross-chunk state fix-up.
-// `cin1/cin2` : incoming state of the wave's first group of this row (GPR==4 loop carry).
-// Returns the outgoing carry (only meaningful for GPR == 4).
-template <typename TL, int GPR>
-__device__ __forceinline__ void section(TL (&v)[kL], const FbSec& sc, const double* __restrict__ Qsec,
-                                        int lane, double& c1, double& c2) {
-  const TL a1 = Sel<TL>::a1(sc), a2 = Sel<TL>::a2(sc);
-  TL s1 = 0, s2 = 0;
+// One biquad section over the lane's chunk(s), including the cross-chunk state fix-up.
+// c1/c2[r]: incoming state of the wave's first group for row-set r (GPR == 4 loop carry), updated.
+template <typename VT, int GPR>
+__device__ __forceinline__ void section(VT (&v)[kL], const FbSec& sc, const double* __restrict__ Qsec, int lane,
+                                        double (&c1)[VOps<VT>::NR], double (&c2)[VOps<VT>::NR]) {
+  using O = VOps<VT>;
+  constexpr int NR = O::NR;
+  const VT na1 = O::splat(-O::a1(sc)), na2 = O::splat(-O::a2(sc));
+  VT s1 = O::splat(0), s2 = O::splat(0);
 #pragma unroll
   for (int n = 0; n < kL; ++n) {
-    TL x = v[n];
-    TL y = x + s1;
-    s1 = fma(-a1, y, s2);
-    s2 = fma(-a2, y, -x);
+    const VT x = v[n];
+    const VT y = x + s1;
+    s1 = O::fma_(na1, y, s2);
+    s2 = O::fma_(na2, y, -x);
     v[n] = y;
   }
-  double e1 = (double)s1, e2 = (double)s2;
-  scan_step<1>(e1, e2, sc.Mp[0]);
-  scan_step<2>(e1, e2, sc.Mp[1]);
-  scan_step<4>(e1, e2, sc.Mp[2]);
-  scan_step<8>(e1, e2, sc.Mp[3]);
-  double i1 = row_shr<1>(e1), i2 = row_shr<1>(e2);   // exclusive; lane 0 of each row -> 0
-  if (GPR > 1) {
-    // group totals (wave-uniform) and the serial chain over the 4 groups of the wave
-    double E1[4], E2[4];
+  double i1[NR], i2[NR];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      E1[g] = read_lane(e1, 16 * g + 15);
-      E2[g] = read_lane(e2, 16 * g + 15);
-    }
-    double C1[4], C2[4];
-    C1[0] = (GPR == 4) ? c1 : 0.0;
-    C2[0] = (GPR == 4) ? c2 : 0.0;
+  for (int r = 0; r < NR; ++r) {
+    double e1 = (double)O::get(s1, r), e2 = (double)O::get(s2, r);
+    scan_step<1>(e1, e2, sc.Mp[0]);
+    scan_step<2>(e1, e2, sc.Mp[1]);
+    scan_step<4>(e1, e2, sc.Mp[2]);
+    scan_step<8>(e1, e2, sc.Mp[3]);
+    i1[r] = row_shr<1>(e1);                            // exclusive; lane 0 of each 16-lane row -> 0
+    i2[r] = row_shr<1>(e2);
+    if (GPR > 1) {
+      // group totals (wave-uniform) and the serial chain over the 4 groups of the wave
+      double E1[4], E2[4];
 #pragma unroll
-    for (int g = 1; g < 4; ++g) {
-      if (g % GPR == 0) {
-        C1[g] = 0.0;
-        C2[g] = 0.0;
-      } else {
-        C1[g] = fma(sc.P[0], C1[g - 1], fma(sc.P[1], C2[g - 1], E1[g - 1]));
-        C2[g] = fma(sc.P[2], C1[g - 1], fma(sc.P[3], C2[g - 1], E2[g - 1]));
+      for (int g = 0; g < 4; ++g) {
+        E1[g] = read_lane(e1, 16 * g + 15);
+        E2[g] = read_lane(e2, 16 * g + 15);
       }
-    }
-    if (GPR == 4) {
-      c1 = fma(sc.P[0], C1[3], fma(sc.P[1], C2[3], E1[3]));
-      c2 = fma(sc.P[2], C1[3], fma(sc.P[3], C2[3], E2[3]));
-    }
-    const int q = lane >> 4;
-    double m1 = q == 0 ? C1[0] : q == 1 ? C1[1] : q == 2 ? C1[2] : C1[3];
-    double m2 = q == 0 ? C2[0] : q == 1 ? C2[1] : q == 2 ? C2[2] : C2[3];
-    const double* Q = Qsec + (lane & 15) * 4;         // M^i of this lane
-    i1 = fma(Q[0], m1, fma(Q[1], m2, i1));
-    i2 = fma(Q[2], m1, fma(Q[3], m2, i2));
-  }
-  const TL t1 = (TL)i1, t2 = (TL)i2;
+      double C1[4], C2[4];
+      C1[0] = (GPR == 4) ? c1[r] : 0.0;
+      C2[0] = (GPR == 4) ? c2[r] : 0.0;
 #pragma unroll
-  for (int n = 0; n < kL; ++n) v[n] = fma(Sel<TL>::h(sc, n, 0), t1, fma(Sel<TL>::h(sc, n, 1), t2, v[n]));
+      for (int g = 1; g < 4; ++g) {
+        if (g % GPR == 0) {
+          C1[g] = 0.0;
+          C2[g] = 0.0;
+        } else {
+          C1[g] = fma(sc.P[0], C1[g - 1], fma(sc.P[1], C2[g - 1], E1[g - 1]));
+          C2[g] = fma(sc.P[2], C1[g - 1], fma(sc.P[3], C2[g - 1], E2[g - 1]));
+        }
+      }
+      if (GPR == 4) {
+        c1[r] = fma(sc.P[0], C1[3], fma(sc.P[1], C2[3], E1[3]));
+        c2[r] = fma(sc.P[2], C1[3], fma(sc.P[3], C2[3], E2[3]));
+      }
+      const int q = lane >> 4;
+      const double m1 = q == 0 ? C1[0] : q == 1 ? C1[1] : q == 2 ? C1[2] : C1[3];
+      const double m2 = q == 0 ? C2[0] : q == 1 ? C2[1] : q == 2 ? C2[2] : C2[3];
+      const double* Q = Qsec + (lane & 15) * 4;        // M^i of this lane
+      i1[r] = fma(Q[0], m1, fma(Q[1], m2, i1[r]));
+      i2[r] = fma(Q[2], m1, fma(Q[3], m2, i2[r]));
+    }
+  }
+  VT t1, t2;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    O::set(t1, r, (typename O::S)i1[r]);
+    O::set(t2, r, (typename O::S)i2[r]);
+  }
+#pragma unroll
+  for (int n = 0; n < kL; ++n) v[n] = O::fma_(O::splat(O::h(sc, n, 0)), t1, O::fma_(O::splat(O::h(sc, n, 1)), t2, v[n]));
 }
 
 // Cooperative (whole wave) coalesced load of the 4 groups' 512-sample segments into the
-// padded chunk-major LDS tile.  seg_base[g] < 0 marks an absent group.
+// padded chunk-major LDS tile.  gbase[g] < 0 marks an absent group.
 __device__ __forceinline__ void tile_load(float* tile, const float* __restrict__ x, int lane,
                                           const int64_t (&gbase)[4], const int (&gt0)[4], int T, bool vec) {
 #pragma unroll
@@ -183,78 +227,108 @@ __device__ __forceinline__ void tile_store(const float* tile, float* __restrict_
   }
 }
 
-// One wave per workgroup.  GPR = 16-lane groups per row (1: T<=512, 2: T<=1024, 4: any T).
-template <typename TL, int GPR>
+// Load the lane's chunk of every row-set through the LDS tile (coalesced global reads, chunk-major
+// registers) and scale it by `gain`.
+template <typename VT>
+__device__ __forceinline__ void load_chunks(VT (&v)[kL], float* tile, const float* __restrict__ x, int lane,
+                                            const int64_t (&xbase)[VOps<VT>::NR][4], const int (&gt0)[4], int T,
+                                            bool vec, typename VOps<VT>::S gain) {
+  using O = VOps<VT>;
+#pragma unroll
+  for (int r = 0; r < O::NR; ++r) {
+    __syncthreads();
+    tile_load(tile, x, lane, xbase[r], gt0, T, vec);
+    __syncthreads();
+    const float* src = tile + lane * kPad;            // (q*16 + i) == lane
+#pragma unroll
+    for (int n = 0; n < kL; n += 4) {
+      const float4 f = *reinterpret_cast<const float4*>(src + n);
+      O::set(v[n], r, (typename O::S)f.x * gain);
+      O::set(v[n + 1], r, (typename O::S)f.y * gain);
+      O::set(v[n + 2], r, (typename O::S)f.z * gain);
+      O::set(v[n + 3], r, (typename O::S)f.w * gain);
+    }
+  }
+}
+
+// One wave per workgroup.  GPR = 16-lane groups per row (1: T<=512, 2: T<=1024, 4: any T);
+// the wave serves NR * 4/GPR rows.
+template <typename VT, int GPR>
 __global__ __launch_bounds__(64) void fb_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                                                 const double* __restrict__ Qtab, const float* __restrict__ x,
                                                 float* __restrict__ y, int64_t R, int C, int T, int nb, int ns,
                                                 int vec) {
+  using O = VOps<VT>;
+  constexpr int NR = O::NR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* tile = reinterpret_cast<float*>(smem_raw);                       // [4][16][kPad]
-  double* carry = reinterpret_cast<double*>(smem_raw + 4 * 16 * kPad * 4); // [nb][ns][2]  (GPR == 4)
+  float* tile = reinterpret_cast<float*>(smem_raw);                        // [4][16][kPad]
+  double* carry = reinterpret_cast<double*>(smem_raw + 4 * 16 * kPad * 4);  // [NR][nb][ns][2]  (GPR == 4)
   const int lane = threadIdx.x;
-  constexpr int RPW = 4 / GPR;                                            // rows per wave
-  const int64_t row0 = (int64_t)blockIdx.x * RPW;
+  constexpr int RPS = 4 / GPR;                                             // rows per row-set
+  const int64_t row0 = (int64_t)blockIdx.x * (RPS * NR);
   const int n_iter = (GPR == 4) ? (T + 4 * kSeg - 1) / (4 * kSeg) : 1;
 
   if (GPR == 4) {
-    for (int j = lane; j < nb * ns * 2; j += 64) carry[j] = 0.0;
+    for (int j = lane; j < NR * nb * ns * 2; j += 64) carry[j] = 0.0;
   }
 
   for (int it = 0; it < n_iter; ++it) {
-    int64_t xbase[4];
+    int64_t xbase[NR][4];
+    int64_t rowg[NR][4];
     int gt0[4];
-    int64_t rowg[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int64_t r = row0 + g / GPR;
-      rowg[g] = r;
       gt0[g] = (it * GPR + g % GPR) * kSeg;
-      xbase[g] = (r < R && gt0[g] < T) ? r * (int64_t)T : -1;
-    }
-    __syncthreads();
-    tile_load(tile, x, lane, xbase, gt0, T, vec != 0);
-    __syncthreads();
-    float xs[kL];
-    {
-      const float* src = tile + lane * kPad;          // (q*16 + i) == lane
 #pragma unroll
-      for (int n = 0; n < kL; n += 4) {
-        float4 f = *reinterpret_cast<const float4*>(src + n);
-        xs[n] = f.x; xs[n + 1] = f.y; xs[n + 2] = f.z; xs[n + 3] = f.w;
+      for (int r = 0; r < NR; ++r) {
+        const int64_t row = row0 + r * RPS + g / GPR;
+        rowg[r][g] = row;
+        xbase[r][g] = (row < R && gt0[g] < T) ? row * (int64_t)T : -1;
       }
     }
+    VT xs[kL];
+    load_chunks<VT>(xs, tile, x, lane, xbase, gt0, T, vec != 0, (typename O::S)1);
     for (int b = 0; b < nb; ++b) {
-      TL v[kL];
-      const TL g = Sel<TL>::g(bands[b]);
+      VT v[kL];
+      const VT gain = O::splat(O::g(bands[b]));
 #pragma unroll
-      for (int n = 0; n < kL; ++n) v[n] = (TL)xs[n] * g;
+      for (int n = 0; n < kL; ++n) v[n] = xs[n] * gain;
       for (int s = 0; s < ns; ++s) {
         const int bs = b * ns + s;
-        double c1 = 0.0, c2 = 0.0;
-        if (GPR == 4) { c1 = carry[bs * 2]; c2 = carry[bs * 2 + 1]; }
-        section<TL, GPR>(v, secs[bs], Qtab + (int64_t)bs * 64, lane, c1, c2);
-        if (GPR == 4 && n_iter > 1) {
-          if (lane == 0) { carry[bs * 2] = c1; carry[bs * 2 + 1] = c2; }
+        double c1[NR], c2[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          c1[r] = (GPR == 4) ? carry[(r * nb * ns + bs) * 2] : 0.0;
+          c2[r] = (GPR == 4) ? carry[(r * nb * ns + bs) * 2 + 1] : 0.0;
+        }
+        section<VT, GPR>(v, secs[bs], Qtab + (int64_t)bs * 64, lane, c1, c2);
+        if (GPR == 4 && n_iter > 1 && lane == 0) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            carry[(r * nb * ns + bs) * 2] = c1[r];
+            carry[(r * nb * ns + bs) * 2 + 1] = c2[r];
+          }
         }
       }
-      __syncthreads();                                // previous tile_store reads are done
-      {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        __syncthreads();                              // earlier readers of the tile are done
         float* dst = tile + lane * kPad;
 #pragma unroll
         for (int n = 0; n < kL; n += 4)
-          *reinterpret_cast<float4*>(dst + n) = make_float4((float)v[n], (float)v[n + 1], (float)v[n + 2], (float)v[n + 3]);
-      }
-      __syncthreads();
-      int64_t ybase[4];
+          *reinterpret_cast<float4*>(dst + n) = make_float4((float)O::get(v[n], r), (float)O::get(v[n + 1], r),
+                                                            (float)O::get(v[n + 2], r), (float)O::get(v[n + 3], r));
+        __syncthreads();
+        int64_t ybase[4];
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        if (xbase[gq] < 0) { ybase[gq] = -1; continue; }
-        const int64_t r = rowg[gq];
-        const int64_t bt = r / C, ch = r - bt * C;
-        ybase[gq] = ((bt * nb + b) * C + ch) * (int64_t)T;
+        for (int gq = 0; gq < 4; ++gq) {
+          if (xbase[r][gq] < 0) { ybase[gq] = -1; continue; }
+          const int64_t row = rowg[r][gq];
+          const int64_t bt = row / C, ch = row - bt * C;
+          ybase[gq] = ((bt * nb + b) * C + ch) * (int64_t)T;
+        }
+        tile_store(tile, y, lane, ybase, gt0, T, vec != 0);
       }
-      tile_store(tile, y, lane, ybase, gt0, T, vec != 0);
     }
   }
 }
@@ -265,82 +339,92 @@ struct FusedBands {
 };
 
 // Fused spec-S extractor for T <= 512, nperseg 64 / hop 32: after the cascade each lane
-// holds chunk i of its row; STFT frame j is chunk j-1 (window first half) followed by
+// holds chunk i of its row(s); STFT frame j is chunk j-1 (window first half) followed by
 // chunk j (second half), so every lane forms two partial windowed DFT sums per bin and
 // one DPP row_shr joins neighbours.  Only the band's own bins are evaluated.
-template <typename TL>
+template <typename VT>
 __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                                                    const float2* __restrict__ dft, const float* __restrict__ x,
                                                    float* __restrict__ feat, int64_t R, int C, int T, int nb, int ns,
                                                    int J, float scale2, FusedBands fbnd, int mode, float eps,
                                                    int vec) {
+  using O = VOps<VT>;
+  constexpr int NR = O::NR;
+  using FT = typename std::conditional<NR == 2, f2, float>::type;      // DFT arithmetic is fp32
+  using FO = VOps<FT>;
   __shared__ __attribute__((aligned(16))) float tile[4 * 16 * kPad];
   const int lane = threadIdx.x;
   const int i = lane & 15;
-  const int64_t row0 = (int64_t)blockIdx.x * 4;
-  int64_t xbase[4];
+  const int64_t row0 = (int64_t)blockIdx.x * (4 * NR);
+  int64_t xbase[NR][4];
   int gt0[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     gt0[g] = 0;
-    xbase[g] = (row0 + g < R) ? (row0 + g) * (int64_t)T : -1;
-  }
-  tile_load(tile, x, lane, xbase, gt0, T, vec != 0);
-  __syncthreads();
-  float xs[kL];
-  {
-    const float* src = tile + lane * kPad;
 #pragma unroll
-    for (int n = 0; n < kL; n += 4) {
-      float4 f = *reinterpret_cast<const float4*>(src + n);
-      xs[n] = f.x; xs[n + 1] = f.y; xs[n + 2] = f.z; xs[n + 3] = f.w;
-    }
+    for (int r = 0; r < NR; ++r) xbase[r][g] = (row0 + r * 4 + g < R) ? (row0 + r * 4 + g) * (int64_t)T : -1;
   }
-  const int64_t row = row0 + (lane >> 4);
-  const int64_t bt = row / C;
-  const int ch = (int)(row - bt * C);
+  VT xs[kL];
+  load_chunks<VT>(xs, tile, x, lane, xbase, gt0, T, vec != 0, (typename O::S)1);
   for (int b = 0; b < nb; ++b) {
-    TL v[kL];
-    const TL g = Sel<TL>::g(bands[b]);
+    VT v[kL];
+    const VT gain = O::splat(O::g(bands[b]));
 #pragma unroll
-    for (int n = 0; n < kL; ++n) v[n] = (TL)xs[n] * g;
+    for (int n = 0; n < kL; ++n) v[n] = xs[n] * gain;
     for (int s = 0; s < ns; ++s) {
-      double c1 = 0.0, c2 = 0.0;
-      section<TL, 1>(v, secs[b * ns + s], nullptr, lane, c1, c2);
+      double c1[NR], c2[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) c1[r] = c2[r] = 0.0;
+      section<VT, 1>(v, secs[b * ns + s], nullptr, lane, c1, c2);
     }
-    float vf[kL];
+    FT vf[kL];
 #pragma unroll
-    for (int n = 0; n < kL; ++n) vf[n] = (float)v[n];
-    if (T < kSeg) {                                   // the STFT sees y[0..T) then zeros, not the filter's ringing
+    for (int n = 0; n < kL; ++n) {
 #pragma unroll
-      for (int n = 0; n < kL; ++n) vf[n] = (i * kL + n < T) ? vf[n] : 0.f;
+      for (int r = 0; r < NR; ++r) {
+        float t = (float)O::get(v[n], r);
+        if (T < kSeg) t = (i * kL + n < T) ? t : 0.f;  // the STFT sees y[0..T) then zeros, not the filter's ringing
+        FO::set(vf[n], r, t);
+      }
     }
     const int klo = fbnd.klo[b], khi = fbnd.khi[b];
-    float acc = 0.f, acc16 = 0.f;
+    float acc[NR], acc16[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = acc16[r] = 0.f;
     for (int k = klo; k <= khi; ++k) {
       const float2* __restrict__ tb = dft + k * 64;
-      float p1r = 0.f, p1i = 0.f, p2r = 0.f, p2i = 0.f;
+      FT p1r = FO::splat(0.f), p1i = FO::splat(0.f), p2r = FO::splat(0.f), p2i = FO::splat(0.f);
 #pragma unroll
       for (int n = 0; n < kL; ++n) {
         const float2 ca = tb[n], cb = tb[kL + n];
-        p1r = fmaf(vf[n], ca.x, p1r);
-        p1i = fmaf(vf[n], ca.y, p1i);
-        p2r = fmaf(vf[n], cb.x, p2r);
-        p2i = fmaf(vf[n], cb.y, p2i);
+        p1r = FO::fma_(vf[n], FO::splat(ca.x), p1r);
+        p1i = FO::fma_(vf[n], FO::splat(ca.y), p1i);
+        p2r = FO::fma_(vf[n], FO::splat(cb.x), p2r);
+        p2i = FO::fma_(vf[n], FO::splat(cb.y), p2i);
       }
-      const float zr = p2r + row_shr<1>(p1r), zi = p2i + row_shr<1>(p1i);
-      const float pw = (zr * zr + zi * zi) * scale2;
-      const float pw16 = (p1r * p1r + p1i * p1i) * scale2;
-      acc += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw) : pw;
-      acc16 += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw16) : pw16;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const float a1r = FO::get(p1r, r), a1i = FO::get(p1i, r);
+        const float zr = FO::get(p2r, r) + row_shr<1>(a1r), zi = FO::get(p2i, r) + row_shr<1>(a1i);
+        const float pw = (zr * zr + zi * zi) * scale2;
+        const float pw16 = (a1r * a1r + a1i * a1i) * scale2;
+        acc[r] += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw) : pw;
+        acc16[r] += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw16) : pw16;
+      }
     }
     const float inv = khi >= klo ? 1.f / (float)(khi - klo + 1) : 0.f;
-    float r = acc * inv, r16 = acc16 * inv;
-    if (mode == ISD_BP_LOGPOWER) { r = logf(r + eps); r16 = logf(r16 + eps); }
-    if (row < R) {
-      float* o = feat + ((bt * nb + b) * C + ch) * (int64_t)J;
-      if (i < J) o[i] = r;
-      if (i == 15 && J == 17) o[16] = r16;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      float o0 = acc[r] * inv, o16 = acc16[r] * inv;
+      if (mode == ISD_BP_LOGPOWER) { o0 = logf(o0 + eps); o16 = logf(o16 + eps); }
+      const int64_t row = row0 + r * 4 + (lane >> 4);
+      if (row < R) {
+        const int64_t bt = row / C;
+        const int ch = (int)(row - bt * C);
+        float* o = feat + ((bt * nb + b) * C + ch) * (int64_t)J;
+        if (i < J) o[i] = o0;
+        if (i == 15 && J == 17) o[16] = o16;
+      }
     }
   }
 }
@@ -442,15 +526,16 @@ extern "C" int isd_fb_plan_destroy(isd_fb_plan* p) {
 
 extern "C" int isd_fb_plan_precision(const isd_fb_plan* p) { return p ? p->precision : ISD_ERR_INVALID; }
 
-template <typename TL, int GPR>
+template <typename VT, int GPR>
 static int fb_launch(const isd_fb_plan* p, const float* x, float* y, int64_t R, int C, int T, hipStream_t st) {
-  const int64_t items = cdiv(R, 4 / GPR);
+  constexpr int NR = VOps<VT>::NR;
+  const int64_t items = cdiv(R, (int64_t)NR * (4 / GPR));
   ISD_CHECK_ARG(items <= 0x7fffffffLL, "isd_fb_forward: too many rows (%lld)", (long long)R);
-  const size_t lds = 4 * 16 * kPad * 4 + (GPR == 4 ? (size_t)p->n_bands * p->n_sections * 2 * 8 : 0);
+  const size_t lds = 4 * 16 * kPad * 4 + (GPR == 4 ? (size_t)NR * p->n_bands * p->n_sections * 2 * 8 : 0);
   ISD_CHECK_ARG(lds <= 64 * 1024, "isd_fb_forward: n_bands*n_sections too large for the carry tile");
   const int vec = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  hipLaunchKernelGGL((fb_kernel<TL, GPR>), dim3((unsigned)items), dim3(64), lds, st, p->d_sec, p->d_band, p->d_Q, x,
+  hipLaunchKernelGGL((fb_kernel<VT, GPR>), dim3((unsigned)items), dim3(64), lds, st, p->d_sec, p->d_band, p->d_Q, x,
                      y, R, C, T, p->n_bands, p->n_sections, vec);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
@@ -471,13 +556,13 @@ extern "C" int isd_fb_forward(const isd_fb_plan* p, const float* x, float* y, in
   return f64 ? fb_launch<double, 4>(p, x, y, R, (int)C, (int)T, st) : fb_launch<float, 4>(p, x, y, R, (int)C, (int)T, st);
 }
 
-template <typename TL>
+template <typename VT>
 static int fused_launch(const isd_fb_plan* fb, const isd_stft_plan* st, const float* x, float* feat, int64_t R, int C,
                         const FusedBands& fbnd, int mode, float eps, hipStream_t stream) {
-  const int64_t items = cdiv(R, 4);
+  const int64_t items = cdiv(R, 4 * VOps<VT>::NR);
   ISD_CHECK_ARG(items <= 0x7fffffffLL, "isd_features_fused: too many rows (%lld)", (long long)R);
   const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  hipLaunchKernelGGL((fused_kernel<TL>), dim3((unsigned)items), dim3(64), 0, stream, fb->d_sec, fb->d_band, st->d_dft,
+  hipLaunchKernelGGL((fused_kernel<VT>), dim3((unsigned)items), dim3(64), 0, stream, fb->d_sec, fb->d_band, st->d_dft,
                      x, feat, R, C, st->T, fb->n_bands, fb->n_sections, st->J, st->scale * st->scale, fbnd, mode, eps,
                      vec);
   ISD_LAUNCH_CHECK();

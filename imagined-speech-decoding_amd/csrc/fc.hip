@@ -138,18 +138,23 @@ __global__ void linear_wgrad_reduce_kernel(const float* __restrict__ part, float
 }
 
 // Mean over tokens, softmax cross-entropy (mean over the global batch), gradient and argmax.
-// One workgroup: the tensors are tiny ([B][n_tok][n_cls], n_cls <= 32) and the loss sum stays deterministic.
+// One thread per trial; per-block partial loss sums go to `part` and the LAST block (agent-scope
+// ticket) adds them in block order, so the loss is deterministic without a second launch.
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ lt, const void* __restrict__ labels,
                                                          int label_bytes, float* __restrict__ lmean,
                                                          float* __restrict__ loss, float* __restrict__ dlt,
                                                          int64_t* __restrict__ pred, int64_t B, int n_tok, int n_cls,
-                                                         float grad_scale) {
+                                                         float grad_scale, float* __restrict__ part,
+                                                         unsigned int* __restrict__ ticket) {
   __shared__ float red[256];
+  __shared__ bool last;
   float lsum = 0.f;
-  for (int64_t b = threadIdx.x; b < B; b += 256) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b < B) {
     float v[32];
     float mx = -INFINITY;
     int am = 0;
+#pragma unroll 1
     for (int c = 0; c < n_cls; ++c) {
       float s = 0.f;
       for (int n = 0; n < n_tok; ++n) s += lt[(b * n_tok + n) * n_cls + c];
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
       for (int c = 0; c < n_cls; ++c) se += expf(v[c] - mx);
       const float lse = mx + logf(se);
       const int64_t yb = label_bytes == 1 ? (int64_t)((const unsigned char*)labels)[b] : ((const int64_t*)labels)[b];
-      lsum += lse - v[yb];
+      lsum = lse - v[yb];
       if (dlt) {
         for (int c = 0; c < n_cls; ++c) {
           const float g = (expf(v[c] - lse) - (c == yb ? 1.f : 0.f)) * grad_scale / (float)n_tok;
@@ -173,14 +178,27 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
       }
     }
   }
-  if (loss) {
-    red[threadIdx.x] = lsum;
+  if (!loss) return;
+  red[threadIdx.x] = lsum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-      __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&part[blockIdx.x], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (t == gridDim.x - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      float tot = 0.f;
+      for (unsigned int k = 0; k < gridDim.x; ++k)
+        tot += __hip_atomic_load(&part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *loss = tot * grad_scale;
     }
-    if (threadIdx.x == 0) *loss = red[0] * grad_scale;
   }
 }
 
@@ -260,16 +278,31 @@ extern "C" int isd_linear_backward(const float* x, const float* w, const float* 
   return ISD_OK;
 }
 
+extern "C" int64_t isd_softmax_ce_workspace_bytes(int64_t B) {
+  if (B < 0) return ISD_ERR_INVALID;
+  return 256 + 4 * cdiv(B > 0 ? B : 1, 256);
+}
+
 extern "C" int isd_softmax_ce(const float* logits_tok, const void* labels, int label_bytes, float* logits_mean,
                               float* loss, float* dlogits_tok, int64_t* pred, int64_t B, int n_tok, int n_cls,
-                              float grad_scale, void* stream) {
+                              float grad_scale, void* workspace, void* stream) {
   ISD_CHECK_ARG(B >= 0 && n_tok >= 1 && n_cls >= 1 && n_cls <= 32, "isd_softmax_ce: bad shape B=%lld n_tok=%d n_cls=%d",
                 (long long)B, n_tok, n_cls);
   ISD_CHECK_ARG(!labels || label_bytes == 1 || label_bytes == 8, "isd_softmax_ce: labels must be uint8 or int64");
   ISD_CHECK_ARG(B == 0 || logits_tok, "isd_softmax_ce: null logits");
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits_tok, labels, label_bytes,
-                     logits_mean, labels ? loss : nullptr, labels ? dlogits_tok : nullptr, pred, B, n_tok, n_cls,
-                     grad_scale);
+  ISD_CHECK_ARG(cdiv(B, 256) <= 0x7fffffffLL, "isd_softmax_ce: B too large");
+  hipStream_t st = (hipStream_t)stream;
+  const bool want_loss = labels && loss;
+  ISD_CHECK_ARG(!want_loss || workspace, "isd_softmax_ce: the loss reduction needs isd_softmax_ce_workspace_bytes(B) bytes");
+  if (B == 0) {
+    if (want_loss) ISD_HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
+    return ISD_OK;
+  }
+  float* scratch = want_loss ? (float*)workspace : nullptr;
+  if (scratch) ISD_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(unsigned int), st));   // arrival ticket
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, logits_tok, labels, label_bytes,
+                     logits_mean, want_loss ? loss : nullptr, labels ? dlogits_tok : nullptr, pred, B, n_tok, n_cls,
+                     grad_scale, scratch ? scratch + 64 : nullptr, reinterpret_cast<unsigned int*>(scratch));
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }

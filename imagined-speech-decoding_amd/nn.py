@@ -158,10 +158,12 @@ class _SoftmaxCEFn(torch.autograd.Function):
             labels = labels.long()
         loss = torch.empty((), dtype=torch.float32, device=lt.device)
         dlt = torch.empty_like(lt)
+        ws = torch.empty(int(_lib.lib().isd_softmax_ce_workspace_bytes(B)) // 4 + 1, dtype=torch.float32,
+                         device=lt.device)
         with torch.cuda.device(lt.device):
             _lib.check(_lib.lib().isd_softmax_ce(lt.data_ptr(), labels.data_ptr(), labels.element_size(), 0,
                                                  loss.data_ptr(), dlt.data_ptr(), 0, B, n_tok, n_cls,
-                                                 float(grad_scale), _stream()))
+                                                 float(grad_scale), ws.data_ptr(), _stream()))
         ctx.save_for_backward(dlt)
         return loss
 
@@ -193,7 +195,7 @@ def token_mean_predict(logits_tok):
     pred = torch.empty((B,), dtype=torch.int64, device=lt.device)
     with torch.cuda.device(lt.device):
         _lib.check(_lib.lib().isd_softmax_ce(lt.data_ptr(), 0, 0, lm.data_ptr(), 0, 0, pred.data_ptr(), B, n_tok,
-                                             n_cls, 1.0, _stream()))
+                                             n_cls, 1.0, 0, _stream()))
     return lm, pred
 
 

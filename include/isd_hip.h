@@ -167,10 +167,13 @@ int isd_linear_backward(const float* x, const float* w, const float* dy, const f
  * logits_tok [B][n_tok][n_cls]; grad_scale = 1 / global batch size (1/B on one GPU);
  * loss receives grad_scale * sum_b CE_b; dlogits_tok gets d loss / d logits_tok.
  * labels == NULL: inference (no loss / gradient).  Any output pointer may be NULL.
+ * workspace: isd_softmax_ce_workspace_bytes(B) bytes of scratch (per-block partial sums + an
+ * arrival ticket; contents need not be initialised); only needed when the loss is requested.
  * ---------------------------------------------------------------------- */
+int64_t isd_softmax_ce_workspace_bytes(int64_t B);
 int isd_softmax_ce(const float* logits_tok, const void* labels, int label_bytes, float* logits_mean,
                    float* loss, float* dlogits_tok, int64_t* pred, int64_t B, int n_tok, int n_cls,
-                   float grad_scale, void* stream);
+                   float grad_scale, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }
