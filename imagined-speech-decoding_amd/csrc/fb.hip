@@ -35,6 +35,7 @@ struct FbSec {                  // constants of one (band, section); wave-unifor
   double hd[kL][2];             // zero-input response seen at the output: row 0 of A^n
   float a1f, a2f;
   float hf[kL][2];
+  float hp[2][kL];              // same table, structure-of-arrays: (h[n], h[n+1]) pairs feed v_pk_fma_f32
 };
 
 struct FbBand {
@@ -66,6 +67,10 @@ template <typename VT> struct VOps;
 template <> struct VOps<float> {
   using S = float;
   static constexpr int NR = 1;
+  // chunk container: 16 register PAIRS, so adjacent samples feed v_pk_fma_f32 without shuffling
+  typedef f2 Arr[kL / 2];
+  static __device__ __forceinline__ float at(const Arr& a, int n) { return (n & 1) ? a[n >> 1].y : a[n >> 1].x; }
+  static __device__ __forceinline__ void put(Arr& a, int n, float s) { if (n & 1) a[n >> 1].y = s; else a[n >> 1].x = s; }
   static __device__ __forceinline__ float splat(float s) { return s; }
   static __device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
   static __device__ __forceinline__ float get(float v, int) { return v; }
@@ -78,6 +83,9 @@ template <> struct VOps<float> {
 template <> struct VOps<f2> {
   using S = float;
   static constexpr int NR = 2;
+  typedef f2 Arr[kL];
+  static __device__ __forceinline__ f2 at(const Arr& a, int n) { return a[n]; }
+  static __device__ __forceinline__ void put(Arr& a, int n, f2 s) { a[n] = s; }
   static __device__ __forceinline__ f2 splat(float s) { return (f2){s, s}; }
   static __device__ __forceinline__ f2 fma_(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
   static __device__ __forceinline__ float get(f2 v, int r) { return r ? v.y : v.x; }
@@ -90,6 +98,9 @@ template <> struct VOps<f2> {
 template <> struct VOps<double> {
   using S = double;
   static constexpr int NR = 1;
+  typedef double Arr[kL];
+  static __device__ __forceinline__ double at(const Arr& a, int n) { return a[n]; }
+  static __device__ __forceinline__ void put(Arr& a, int n, double s) { a[n] = s; }
   static __device__ __forceinline__ double splat(double s) { return s; }
   static __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
   static __device__ __forceinline__ double get(double v, int) { return v; }
@@ -110,19 +121,19 @@ __device__ __forceinline__ void scan_step(double& e1, double& e2, const double* 
 // One biquad section over the lane's chunk(s), including the cross-chunk state fix-up.
 // c1/c2[r]: incoming state of the wave's first group for row-set r (GPR == 4 loop carry), updated.
 template <typename VT, int GPR>
-__device__ __forceinline__ void section(VT (&v)[kL], const FbSec& sc, const double* __restrict__ Qsec, int lane,
-                                        double (&c1)[VOps<VT>::NR], double (&c2)[VOps<VT>::NR]) {
+__device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& sc, const double* __restrict__ Qsec,
+                                        int lane, double (&c1)[VOps<VT>::NR], double (&c2)[VOps<VT>::NR]) {
   using O = VOps<VT>;
   constexpr int NR = O::NR;
   const VT na1 = O::splat(-O::a1(sc)), na2 = O::splat(-O::a2(sc));
   VT s1 = O::splat(0), s2 = O::splat(0);
 #pragma unroll
   for (int n = 0; n < kL; ++n) {
-    const VT x = v[n];
+    const VT x = O::at(v, n);
     const VT y = x + s1;
     s1 = O::fma_(na1, y, s2);
     s2 = O::fma_(na2, y, -x);
-    v[n] = y;
+    O::put(v, n, y);
   }
   double i1[NR], i2[NR];
 #pragma unroll
@@ -173,8 +184,18 @@ __device__ __forceinline__ void section(VT (&v)[kL], const FbSec& sc, const doub
     O::set(t1, r, (typename O::S)i1[r]);
     O::set(t2, r, (typename O::S)i2[r]);
   }
+  if constexpr (std::is_same<VT, float>::value) {
+    // adjacent samples share one v_pk_fma_f32 (unpacked v_fma_f32 issues at half the fp32 peak)
+    const f2 T1 = {t1, t1}, T2 = {t2, t2};
 #pragma unroll
-  for (int n = 0; n < kL; ++n) v[n] = O::fma_(O::splat(O::h(sc, n, 0)), t1, O::fma_(O::splat(O::h(sc, n, 1)), t2, v[n]));
+    for (int j = 0; j < kL / 2; ++j)
+      v[j] = __builtin_elementwise_fma((f2){sc.hp[0][2 * j], sc.hp[0][2 * j + 1]}, T1,
+                                       __builtin_elementwise_fma((f2){sc.hp[1][2 * j], sc.hp[1][2 * j + 1]}, T2, v[j]));
+  } else {
+#pragma unroll
+    for (int n = 0; n < kL; ++n)
+      v[n] = O::fma_(O::splat(O::h(sc, n, 0)), t1, O::fma_(O::splat(O::h(sc, n, 1)), t2, v[n]));
+  }
 }
 
 // Cooperative (whole wave) coalesced load of the 4 groups' 512-sample segments into the
@@ -230,9 +251,9 @@ __device__ __forceinline__ void tile_store(const float* tile, float* __restrict_
 // Load the lane's chunk of every row-set through the LDS tile (coalesced global reads, chunk-major
 // registers) and scale it by `gain`.
 template <typename VT>
-__device__ __forceinline__ void load_chunks(VT (&v)[kL], float* tile, const float* __restrict__ x, int lane,
-                                            const int64_t (&xbase)[VOps<VT>::NR][4], const int (&gt0)[4], int T,
-                                            bool vec, typename VOps<VT>::S gain) {
+__device__ __forceinline__ void load_chunks(typename VOps<VT>::Arr& v, float* tile, const float* __restrict__ x,
+                                            int lane, const int64_t (&xbase)[VOps<VT>::NR][4], const int (&gt0)[4],
+                                            int T, bool vec) {
   using O = VOps<VT>;
 #pragma unroll
   for (int r = 0; r < O::NR; ++r) {
@@ -243,10 +264,17 @@ __device__ __forceinline__ void load_chunks(VT (&v)[kL], float* tile, const floa
 #pragma unroll
     for (int n = 0; n < kL; n += 4) {
       const float4 f = *reinterpret_cast<const float4*>(src + n);
-      O::set(v[n], r, (typename O::S)f.x * gain);
-      O::set(v[n + 1], r, (typename O::S)f.y * gain);
-      O::set(v[n + 2], r, (typename O::S)f.z * gain);
-      O::set(v[n + 3], r, (typename O::S)f.w * gain);
+      if constexpr (O::NR == 1) {
+        O::put(v, n, (typename O::S)f.x);
+        O::put(v, n + 1, (typename O::S)f.y);
+        O::put(v, n + 2, (typename O::S)f.z);
+        O::put(v, n + 3, (typename O::S)f.w);
+      } else {
+        O::set(v[n], r, f.x);
+        O::set(v[n + 1], r, f.y);
+        O::set(v[n + 2], r, f.z);
+        O::set(v[n + 3], r, f.w);
+      }
     }
   }
 }
@@ -286,13 +314,14 @@ __global__ __launch_bounds__(64) void fb_kernel(const FbSec* __restrict__ secs, 
         xbase[r][g] = (row < R && gt0[g] < T) ? row * (int64_t)T : -1;
       }
     }
-    VT xs[kL];
-    load_chunks<VT>(xs, tile, x, lane, xbase, gt0, T, vec != 0, (typename O::S)1);
+    typename O::Arr xs;
+    load_chunks<VT>(xs, tile, x, lane, xbase, gt0, T, vec != 0);
+    constexpr int NA = sizeof(typename O::Arr) / sizeof(xs[0]);
     for (int b = 0; b < nb; ++b) {
-      VT v[kL];
-      const VT gain = O::splat(O::g(bands[b]));
+      typename O::Arr v;
+      const auto gain = O::g(bands[b]);
 #pragma unroll
-      for (int n = 0; n < kL; ++n) v[n] = xs[n] * gain;
+      for (int n = 0; n < NA; ++n) v[n] = xs[n] * gain;
       for (int s = 0; s < ns; ++s) {
         const int bs = b * ns + s;
         double c1[NR], c2[NR];
@@ -316,8 +345,9 @@ __global__ __launch_bounds__(64) void fb_kernel(const FbSec* __restrict__ secs, 
         float* dst = tile + lane * kPad;
 #pragma unroll
         for (int n = 0; n < kL; n += 4)
-          *reinterpret_cast<float4*>(dst + n) = make_float4((float)O::get(v[n], r), (float)O::get(v[n + 1], r),
-                                                            (float)O::get(v[n + 2], r), (float)O::get(v[n + 3], r));
+          *reinterpret_cast<float4*>(dst + n) =
+              make_float4((float)O::get(O::at(v, n), r), (float)O::get(O::at(v, n + 1), r),
+                          (float)O::get(O::at(v, n + 2), r), (float)O::get(O::at(v, n + 3), r));
         __syncthreads();
         int64_t ybase[4];
 #pragma unroll
@@ -364,28 +394,33 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
 #pragma unroll
     for (int r = 0; r < NR; ++r) xbase[r][g] = (row0 + r * 4 + g < R) ? (row0 + r * 4 + g) * (int64_t)T : -1;
   }
-  VT xs[kL];
-  load_chunks<VT>(xs, tile, x, lane, xbase, gt0, T, vec != 0, (typename O::S)1);
+  typename O::Arr xs;
+  load_chunks<VT>(xs, tile, x, lane, xbase, gt0, T, vec != 0);
+  constexpr int NA = sizeof(typename O::Arr) / sizeof(xs[0]);
   for (int b = 0; b < nb; ++b) {
-    VT v[kL];
-    const VT gain = O::splat(O::g(bands[b]));
+    typename O::Arr v;
+    const auto gain = O::g(bands[b]);
 #pragma unroll
-    for (int n = 0; n < kL; ++n) v[n] = xs[n] * gain;
+    for (int n = 0; n < NA; ++n) v[n] = xs[n] * gain;
     for (int s = 0; s < ns; ++s) {
       double c1[NR], c2[NR];
 #pragma unroll
       for (int r = 0; r < NR; ++r) c1[r] = c2[r] = 0.0;
       section<VT, 1>(v, secs[b * ns + s], nullptr, lane, c1, c2);
     }
-    FT vf[kL];
+    typename FO::Arr vf;                              // fp32 copy for the DFT (aliases v when VT is fp32)
 #pragma unroll
     for (int n = 0; n < kL; ++n) {
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        float t = (float)O::get(v[n], r);
-        if (T < kSeg) t = (i * kL + n < T) ? t : 0.f;  // the STFT sees y[0..T) then zeros, not the filter's ringing
-        FO::set(vf[n], r, t);
+      if constexpr (NR == 1) {
+        FO::put(vf, n, (float)O::at(v, n));
+      } else {
+        vf[n] = v[n];
       }
+    }
+    if (T < kSeg) {                                   // the STFT sees y[0..T) then zeros, not the filter's ringing
+#pragma unroll
+      for (int n = 0; n < kL; ++n)
+        if (i * kL + n >= T) FO::put(vf, n, FO::splat(0.f));
     }
     const int klo = fbnd.klo[b], khi = fbnd.khi[b];
     float acc[NR], acc16[NR];
@@ -393,21 +428,41 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
     for (int r = 0; r < NR; ++r) acc[r] = acc16[r] = 0.f;
     for (int k = klo; k <= khi; ++k) {
       const float2* __restrict__ tb = dft + k * 64;
-      FT p1r = FO::splat(0.f), p1i = FO::splat(0.f), p2r = FO::splat(0.f), p2i = FO::splat(0.f);
+      float a1r[NR], a1i[NR], a2r[NR], a2i[NR];
+      if constexpr (NR == 1) {
+        // one row: pack (re, im) of each partial sum in a register pair -> v_pk_fma_f32
+        f2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
 #pragma unroll
-      for (int n = 0; n < kL; ++n) {
-        const float2 ca = tb[n], cb = tb[kL + n];
-        p1r = FO::fma_(vf[n], FO::splat(ca.x), p1r);
-        p1i = FO::fma_(vf[n], FO::splat(ca.y), p1i);
-        p2r = FO::fma_(vf[n], FO::splat(cb.x), p2r);
-        p2i = FO::fma_(vf[n], FO::splat(cb.y), p2i);
+        for (int j = 0; j < kL / 2; ++j) {
+          const f2 pr = vf[j];                                            // samples 2j, 2j+1; splats fold into op_sel
+          const f2 x0 = __builtin_shufflevector(pr, pr, 0, 0), x1 = __builtin_shufflevector(pr, pr, 1, 1);
+          const float2 ca0 = tb[2 * j], cb0 = tb[kL + 2 * j], ca1 = tb[2 * j + 1], cb1 = tb[kL + 2 * j + 1];
+          p1 = __builtin_elementwise_fma(x0, (f2){ca0.x, ca0.y}, p1);
+          p2 = __builtin_elementwise_fma(x0, (f2){cb0.x, cb0.y}, p2);
+          p1 = __builtin_elementwise_fma(x1, (f2){ca1.x, ca1.y}, p1);
+          p2 = __builtin_elementwise_fma(x1, (f2){cb1.x, cb1.y}, p2);
+        }
+        a1r[0] = p1.x; a1i[0] = p1.y; a2r[0] = p2.x; a2i[0] = p2.y;
+      } else {
+        FT p1r = FO::splat(0.f), p1i = FO::splat(0.f), p2r = FO::splat(0.f), p2i = FO::splat(0.f);
+#pragma unroll
+        for (int n = 0; n < kL; ++n) {
+          const float2 ca = tb[n], cb = tb[kL + n];
+          p1r = FO::fma_(vf[n], FO::splat(ca.x), p1r);
+          p1i = FO::fma_(vf[n], FO::splat(ca.y), p1i);
+          p2r = FO::fma_(vf[n], FO::splat(cb.x), p2r);
+          p2i = FO::fma_(vf[n], FO::splat(cb.y), p2i);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          a1r[r] = FO::get(p1r, r); a1i[r] = FO::get(p1i, r); a2r[r] = FO::get(p2r, r); a2i[r] = FO::get(p2i, r);
+        }
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        const float a1r = FO::get(p1r, r), a1i = FO::get(p1i, r);
-        const float zr = FO::get(p2r, r) + row_shr<1>(a1r), zi = FO::get(p2i, r) + row_shr<1>(a1i);
+        const float zr = a2r[r] + row_shr<1>(a1r[r]), zi = a2i[r] + row_shr<1>(a1i[r]);
         const float pw = (zr * zr + zi * zi) * scale2;
-        const float pw16 = (a1r * a1r + a1i * a1i) * scale2;
+        const float pw16 = (a1r[r] * a1r[r] + a1i[r] * a1i[r]) * scale2;
         acc[r] += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw) : pw;
         acc16[r] += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw16) : pw16;
       }
@@ -470,6 +525,8 @@ extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections
         sc.hd[k][1] = An[1];
         sc.hf[k][0] = (float)An[0];
         sc.hf[k][1] = (float)An[1];
+        sc.hp[0][k] = (float)An[0];
+        sc.hp[1][k] = (float)An[1];
         mat2_mul(A, An, An);
       }
       double Mk[4];
