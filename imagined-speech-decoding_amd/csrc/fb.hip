@@ -368,6 +368,90 @@ struct FusedBands {
   int khi[kMaxBands];
 };
 
+// Windowed DFT of the band's own bins over the lane's chunk (register pairs) and the reduction to
+// band magnitude / power.  Frame j of the row is chunk j-1 (first window half, table entries 0..31)
+// followed by chunk j (second half, 32..63): every lane forms both partial sums, `row_shr:1` joins
+// neighbours.  o0 = frame (lane & 15), o16 = frame 16 (meaningful on lane 15).
+__device__ __forceinline__ void band_reduce_pairs(const f2 (&vf)[kL / 2], const float2* __restrict__ dft, int klo,
+                                                  int khi, bool mine_lo_hi_valid, int my_klo, int my_khi, float scale2,
+                                                  int mode, float& o0, float& o16) {
+  float acc = 0.f, acc16 = 0.f;
+  for (int k = klo; k <= khi; ++k) {
+    const float2* __restrict__ tb = dft + k * 64;
+    f2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < kL / 2; ++j) {
+      const f2 pr = vf[j];                                              // samples 2j, 2j+1
+      const f2 x0 = __builtin_shufflevector(pr, pr, 0, 0), x1 = __builtin_shufflevector(pr, pr, 1, 1);
+      const float2 ca0 = tb[2 * j], cb0 = tb[kL + 2 * j], ca1 = tb[2 * j + 1], cb1 = tb[kL + 2 * j + 1];
+      p1 = __builtin_elementwise_fma(x0, (f2){ca0.x, ca0.y}, p1);
+      p2 = __builtin_elementwise_fma(x0, (f2){cb0.x, cb0.y}, p2);
+      p1 = __builtin_elementwise_fma(x1, (f2){ca1.x, ca1.y}, p1);
+      p2 = __builtin_elementwise_fma(x1, (f2){cb1.x, cb1.y}, p2);
+    }
+    const float zr = p2.x + row_shr<1>(p1.x), zi = p2.y + row_shr<1>(p1.y);
+    float pw = (zr * zr + zi * zi) * scale2;
+    float pw16 = (p1.x * p1.x + p1.y * p1.y) * scale2;
+    if (mode == ISD_BP_MAGNITUDE) { pw = sqrtf(pw); pw16 = sqrtf(pw16); }
+    const bool in = !mine_lo_hi_valid || (k >= my_klo && k <= my_khi);
+    acc += in ? pw : 0.f;
+    acc16 += in ? pw16 : 0.f;
+  }
+  o0 = acc;
+  o16 = acc16;
+}
+
+// Band aggregation of materialised filtered signals y[B][nb][C][T] (nperseg 64 / hop 32, T <= 512):
+// same chunk layout as the filterbank (coalesced float4 loads through the LDS tile), direct DFT of
+// each row's own band bins.  HBM-bound: reads nb*C*T*4 bytes per trial, writes nb*C*J*4.
+__global__ __launch_bounds__(64) void bandpower_direct_kernel(const float2* __restrict__ dft,
+                                                              const float* __restrict__ y, float* __restrict__ feat,
+                                                              int64_t R, int C, int T, int nb, int J, float scale2,
+                                                              FusedBands fbnd, int mode, float eps, int vec) {
+  using O = VOps<float>;
+  __shared__ __attribute__((aligned(16))) float tile[4 * 16 * kPad];
+  const int lane = threadIdx.x;
+  const int i = lane & 15;
+  const int64_t row0 = (int64_t)blockIdx.x * 4;
+  int64_t xbase[1][4];
+  int gt0[4];
+  int wlo = 1 << 30, whi = -1;                                  // wave-uniform union of the 4 rows' bin ranges
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    gt0[g] = 0;
+    const int64_t r = row0 + g;
+    xbase[0][g] = (r < R) ? r * (int64_t)T : -1;
+    if (r < R) {
+      const int band = (int)((r / C) % nb);
+      if (fbnd.khi[band] >= fbnd.klo[band]) {
+        wlo = fbnd.klo[band] < wlo ? fbnd.klo[band] : wlo;
+        whi = fbnd.khi[band] > whi ? fbnd.khi[band] : whi;
+      }
+    }
+  }
+  typename O::Arr vf;
+  load_chunks<float>(vf, tile, y, lane, xbase, gt0, T, vec != 0);
+  if (T < kSeg) {
+#pragma unroll
+    for (int n = 0; n < kL; ++n)
+      if (i * kL + n >= T) O::put(vf, n, 0.f);
+  }
+  const int64_t row = row0 + (lane >> 4);
+  const int band = (int)((row / C) % nb);
+  const int klo = fbnd.klo[band], khi = fbnd.khi[band];
+  float o0, o16;
+  band_reduce_pairs(vf, dft, wlo, whi, true, klo, khi, scale2, mode, o0, o16);
+  const float inv = khi >= klo ? 1.f / (float)(khi - klo + 1) : 0.f;
+  o0 *= inv;
+  o16 *= inv;
+  if (mode == ISD_BP_LOGPOWER) { o0 = logf(o0 + eps); o16 = logf(o16 + eps); }
+  if (row < R) {
+    float* o = feat + row * (int64_t)J;                         // feat has the same [B][nb][C] row order as y
+    if (i < J) o[i] = o0;
+    if (i == 15 && J == 17) o[16] = o16;
+  }
+}
+
 // Fused spec-S extractor for T <= 512, nperseg 64 / hop 32: after the cascade each lane
 // holds chunk i of its row(s); STFT frame j is chunk j-1 (window first half) followed by
 // chunk j (second half), so every lane forms two partial windowed DFT sums per bin and
@@ -426,24 +510,11 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
     float acc[NR], acc16[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = acc16[r] = 0.f;
-    for (int k = klo; k <= khi; ++k) {
-      const float2* __restrict__ tb = dft + k * 64;
-      float a1r[NR], a1i[NR], a2r[NR], a2i[NR];
-      if constexpr (NR == 1) {
-        // one row: pack (re, im) of each partial sum in a register pair -> v_pk_fma_f32
-        f2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < kL / 2; ++j) {
-          const f2 pr = vf[j];                                            // samples 2j, 2j+1; splats fold into op_sel
-          const f2 x0 = __builtin_shufflevector(pr, pr, 0, 0), x1 = __builtin_shufflevector(pr, pr, 1, 1);
-          const float2 ca0 = tb[2 * j], cb0 = tb[kL + 2 * j], ca1 = tb[2 * j + 1], cb1 = tb[kL + 2 * j + 1];
-          p1 = __builtin_elementwise_fma(x0, (f2){ca0.x, ca0.y}, p1);
-          p2 = __builtin_elementwise_fma(x0, (f2){cb0.x, cb0.y}, p2);
-          p1 = __builtin_elementwise_fma(x1, (f2){ca1.x, ca1.y}, p1);
-          p2 = __builtin_elementwise_fma(x1, (f2){cb1.x, cb1.y}, p2);
-        }
-        a1r[0] = p1.x; a1i[0] = p1.y; a2r[0] = p2.x; a2i[0] = p2.y;
-      } else {
+    if constexpr (NR == 1) {
+      band_reduce_pairs(vf, dft, klo, khi, false, 0, 0, scale2, mode, acc[0], acc16[0]);
+    } else {
+      for (int k = klo; k <= khi; ++k) {
+        const float2* __restrict__ tb = dft + k * 64;
         FT p1r = FO::splat(0.f), p1i = FO::splat(0.f), p2r = FO::splat(0.f), p2i = FO::splat(0.f);
 #pragma unroll
         for (int n = 0; n < kL; ++n) {
@@ -455,16 +526,13 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-          a1r[r] = FO::get(p1r, r); a1i[r] = FO::get(p1i, r); a2r[r] = FO::get(p2r, r); a2i[r] = FO::get(p2i, r);
+          const float a1r = FO::get(p1r, r), a1i = FO::get(p1i, r);
+          const float zr = FO::get(p2r, r) + row_shr<1>(a1r), zi = FO::get(p2i, r) + row_shr<1>(a1i);
+          const float pw = (zr * zr + zi * zi) * scale2;
+          const float pw16 = (a1r * a1r + a1i * a1i) * scale2;
+          acc[r] += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw) : pw;
+          acc16[r] += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw16) : pw16;
         }
-      }
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const float zr = a2r[r] + row_shr<1>(a1r[r]), zi = a2i[r] + row_shr<1>(a1i[r]);
-        const float pw = (zr * zr + zi * zi) * scale2;
-        const float pw16 = (a1r[r] * a1r[r] + a1i[r] * a1i[r]) * scale2;
-        acc[r] += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw) : pw;
-        acc16[r] += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw16) : pw16;
       }
     }
     const float inv = khi >= klo ? 1.f / (float)(khi - klo + 1) : 0.f;
@@ -646,4 +714,17 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
   hipStream_t s = (hipStream_t)stream;
   return fb->precision == ISD_FB_F64 ? fused_launch<double>(fb, st, x, feat, B * C, (int)C, fbnd, mode, eps, s)
                                      : fused_launch<float>(fb, st, x, feat, B * C, (int)C, fbnd, mode, eps, s);
+}
+
+int isd::bandpower_direct(const isd_stft_plan* st, const float* y, float* feat, int64_t R, int C, int nb,
+                          const int* klo, const int* khi, int mode, float eps, hipStream_t stream) {
+  FusedBands fbnd = {};
+  for (int b = 0; b < nb; ++b) { fbnd.klo[b] = klo[b]; fbnd.khi[b] = khi[b]; }
+  const int64_t items = cdiv(R, 4);
+  ISD_CHECK_ARG(items <= 0x7fffffffLL, "isd_stft_bandpower: too many rows (%lld)", (long long)R);
+  const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  hipLaunchKernelGGL(bandpower_direct_kernel, dim3((unsigned)items), dim3(64), 0, stream, st->d_dft, y, feat, R, C,
+                     st->T, nb, st->J, st->scale * st->scale, fbnd, mode, eps, vec);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
 }

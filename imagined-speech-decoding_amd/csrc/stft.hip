@@ -224,6 +224,9 @@ extern "C" int isd_stft_bandpower(const isd_stft_plan* p, const float* y, float*
   int rc = fill_band_args(p, n_bands, klo, khi, ba.klo, ba.khi, "isd_stft_bandpower");
   if (rc) return rc;
   if (B == 0) return ISD_OK;
+  if (p->n == 64 && p->hop == 32 && p->T <= 512 && p->d_dft && n_bands_in == n_bands)
+    return bandpower_direct(p, y, feat, B * n_bands * C, (int)C, n_bands, ba.klo, ba.khi, mode, eps,
+                            (hipStream_t)stream);
   return stft_launch(p, 1, y, feat, B * n_bands_in * C, (int)C, n_bands_in, n_bands, ba, mode, eps,
                      (hipStream_t)stream);
 }

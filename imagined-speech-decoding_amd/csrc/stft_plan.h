@@ -12,6 +12,9 @@ struct isd_stft_plan {
 
 namespace isd {
 constexpr int kMaxBands = 64;
+// direct-DFT band aggregation (fb.hip) for nperseg 64 / hop 32 / T <= 512, per-band input
+int bandpower_direct(const isd_stft_plan* st, const float* y, float* feat, int64_t R, int C, int nb, const int* klo,
+                     const int* khi, int mode, float eps, hipStream_t stream);
 int fill_band_args(const isd_stft_plan* p, int n_bands, const int* klo, const int* khi, int* oklo, int* okhi,
                    const char* who);
 }  // namespace isd
