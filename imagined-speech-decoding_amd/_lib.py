@@ -55,6 +55,13 @@ SIGNATURES = {
     "isd_linear_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "isd_linear_workspace_bytes": (_i64, [_i64, _i, _i]),
     "isd_linear_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
+    "isd_eegnet_plan_create": (_i, [C.POINTER(_p), _i, _i, _i, _i]),
+    "isd_eegnet_plan_destroy": (_i, [_p]),
+    "isd_eegnet_param_count": (_i64, [_p]),
+    "isd_eegnet_buffer_count": (_i64, [_p]),
+    "isd_eegnet_workspace_bytes": (_i64, [_p, _i64]),
+    "isd_eegnet_forward": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _f, C.c_uint64, _p]),
+    "isd_eegnet_backward": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, C.c_uint64, _p]),
     "isd_softmax_ce_workspace_bytes": (_i64, [_i64]),
     "isd_softmax_ce": (_i, [_p, _p, _i, _p, _p, _p, _p, _i64, _i, _i, _f, _p, _p]),
 }

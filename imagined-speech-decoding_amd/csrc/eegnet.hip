@@ -1,0 +1,923 @@
+// EEGNet_Encoder (reference: src/fast/models/fast.py:122-167) forward + backward on gfx950.
+//
+//   temporal Conv2d(1->8,(1,K),pad K/2) -> BN1 -> depthwise spatial Conv2d(8->16,(C,1),groups 8) -> BN2 -> ELU
+//   -> AvgPool(1,4) -> depthwise Conv2d(16,(1,16),pad 8) -> pointwise 1x1 -> BN3 -> ELU -> AvgPool(1,8)
+//   -> AdaptiveAvgPool -> Linear(16 -> F).
+//
+// The reference materialises the temporal-conv output a1[B,8,C,T+1] (8x the input; 34 GB at the stress
+// configuration).  Here it is never formed.  The temporal and spatial convolutions commute and BN1 is an
+// affine map per filter, so
+//     z[b,g,t]  = sum_c Ws[g,c] x[b,c,t]                       (16 rows instead of 8*C)
+//     u[b,g,t'] = sum_k Wt[f(g),k] zpad[b,g,t'+k]
+//     a2        = s1[f] u + o1[f] sum_c Ws[g,c]                (the BN1 + spatial-conv output)
+// and the BN1 batch statistics follow from the input alone:
+//     mean(a1_f)   = sum_k Wt[f,k] m[k],      m[k]    = mean xpad[.+k]
+//     mean(a1_f^2) = Wt[f]^T G Wt[f],         G[k,k'] = mean xpad[.+k] xpad[.+k']  (autocorrelation of x
+//                                                       with exact edge corrections for the zero padding).
+// The parameter gradients of stage 1 are assembled from the same quantities (dWt needs G and the
+// cross-correlation of da2 with z; dWs is one GEMM of x with the back-filtered da2).  Statistics and
+// cross-batch reductions accumulate in fp64.  Dropout: inference / p = 0 only (train-mode dropout would
+// break parity with any reference RNG stream).
+#include "common.h"
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+#include <vector>
+
+namespace isd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kF1 = 8, kF2 = 16, kK2 = 16, kP2 = 8, kMaxK = 64;
+
+// offsets (floats) inside the flat parameter block, reference state_dict order
+struct EegOff {
+  int Wt, g1, b1, Ws, g2, b2, Wd, Wp, g3, b3, Wl, bl, total;
+};
+// offsets inside the buffer block: rm1 rv1 rm2 rv2 rm3 rv3
+constexpr int kRm1 = 0, kRv1 = 8, kRm2 = 16, kRv2 = 32, kRm3 = 48, kRv3 = 64, kBufTotal = 80;
+
+// fp64 statistics block (doubles) in the workspace
+struct EegStats {
+  double A[kMaxK];              // sum_rows sum_s x[s] x[s+d]
+  double H[32][kMaxK];          // head prefix:  H[a][d] = sum_rows sum_{s<a} x[s] x[s+d]
+  double Tl[33][kMaxK];         // tail suffix:  Tl[e][d] = sum_rows sum_{s>T-e} x[s] x[s+d]
+  double S;                     // sum of all samples
+  double Hs[32];                // Hs[a] = sum_rows sum_{s<a} x[s]
+  double Ts[33];                // Ts[e] = sum_rows sum_{s>T-e} x[s]
+  double u1[kF2], u2[kF2];      // sum u, sum u^2 per g
+  double a1[kF2], a2[kF2];      // sum a4, sum a4^2 per h
+  double dy3s[kF2], dy3x[kF2];  // BN3 backward sums
+  double dy2s[kF2], dy2x[kF2];  // BN2 backward sums
+  double Sd[kF2], Su[kF2];      // sum da2, sum da2*u
+  double T1[kF2][kMaxK];        // sum da2[t'] zpad[t'+k]
+  double dWp[kF2][kF2], dWd[kF2][kK2];
+};
+
+// derived per-step coefficients (floats/doubles) in the workspace
+struct EegCoef {
+  double m[kMaxK];              // mean xpad[.+k]
+  double G[kMaxK][kMaxK];       // mean xpad[.+k] xpad[.+k']
+  double mu1[kF1], sig1[kF1];
+  float s1[kF1], o1[kF1];
+  float wsum[kF2];
+  double muu[kF2], varu[kF2];   // stats of u
+  float mu2[kF2], sig2[kF2], A2[kF2], B2[kF2];   // y2 = A2 u + B2
+  float mu3[kF2], sig3[kF2], A3[kF2], B3[kF2];   // y3 = A3 a4 + B3
+  float cA3[kF2], cB3[kF2], cC3[kF2];            // da4 = cA3 (dy3 - cB3 - xhat3 cC3)
+  float cA2[kF2], cB2[kF2], cC2[kF2];
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// counter-based dropout mask: keep-scale 1/(1-p) or 0 for element `idx` of stream `seed` (own RNG stream;
+// statistically equivalent to nn.Dropout, not bit-identical to any torch generator)
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p) {
+  if (p <= 0.f) return 1.f;
+  uint64_t v = (idx + 0x9E3779B97F4A7C15ull) ^ seed;
+  v ^= v >> 30; v *= 0xBF58476D1CE4E5B9ull;
+  v ^= v >> 27; v *= 0x94D049BB133111EBull;
+  v ^= v >> 31;
+  const float uu = (float)(v >> 40) * (1.f / 16777216.f);
+  return uu >= p ? 1.f / (1.f - p) : 0.f;
+}
+__device__ __forceinline__ float elu_f(float y) { return y > 0.f ? y : expm1f(y); }
+__device__ __forceinline__ float elu_grad_f(float y) { return y > 0.f ? 1.f : expf(y); }
+
+// block-wide sum of one float per thread, result valid on thread 0
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// x statistics: autocorrelation over 64 lags + the head/tail pieces the zero padding cuts off.
+// One wave per workgroup, persistent over rows; lane = sample inside a 64-sample block, the 64 lag
+// accumulators live in registers; lane = lag for the edge terms.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void eeg_stats_kernel(const float* __restrict__ x, EegStats* __restrict__ st,
+                                                       int64_t rows, int T) {
+  extern __shared__ float xrow[];                      // [T + 2*kMaxK] zero extended
+  const int lane = threadIdx.x;
+  float acc[kMaxK];
+#pragma unroll
+  for (int d = 0; d < kMaxK; ++d) acc[d] = 0.f;
+  double Hacc[32], Tacc[33];
+#pragma unroll
+  for (int a = 0; a < 32; ++a) Hacc[a] = 0.0;
+#pragma unroll
+  for (int e = 0; e < 33; ++e) Tacc[e] = 0.0;
+  double Ssum = 0.0, HsAcc = 0.0, TsAcc = 0.0;           // lane a: Hs[a]; lane e: Ts[e]
+  double Aacc = 0.0;                                     // lane d: A[d] (folded from the fp32 accumulators)
+  const int fold_every = T >= 8192 ? 1 : 8192 / T;       // bound the fp32 run length to ~8k products
+  int since_fold = 0;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    __syncthreads();
+    const float* src = x + r * (int64_t)T;
+    for (int t = lane; t < T + 2 * kMaxK; t += 64) xrow[t] = (t < T) ? src[t] : 0.f;
+    __syncthreads();
+    float rs = 0.f;
+    for (int s0 = 0; s0 < T; s0 += 64) {
+      const float xs = xrow[s0 + lane];                  // 0 beyond T
+      rs += xs;
+#pragma unroll
+      for (int d = 0; d < kMaxK; ++d) acc[d] = fmaf(xs, xrow[s0 + lane + d], acc[d]);
+    }
+    Ssum += (double)wave_sum(rs);
+    // fold the per-lane lag accumulators into fp64, lane d <- A[d]
+    if (++since_fold >= fold_every) {
+      since_fold = 0;
+#pragma unroll
+      for (int d = 0; d < kMaxK; ++d) {
+        const float tot = wave_sum(acc[d]);
+        if (lane == d) Aacc += (double)tot;
+        acc[d] = 0.f;
+      }
+    }
+    // head: lane = lag d;  H[a][d] = sum_{s<a} x[s] x[s+d]
+    float pre = 0.f;
+#pragma unroll
+    for (int s = 0; s < 31; ++s) {
+      pre = fmaf(xrow[s], xrow[s + lane], pre);
+      Hacc[s + 1] += (double)pre;
+    }
+    // tail: Tl[e][d] = sum_{s=T-e+1}^{T-1} x[s] x[s+d]   (x is zero beyond T)
+    float suf = 0.f;
+#pragma unroll
+    for (int i2 = 1; i2 <= 31; ++i2) {
+      const int s = T - i2;
+      if (s >= 0) suf = fmaf(xrow[s], xrow[s + lane], suf);
+      Tacc[i2 + 1] += (double)suf;
+    }
+    // prefix / suffix sums of the samples themselves: lane a -> sum_{s<a} x[s]; lane e -> sum_{s>T-e} x[s]
+    if (lane < 32) {
+      float p = 0.f;
+      for (int s = 0; s < lane; ++s) p += xrow[s];
+      HsAcc += (double)p;
+    }
+    if (lane < 33) {
+      float p = 0.f;
+      for (int s = T - lane + 1; s < T; ++s) p += (s >= 0) ? xrow[s] : 0.f;
+      TsAcc += (double)p;
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < kMaxK; ++d) {
+    const float tot = wave_sum(acc[d]);
+    if (lane == d) Aacc += (double)tot;
+  }
+  atomicAdd(&st->A[lane], Aacc);
+#pragma unroll
+  for (int a = 1; a < 32; ++a) atomicAdd(&st->H[a][lane], Hacc[a]);
+#pragma unroll
+  for (int e = 2; e < 33; ++e) atomicAdd(&st->Tl[e][lane], Tacc[e]);
+  if (lane == 0) atomicAdd(&st->S, Ssum);
+  if (lane < 32) atomicAdd(&st->Hs[lane], HsAcc);
+  if (lane < 33) atomicAdd(&st->Ts[lane], TsAcc);
+}
+
+// BN1 coefficients.  training: from the x statistics; eval: from the running buffers.  One block.
+__global__ __launch_bounds__(256) void eeg_finalize1_kernel(const float* __restrict__ params, float* __restrict__ bufs,
+                                                            const EegStats* __restrict__ st, EegCoef* __restrict__ co,
+                                                            EegOff off, int C, int K, int T, int64_t rows,
+                                                            int training, float momentum, float eps) {
+  const int P = K / 2;
+  const double N1 = (double)rows * (double)(T + 2 * P - K + 1);
+  const float* Wt = params + off.Wt;
+  const float* Ws = params + off.Ws;
+  if (threadIdx.x < kF2) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += Ws[threadIdx.x * C + c];
+    co->wsum[threadIdx.x] = s;
+  }
+  if (training) {
+    // m[k], G[k][k'] with a = k - P:  range of s = t'+a is [max(a,0), min(T+a, T-1-d)]
+    for (int e = threadIdx.x; e < K * K; e += 256) {
+      const int k = e / K, k2 = e - k * K;
+      const int ka = k < k2 ? k : k2, kb = k < k2 ? k2 : k;
+      const int a = ka - P, a2 = kb - P, d = kb - ka;
+      double v = st->A[d];
+      if (a > 0) v -= st->H[a][d];
+      if (a2 <= -2) v -= st->Tl[-a][d];                   // s from T+a+1 .. T-1 (terms past T-1-d vanish)
+      co->G[k][k2] = v / N1;
+    }
+    for (int k = threadIdx.x; k < K; k += 256) {
+      const int a = k - P;
+      double v = st->S;
+      if (a > 0) v -= st->Hs[a];
+      if (a < 0) v -= st->Ts[-a];                          // s from T+a+1 .. T-1
+      co->m[k] = v / N1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kF1) {
+    const int f = threadIdx.x;
+    double mu, var;
+    if (training) {
+      mu = 0.0;
+      double e2 = 0.0;
+      for (int k = 0; k < K; ++k) {
+        mu += (double)Wt[f * K + k] * co->m[k];
+        double row = 0.0;
+        for (int k2 = 0; k2 < K; ++k2) row += co->G[k][k2] * (double)Wt[f * K + k2];
+        e2 += (double)Wt[f * K + k] * row;
+      }
+      var = e2 - mu * mu;
+      if (var < 0.0) var = 0.0;
+      bufs[kRm1 + f] = (1.f - momentum) * bufs[kRm1 + f] + momentum * (float)mu;
+      bufs[kRv1 + f] = (1.f - momentum) * bufs[kRv1 + f] + momentum * (float)(var * N1 / (N1 > 1.0 ? N1 - 1.0 : 1.0));
+    } else {
+      mu = bufs[kRm1 + f];
+      var = bufs[kRv1 + f];
+    }
+    const double sig = sqrt(var + (double)eps);
+    co->mu1[f] = mu;
+    co->sig1[f] = sig;
+    const float s1 = (float)((double)params[off.g1 + f] / sig);
+    co->s1[f] = s1;
+    co->o1[f] = params[off.b1 + f] - (float)mu * s1;
+  }
+}
+
+// z[b,g,t] = sum_c Ws[g,c] x[b,c,t]   (one thread per (b,t), all 16 rows in registers)
+__global__ __launch_bounds__(256) void eeg_spatial_kernel(const float* __restrict__ x, const float* __restrict__ Ws,
+                                                          float* __restrict__ z, int C, int T) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  float acc[kF2];
+#pragma unroll
+  for (int g = 0; g < kF2; ++g) acc[g] = 0.f;
+  const float* xb = x + (int64_t)b * C * T + t;
+  for (int c = 0; c < C; ++c) {
+    const float xv = xb[(int64_t)c * T];
+#pragma unroll
+    for (int g = 0; g < kF2; ++g) acc[g] = fmaf(Ws[g * C + c], xv, acc[g]);
+  }
+  float* zb = z + (int64_t)b * kF2 * T + t;
+#pragma unroll
+  for (int g = 0; g < kF2; ++g) zb[(int64_t)g * T] = acc[g];
+}
+
+// u[b,g,t'] = sum_k Wt[f,k] zpad[b,g,t'+k]; per-g sums of u and u^2 (fp64 atomics).  grid (ceil(Tp/256), B*16)
+__global__ __launch_bounds__(256) void eeg_tconv_kernel(const float* __restrict__ z, const float* __restrict__ Wt,
+                                                        float* __restrict__ u, EegStats* __restrict__ st, int K, int T,
+                                                        int Tp, int want_stats) {
+  __shared__ float red[4];
+  const int bg = blockIdx.y, g = bg & (kF2 - 1), f = g >> 1, P = K / 2;
+  const int tp = blockIdx.x * 256 + threadIdx.x;
+  const float* zr = z + (int64_t)bg * T;
+  const float* w = Wt + f * K;
+  float acc = 0.f;
+  if (tp < Tp) {
+    for (int k = 0; k < K; ++k) {
+      const int t = tp + k - P;
+      if (t >= 0 && t < T) acc = fmaf(w[k], zr[t], acc);
+    }
+    u[(int64_t)bg * Tp + tp] = acc;
+  }
+  if (want_stats) {
+    const float s1 = block_sum(tp < Tp ? acc : 0.f, red);
+    const float s2 = block_sum(tp < Tp ? acc * acc : 0.f, red);
+    if (threadIdx.x == 0) {
+      atomicAdd(&st->u1[g], (double)s1);
+      atomicAdd(&st->u2[g], (double)s2);
+    }
+  }
+}
+
+// BN2 coefficients: y2 = A2 u + B2
+__global__ void eeg_finalize2_kernel(const float* __restrict__ params, float* __restrict__ bufs,
+                                     const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N2,
+                                     int training, float momentum, float eps) {
+  const int g = threadIdx.x;
+  if (g >= kF2) return;
+  const int f = g >> 1;
+  const float s1 = co->s1[f], c1 = co->o1[f] * co->wsum[g];
+  double mu2, var2;
+  if (training) {
+    const double muu = st->u1[g] / N2;
+    double varu = st->u2[g] / N2 - muu * muu;
+    if (varu < 0.0) varu = 0.0;
+    co->muu[g] = muu;
+    co->varu[g] = varu;
+    mu2 = (double)s1 * muu + (double)c1;
+    var2 = (double)s1 * (double)s1 * varu;
+    bufs[kRm2 + g] = (1.f - momentum) * bufs[kRm2 + g] + momentum * (float)mu2;
+    bufs[kRv2 + g] = (1.f - momentum) * bufs[kRv2 + g] + momentum * (float)(var2 * N2 / (N2 > 1.0 ? N2 - 1.0 : 1.0));
+  } else {
+    mu2 = bufs[kRm2 + g];
+    var2 = bufs[kRv2 + g];
+  }
+  const double sig2 = sqrt(var2 + (double)eps);
+  const double g2 = params[off.g2 + g], b2 = params[off.b2 + g];
+  co->mu2[g] = (float)mu2;
+  co->sig2[g] = (float)sig2;
+  co->A2[g] = (float)(g2 * (double)s1 / sig2);
+  co->B2[g] = (float)(b2 + g2 * ((double)c1 - mu2) / sig2);
+}
+
+// p2[b,g,v] = mean_{r<4} ELU(A2 u[b,g,4v+r] + B2)
+__global__ __launch_bounds__(256) void eeg_pool2_kernel(const float* __restrict__ u, const EegCoef* __restrict__ co,
+                                                        float* __restrict__ p2, int Tp, int T2, float dp,
+                                                        uint64_t seed) {
+  const int bg = blockIdx.y, g = bg & (kF2 - 1);
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= T2) return;
+  const float A = co->A2[g], Bc = co->B2[g];
+  const float* ur = u + (int64_t)bg * Tp + 4 * v;
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) s += elu_f(fmaf(A, ur[r], Bc));
+  p2[(int64_t)bg * T2 + v] = 0.25f * s * drop_scale(seed, (uint64_t)bg * T2 + v, dp);
+}
+
+// a3[b,g,w] = sum_k Wd[g,k] p2pad[b,g,w+k];  a4[b,h,w] = sum_g Wp[h,g] a3[b,g,w];  BN3 sums.
+// One thread per (b, w); optionally stores a3.  grid (ceil(T2p/256), B)
+__global__ __launch_bounds__(256) void eeg_sep_kernel(const float* __restrict__ p2, const float* __restrict__ Wd,
+                                                      const float* __restrict__ Wp, float* __restrict__ a3out,
+                                                      float* __restrict__ a4, EegStats* __restrict__ st, int T2,
+                                                      int T2p, int want_stats) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  const bool live = w < T2p;
+  float a3[kF2], o[kF2];
+#pragma unroll
+  for (int g = 0; g < kF2; ++g) {
+    float acc = 0.f;
+    if (live) {
+      const float* pr = p2 + ((int64_t)b * kF2 + g) * T2;
+#pragma unroll
+      for (int k = 0; k < kK2; ++k) {
+        const int v = w + k - kP2;
+        if (v >= 0 && v < T2) acc = fmaf(Wd[g * kK2 + k], pr[v], acc);
+      }
+      if (a3out) a3out[((int64_t)b * kF2 + g) * T2p + w] = acc;
+    }
+    a3[g] = acc;
+  }
+#pragma unroll
+  for (int h = 0; h < kF2; ++h) {
+    float acc = 0.f;
+#pragma unroll
+    for (int g = 0; g < kF2; ++g) acc = fmaf(Wp[h * kF2 + g], a3[g], acc);
+    o[h] = acc;
+    if (live) a4[((int64_t)b * kF2 + h) * T2p + w] = acc;
+  }
+  if (want_stats) {
+#pragma unroll
+    for (int h = 0; h < kF2; ++h) {
+      const float s1 = block_sum(live ? o[h] : 0.f, red);
+      const float s2 = block_sum(live ? o[h] * o[h] : 0.f, red);
+      if (threadIdx.x == 0) {
+        atomicAdd(&st->a1[h], (double)s1);
+        atomicAdd(&st->a2[h], (double)s2);
+      }
+    }
+  }
+}
+
+__global__ void eeg_finalize3_kernel(const float* __restrict__ params, float* __restrict__ bufs,
+                                     const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N3,
+                                     int training, float momentum, float eps) {
+  const int h = threadIdx.x;
+  if (h >= kF2) return;
+  double mu, var;
+  if (training) {
+    mu = st->a1[h] / N3;
+    var = st->a2[h] / N3 - mu * mu;
+    if (var < 0.0) var = 0.0;
+    bufs[kRm3 + h] = (1.f - momentum) * bufs[kRm3 + h] + momentum * (float)mu;
+    bufs[kRv3 + h] = (1.f - momentum) * bufs[kRv3 + h] + momentum * (float)(var * N3 / (N3 > 1.0 ? N3 - 1.0 : 1.0));
+  } else {
+    mu = bufs[kRm3 + h];
+    var = bufs[kRv3 + h];
+  }
+  const double sig = sqrt(var + (double)eps);
+  const double g3 = params[off.g3 + h], b3 = params[off.b3 + h];
+  co->mu3[h] = (float)mu;
+  co->sig3[h] = (float)sig;
+  co->A3[h] = (float)(g3 / sig);
+  co->B3[h] = (float)(b3 - g3 * mu / sig);
+}
+
+// pooled[b,h] = mean_{w < 8*T3} ELU(A3 a4 + B3)   (AvgPool(1,8) floor + AdaptiveAvgPool); one wave per row
+__global__ __launch_bounds__(256) void eeg_pool3_kernel(const float* __restrict__ a4, const EegCoef* __restrict__ co,
+                                                        float* __restrict__ pooled, int64_t rows, int T2p, int T3,
+                                                        float dp, uint64_t seed) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int h = (int)(row & (kF2 - 1));
+  const float A = co->A3[h], Bc = co->B3[h];
+  const float* ar = a4 + row * T2p;
+  float s = 0.f;
+  for (int w = lane; w < 8 * T3; w += 64)
+    s += elu_f(fmaf(A, ar[w], Bc)) * drop_scale(seed ^ 0x5bd1e995u, (uint64_t)row * T3 + (w >> 3), dp);
+  s = wave_sum(s);
+  if (lane == 0) pooled[row] = T3 > 0 ? s / (float)(8 * T3) : 0.f;
+}
+
+// ---------------------------------------------------------------- backward
+// dy3 = de3 * ELU'(y3); sums of dy3 and dy3*xhat3 per h.  One wave per (b,h) row.
+__global__ __launch_bounds__(256) void eeg_bwd3_sums_kernel(const float* __restrict__ a4,
+                                                            const float* __restrict__ dpooled,
+                                                            const EegCoef* __restrict__ co, EegStats* __restrict__ st,
+                                                            int64_t rows, int T2p, int T3, float dp, uint64_t seed) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int h = (int)(row & (kF2 - 1));
+  const float A = co->A3[h], Bc = co->B3[h], mu = co->mu3[h], isg = 1.f / co->sig3[h];
+  const float de = T3 > 0 ? dpooled[row] / (float)(8 * T3) : 0.f;
+  const float* ar = a4 + row * T2p;
+  float s1 = 0.f, s2 = 0.f;
+  for (int w = lane; w < 8 * T3; w += 64) {
+    const float av = ar[w];
+    const float dy = de * drop_scale(seed ^ 0x5bd1e995u, (uint64_t)row * T3 + (w >> 3), dp) *
+                     elu_grad_f(fmaf(A, av, Bc));
+    s1 += dy;
+    s2 += dy * (av - mu) * isg;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    atomicAdd(&st->dy3s[h], (double)s1);
+    atomicAdd(&st->dy3x[h], (double)s2);
+  }
+}
+
+// BN backward coefficients for stage `which` (3 or 2) and the gamma/beta gradients
+__global__ void eeg_bwd_bn_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
+                                       const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N,
+                                       int which) {
+  const int h = threadIdx.x;
+  if (h >= kF2) return;
+  if (which == 3) {
+    dparams[off.g3 + h] = (float)st->dy3x[h];
+    dparams[off.b3 + h] = (float)st->dy3s[h];
+    co->cA3[h] = params[off.g3 + h] / co->sig3[h];
+    co->cB3[h] = (float)(st->dy3s[h] / N);
+    co->cC3[h] = (float)(st->dy3x[h] / N);
+  } else {
+    dparams[off.g2 + h] = (float)st->dy2x[h];
+    dparams[off.b2 + h] = (float)st->dy2s[h];
+    co->cA2[h] = params[off.g2 + h] / co->sig2[h];
+    co->cB2[h] = (float)(st->dy2s[h] / N);
+    co->cC2[h] = (float)(st->dy2x[h] / N);
+  }
+}
+
+// da4 = cA3 (dy3 - cB3 - xhat3 cC3);  da3[b,g,w] = sum_h Wp[h,g] da4[b,h,w].  One thread per (b,w).
+__global__ __launch_bounds__(256) void eeg_bwd_sep_kernel(const float* __restrict__ a4,
+                                                          const float* __restrict__ dpooled,
+                                                          const float* __restrict__ Wp, const EegCoef* __restrict__ co,
+                                                          float* __restrict__ da4, float* __restrict__ da3, int T2p,
+                                                          int T3, float dp, uint64_t seed) {
+  const int b = blockIdx.y;
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= T2p) return;
+  float d4[kF2];
+#pragma unroll
+  for (int h = 0; h < kF2; ++h) {
+    const int64_t row = (int64_t)b * kF2 + h;
+    const float av = a4[row * T2p + w];
+    const float de = (w < 8 * T3 && T3 > 0)
+                         ? dpooled[row] / (float)(8 * T3) * drop_scale(seed ^ 0x5bd1e995u, (uint64_t)row * T3 + (w >> 3), dp)
+                         : 0.f;
+    const float dy = de * elu_grad_f(fmaf(co->A3[h], av, co->B3[h]));
+    const float xh = (av - co->mu3[h]) / co->sig3[h];
+    d4[h] = co->cA3[h] * (dy - co->cB3[h] - xh * co->cC3[h]);
+    da4[row * T2p + w] = d4[h];
+  }
+#pragma unroll
+  for (int g = 0; g < kF2; ++g) {
+    float acc = 0.f;
+#pragma unroll
+    for (int h = 0; h < kF2; ++h) acc = fmaf(Wp[h * kF2 + g], d4[h], acc);
+    da3[((int64_t)b * kF2 + g) * T2p + w] = acc;
+  }
+}
+
+// dWp[h,g] = sum_{b,w} da4[b,h,w] a3[b,g,w];  dWd[g,k] = sum_{b,w} da3[b,g,w] p2pad[b,g,w+k].
+// One block per output element (512 blocks), fp64 block result.
+__global__ __launch_bounds__(256) void eeg_bwd_sepw_kernel(const float* __restrict__ da4, const float* __restrict__ a3,
+                                                           const float* __restrict__ da3, const float* __restrict__ p2,
+                                                           EegStats* __restrict__ st, int B, int T2, int T2p) {
+  __shared__ float red[4];
+  const int o = blockIdx.x;
+  float s = 0.f;
+  if (o < kF2 * kF2) {
+    const int h = o / kF2, g = o - h * kF2;
+    for (int64_t e = threadIdx.x; e < (int64_t)B * T2p; e += 256) {
+      const int64_t b = e / T2p;
+      const int w = (int)(e - b * T2p);
+      s = fmaf(da4[(b * kF2 + h) * T2p + w], a3[(b * kF2 + g) * T2p + w], s);
+    }
+  } else {
+    const int o2 = o - kF2 * kF2;
+    const int g = o2 / kK2, k = o2 - g * kK2;
+    for (int64_t e = threadIdx.x; e < (int64_t)B * T2p; e += 256) {
+      const int64_t b = e / T2p;
+      const int w = (int)(e - b * T2p);
+      const int v = w + k - kP2;
+      if (v >= 0 && v < T2) s = fmaf(da3[(b * kF2 + g) * T2p + w], p2[(b * kF2 + g) * T2 + v], s);
+    }
+  }
+  const float tot = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    if (o < kF2 * kF2) st->dWp[o / kF2][o % kF2] = (double)tot;
+    else st->dWd[(o - kF2 * kF2) / kK2][(o - kF2 * kF2) % kK2] = (double)tot;
+  }
+}
+
+// dp2 -> de2 -> dy2 = de2 ELU'(y2), written to dy2[b,g,t'] (zero past 4*T2); BN2 backward sums.
+__global__ __launch_bounds__(256) void eeg_bwd_pool2_kernel(const float* __restrict__ da3, const float* __restrict__ Wd,
+                                                            const float* __restrict__ u, const EegCoef* __restrict__ co,
+                                                            float* __restrict__ dy2, EegStats* __restrict__ st, int Tp,
+                                                            int T2, int T2p, float dpr, uint64_t seed) {
+  __shared__ float red[4];
+  const int bg = blockIdx.y, g = bg & (kF2 - 1);
+  const int tp = blockIdx.x * 256 + threadIdx.x;
+  float dy = 0.f, xh = 0.f;
+  if (tp < Tp) {
+    const int v = tp >> 2;
+    if (v < T2) {
+      float dp = 0.f;                                   // dp2[v] = sum_k Wd[g,k] da3[v - k + 8]
+#pragma unroll
+      for (int k = 0; k < kK2; ++k) {
+        const int w = v - k + kP2;
+        if (w >= 0 && w < T2p) dp = fmaf(Wd[g * kK2 + k], da3[(int64_t)bg * T2p + w], dp);
+      }
+      dp *= drop_scale(seed, (uint64_t)bg * T2 + v, dpr);
+      const float uv = u[(int64_t)bg * Tp + tp];
+      const float y2 = fmaf(co->A2[g], uv, co->B2[g]);
+      dy = 0.25f * dp * elu_grad_f(y2);
+      // xhat2 = (a2 - mu2)/sig2 with a2 = s1 u + c1  ==  (y2 - beta2)/gamma2 ; use the direct form
+      xh = (co->s1[g >> 1] * uv + co->o1[g >> 1] * co->wsum[g] - co->mu2[g]) / co->sig2[g];
+    }
+    dy2[(int64_t)bg * Tp + tp] = dy;
+  }
+  const float s1 = block_sum(dy, red);
+  const float s2 = block_sum(dy * xh, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&st->dy2s[g], (double)s1);
+    atomicAdd(&st->dy2x[g], (double)s2);
+  }
+}
+
+// da2 = cA2 (dy2 - cB2 - xhat2 cC2) in place; Sd = sum da2, Su = sum da2*u
+__global__ __launch_bounds__(256) void eeg_bwd_bn2_kernel(float* __restrict__ dy2, const float* __restrict__ u,
+                                                          const EegCoef* __restrict__ co, EegStats* __restrict__ st,
+                                                          int Tp) {
+  __shared__ float red[4];
+  const int bg = blockIdx.y, g = bg & (kF2 - 1);
+  const int tp = blockIdx.x * 256 + threadIdx.x;
+  float d = 0.f, du = 0.f;
+  if (tp < Tp) {
+    const float uv = u[(int64_t)bg * Tp + tp];
+    const float xh = (co->s1[g >> 1] * uv + co->o1[g >> 1] * co->wsum[g] - co->mu2[g]) / co->sig2[g];
+    d = co->cA2[g] * (dy2[(int64_t)bg * Tp + tp] - co->cB2[g] - xh * co->cC2[g]);
+    dy2[(int64_t)bg * Tp + tp] = d;
+    du = d * uv;
+  }
+  const float s1 = block_sum(d, red);
+  const float s2 = block_sum(du, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&st->Sd[g], (double)s1);
+    atomicAdd(&st->Su[g], (double)s2);
+  }
+}
+
+// T1[g][k] = sum_{b,t'} da2[b,g,t'] zpad[b,g,t'+k]  (lane = t' inside a 64 block, K accumulators in registers)
+// and v[b,g,t] = sum_k Wt[f,k] da2[b,g,t-k+P].   grid (B*16), one wave per (b,g) row.
+__global__ __launch_bounds__(64) void eeg_bwd_corr_kernel(const float* __restrict__ da2, const float* __restrict__ z,
+                                                          const float* __restrict__ Wt, float* __restrict__ v,
+                                                          EegStats* __restrict__ st, int K, int T, int Tp) {
+  extern __shared__ float sm[];                         // zpad [T + 2P + 64], da2 row padded [Tp + 2K + 64]
+  const int bg = blockIdx.x, g = bg & (kF2 - 1), f = g >> 1, P = K / 2, lane = threadIdx.x;
+  float* zp = sm;
+  float* dp = sm + T + 2 * P + 64;
+  const float* zr = z + (int64_t)bg * T;
+  const float* dr = da2 + (int64_t)bg * Tp;
+  for (int i = lane; i < T + 2 * P + 64; i += 64) {
+    const int t = i - P;
+    zp[i] = (t >= 0 && t < T) ? zr[t] : 0.f;
+  }
+  for (int i = lane; i < Tp + 2 * K + 64; i += 64) {
+    const int t = i - K;
+    dp[i] = (t >= 0 && t < Tp) ? dr[t] : 0.f;
+  }
+  __syncthreads();
+  float acc[kMaxK];
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) acc[k] = 0.f;
+  for (int t0 = 0; t0 < Tp; t0 += 64) {
+    const float dv = dp[K + t0 + lane];                 // 0 beyond Tp
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k)
+      if (k < K) acc[k] = fmaf(dv, zp[t0 + lane + k], acc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) {
+    if (k < K) {
+      const float tot = wave_sum(acc[k]);
+      if (lane == 0) atomicAdd(&st->T1[g][k], (double)tot);
+    }
+  }
+  const float* w = Wt + f * K;
+  for (int t = lane; t < T; t += 64) {
+    float a = 0.f;
+    for (int k = 0; k < K; ++k) a = fmaf(w[k], dp[K + t - k + P], a);   // index t-k+P in [-K, Tp+K) is padded
+    v[(int64_t)bg * T + t] = a;
+  }
+}
+
+// dWs_raw[g,c] = sum_{b,t} v[b,g,t] x[b,c,t] on the matrix cores; persistent waves, partial slabs.
+// A[g][t] = v, B[t][c] = x; K = 4 time steps per MFMA; a wave owns all C/16 channel tiles (<= 16).
+__global__ __launch_bounds__(64) void eeg_bwd_dws_kernel(const float* __restrict__ v, const float* __restrict__ x,
+                                                         float* __restrict__ part, int B, int C, int T) {
+  const int lane = threadIdx.x, q = lane >> 4, jl = lane & 15;
+  const int c_base = blockIdx.y * 256;                    // 16 channel tiles per wave
+  const int n_ctile = (C - c_base + 15) / 16 < 16 ? (C - c_base + 15) / 16 : 16;
+  f32x4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int chunks_per_b = (T + 255) / 256;
+  const int64_t n_chunks = (int64_t)B * chunks_per_b;
+  for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    const int64_t b = ch / chunks_per_b;
+    const int t_lo = (int)(ch - b * chunks_per_b) * 256;
+    const int t_hi = t_lo + 256 < T ? t_lo + 256 : T;
+    const float* vr = v + (b * kF2 + jl) * (int64_t)T;
+    for (int t0 = t_lo; t0 < t_hi; t0 += 4) {
+      const int t = t0 + q;
+      const float af = t < t_hi ? vr[t] : 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 16; ++ct) {
+        if (ct < n_ctile) {
+          const int c = c_base + ct * 16 + jl;
+          const float bf = (c < C && t < t_hi) ? x[(b * C + c) * (int64_t)T + t] : 0.f;
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[ct], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* slab = part + (int64_t)blockIdx.x * kF2 * C;
+#pragma unroll
+  for (int ct = 0; ct < 16; ++ct) {
+    if (ct < n_ctile) {
+      const int c = c_base + ct * 16 + jl;
+      if (c < C) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(4 * q + r) * C + c] = acc[ct][r];
+      }
+    }
+  }
+}
+
+// dWs[g,c] = s1[f] * sum_slabs raw + o1[f] * Sd[g]
+__global__ __launch_bounds__(256) void eeg_bwd_dws_reduce_kernel(const float* __restrict__ part, int n_slabs,
+                                                                 const EegStats* __restrict__ st,
+                                                                 const EegCoef* __restrict__ co,
+                                                                 float* __restrict__ dWs, int C) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= kF2 * C) return;
+  const int g = e / C, f = g >> 1;
+  float s0 = 0.f, s1 = 0.f;
+  int k = 0;
+  for (; k + 1 < n_slabs; k += 2) {
+    s0 += part[(int64_t)k * kF2 * C + e];
+    s1 += part[(int64_t)(k + 1) * kF2 * C + e];
+  }
+  if (k < n_slabs) s0 += part[(int64_t)k * kF2 * C + e];
+  dWs[e] = co->s1[f] * (s0 + s1) + co->o1[f] * (float)st->Sd[g];
+}
+
+// Final assembly of the stage-1 gradients (dWt, dgamma1, dbeta1) and the separable weights.  One block.
+__global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restrict__ params,
+                                                            float* __restrict__ dparams,
+                                                            const EegStats* __restrict__ st,
+                                                            const EegCoef* __restrict__ co, EegOff off, int C, int K,
+                                                            double N1) {
+  const float* Wt = params + off.Wt;
+  for (int e = threadIdx.x; e < kF2 * kF2; e += 256) dparams[off.Wp + e] = (float)st->dWp[e / kF2][e % kF2];
+  for (int e = threadIdx.x; e < kF2 * kK2; e += 256) dparams[off.Wd + e] = (float)st->dWd[e / kK2][e % kK2];
+  __shared__ double SD[kF1], SU[kF1];
+  if (threadIdx.x < kF1) {
+    const int f = threadIdx.x;
+    const double sd = (double)co->wsum[2 * f] * st->Sd[2 * f] + (double)co->wsum[2 * f + 1] * st->Sd[2 * f + 1];
+    const double su = st->Su[2 * f] + st->Su[2 * f + 1];
+    SD[f] = sd;
+    SU[f] = su;
+    dparams[off.b1 + f] = (float)sd;
+    dparams[off.g1 + f] = (float)((su - co->mu1[f] * sd) / co->sig1[f]);
+  }
+  __syncthreads();
+  // dWt[f,k] = (g1/sig1) [ T1 - meanD N1 m[k] - (meanDa/sig1) (N1 (Wt G)[k] - mu1 N1 m[k]) ]
+  for (int e = threadIdx.x; e < kF1 * K; e += 256) {
+    const int f = e / K, k = e - f * K;
+    const double sig = co->sig1[f], mu = co->mu1[f];
+    const double t1 = st->T1[2 * f][k] + st->T1[2 * f + 1][k];
+    const double meanD = SD[f] / N1;
+    const double meanDa = (SU[f] - mu * SD[f]) / (sig * N1);
+    double wg = 0.0;
+    for (int k2 = 0; k2 < K; ++k2) wg += (double)Wt[f * K + k2] * co->G[k2][k];
+    const double val = ((double)params[off.g1 + f] / sig) *
+                       (t1 - meanD * N1 * co->m[k] - (meanDa / sig) * (N1 * wg - mu * N1 * co->m[k]));
+    dparams[off.Wt + e] = (float)val;
+  }
+}
+
+}  // namespace isd
+
+using namespace isd;
+
+struct isd_eegnet_plan {
+  int C, F, K, T, Tp, T2, T2p, T3;
+  EegOff off;
+};
+
+static inline int64_t al64(int64_t v) { return (v + 63) / 64 * 64; }
+
+extern "C" int isd_eegnet_plan_create(isd_eegnet_plan** out, int in_channels, int feature_dim, int kernel_length,
+                                      int T) {
+  ISD_CHECK_ARG(out, "isd_eegnet_plan_create: null argument");
+  ISD_CHECK_ARG(in_channels >= 1 && in_channels <= 16384, "isd_eegnet_plan_create: in_channels=%d", in_channels);
+  ISD_CHECK_ARG(feature_dim >= 1 && feature_dim <= 64, "isd_eegnet_plan_create: feature_dim=%d not in [1,64]", feature_dim);
+  ISD_CHECK_ARG(kernel_length >= 2 && kernel_length <= kMaxK && (kernel_length & 1) == 0,
+                "isd_eegnet_plan_create: kernel_length=%d must be even and <= %d", kernel_length, kMaxK);
+  isd_eegnet_plan* p = new isd_eegnet_plan();
+  p->C = in_channels; p->F = feature_dim; p->K = kernel_length; p->T = T;
+  p->Tp = T + 2 * (kernel_length / 2) - kernel_length + 1;
+  p->T2 = p->Tp / 4;
+  p->T2p = p->T2 + 2 * kP2 - kK2 + 1;
+  p->T3 = p->T2p / 8;
+  if (T < 1 || p->T3 < 1) {
+    set_error("isd_eegnet_plan_create: T=%d is too short (the second AvgPool needs >= 8 samples: T >= 28)", T);
+    delete p;
+    return ISD_ERR_INVALID;
+  }
+  int o = 0;
+  EegOff& f = p->off;
+  f.Wt = o; o += kF1 * kernel_length;
+  f.g1 = o; o += kF1;
+  f.b1 = o; o += kF1;
+  f.Ws = o; o += kF2 * in_channels;
+  f.g2 = o; o += kF2;
+  f.b2 = o; o += kF2;
+  f.Wd = o; o += kF2 * kK2;
+  f.Wp = o; o += kF2 * kF2;
+  f.g3 = o; o += kF2;
+  f.b3 = o; o += kF2;
+  f.Wl = o; o += feature_dim * kF2;
+  f.bl = o; o += feature_dim;
+  f.total = o;
+  *out = p;
+  return ISD_OK;
+}
+
+extern "C" int isd_eegnet_plan_destroy(isd_eegnet_plan* p) {
+  delete p;
+  return ISD_OK;
+}
+extern "C" int64_t isd_eegnet_param_count(const isd_eegnet_plan* p) { return p ? p->off.total : ISD_ERR_INVALID; }
+extern "C" int64_t isd_eegnet_buffer_count(const isd_eegnet_plan* p) { return p ? kBufTotal : ISD_ERR_INVALID; }
+
+namespace {
+struct EegWs {          // float offsets into the workspace
+  int64_t stats, coef, z, u, p2, a4, pooled, dpooled, a3, da4, da3, dy2, v, part, lin, total;
+  int n_slabs;
+};
+EegWs eeg_layout(const isd_eegnet_plan* p, int64_t B) {
+  EegWs w;
+  int64_t o = 0;
+  w.stats = o; o += al64((int64_t)(sizeof(EegStats) + 3) / 4);
+  w.coef = o; o += al64((int64_t)(sizeof(EegCoef) + 3) / 4);
+  w.z = o; o += al64(B * kF2 * p->T);
+  w.u = o; o += al64(B * kF2 * p->Tp);
+  w.p2 = o; o += al64(B * kF2 * p->T2);
+  w.a4 = o; o += al64(B * kF2 * p->T2p);
+  w.pooled = o; o += al64(B * kF2);
+  w.dpooled = o; o += al64(B * kF2);
+  w.a3 = o; o += al64(B * kF2 * p->T2p);
+  w.da4 = o; o += al64(B * kF2 * p->T2p);
+  w.da3 = o; o += al64(B * kF2 * p->T2p);
+  w.dy2 = o; o += al64(B * kF2 * p->Tp);
+  w.v = o; o += al64(B * kF2 * p->T);
+  w.n_slabs = 1024;
+  w.part = o; o += al64((int64_t)w.n_slabs * kF2 * p->C);
+  w.lin = o; o += al64(isd_linear_workspace_bytes(B, kF2, p->F) / 4 + 64);
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+extern "C" int64_t isd_eegnet_workspace_bytes(const isd_eegnet_plan* p, int64_t B) {
+  if (!p || B < 0) return ISD_ERR_INVALID;
+  return eeg_layout(p, B).total * 4;
+}
+
+extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, const float* params, float* buffers,
+                                  float* out, void* workspace, int64_t B, int training, float momentum, float eps,
+                                  float dropout_p, uint64_t seed, void* stream) {
+  ISD_CHECK_ARG(p, "isd_eegnet_forward: null plan");
+  ISD_CHECK_ARG(B >= 0 && B <= 0x7fffffff / kF2, "isd_eegnet_forward: B=%lld", (long long)B);
+  if (B == 0) return ISD_OK;
+  ISD_CHECK_ARG(x && params && buffers && out && workspace, "isd_eegnet_forward: null argument");
+  ISD_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "isd_eegnet_forward: dropout_p=%g not in [0,1)", dropout_p);
+  const float dp = training ? dropout_p : 0.f;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const EegWs w = eeg_layout(p, B);
+  EegStats* S = (EegStats*)(ws + w.stats);
+  EegCoef* Cf = (EegCoef*)(ws + w.coef);
+  const int C = p->C, K = p->K, T = p->T, Tp = p->Tp, T2 = p->T2, T2p = p->T2p, T3 = p->T3;
+  const int64_t rows = B * C;
+  ISD_HIP_TRY(hipMemsetAsync(S, 0, sizeof(EegStats), st));
+  if (training) {
+    const size_t lds = sizeof(float) * (size_t)(T + 2 * kMaxK);
+    ISD_CHECK_ARG(lds <= 64 * 1024, "isd_eegnet_forward: T=%d too long for the statistics tile", T);
+    const int grid = rows < 2048 ? (int)rows : 2048;
+    hipLaunchKernelGGL(eeg_stats_kernel, dim3(grid), dim3(64), lds, st, x, S, rows, T);
+  }
+  hipLaunchKernelGGL(eeg_finalize1_kernel, dim3(1), dim3(256), 0, st, params, buffers, S, Cf, p->off, C, K, T, rows,
+                     training, momentum, eps);
+  hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(T, 256), (unsigned)B), dim3(256), 0, st, x,
+                     params + p->off.Ws, ws + w.z, C, T);
+  hipLaunchKernelGGL(eeg_tconv_kernel, dim3((unsigned)cdiv(Tp, 256), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.z,
+                     params + p->off.Wt, ws + w.u, S, K, T, Tp, training);
+  hipLaunchKernelGGL(eeg_finalize2_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
+                     (double)B * (double)Tp, training, momentum, eps);
+  hipLaunchKernelGGL(eeg_pool2_kernel, dim3((unsigned)cdiv(T2, 256), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.u,
+                     Cf, ws + w.p2, Tp, T2, dp, seed);
+  hipLaunchKernelGGL(eeg_sep_kernel, dim3((unsigned)cdiv(T2p, 256), (unsigned)B), dim3(256), 0, st, ws + w.p2,
+                     params + p->off.Wd, params + p->off.Wp, training ? ws + w.a3 : nullptr, ws + w.a4, S, T2, T2p,
+                     training);
+  hipLaunchKernelGGL(eeg_finalize3_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
+                     (double)B * (double)T2p, training, momentum, eps);
+  hipLaunchKernelGGL(eeg_pool3_kernel, dim3((unsigned)cdiv(B * kF2, 4)), dim3(256), 0, st, ws + w.a4, Cf,
+                     ws + w.pooled, B * kF2, T2p, T3, dp, seed);
+  ISD_LAUNCH_CHECK();
+  return isd_linear_forward(ws + w.pooled, params + p->off.Wl, params + p->off.bl, out, nullptr, B, kF2, p->F, 0,
+                            stream);
+}
+
+extern "C" int isd_eegnet_backward(const isd_eegnet_plan* p, const float* x, const float* params, const float* dout,
+                                   float* dparams, void* workspace, int64_t B, float dropout_p, uint64_t seed,
+                                   void* stream) {
+  ISD_CHECK_ARG(p, "isd_eegnet_backward: null plan");
+  ISD_CHECK_ARG(B >= 1, "isd_eegnet_backward: B=%lld", (long long)B);
+  ISD_CHECK_ARG(x && params && dout && dparams && workspace, "isd_eegnet_backward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const EegWs w = eeg_layout(p, B);
+  EegStats* S = (EegStats*)(ws + w.stats);
+  EegCoef* Cf = (EegCoef*)(ws + w.coef);
+  const int C = p->C, K = p->K, T = p->T, Tp = p->Tp, T2 = p->T2, T2p = p->T2p, T3 = p->T3;
+  const int64_t rows16 = B * kF2;
+  ISD_HIP_TRY(hipMemsetAsync((char*)S + offsetof(EegStats, dy3s), 0, sizeof(EegStats) - offsetof(EegStats, dy3s), st));
+  int rc = isd_linear_backward(ws + w.pooled, params + p->off.Wl, dout, nullptr, ws + w.dpooled, dparams + p->off.Wl,
+                               dparams + p->off.bl, ws + w.lin, B, kF2, p->F, 0, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(eeg_bwd3_sums_kernel, dim3((unsigned)cdiv(rows16, 4)), dim3(256), 0, st, ws + w.a4, ws + w.dpooled,
+                     Cf, S, rows16, T2p, T3, dropout_p, seed);
+  hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
+                     (double)B * (double)T2p, 3);
+  hipLaunchKernelGGL(eeg_bwd_sep_kernel, dim3((unsigned)cdiv(T2p, 256), (unsigned)B), dim3(256), 0, st, ws + w.a4,
+                     ws + w.dpooled, params + p->off.Wp, Cf, ws + w.da4, ws + w.da3, T2p, T3, dropout_p, seed);
+  hipLaunchKernelGGL(eeg_bwd_sepw_kernel, dim3(kF2 * kF2 + kF2 * kK2), dim3(256), 0, st, ws + w.da4, ws + w.a3,
+                     ws + w.da3, ws + w.p2, S, (int)B, T2, T2p);
+  hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3((unsigned)cdiv(Tp, 256), (unsigned)rows16), dim3(256), 0, st,
+                     ws + w.da3, params + p->off.Wd, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, dropout_p, seed);
+  hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
+                     (double)B * (double)Tp, 2);
+  hipLaunchKernelGGL(eeg_bwd_bn2_kernel, dim3((unsigned)cdiv(Tp, 256), (unsigned)rows16), dim3(256), 0, st, ws + w.dy2,
+                     ws + w.u, Cf, S, Tp);
+  {
+    const size_t lds = sizeof(float) * (size_t)((T + K + 64) + (Tp + 2 * K + 64));
+    ISD_CHECK_ARG(lds <= 64 * 1024, "isd_eegnet_backward: T=%d too long for the correlation tile", T);
+    hipLaunchKernelGGL(eeg_bwd_corr_kernel, dim3((unsigned)rows16), dim3(64), lds, st, ws + w.dy2, ws + w.z,
+                       params + p->off.Wt, ws + w.v, S, K, T, Tp);
+  }
+  const int64_t n_chunks = B * ((T + 255) / 256);
+  const int slabs = n_chunks < w.n_slabs ? (int)n_chunks : w.n_slabs;
+  hipLaunchKernelGGL(eeg_bwd_dws_kernel, dim3(slabs, (unsigned)cdiv(C, 256)), dim3(64), 0, st, ws + w.v, x, ws + w.part,
+                     (int)B, C, T);
+  hipLaunchKernelGGL(eeg_bwd_dws_reduce_kernel, dim3((unsigned)cdiv((int64_t)kF2 * C, 256)), dim3(256), 0, st,
+                     ws + w.part, slabs, S, Cf, dparams + p->off.Ws, C);
+  hipLaunchKernelGGL(eeg_bwd_final_kernel, dim3(1), dim3(256), 0, st, params, dparams, S, Cf, p->off, C, K,
+                     (double)(B * C) * (double)Tp);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}

@@ -173,6 +173,56 @@ class _SoftmaxCEFn(torch.autograd.Function):
         return dlt * g, None, None
 
 
+class EEGNetPlan:
+    def __init__(self, in_channels, feature_dim, kernel_length, T):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().isd_eegnet_plan_create(C.byref(self._h), int(in_channels), int(feature_dim),
+                                                     int(kernel_length), int(T)))
+        self.n_params = int(_lib.lib().isd_eegnet_param_count(self._h))
+        self.F = int(feature_dim)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().isd_eegnet_plan_destroy(h)
+            except Exception:
+                pass
+
+
+class _EEGNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flat, bufs, plan, training, momentum, eps, dropout_p, seed):
+        x, flat = _f32c(x, "x"), _f32c(flat, "params")
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient w.r.t. the EEG input is not provided by the HIP EEGNet head")
+        B = x.shape[0]
+        out = torch.empty((B, plan.F), dtype=torch.float32, device=x.device)
+        ws = torch.empty(max(int(_lib.lib().isd_eegnet_workspace_bytes(plan._h, B)) // 4, 1), dtype=torch.float32,
+                         device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_eegnet_forward(plan._h, x.data_ptr(), flat.data_ptr(), bufs.data_ptr(),
+                                                     out.data_ptr(), ws.data_ptr(), B, int(training), float(momentum),
+                                                     float(eps), float(dropout_p), int(seed), _stream()))
+        ctx.plan, ctx.ws, ctx.dp, ctx.seed, ctx.training = plan, ws, float(dropout_p), int(seed), training
+        ctx.save_for_backward(x, flat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, flat = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("EEGNet_Encoder backward needs a train-mode forward (batch statistics)")
+        dflat = torch.empty_like(flat)
+        dout = _f32c(dout, "dout")
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_eegnet_backward(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dout.data_ptr(),
+                                                      dflat.data_ptr(), ctx.ws.data_ptr(), x.shape[0], ctx.dp,
+                                                      ctx.seed, _stream()))
+        ctx.ws = None
+        return None, dflat, None, None, None, None, None, None, None
+
+
 def linear(x, weight, bias=None, act=False):
     return _LinearFn.apply(x, weight, bias, act)
 
@@ -304,6 +354,68 @@ class Conv4Layers(_Conv4Params, _FlatParamMixin):
         flat = self.flat_params()
         theta = torch.cat([p.reshape(-1) for p in self.ordered()]) if torch.is_grad_enabled() else flat
         return _ConvStackFn.apply(x, theta, self._plan(x.shape[-1])).squeeze(1)
+
+
+class EEGNet_Encoder(nn.Module, _FlatParamMixin):
+    """Drop-in for the reference's ``EEGNet_Encoder(in_channels, feature_dim, kernel_length=64, dropout=0.25)``
+    (fast.py:122-167); same sub-module / parameter / buffer names, ``forward(x[B', C, T]) -> [B', feature_dim]``.
+    Train-mode dropout uses the library's own counter-based stream (statistically nn.Dropout)."""
+
+    def __init__(self, in_channels, feature_dim, kernel_length=64, dropout=0.25):
+        super().__init__()
+        self.in_channels, self.feature_dim, self.kernel_length, self.p = in_channels, feature_dim, kernel_length, dropout
+        F1, F2 = 8, 16
+        self.temporal_conv = nn.Sequential(
+            nn.Conv2d(1, F1, (1, kernel_length), padding=(0, kernel_length // 2), bias=False), nn.BatchNorm2d(F1))
+        self.spatial_conv = nn.Sequential(
+            nn.Conv2d(F1, F2, (in_channels, 1), groups=F1, bias=False), nn.BatchNorm2d(F2), nn.ELU(),
+            nn.AvgPool2d((1, 4)), nn.Dropout(dropout))
+        self.separable_conv = nn.Sequential(
+            nn.Conv2d(F2, F2, (1, 16), padding=(0, 8), groups=F2, bias=False), nn.Conv2d(F2, F2, (1, 1), bias=False),
+            nn.BatchNorm2d(F2), nn.ELU(), nn.AvgPool2d((1, 8)), nn.Dropout(dropout))
+        self.projector = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), nn.Linear(F2, feature_dim))
+        self._plans = {}
+        self._calls = 0
+
+    def _bns(self):
+        return [self.temporal_conv[1], self.spatial_conv[1], self.separable_conv[2]]
+
+    def _ordered_params(self):
+        b1, b2, b3 = self._bns()
+        return [self.temporal_conv[0].weight, b1.weight, b1.bias, self.spatial_conv[0].weight, b2.weight, b2.bias,
+                self.separable_conv[0].weight, self.separable_conv[1].weight, b3.weight, b3.bias,
+                self.projector[2].weight, self.projector[2].bias]
+
+    def flat_buffers(self):
+        bufs = [t for bn in self._bns() for t in (bn.running_mean, bn.running_var)]
+        flat = self._as_flat(bufs)
+        if flat is None:
+            flat = torch.cat([t.detach().reshape(-1).float() for t in bufs]).contiguous()
+            off = 0
+            for bn in self._bns():
+                for name in ("running_mean", "running_var"):
+                    n = bn._buffers[name].numel()
+                    bn._buffers[name] = flat[off:off + n]
+                    off += n
+        return flat
+
+    def forward(self, x):
+        if x.dim() != 3:
+            raise ValueError("expected [batch, channels, time]")
+        T = x.shape[-1]
+        plan = self._plans.get(T)
+        if plan is None:
+            plan = self._plans[T] = EEGNetPlan(self.in_channels, self.feature_dim, self.kernel_length, T)
+        flat = self.flat_params()
+        theta = torch.cat([p.reshape(-1) for p in self._ordered_params()]) if torch.is_grad_enabled() else flat
+        bn = self._bns()[0]
+        self._calls += 1
+        if self.training:
+            for b in self._bns():
+                b.num_batches_tracked += 1
+        return _EEGNetFn.apply(x, theta, self.flat_buffers(), plan, self.training,
+                               0.1 if bn.momentum is None else bn.momentum, bn.eps, self.p if self.training else 0.0,
+                               (torch.initial_seed() + self._calls) & 0x7FFFFFFFFFFFFFFF)
 
 
 class Head(nn.Module, _FlatParamMixin):

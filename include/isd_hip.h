@@ -175,6 +175,32 @@ int isd_softmax_ce(const float* logits_tok, const void* labels, int label_bytes,
                    float* loss, float* dlogits_tok, int64_t* pred, int64_t B, int n_tok, int n_cls,
                    float grad_scale, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------
+ * EEGNet_Encoder (src/fast/models/fast.py:122-167): the "EEGNet-style depthwise CNN" head.
+ *   x [B][C][T] f32 -> out [B][feature_dim];  kernel_length even, <= 64 (reference default 64).
+ * Flat parameter block (reference state_dict order, trainable tensors only):
+ *   temporal_conv.0.weight [8,1,1,K] | temporal_conv.1.weight [8] | .bias [8] | spatial_conv.0.weight [16,1,C,1] |
+ *   spatial_conv.1.weight [16] | .bias [16] | separable_conv.0.weight [16,1,1,16] | separable_conv.1.weight [16,16,1,1] |
+ *   separable_conv.2.weight [16] | .bias [16] | projector.2.weight [F,16] | projector.2.bias [F]
+ * Buffer block (80 floats): running_mean/var of BN1 (8,8), BN2 (16,16), BN3 (16,16); updated in place when training.
+ * training != 0: batch statistics (biased variance for the normalisation, unbiased for the running update);
+ * dropout_p (train only) uses a counter-based mask keyed by `seed` (pass the same p and seed to backward): it is
+ * statistically, not bitwise, nn.Dropout.  The temporal-conv activation [B,8,C,T+1] is never formed.
+ * backward: parameter gradients only (x is data); one backward per forward, same workspace.
+ * ---------------------------------------------------------------------- */
+typedef struct isd_eegnet_plan isd_eegnet_plan;
+int isd_eegnet_plan_create(isd_eegnet_plan** out, int in_channels, int feature_dim, int kernel_length, int T);
+int isd_eegnet_plan_destroy(isd_eegnet_plan* plan);
+int64_t isd_eegnet_param_count(const isd_eegnet_plan* plan);
+int64_t isd_eegnet_buffer_count(const isd_eegnet_plan* plan);
+int64_t isd_eegnet_workspace_bytes(const isd_eegnet_plan* plan, int64_t B);
+int isd_eegnet_forward(const isd_eegnet_plan* plan, const float* x, const float* params, float* buffers,
+                       float* out, void* workspace, int64_t B, int training, float momentum, float eps,
+                       float dropout_p, uint64_t seed, void* stream);
+int isd_eegnet_backward(const isd_eegnet_plan* plan, const float* x, const float* params, const float* dout,
+                        float* dparams, void* workspace, int64_t B, float dropout_p, uint64_t seed,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,97 @@
+"""GPU parity: factorised HIP EEGNet_Encoder vs the golden vectors captured from the reference and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import cnn as ocnn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def inn():
+    import isd_amd.nn as m
+    assert torch.cuda.is_available()
+    return m
+
+
+def _sd(g, prefix):
+    return {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+
+
+def _grad_err(got, want, scale):
+    return float(np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64)).max() / scale)
+
+
+@pytest.mark.parametrize("tag,C,T", [("z6", 6, 250), ("c128", 128, 96)])
+def test_eegnet_matches_reference_golden(inn, tag, C, T):
+    g = load_golden("g7_eegnet.npz")
+    m = inn.EEGNet_Encoder(C, 32, dropout=0.0).cuda()
+    m.load_state_dict(_sd(g, f"{tag}.sd."))
+    x = torch.from_numpy(g[f"{tag}.x"]).cuda()
+    m.eval()
+    with torch.no_grad():
+        y_eval = m(x)
+    assert y_eval.shape == (x.shape[0], 32)
+    assert rel_err(y_eval.cpu(), g[f"{tag}.y_eval"]) < 1e-4
+    m.train()
+    y = m(x)
+    assert rel_err(y.detach().cpu(), g[f"{tag}.y_train"]) < 1e-4
+    y.square().sum().backward()
+    # BN1's gamma/beta gradients are ~0 by scale invariance (BN2 follows): compare against the gradient scale
+    scale = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith(f"{tag}.grad."))
+    for k, p in m.named_parameters():
+        want = g[f"{tag}.grad.{k}"]
+        tol = 1e-4 * max(float(np.abs(want).max()), 1e-3 * scale)
+        assert np.abs(p.grad.cpu().numpy() - want).max() < tol + 1e-7, k
+    sd_after = _sd(g, f"{tag}.sd_after.")
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert rel_err(v.cpu(), sd_after[k]) < 1e-4, k
+        if "num_batches_tracked" in k:
+            assert int(v) == int(sd_after[k])
+
+
+@pytest.mark.parametrize("C,T,K,B", [(4, 64, 64, 3), (9, 333, 32, 5), (64, 512, 64, 4), (300, 40, 16, 2)])
+def test_eegnet_vs_oracle_shapes(inn, C, T, K, B):
+    torch.manual_seed(C + T)
+    m = inn.EEGNet_Encoder(C, 16, kernel_length=K, dropout=0.0).cuda()
+    with torch.no_grad():
+        for bn in m._bns():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    p = {k: v.detach().cpu().clone().double() for k, v in m.state_dict().items()}
+    for k, v in p.items():
+        if "running" not in k and "num_batches" not in k:
+            v.requires_grad_()
+    x = torch.randn(B, C, T)
+    w = torch.randn(B, 16)
+    m.train()
+    y = m(x.cuda())
+    (y * w.cuda()).sum().backward()
+    yr = ocnn.eegnet_encoder(x.double(), p, training=True, kernel_length=K)
+    (yr * w.double()).sum().backward()
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-4
+    scale = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
+    for k, q in m.named_parameters():
+        want = p[k].grad
+        # BN1's gamma/beta gradients vanish up to eps effects (BN2 renormalises): they are fp32 cancellation
+        # residue ~1e-6 of the gradient scale in the reference too, so they are compared on that scale
+        floor = 5e-2 if k.startswith("temporal_conv.1.") else 1e-3
+        tol = 1e-4 * max(float(want.abs().max()), floor * scale)
+        assert float((q.grad.cpu().double() - want).abs().max()) < tol + 1e-7, k
+
+
+def test_eegnet_dropout_is_unbiased_and_deterministic_per_seed(inn):
+    torch.manual_seed(0)
+    m = inn.EEGNet_Encoder(8, 32, dropout=0.25).cuda().train()
+    x = torch.randn(64, 8, 256, device="cuda")
+    m.p = 0.0
+    ref = m(x).detach()
+    m.p = 0.25
+    outs = torch.stack([m(x).detach() for _ in range(24)])
+    assert not torch.equal(outs[0], outs[1])                       # fresh mask per call
+    assert float((outs.mean(0) - ref).abs().mean() / ref.abs().mean()) < 0.2
+    with pytest.raises(Exception):
+        inn.EEGNet_Encoder(8, 32).cuda()(torch.randn(2, 8, 20, device="cuda"))   # too short for the pooling
