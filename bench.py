@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="trials per GPU")
     ap.add_argument("--two-kernel", action="store_true", help="materialise the filtered signals (fb + bandpower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bf16", action="store_true", help="config 3: bf16 activations/grads in the CNN, fp32 accumulate")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -111,7 +112,7 @@ def main():
 
     torch.manual_seed(42)                                        # reference default seed (train_fast.py:275)
     fx = isd_amd.FeatureExtractor(T, fs, isd_amd.BANDS_9)
-    model = _FeatureModel(nb * C, 32, 5, 4).to(dev)
+    model = _FeatureModel(nb * C, 32, 5, 4, "bf16" if args.bf16 else "f32").to(dev)
     trainer = isd_amd.Trainer(model, lr=5e-4, weight_decay=1e-2, schedule=None)
     feats = torch.empty((B, nb, C, fx.n_frames), dtype=torch.float32, device=dev)
     yfilt = torch.empty((B, nb, C, T), dtype=torch.float32, device=dev) if args.two_kernel else None
@@ -189,7 +190,8 @@ def main():
             "metric": "trials/sec end-to-end (filterbank+CNN fwd+bwd)", "value": round(global_batch * args.steps / dt, 1),
             "unit": "trials/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16 activations/grads in the CNN, f32 features + accumulate" if args.bf16 else "f32",
+            "data": "synthetic",
             "config": {"workload": "cfg2: 64ch x 2s@256Hz EEG, 9-band Butterworth(4) filterbank -> STFT(64/32) "
                                    "log band power -> Conv4Layers(576,32)+Linear(32,5) fwd+bwd, softmax-CE, AdamW",
                        "trials_per_gpu": B, "global_batch": global_batch, "parallelism": f"dp{world}",

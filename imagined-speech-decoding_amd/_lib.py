@@ -46,6 +46,7 @@ SIGNATURES = {
     "isd_features_fused": (_i, [_p, _p, _p, _p, _i64, _i64, _pi, _pi, _i, _f, _p]),
     "isd_conv4_plan_create": (_i, [C.POINTER(_p), _i, _i, _pi, _pi, _i, _i, _i, _i]),
     "isd_conv4_plan_destroy": (_i, [_p]),
+    "isd_conv4_plan_set_activation_dtype": (_i, [_p, _i]),
     "isd_conv4_param_count": (_i64, [_p]),
     "isd_conv4_param_offset": (_i64, [_p, _i, _i]),
     "isd_conv4_windows": (_i, [_p, _i64]),

@@ -54,9 +54,9 @@ class _FlatModel(nn.Module, _FlatParamMixin):
 
 
 class _FeatureModel(_FlatModel):
-    def __init__(self, in_channels, feature_dim, n_classes, n_layers):
+    def __init__(self, in_channels, feature_dim, n_classes, n_layers, act_dtype="f32"):
         super().__init__()
-        self.net = FeatureCNN(in_channels, feature_dim, n_classes, n_layers)
+        self.net = FeatureCNN(in_channels, feature_dim, n_classes, n_layers, act_dtype)
 
     def _conv(self):
         return self.net.cnn
@@ -361,8 +361,11 @@ class FilterbankCNNClassifier(_Estimator):
     """
 
     def __init__(self, fs=256.0, bands=BANDS_9, order=4, nperseg=64, noverlap=None, eps=1e-10, feature_dim=32,
-                 n_classes=5, n_layers=4, fused=None, **kw):
+                 n_classes=5, n_layers=4, fused=None, precision="fp32", **kw):
         super().__init__(**kw)
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision          # 'bf16' = BASELINE config 3 (bf16 activations/grads, fp32 accumulate)
         self.fs, self.bands, self.order = fs, bands, order
         self.nperseg, self.noverlap, self.eps = nperseg, noverlap, eps
         self.feature_dim, self.n_classes, self.n_layers, self.fused = feature_dim, n_classes, n_layers, fused
@@ -380,7 +383,8 @@ class FilterbankCNNClassifier(_Estimator):
 
     def _build(self, X):
         fx = self._extractor(X.shape[-1])
-        return _FeatureModel(fx.n_bands * X.shape[1], self.feature_dim, self.n_classes, self.n_layers)
+        return _FeatureModel(fx.n_bands * X.shape[1], self.feature_dim, self.n_classes, self.n_layers,
+                             "bf16" if self.precision == "bf16" else "f32")
 
     def _inputs(self, xb):
         f = self.extract_features(xb)

@@ -15,6 +15,7 @@
 #include "common.h"
 #include <math.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 namespace isd {
@@ -33,6 +34,34 @@ struct ZoneDesc {
   int64_t wg_off;   // offset of the zone's dWeff block [F][Cz+1][5] in the wgrad result
 };
 
+// Activation storage type: float, or bf16 (config 3: bf16 activations / activation gradients, fp32
+// accumulate).  Values are rounded to bf16 (RNE) where they are stored and where operands are staged, so
+// the products equal those of a bf16 MFMA with fp32 accumulation; the MFMA itself stays the fp32 one.
+struct bf16_t { unsigned short v; };
+__device__ __forceinline__ float bf16_round(float x) {
+  unsigned int u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return x;                     // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xffff0000u);
+}
+template <typename AT> struct Act;
+template <> struct Act<float> {
+  static constexpr bool kBf16 = false;
+  static __device__ __forceinline__ float ld(const void* p, int64_t i) { return ((const float*)p)[i]; }
+  static __device__ __forceinline__ void st(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+  static __device__ __forceinline__ float rnd(float v) { return v; }
+};
+template <> struct Act<bf16_t> {
+  static constexpr bool kBf16 = true;
+  static __device__ __forceinline__ float ld(const void* p, int64_t i) {
+    return __uint_as_float((unsigned int)((const unsigned short*)p)[i] << 16);
+  }
+  static __device__ __forceinline__ void st(void* p, int64_t i, float v) {
+    ((unsigned short*)p)[i] = (unsigned short)(__float_as_uint(bf16_round(v)) >> 16);
+  }
+  static __device__ __forceinline__ float rnd(float v) { return bf16_round(v); }
+};
+
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
@@ -45,7 +74,7 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 __global__ __launch_bounds__(256) void prep_fused_kernel(const float* __restrict__ params,
                                                          const ZoneDesc* __restrict__ zones,
                                                          float* __restrict__ wfrag, float* __restrict__ beff, int F,
-                                                         int nbw) {
+                                                         int nbw, int bf16) {
   __shared__ float red[256];
   const int z = blockIdx.y;
   const ZoneDesc zd = zones[z];
@@ -68,7 +97,7 @@ __global__ __launch_bounds__(256) void prep_fused_kernel(const float* __restrict
     float acc = 0.f;
     if (c < zd.cin)
       for (int f = 0; f < F; ++f) acc = fmaf(W2[(g * F + f) * zd.cin + c], W1[f * kTaps + k], acc);
-    wfrag[zd.eff_off + e] = acc;
+    wfrag[zd.eff_off + e] = bf16 ? bf16_round(acc) : acc;
     return;
   }
   const int g = blockIdx.x - nbw;                      // one block per beff[g]
@@ -86,7 +115,8 @@ __global__ __launch_bounds__(256) void prep_fused_kernel(const float* __restrict
 
 // cnn3 / cnn4 weights [F][F][5] -> frag order, forward and transposed+flipped (dgrad) copies.
 __global__ void prep_conv_kernel(const float* __restrict__ params, const ZoneDesc* __restrict__ zones,
-                                 float* __restrict__ wf, float* __restrict__ wt, int F, int layer, int64_t zstride) {
+                                 float* __restrict__ wf, float* __restrict__ wt, int F, int layer, int64_t zstride,
+                                 int bf16) {
   const int z = blockIdx.y;
   const ZoneDesc zd = zones[z];
   const int GT = F / 16;
@@ -101,8 +131,10 @@ __global__ void prep_conv_kernel(const float* __restrict__ params, const ZoneDes
     const int cg = blk / (GT * kTaps);
     const int g = gt * 16 + (lane & 15);
     const int c = cg * 4 + (lane >> 4);
-    wf[z * zstride + e] = W[(g * F + c) * kTaps + k];
-    wt[z * zstride + e] = W[(c * F + g) * kTaps + (kTaps - 1 - k)];   // dIn[g] <- dOut[c], flipped taps
+    const float a = W[(g * F + c) * kTaps + k];
+    const float b = W[(c * F + g) * kTaps + (kTaps - 1 - k)];        // dIn[g] <- dOut[c], flipped taps
+    wf[z * zstride + e] = bf16 ? bf16_round(a) : a;
+    wt[z * zstride + e] = bf16 ? bf16_round(b) : b;
   }
 }
 
@@ -110,8 +142,8 @@ __global__ void prep_conv_kernel(const float* __restrict__ params, const ZoneDes
 // Forward convolution (also used as dgrad with transposed weights).
 // ---------------------------------------------------------------------------------------
 struct ConvArgs {
-  const float* in;
-  float* out;
+  const void* in;            // MODE 0: fp32 trials; MODE 1: activations of type AT
+  void* out;                 // activations of type AT
   const float* wfrag;        // frag-ordered weights (per-zone offset from ZoneDesc or z*wz_stride)
   const float* bias;         // [Z][F] or null
   const ZoneDesc* zones;
@@ -128,8 +160,9 @@ struct ConvArgs {
 // LDS rows are unpadded copies of the source rows (stride RS >= Tin); zero padding, the ragged last
 // time tile and the channel round-up are handled by masking the B fragment, so staging moves only
 // real data (float4 when the block is contiguous and aligned).
-template <int MODE>
+template <int MODE, typename AT>
 __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
+  using IT = typename std::conditional<MODE == 0, float, AT>::type;   // storage type of the input
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int z = blockIdx.y;
   const ZoneDesc zd = a.zones[z];
@@ -167,38 +200,42 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
       const int ckc4 = (ckc + 3) & ~3;
       __syncthreads();
       if (a.lin) {
-        // one contiguous block of ckc*Tin floats per item
+        // one contiguous block of ckc*Tin elements per item
         const int cnt = ckc * a.Tin;
         for (int ii = wave; ii < n_items; ii += 4) {
           const int64_t item = item0 + ii;
-          const float* src = (MODE == 0)
-                                 ? a.in + (item * a.Ctot + a.chan_idx[zd.idx_off + c_lo]) * (int64_t)a.Tx
-                                 : a.in + ((item * a.Z + z) * a.F + c_lo) * (int64_t)a.Tin;
+          const int64_t soff = (MODE == 0) ? (item * a.Ctot + a.chan_idx[zd.idx_off + c_lo]) * (int64_t)a.Tx
+                                           : ((item * a.Z + z) * a.F + c_lo) * (int64_t)a.Tin;
           float* dst = in_tile + ii * kCK * a.RS;
-          if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
-            const float4* s4 = reinterpret_cast<const float4*>(src);
-            float4* d4 = reinterpret_cast<float4*>(dst);
-            for (int e = lane; e < (cnt >> 2); e += 64) d4[e] = s4[e];
+          if constexpr (std::is_same<IT, float>::value && !Act<AT>::kBf16) {
+            const float* src = (const float*)a.in + soff;
+            if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
+              const float4* s4 = reinterpret_cast<const float4*>(src);
+              float4* d4 = reinterpret_cast<float4*>(dst);
+              for (int e = lane; e < (cnt >> 2); e += 64) d4[e] = s4[e];
+            } else {
+              for (int e = lane; e < cnt; e += 64) dst[e] = src[e];
+            }
           } else {
-            for (int e = lane; e < cnt; e += 64) dst[e] = src[e];
+            for (int e = lane; e < cnt; e += 64) dst[e] = Act<AT>::rnd(Act<IT>::ld(a.in, soff + e));
           }
         }
       } else {
-        // one wave per row, lanes along time (coalesced 256-byte segments)
+        // one wave per row, lanes along time (coalesced segments)
         const int rows = n_items * ckc;
         for (int r = wave; r < rows; r += 4) {
           const int ii = r / ckc, cc = r - ii * ckc;
           const int64_t item = item0 + ii;
-          const float* src;
+          int64_t soff;
           if (MODE == 0) {
             const int64_t b = item / a.N;
             const int n = (int)(item - b * a.N);
-            src = a.in + (b * a.Ctot + a.chan_idx[zd.idx_off + c_lo + cc]) * (int64_t)a.Tx + (int64_t)n * a.S;
+            soff = (b * a.Ctot + a.chan_idx[zd.idx_off + c_lo + cc]) * (int64_t)a.Tx + (int64_t)n * a.S;
           } else {
-            src = a.in + ((item * a.Z + z) * a.F + c_lo + cc) * (int64_t)a.Tin;
+            soff = ((item * a.Z + z) * a.F + c_lo + cc) * (int64_t)a.Tin;
           }
           float* dst = in_tile + (ii * kCK + cc) * a.RS;
-          for (int t = lane; t < a.Tin; t += 64) dst[t] = src[t];
+          for (int t = lane; t < a.Tin; t += 64) dst[t] = Act<AT>::rnd(Act<IT>::ld(a.in, soff + t));
         }
       }
       {
@@ -246,7 +283,7 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
           const int g = gt * 16 + 4 * q + r;
           float v = acc[j][gt][r];
           if (a.bias) v += a.bias[z * a.F + g];
-          a.out[((item * a.Z + z) * a.F + g) * (int64_t)a.Tout + t] = v;
+          Act<AT>::st(a.out, ((item * a.Z + z) * a.F + g) * (int64_t)a.Tout + t, v);
         }
       }
     }
@@ -257,14 +294,14 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
 // GELU + mean over time (fast.py:117-118) and its backward (in place on the activation).
 // one 16-lane row per (item, zone, filter) row of length T
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gelu_mean_fwd_kernel(const float* __restrict__ a, float* __restrict__ feat,
+template <typename AT>
+__global__ __launch_bounds__(256) void gelu_mean_fwd_kernel(const void* __restrict__ a, float* __restrict__ feat,
                                                             int64_t rows, int T) {
   const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   const int i = threadIdx.x & 15;
   float s = 0.f;
   if (row < rows) {
-    const float* p = a + row * T;
-    for (int t = i; t < T; t += 16) s += gelu_f(p[t]);
+    for (int t = i; t < T; t += 16) s += gelu_f(Act<AT>::ld(a, row * T + t));
   }
   s += row_shr<8>(s);   // lanes >= 8 accumulate lanes - 8 ... finish with a butterfly via shifts
   s += row_shr<4>(s);
@@ -273,14 +310,14 @@ __global__ __launch_bounds__(256) void gelu_mean_fwd_kernel(const float* __restr
   if (row < rows && i == 15) feat[row] = s / (float)T;
 }
 
-__global__ __launch_bounds__(256) void gelu_mean_bwd_kernel(float* __restrict__ a, const float* __restrict__ dfeat,
+template <typename AT>
+__global__ __launch_bounds__(256) void gelu_mean_bwd_kernel(void* __restrict__ a, const float* __restrict__ dfeat,
                                                             int64_t rows, int T) {
   const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   const int i = threadIdx.x & 15;
   if (row >= rows) return;
   const float g = dfeat[row] / (float)T;
-  float* p = a + row * T;
-  for (int t = i; t < T; t += 16) p[t] = g * gelu_grad_f(p[t]);
+  for (int t = i; t < T; t += 16) Act<AT>::st(a, row * T + t, g * gelu_grad_f(Act<AT>::ld(a, row * T + t)));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -290,8 +327,8 @@ __global__ __launch_bounds__(256) void gelu_mean_bwd_kernel(float* __restrict__ 
 // Each workgroup reduces a contiguous range of items and writes one partial slab.
 // ---------------------------------------------------------------------------------------
 struct WgradArgs {
-  const float* dout;         // [items][Z][F][Tout]
-  const float* in;           // MODE 0: raw trials, MODE 1: [items][Z][F][Tin]
+  const void* dout;          // [items][Z][F][Tout], type AT
+  const void* in;            // MODE 0: raw fp32 trials, MODE 1: [items][Z][F][Tin] of type AT
   float* part;               // [n_wg * n_grp][slab_size]
   const ZoneDesc* zones;
   const int* chan_idx;
@@ -309,8 +346,9 @@ struct WgradArgs {
 //                and write separate slabs (summed by reduce_slabs_kernel);
 //   roles == 8 : a wave owns one c-tile and both g-tiles.
 // LDS rows are unpadded copies (RSo >= Tout, RSi >= Tin); range / padding handled by masks.
-template <int MODE>
+template <int MODE, typename AT>
 __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
+  using IT = typename std::conditional<MODE == 0, float, AT>::type;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int z = blockIdx.y;
   const ZoneDesc zd = a.zones[z];
@@ -355,17 +393,22 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
     {
       const int cnt = a.F * a.Tout;
       for (int ii = wave; ii < n_it; ii += 4) {
-        const float* src = a.dout + ((is + ii) * a.Z + z) * (int64_t)cnt;
+        const int64_t soff = ((is + ii) * a.Z + z) * (int64_t)cnt;
         float* dst = do_tile + ii * a.F * a.RSo;
-        if (a.RSo == a.Tout && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
-          const float4* s4 = reinterpret_cast<const float4*>(src);
-          float4* d4 = reinterpret_cast<float4*>(dst);
-          for (int e = lane; e < (cnt >> 2); e += 64) d4[e] = s4[e];
-        } else if (a.RSo == a.Tout) {
-          for (int e = lane; e < cnt; e += 64) dst[e] = src[e];
+        if constexpr (!Act<AT>::kBf16) {
+          const float* src = (const float*)a.dout + soff;
+          if (a.RSo == a.Tout && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(dst);
+            for (int e = lane; e < (cnt >> 2); e += 64) d4[e] = s4[e];
+            continue;
+          }
+        }
+        if (a.RSo == a.Tout) {
+          for (int e = lane; e < cnt; e += 64) dst[e] = Act<AT>::ld(a.dout, soff + e);
         } else {
           for (int g = 0; g < a.F; ++g)
-            for (int t = lane; t < a.Tout; t += 64) dst[g * a.RSo + t] = src[g * a.Tout + t];
+            for (int t = lane; t < a.Tout; t += 64) dst[g * a.RSo + t] = Act<AT>::ld(a.dout, soff + g * a.Tout + t);
         }
       }
     }
@@ -374,16 +417,20 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
         const int cnt = cw_real * a.Tin;
         for (int ii = wave; ii < n_it; ii += 4) {
           const int64_t item = is + ii;
-          const float* src = (MODE == 0)
-                                 ? a.in + (item * a.Ctot + a.chan_idx[zd.idx_off + c_base]) * (int64_t)a.Tx
-                                 : a.in + ((item * a.Z + z) * a.F + c_base) * (int64_t)a.Tin;
+          const int64_t soff = (MODE == 0) ? (item * a.Ctot + a.chan_idx[zd.idx_off + c_base]) * (int64_t)a.Tx
+                                           : ((item * a.Z + z) * a.F + c_base) * (int64_t)a.Tin;
           float* dst = in_tile + ii * a.CW * a.RSi;
-          if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
-            const float4* s4 = reinterpret_cast<const float4*>(src);
-            float4* d4 = reinterpret_cast<float4*>(dst);
-            for (int e = lane; e < (cnt >> 2); e += 64) d4[e] = s4[e];
+          if constexpr (std::is_same<IT, float>::value && !Act<AT>::kBf16) {
+            const float* src = (const float*)a.in + soff;
+            if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
+              const float4* s4 = reinterpret_cast<const float4*>(src);
+              float4* d4 = reinterpret_cast<float4*>(dst);
+              for (int e = lane; e < (cnt >> 2); e += 64) d4[e] = s4[e];
+            } else {
+              for (int e = lane; e < cnt; e += 64) dst[e] = src[e];
+            }
           } else {
-            for (int e = lane; e < cnt; e += 64) dst[e] = src[e];
+            for (int e = lane; e < cnt; e += 64) dst[e] = Act<AT>::rnd(Act<IT>::ld(a.in, soff + e));
           }
         }
       } else {
@@ -391,16 +438,16 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
         for (int r = wave; r < rows; r += 4) {
           const int ii = r / cw_real, cc = r - ii * cw_real;
           const int64_t item = is + ii;
-          const float* src;
+          int64_t soff;
           if (MODE == 0) {
             const int64_t b = item / a.N;
             const int n = (int)(item - b * a.N);
-            src = a.in + (b * a.Ctot + a.chan_idx[zd.idx_off + c_base + cc]) * (int64_t)a.Tx + (int64_t)n * a.S;
+            soff = (b * a.Ctot + a.chan_idx[zd.idx_off + c_base + cc]) * (int64_t)a.Tx + (int64_t)n * a.S;
           } else {
-            src = a.in + ((item * a.Z + z) * a.F + c_base + cc) * (int64_t)a.Tin;
+            soff = ((item * a.Z + z) * a.F + c_base + cc) * (int64_t)a.Tin;
           }
           float* dst = in_tile + (ii * a.CW + cc) * a.RSi;
-          for (int t = lane; t < a.Tin; t += 64) dst[t] = src[t];
+          for (int t = lane; t < a.Tin; t += 64) dst[t] = Act<AT>::rnd(Act<IT>::ld(a.in, soff + t));
         }
       }
     }
@@ -539,6 +586,7 @@ struct isd_conv4_plan {
   int64_t wg_size;         // floats of all dWeff blocks
   int max_cz;
   int contiguous;          // every zone's channel list is consecutive -> rows of a zone are adjacent in memory
+  int act_bf16;            // activations / activation gradients stored as bf16 (config 3)
   ZoneDesc* d_zones;
   int* d_idx;
 };
@@ -563,7 +611,7 @@ extern "C" int isd_conv4_plan_create(isd_conv4_plan** out, int c_total, int n_zo
                 window_len, slide_step);
   isd_conv4_plan* p = new isd_conv4_plan();
   p->Ctot = c_total; p->Z = n_zones; p->F = feature_dim; p->n_layers = n_layers; p->W = window_len; p->S = slide_step;
-  p->d_zones = nullptr; p->d_idx = nullptr;
+  p->d_zones = nullptr; p->d_idx = nullptr; p->act_bf16 = 0;
   const int F = feature_dim, GT = F / 16;
   std::vector<ZoneDesc> zd(n_zones);
   std::vector<int> idx;
@@ -613,6 +661,12 @@ extern "C" int isd_conv4_plan_destroy(isd_conv4_plan* p) {
   if (p->d_zones) (void)hipFree(p->d_zones);
   if (p->d_idx) (void)hipFree(p->d_idx);
   delete p;
+  return ISD_OK;
+}
+
+extern "C" int isd_conv4_plan_set_activation_dtype(isd_conv4_plan* p, int dtype) {
+  ISD_CHECK_ARG(p && (dtype == ISD_ACT_F32 || dtype == ISD_ACT_BF16), "isd_conv4_plan_set_activation_dtype: bad argument");
+  p->act_bf16 = dtype == ISD_ACT_BF16;
   return ISD_OK;
 }
 
@@ -717,16 +771,17 @@ extern "C" int64_t isd_conv4_workspace_bytes(const isd_conv4_plan* p, int64_t B,
   return g.total * 4;
 }
 
-static int launch_conv(int mode, const ConvArgs& a, int n_zones, hipStream_t st) {
+static int launch_conv(int mode, int bf16, const ConvArgs& a, int n_zones, hipStream_t st) {
   const int64_t blocks = cdiv(a.items, a.IPW);
   ISD_CHECK_ARG(blocks <= 0x7fffffffLL, "conv4: too many items");
   const int GT = a.F / 16;
   const size_t lds = sizeof(float) * ((((size_t)a.IPW * kCK * a.RS + 3) & ~(size_t)3) + (size_t)(kCK / 4) * kTaps * GT * 64);
   ISD_CHECK_ARG(lds <= 64 * 1024, "conv4: LDS tile of %zu bytes exceeds 64 KiB (window too long)", lds);
-  if (mode == 0)
-    hipLaunchKernelGGL((conv5_fwd_kernel<0>), dim3((unsigned)blocks, n_zones), dim3(256), lds, st, a);
-  else
-    hipLaunchKernelGGL((conv5_fwd_kernel<1>), dim3((unsigned)blocks, n_zones), dim3(256), lds, st, a);
+  const dim3 grid((unsigned)blocks, n_zones);
+  if (mode == 0 && !bf16) hipLaunchKernelGGL((conv5_fwd_kernel<0, float>), grid, dim3(256), lds, st, a);
+  else if (mode == 0) hipLaunchKernelGGL((conv5_fwd_kernel<0, bf16_t>), grid, dim3(256), lds, st, a);
+  else if (!bf16) hipLaunchKernelGGL((conv5_fwd_kernel<1, float>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((conv5_fwd_kernel<1, bf16_t>), grid, dim3(256), lds, st, a);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
@@ -746,14 +801,14 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
   {
     const int nbw = (int)cdiv(((int64_t)(p->max_cz + 3) / 4) * kTaps * (F / 16) * 64, 256);
     hipLaunchKernelGGL(prep_fused_kernel, dim3(nbw + F, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_eff,
-                       ws + g.o_beff, F, nbw);
+                       ws + g.o_beff, F, nbw, p->act_bf16);
     ISD_LAUNCH_CHECK();
   }
   if (p->n_layers == 4) {
     hipLaunchKernelGGL(prep_conv_kernel, dim3(4, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_w3,
-                       ws + g.o_w3t, F, 0, p->conv_zstride);
+                       ws + g.o_w3t, F, 0, p->conv_zstride, p->act_bf16);
     hipLaunchKernelGGL(prep_conv_kernel, dim3(4, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_w4,
-                       ws + g.o_w4t, F, 1, p->conv_zstride);
+                       ws + g.o_w4t, F, 1, p->conv_zstride, p->act_bf16);
     ISD_LAUNCH_CHECK();
   }
   ConvArgs a = {};
@@ -763,27 +818,41 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
   // cnn1 o cnn2
   a.in = x; a.out = ws + g.o_a2; a.wfrag = ws + g.o_eff; a.bias = ws + g.o_beff; a.Tin = p->W; a.pad = 0; a.RS = g.RS_a;
   a.lin = g.lin0;
-  rc = launch_conv(0, a, p->Z, st);
+  rc = launch_conv(0, p->act_bf16, a, p->Z, st);
   if (rc) return rc;
   const float* last = ws + g.o_a2;
   if (p->n_layers == 4) {
     a.bias = nullptr; a.Tin = g.T1; a.pad = 2; a.RS = g.RS_b; a.wz_stride = p->conv_zstride; a.lin = 1;
     a.in = ws + g.o_a2; a.out = ws + g.o_a3; a.wfrag = ws + g.o_w3;
-    rc = launch_conv(1, a, p->Z, st);
+    rc = launch_conv(1, p->act_bf16, a, p->Z, st);
     if (rc) return rc;
     a.in = ws + g.o_a3; a.out = ws + g.o_a4; a.wfrag = ws + g.o_w4;
-    rc = launch_conv(1, a, p->Z, st);
+    rc = launch_conv(1, p->act_bf16, a, p->Z, st);
     if (rc) return rc;
     last = ws + g.o_a4;
   }
   const int64_t rows = g.items * p->Z * F;
-  hipLaunchKernelGGL(gelu_mean_fwd_kernel, dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, last, feat, rows,
-                     g.T1);
+  if (p->act_bf16)
+    hipLaunchKernelGGL((gelu_mean_fwd_kernel<bf16_t>), dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, last,
+                       feat, rows, g.T1);
+  else
+    hipLaunchKernelGGL((gelu_mean_fwd_kernel<float>), dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, last, feat,
+                       rows, g.T1);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
 
-static int launch_wgrad(int mode, WgradArgs& a, int n_zones, int cin_max, hipStream_t st) {
+template <int MODE, typename AT>
+static int launch_wgrad_t(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  if (lds > 48 * 1024)
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_wgrad_kernel<MODE, AT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+  hipLaunchKernelGGL((conv5_wgrad_kernel<MODE, AT>), grid, dim3(256), lds, st, a);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+static int launch_wgrad(int mode, int bf16, WgradArgs& a, int n_zones, int cin_max, hipStream_t st) {
   const int64_t per_item = (int64_t)a.F * a.RSo + (int64_t)a.CW * a.RSi;
   int ips = (int)((96 * 1024 / 4 - 4) / per_item);
   ISD_CHECK_ARG(ips >= 1, "conv4 wgrad: window too long for the LDS tile");
@@ -795,17 +864,9 @@ static int launch_wgrad(int mode, WgradArgs& a, int n_zones, int cin_max, hipStr
   const size_t lds = sizeof(float) * ((size_t)ips * per_item + 4);
   const int64_t wgs = cdiv(a.items, a.items_per_wg);
   const int zgroups = (cin_max + a.CW - 1) / a.CW;
-  if (mode == 0) {
-    if (lds > 48 * 1024)
-      ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((conv5_wgrad_kernel<0>), dim3((unsigned)wgs, n_zones, zgroups), dim3(256), lds, st, a);
-  } else {
-    if (lds > 48 * 1024)
-      ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((conv5_wgrad_kernel<1>), dim3((unsigned)wgs, n_zones, zgroups), dim3(256), lds, st, a);
-  }
-  ISD_LAUNCH_CHECK();
-  return ISD_OK;
+  const dim3 grid((unsigned)wgs, n_zones, zgroups);
+  if (mode == 0) return bf16 ? launch_wgrad_t<0, bf16_t>(a, grid, lds, st) : launch_wgrad_t<0, float>(a, grid, lds, st);
+  return bf16 ? launch_wgrad_t<1, bf16_t>(a, grid, lds, st) : launch_wgrad_t<1, float>(a, grid, lds, st);
 }
 
 // cnn3 / cnn4 gradient in natural [F][F][5] layout -> flat gradient block
@@ -836,8 +897,12 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
   const int F = p->F;
   const int64_t rows = g.items * p->Z * F;
   float* top = ws + (p->n_layers == 4 ? g.o_a4 : g.o_a2);        // activation that fed GELU
-  hipLaunchKernelGGL(gelu_mean_bwd_kernel, dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, top, dfeat, rows,
-                     g.T1);
+  if (p->act_bf16)
+    hipLaunchKernelGGL((gelu_mean_bwd_kernel<bf16_t>), dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, top,
+                       dfeat, rows, g.T1);
+  else
+    hipLaunchKernelGGL((gelu_mean_bwd_kernel<float>), dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, top, dfeat,
+                       rows, g.T1);
   ISD_LAUNCH_CHECK();
   WgradArgs w = {};
   w.zones = p->d_zones; w.chan_idx = p->d_idx; w.items = g.items;
@@ -852,23 +917,23 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
   if (p->n_layers == 4) {
     w.dout = ws + g.o_a4; w.in = ws + g.o_a3; w.Tin = g.T1; w.pad = 2; w.RSo = g.T1; w.RSi = g.T1; w.lin = 1;
     w.slab_size = g.slab1; w.wz_stride = (int64_t)F * F * kTaps; w.items_per_wg = g.ipw1; w.CW = g.cw1;
-    rc = launch_wgrad(1, w, p->Z, F, st);
+    rc = launch_wgrad(1, p->act_bf16, w, p->Z, F, st);
     if (rc) return rc;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdiv(g.slab1, 64)), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg34, g.slab1, g.ns1);
     hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 1);
     ISD_LAUNCH_CHECK();
     a.in = ws + g.o_a4; a.out = ws + g.o_s; a.wfrag = ws + g.o_w4t;
-    rc = launch_conv(1, a, p->Z, st);
+    rc = launch_conv(1, p->act_bf16, a, p->Z, st);
     if (rc) return rc;
     // cnn3: dW3 = wgrad(G3, A2); G2 = dgrad(G3) (into the A4 buffer, free now)
     w.dout = ws + g.o_s; w.in = ws + g.o_a2;
-    rc = launch_wgrad(1, w, p->Z, F, st);
+    rc = launch_wgrad(1, p->act_bf16, w, p->Z, F, st);
     if (rc) return rc;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdiv(g.slab1, 64)), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg34, g.slab1, g.ns1);
     hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 0);
     ISD_LAUNCH_CHECK();
     a.in = ws + g.o_s; a.out = ws + g.o_a4; a.wfrag = ws + g.o_w3t;
-    rc = launch_conv(1, a, p->Z, st);
+    rc = launch_conv(1, p->act_bf16, a, p->Z, st);
     if (rc) return rc;
     g2 = ws + g.o_a4;
   }
@@ -877,7 +942,7 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
   w.RSo = g.T1; w.lin = g.lin0;
   w.RSi = g.lin0 ? p->W : (p->W | 1);
   w.slab_size = g.slab0; w.wz_stride = 0; w.items_per_wg = g.ipw0; w.CW = g.cw0;
-  rc = launch_wgrad(0, w, p->Z, p->max_cz + 1, st);
+  rc = launch_wgrad(0, p->act_bf16, w, p->Z, p->max_cz + 1, st);
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdiv(g.slab0, 64)), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg, g.slab0, g.ns0);
   {

@@ -35,7 +35,7 @@ def _f32c(t, name):
 class ConvStackPlan:
     """isd_conv4_plan wrapper: static geometry of a zone-wise Conv4Layers stack."""
 
-    def __init__(self, c_total, zone_idx, feature_dim, n_layers, window_len, slide_step):
+    def __init__(self, c_total, zone_idx, feature_dim, n_layers, window_len, slide_step, act_dtype="f32"):
         self.c_total, self.zone_idx = int(c_total), [list(map(int, z)) for z in zone_idx]
         self.F, self.n_layers = int(feature_dim), int(n_layers)
         self.window_len, self.slide_step = int(window_len), int(slide_step)
@@ -46,6 +46,10 @@ class ConvStackPlan:
                                                     _lib.int_array(flat), self.F, self.n_layers, self.window_len,
                                                     self.slide_step))
         self.n_params = int(_lib.lib().isd_conv4_param_count(self._h))
+        if act_dtype not in ("f32", "bf16"):
+            raise ValueError("act_dtype must be 'f32' or 'bf16'")
+        self.act_dtype = act_dtype
+        _lib.check(_lib.lib().isd_conv4_plan_set_activation_dtype(self._h, 1 if act_dtype == "bf16" else 0))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -334,8 +338,9 @@ class Conv4Layers(_Conv4Params, _FlatParamMixin):
     ``Head_cls(n_zone_channels, feature_dim)`` of fast.py:203-210.
     """
 
-    def __init__(self, channels, dim=32, n_layers=4):
+    def __init__(self, channels, dim=32, n_layers=4, act_dtype="f32"):
         super().__init__(channels, dim, n_layers)
+        self.act_dtype = act_dtype          # 'bf16': bf16 activations / gradients, fp32 accumulate (config 3)
         self._plans = {}
 
     def _ordered_params(self):
@@ -344,7 +349,8 @@ class Conv4Layers(_Conv4Params, _FlatParamMixin):
     def _plan(self, T):
         pl = self._plans.get(T)
         if pl is None:
-            pl = ConvStackPlan(self.channels, [list(range(self.channels))], self.dim, self.n_layers, T, 1)
+            pl = ConvStackPlan(self.channels, [list(range(self.channels))], self.dim, self.n_layers, T, 1,
+                               self.act_dtype)
             self._plans[T] = pl
         return pl
 
@@ -426,8 +432,9 @@ class Head(nn.Module, _FlatParamMixin):
     sliding windows of ``FAST.forward_head`` into the kernels' index arithmetic.
     """
 
-    def __init__(self, head, electrodes, zone_dict, feature_dim):
+    def __init__(self, head, electrodes, zone_dict, feature_dim, act_dtype="f32"):
         super().__init__()
+        self.act_dtype = act_dtype
         if head != "Conv4Layers":
             raise NotImplementedError(f"head '{head}' is not provided by the HIP path yet (Conv4Layers is)")
         self.electrodes = list(electrodes)
@@ -447,7 +454,7 @@ class Head(nn.Module, _FlatParamMixin):
         pl = self._plans.get(key)
         if pl is None:
             pl = ConvStackPlan(len(self.electrodes), [v.tolist() for v in self.index_dict.values()], self.feature_dim,
-                               4, window_len, slide_step)
+                               4, window_len, slide_step, self.act_dtype)
             self._plans[key] = pl
         return pl
 
@@ -478,7 +485,8 @@ class FAST(nn.Module):
         super().__init__()
         self.config = config
         self.n_tokens = (config.seq_len - config.window_len) // config.slide_step + 1
-        self.head = Head(config.head, config.electrodes, config.zone_dict, config.dim_cnn)
+        self.head = Head(config.head, config.electrodes, config.zone_dict, config.dim_cnn,
+                         getattr(config, "act_dtype", "f32"))
         self.input_layer = nn.Sequential(nn.Linear(config.dim_cnn * len(config.zone_dict), config.dim_token), nn.GELU())
         self.last_layer = nn.Linear(config.dim_token, config.n_classes)
 
@@ -512,9 +520,9 @@ class FeatureCNN(nn.Module):
     """Build-defined classifier over spec-S features: ``Conv4Layers(nb*C, F)`` through the
     unmodified head contract, then ``Linear(F, n_classes)``.  ``n_layers=2`` is BASELINE config 1's 2-layer CNN."""
 
-    def __init__(self, in_channels, feature_dim=32, n_classes=5, n_layers=4):
+    def __init__(self, in_channels, feature_dim=32, n_classes=5, n_layers=4, act_dtype="f32"):
         super().__init__()
-        self.cnn = Conv4Layers(in_channels, feature_dim, n_layers)
+        self.cnn = Conv4Layers(in_channels, feature_dim, n_layers, act_dtype)
         self.fc = nn.Linear(feature_dim, n_classes)
 
     def token_logits(self, feats):

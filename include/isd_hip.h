@@ -129,6 +129,11 @@ int isd_conv4_plan_create(isd_conv4_plan** out, int c_total, int n_zones, const 
                           const int* zone_channels, int feature_dim, int n_layers, int window_len,
                           int slide_step);
 int isd_conv4_plan_destroy(isd_conv4_plan* plan);
+/* BASELINE config 3: ISD_ACT_BF16 stores activations and activation gradients as bf16 and rounds the staged
+ * operands (inputs, weights) to bf16, accumulating in fp32 -- the arithmetic of bf16-mixed autocast
+ * (scripts/train_fast.py:277).  Parameters, parameter gradients, features and the FC head stay fp32. */
+enum { ISD_ACT_F32 = 0, ISD_ACT_BF16 = 1 };
+int isd_conv4_plan_set_activation_dtype(isd_conv4_plan* plan, int dtype);
 int64_t isd_conv4_param_count(const isd_conv4_plan* plan);
 /* which: 0 cnn1.weight, 1 cnn1.bias, 2 cnn2.weight, 3 cnn3.weight, 4 cnn4.weight -> offset in floats */
 int64_t isd_conv4_param_offset(const isd_conv4_plan* plan, int zone, int which);

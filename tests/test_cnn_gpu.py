@@ -199,3 +199,30 @@ def test_full_size_feature_cnn_gradient_is_mean_of_shards(inn):
     got = grads(slice(0, 16))
     ref = torch.cat([p[k].grad.reshape(-1) for k, _ in m.named_parameters()])
     assert rel_err(got.cpu(), ref) < TOL
+
+
+# ------------------------------------------------------------------ BASELINE config 3: bf16 activations / grads
+def test_bf16_activation_mode_tolerance_vs_fp32(inn):
+    """bf16 storage of activations + activation gradients, operands rounded to bf16, fp32 accumulate.
+    Stated tolerance vs the fp32 path: logits 2e-2 relative, parameter gradients 5e-2 relative."""
+    torch.manual_seed(0)
+    m32 = inn.FeatureCNN(9 * 8, 32, 5).cuda()
+    m16 = inn.FeatureCNN(9 * 8, 32, 5, act_dtype="bf16").cuda()
+    m16.load_state_dict(m32.state_dict())
+    feats = torch.randn(64, 9, 8, 17, device="cuda") * 2 - 5
+    y = torch.randint(0, 5, (64,), device="cuda")
+    outs = []
+    for m in (m32, m16):
+        loss = inn.token_mean_cross_entropy(m.token_logits(feats), y)
+        loss.backward()
+        outs.append((m(feats).detach(), torch.cat([p.grad.reshape(-1) for p in m.parameters()])))
+    (l32, g32), (l16, g16) = outs
+    assert 0 < rel_err(l16.cpu(), l32.cpu()) < 2e-2            # different arithmetic, bounded deviation
+    assert rel_err(g16.cpu(), g32.cpu()) < 5e-2
+    # the same on the zone-wise raw-EEG head
+    h32 = inn.Head("Conv4Layers", ocnn.ELECTRODES, ocnn.ZONES, 32).cuda()
+    h16 = inn.Head("Conv4Layers", ocnn.ELECTRODES, ocnn.ZONES, 32, act_dtype="bf16").cuda()
+    h16.load_state_dict(h32.state_dict())
+    x = torch.randn(4, 64, 250, device="cuda")
+    a, b = h32(x).detach(), h16(x).detach()
+    assert 0 < rel_err(b.cpu(), a.cpu()) < 2e-2
