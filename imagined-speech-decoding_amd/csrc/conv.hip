@@ -202,7 +202,10 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
       if (a.lin) {
         // one contiguous block of ckc*Tin elements per item
         const int cnt = ckc * a.Tin;
-        for (int ii = wave; ii < n_items; ii += 4) {
+        // few items: the whole workgroup copies each block; many items: one wave per item
+        const int tid0 = n_items < 4 ? (int)threadIdx.x : lane;
+        const int tstep = n_items < 4 ? 256 : 64;
+        for (int ii = n_items < 4 ? 0 : wave; ii < n_items; ii += n_items < 4 ? 1 : 4) {
           const int64_t item = item0 + ii;
           const int64_t soff = (MODE == 0) ? (item * a.Ctot + a.chan_idx[zd.idx_off + c_lo]) * (int64_t)a.Tx
                                            : ((item * a.Z + z) * a.F + c_lo) * (int64_t)a.Tin;
@@ -212,12 +215,12 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
             if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
               const float4* s4 = reinterpret_cast<const float4*>(src);
               float4* d4 = reinterpret_cast<float4*>(dst);
-              for (int e = lane; e < (cnt >> 2); e += 64) d4[e] = s4[e];
+              for (int e = tid0; e < (cnt >> 2); e += tstep) d4[e] = s4[e];
             } else {
-              for (int e = lane; e < cnt; e += 64) dst[e] = src[e];
+              for (int e = tid0; e < cnt; e += tstep) dst[e] = src[e];
             }
           } else {
-            for (int e = lane; e < cnt; e += 64) dst[e] = Act<AT>::rnd(Act<IT>::ld(a.in, soff + e));
+            for (int e = tid0; e < cnt; e += tstep) dst[e] = Act<AT>::rnd(Act<IT>::ld(a.in, soff + e));
           }
         }
       } else {
@@ -389,10 +392,13 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
   for (int64_t is = i_lo; is < i_hi; is += a.IPS) {
     const int n_it = (int)((i_hi - is) < a.IPS ? (i_hi - is) : a.IPS);
     __syncthreads();
-    // dOut: [F][Tout] of an item is contiguous
+    // dOut: [F][Tout] of an item is contiguous; few items -> the whole workgroup copies each block
+    const bool wg_copy = n_it < 4;
+    const int tid0 = wg_copy ? (int)threadIdx.x : lane;
+    const int tstep = wg_copy ? 256 : 64;
     {
       const int cnt = a.F * a.Tout;
-      for (int ii = wave; ii < n_it; ii += 4) {
+      for (int ii = wg_copy ? 0 : wave; ii < n_it; ii += wg_copy ? 1 : 4) {
         const int64_t soff = ((is + ii) * a.Z + z) * (int64_t)cnt;
         float* dst = do_tile + ii * a.F * a.RSo;
         if constexpr (!Act<AT>::kBf16) {
@@ -400,22 +406,22 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
           if (a.RSo == a.Tout && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
             const float4* s4 = reinterpret_cast<const float4*>(src);
             float4* d4 = reinterpret_cast<float4*>(dst);
-            for (int e = lane; e < (cnt >> 2); e += 64) d4[e] = s4[e];
+            for (int e = tid0; e < (cnt >> 2); e += tstep) d4[e] = s4[e];
             continue;
           }
         }
         if (a.RSo == a.Tout) {
-          for (int e = lane; e < cnt; e += 64) dst[e] = Act<AT>::ld(a.dout, soff + e);
+          for (int e = tid0; e < cnt; e += tstep) dst[e] = Act<AT>::ld(a.dout, soff + e);
         } else {
           for (int g = 0; g < a.F; ++g)
-            for (int t = lane; t < a.Tout; t += 64) dst[g * a.RSo + t] = Act<AT>::ld(a.dout, soff + g * a.Tout + t);
+            for (int t = tid0; t < a.Tout; t += tstep) dst[g * a.RSo + t] = Act<AT>::ld(a.dout, soff + g * a.Tout + t);
         }
       }
     }
     if (cw_real > 0) {
       if (a.lin) {
         const int cnt = cw_real * a.Tin;
-        for (int ii = wave; ii < n_it; ii += 4) {
+        for (int ii = wg_copy ? 0 : wave; ii < n_it; ii += wg_copy ? 1 : 4) {
           const int64_t item = is + ii;
           const int64_t soff = (MODE == 0) ? (item * a.Ctot + a.chan_idx[zd.idx_off + c_base]) * (int64_t)a.Tx
                                            : ((item * a.Z + z) * a.F + c_base) * (int64_t)a.Tin;
@@ -425,12 +431,12 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
             if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
               const float4* s4 = reinterpret_cast<const float4*>(src);
               float4* d4 = reinterpret_cast<float4*>(dst);
-              for (int e = lane; e < (cnt >> 2); e += 64) d4[e] = s4[e];
+              for (int e = tid0; e < (cnt >> 2); e += tstep) d4[e] = s4[e];
             } else {
-              for (int e = lane; e < cnt; e += 64) dst[e] = src[e];
+              for (int e = tid0; e < cnt; e += tstep) dst[e] = src[e];
             }
           } else {
-            for (int e = lane; e < cnt; e += 64) dst[e] = Act<AT>::rnd(Act<IT>::ld(a.in, soff + e));
+            for (int e = tid0; e < cnt; e += tstep) dst[e] = Act<AT>::rnd(Act<IT>::ld(a.in, soff + e));
           }
         }
       } else {
