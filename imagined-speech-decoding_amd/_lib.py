@@ -54,7 +54,14 @@ SIGNATURES = {
     "isd_conv4_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
     "isd_conv4_backward": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "isd_linear_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
+    "isd_linear_residual_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _p]),
     "isd_linear_workspace_bytes": (_i64, [_i64, _i, _i]),
+    "isd_embed_forward": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p]),
+    "isd_embed_backward": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p]),
+    "isd_layernorm_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),
+    "isd_layernorm_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
+    "isd_attention_forward": (_i, [_p, _p, _p, _i64, _i, _i, _i, _f, C.c_uint64, _p]),
+    "isd_attention_backward": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _f, C.c_uint64, _p]),
     "isd_linear_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "isd_eegnet_plan_create": (_i, [C.POINTER(_p), _i, _i, _i, _i]),
     "isd_eegnet_plan_destroy": (_i, [_p]),

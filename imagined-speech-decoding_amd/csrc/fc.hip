@@ -24,7 +24,8 @@ __device__ __forceinline__ float gelu1_grad(float x) {
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y,
                                                          float* __restrict__ pre, int64_t M, int K, int Nout,
-                                                         int64_t so, int64_t si, int act) {
+                                                         int64_t so, int64_t si, int act,
+                                                         const float* __restrict__ res) {
   __shared__ float xs[64 * kRS];
   __shared__ float wsm[64 * kRS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
       const int o = o0 + t * 16 + 4 * (lane >> 4) + r;
       if (o < Nout) {
         float v = acc[t][r] + (bias ? bias[o] : 0.f);
+        if (res) v += res[m * Nout + o];
         if (pre) pre[m * Nout + o] = v;
         y[m * Nout + o] = act ? gelu1(v) : v;
       }
@@ -87,6 +89,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   __shared__ float xs[64 * 80];   // [64 samples][64 inputs]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i0 = blockIdx.y * 64;
+  const int n0 = blockIdx.z * 64;                       // output-feature chunk
+  const int nn = (Nout - n0) < 64 ? (Nout - n0) : 64;
   const int64_t m_lo = (int64_t)blockIdx.x * m_per_wg;
   const int64_t m_hi = (m_lo + m_per_wg) < M ? (m_lo + m_per_wg) : M;
   f32x4 acc[4];
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
       const int r = e >> 6, c = e & 63;
       const int64_t m = ms + r;
       const bool ok = m < m_hi;
-      ds[r * 80 + c] = (ok && c < Nout) ? dpre[m * Nout + c] : 0.f;
+      ds[r * 80 + c] = (ok && c < nn) ? dpre[m * Nout + n0 + c] : 0.f;
       const int i = i0 + c;
       xs[r * 80 + c] = !ok ? 0.f : (i < K ? x[m * K + i] : (i == K ? 1.f : 0.f));
     }
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
       const float bf = br[mm * 80];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        if (t * 16 < Nout) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[mm * 80 + t * 16], bf, acc[t], 0, 0, 0);
+        if (t * 16 < nn) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[mm * 80 + t * 16], bf, acc[t], 0, 0, 0);
     }
   }
   const int i = i0 + wave * 16 + (lane & 15);
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int o = t * 16 + 4 * (lane >> 4) + r;
-      if (o < Nout) slab[(int64_t)o * (K + 1) + i] = acc[t][r];
+      if (o < nn) slab[(int64_t)(n0 + o) * (K + 1) + i] = acc[t][r];
     }
 }
 
@@ -207,13 +211,21 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
 using namespace isd;
 
 static int launch_linear(const float* x, const float* w, const float* bias, float* y, float* pre, int64_t M, int K,
-                         int Nout, int64_t so, int64_t si, int act, hipStream_t st) {
+                         int Nout, int64_t so, int64_t si, int act, hipStream_t st, const float* res = nullptr) {
   const int64_t gx = cdiv(M, 64);
   ISD_CHECK_ARG(gx <= 0x7fffffffLL, "linear: M too large");
   hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)gx, (unsigned)cdiv(Nout, 64)), dim3(256), 0, st, x, w, bias, y,
-                     pre, M, K, Nout, so, si, act);
+                     pre, M, K, Nout, so, si, act, res);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
+}
+
+extern "C" int isd_linear_residual_forward(const float* x, const float* w, const float* bias, const float* res,
+                                           float* y, int64_t M, int K, int N, void* stream) {
+  ISD_CHECK_ARG(M >= 0 && K >= 1 && N >= 1 && K <= (1 << 20) && N <= (1 << 20), "isd_linear_residual_forward: bad shape");
+  if (M == 0) return ISD_OK;
+  ISD_CHECK_ARG(x && w && y && res, "isd_linear_residual_forward: null argument");
+  return launch_linear(x, w, bias, y, nullptr, M, K, N, K, 1, 0, (hipStream_t)stream, res);
 }
 
 extern "C" int isd_linear_forward(const float* x, const float* w, const float* bias, float* y, float* pre, int64_t M,
@@ -245,7 +257,6 @@ extern "C" int isd_linear_backward(const float* x, const float* w, const float* 
                                    float* dw, float* db, void* workspace, int64_t M, int K, int N, int act,
                                    void* stream) {
   ISD_CHECK_ARG(M >= 0 && K >= 1 && N >= 1, "isd_linear_backward: bad shape");
-  ISD_CHECK_ARG(N <= 64, "isd_linear_backward: N=%d > 64 output features is not supported", N);
   ISD_CHECK_ARG(act == 0 || (act == 1 && pre), "isd_linear_backward: gelu needs the saved pre-activation");
   ISD_CHECK_ARG(dw, "isd_linear_backward: null dw");
   hipStream_t st = (hipStream_t)stream;
@@ -270,8 +281,8 @@ extern "C" int isd_linear_backward(const float* x, const float* w, const float* 
   }
   int mp;
   const int slabs = wgrad_slabs(M, &mp);
-  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(slabs, (unsigned)cdiv(K + 1, 64)), dim3(256), 0, st, dsrc, x, part, M, K,
-                     N, mp);
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(slabs, (unsigned)cdiv(K + 1, 64), (unsigned)cdiv(N, 64)), dim3(256), 0,
+                     st, dsrc, x, part, M, K, N, mp);
   hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)cdiv((int64_t)N * (K + 1), 256)), dim3(256), 0, st, part,
                      dw, db, K, N, slabs);
   ISD_LAUNCH_CHECK();

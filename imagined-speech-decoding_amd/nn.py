@@ -227,8 +227,131 @@ class _EEGNetFn(torch.autograd.Function):
         return None, dflat, None, None, None, None, None, None, None
 
 
+class _LinearResFn(torch.autograd.Function):
+    """y = x @ w.T + b + res (residual fused in the epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res):
+        x, w, b, res = _f32c(x, "x"), _f32c(w, "weight"), _f32c(b, "bias"), _f32c(res, "res")
+        K, N = x.shape[-1], w.shape[0]
+        M = x.numel() // K
+        y = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_linear_residual_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), res.data_ptr(),
+                                                              y.data_ptr(), M, K, N, _stream()))
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        K, N = x.shape[-1], w.shape[0]
+        M = x.numel() // K
+        dx, dw = torch.empty_like(x), torch.empty_like(w)
+        db = torch.empty(N, dtype=torch.float32, device=x.device)
+        ws = torch.empty(max(int(_lib.lib().isd_linear_workspace_bytes(M, K, N)) // 4, 1), dtype=torch.float32,
+                         device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_linear_backward(x.data_ptr(), w.data_ptr(), dy.data_ptr(), 0, dx.data_ptr(),
+                                                      dw.data_ptr(), db.data_ptr(), ws.data_ptr(), M, K, N, 0,
+                                                      _stream()))
+        return dx, dw, db, dy
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x, w, b = _f32c(x, "x"), _f32c(w, "weight"), _f32c(b, "bias")
+        D = x.shape[-1]
+        M = x.numel() // D
+        y = torch.empty_like(x)
+        stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_layernorm_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                                        stats.data_ptr(), M, D, float(eps), _stream()))
+        ctx.save_for_backward(x, w, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, stats = ctx.saved_tensors
+        dy = _f32c(dy, "dy")
+        D = x.shape[-1]
+        M = x.numel() // D
+        dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(w)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_layernorm_backward(x.data_ptr(), w.data_ptr(), dy.data_ptr(), stats.data_ptr(),
+                                                         dx.data_ptr(), dw.data_ptr(), db.data_ptr(), M, D, _stream()))
+        return dx, dw, db, None
+
+
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, num_heads, dropout_p, seed):
+        qkv = _f32c(qkv, "qkv")
+        B, S, D3 = qkv.shape
+        D = D3 // 3
+        out = torch.empty((B, S, D), dtype=torch.float32, device=qkv.device)
+        probs = torch.empty((B, num_heads, S, S), dtype=torch.float32, device=qkv.device)
+        with torch.cuda.device(qkv.device):
+            _lib.check(_lib.lib().isd_attention_forward(qkv.data_ptr(), out.data_ptr(), probs.data_ptr(), B, S,
+                                                        num_heads, D // num_heads, float(dropout_p), int(seed),
+                                                        _stream()))
+        ctx.cfg = (num_heads, float(dropout_p), int(seed))
+        ctx.save_for_backward(qkv, probs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        qkv, probs = ctx.saved_tensors
+        H, p, seed = ctx.cfg
+        dctx = _f32c(dctx, "dctx")
+        B, S, D3 = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        with torch.cuda.device(qkv.device):
+            _lib.check(_lib.lib().isd_attention_backward(qkv.data_ptr(), probs.data_ptr(), dctx.data_ptr(),
+                                                         dqkv.data_ptr(), B, S, H, (D3 // 3) // H, p, seed, _stream()))
+        return dqkv, None, None, None
+
+
+class _EmbedFn(torch.autograd.Function):
+    """tokens = cat(cls, x) + pos  (fast.py:263-265)."""
+
+    @staticmethod
+    def forward(ctx, x, cls, pos):
+        x, cls, pos = _f32c(x, "x"), _f32c(cls, "cls_token"), _f32c(pos, "pos_embedding")
+        B, N, D = x.shape
+        tok = torch.empty((B, N + 1, D), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_embed_forward(x.data_ptr(), cls.data_ptr(), pos.data_ptr(), tok.data_ptr(), B, N, D,
+                                                    _stream()))
+        ctx.shape = (B, N, D, tuple(cls.shape), tuple(pos.shape))
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        B, N, D, cshape, pshape = ctx.shape
+        dtok = _f32c(dtok, "dtok")
+        dx = torch.empty((B, N, D), dtype=torch.float32, device=dtok.device)
+        dcls = torch.empty(D, dtype=torch.float32, device=dtok.device)
+        dpos = torch.zeros(pshape, dtype=torch.float32, device=dtok.device)        # rows past N+1 get no gradient
+        with torch.cuda.device(dtok.device):
+            _lib.check(_lib.lib().isd_embed_backward(dtok.data_ptr(), dx.data_ptr(), dcls.data_ptr(), dpos.data_ptr(), B,
+                                                     N, D, _stream()))
+        return dx, dcls.view(cshape), dpos
+
+
 def linear(x, weight, bias=None, act=False):
     return _LinearFn.apply(x, weight, bias, act)
+
+
+def linear_residual(x, weight, bias, res):
+    return _LinearResFn.apply(x, weight, bias, res)
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    return _LayerNormFn.apply(x, weight, bias, eps)
 
 
 def token_mean_cross_entropy(logits_tok, labels, global_batch=None):
@@ -472,12 +595,43 @@ class Head(nn.Module, _FlatParamMixin):
         return _ConvStackFn.apply(x, self._theta(), self._plan(int(x.shape[-1]), 1))
 
 
+class AttentionBlock(nn.Module):
+    """Drop-in for the reference's ``AttentionBlock(embed_dim, hidden_dim, num_heads, dropout)`` (fast.py:10-29):
+    pre-LN multi-head self-attention + pre-LN MLP, both with residuals.  Same sub-module / parameter names."""
+    _calls = 0
+
+    def __init__(self, embed_dim, hidden_dim, num_heads, dropout=0.0):
+        super().__init__()
+        self.layer_norm_1 = nn.LayerNorm(embed_dim)
+        self.attn = nn.MultiheadAttention(embed_dim, num_heads, dropout=dropout, batch_first=True)
+        self.layer_norm_2 = nn.LayerNorm(embed_dim)
+        self.linear = nn.Sequential(nn.Linear(embed_dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                    nn.Linear(hidden_dim, embed_dim), nn.Dropout(dropout))
+        self.num_heads, self.p = num_heads, dropout
+
+    def forward(self, x):
+        p = self.p if self.training else 0.0
+        AttentionBlock._calls += 1
+        seed = (torch.initial_seed() + 7919 * AttentionBlock._calls) & 0x7FFFFFFFFFFFFFFF
+        h = layer_norm(x, self.layer_norm_1.weight, self.layer_norm_1.bias, self.layer_norm_1.eps)
+        qkv = linear(h, self.attn.in_proj_weight, self.attn.in_proj_bias)
+        ctx = _AttentionFn.apply(qkv, self.num_heads, p, seed)
+        x = linear_residual(ctx, self.attn.out_proj.weight, self.attn.out_proj.bias, x)
+        h = layer_norm(x, self.layer_norm_2.weight, self.layer_norm_2.bias, self.layer_norm_2.eps)
+        h = linear(h, self.linear[0].weight, self.linear[0].bias, act=True)
+        if p > 0.0:
+            h = torch.nn.functional.dropout(h, p, True)
+            return x + torch.nn.functional.dropout(linear(h, self.linear[3].weight, self.linear[3].bias), p, True)
+        return linear_residual(h, self.linear[3].weight, self.linear[3].bias, x)
+
+
 class FAST(nn.Module):
-    """The reference's ``FAST(config)`` restricted to the CNN + FC-head path (``forward_mode='train_head'``).
+    """The reference's ``FAST(config)`` (fast.py:213-284) on the HIP kernels: ``forward_head``,
+    ``batched_forward_head``, ``forward_transformer`` and the three forward modes.
 
     Parameter names equal the reference's (``head.encoders.<Zone>.cnn1.weight``, ``input_layer.0.weight``,
-    ``last_layer.weight`` ...), so ``load_state_dict(reference_state_dict, strict=False)`` works.
-    The transformer tail (``forward_mode='default'``) is listed as "next" in SURVEY.md 8(f).
+    ``transformer.0.attn.in_proj_weight``, ``pos_embedding``, ``cls_token``, ``last_layer.weight`` ...), so
+    ``load_state_dict(reference_state_dict)`` works unchanged.
     """
     name = "FAST"
 
@@ -488,7 +642,12 @@ class FAST(nn.Module):
         self.head = Head(config.head, config.electrodes, config.zone_dict, config.dim_cnn,
                          getattr(config, "act_dtype", "f32"))
         self.input_layer = nn.Sequential(nn.Linear(config.dim_cnn * len(config.zone_dict), config.dim_token), nn.GELU())
+        self.transformer = nn.Sequential(*[AttentionBlock(config.dim_token, config.dim_token * 2, config.num_heads,
+                                                          dropout=config.dropout) for _ in range(config.num_layers)])
+        self.pos_embedding = nn.Parameter(torch.randn(1, self.n_tokens + 1, config.dim_token))
+        self.cls_token = nn.Parameter(torch.randn(1, 1, config.dim_token))
         self.last_layer = nn.Linear(config.dim_token, config.n_classes)
+        self.dropout = nn.Dropout(config.dropout)
 
     def forward_head(self, x, step_override=None):
         step = self.config.slide_step if step_override is None else step_override
@@ -505,14 +664,27 @@ class FAST(nn.Module):
         tok = linear(feat.reshape(B, N, Z * Fd), self.input_layer[0].weight, self.input_layer[0].bias, act=True)
         return linear(tok, self.last_layer.weight, self.last_layer.bias)   # [B, N, n_classes]
 
-    def forward(self, x, forward_mode="train_head"):
+    def forward_transformer(self, feature):
+        """feature [B, N, Z, F] -> logits [B, n_classes]  (fast.py:260-268)."""
+        B, N, Z, Fd = feature.shape
+        tok = linear(feature.reshape(B, N, Z * Fd), self.input_layer[0].weight, self.input_layer[0].bias, act=True)
+        tok = _EmbedFn.apply(tok, self.cls_token, self.pos_embedding[:, :N + 1].contiguous())
+        tok = self.transformer(tok)
+        cls = self.dropout(tok[:, 0].contiguous())
+        return linear(cls, self.last_layer.weight, self.last_layer.bias)
+
+    def forward(self, x, forward_mode="default"):
+        if forward_mode == "default":
+            return self.forward_transformer(self.forward_head(x))
         if forward_mode == "train_head":
             lt = self.token_logits(x)
             if torch.is_grad_enabled():
                 return lt.mean(dim=1)
             return token_mean_predict(lt)[0]
-        if forward_mode in ("default", "train_transformer"):
-            raise NotImplementedError("the transformer tail is not part of the HIP hot path yet (SURVEY.md 8f)")
+        if forward_mode == "train_transformer":
+            with torch.no_grad():
+                feat = self.forward_head(x)
+            return self.forward_transformer(feat)
         raise NotImplementedError
 
 

@@ -158,8 +158,11 @@ int isd_conv4_backward(const isd_conv4_plan* plan, const float* x, const float* 
  * ---------------------------------------------------------------------- */
 int isd_linear_forward(const float* x, const float* w, const float* bias, float* y, float* pre,
                        int64_t M, int K, int N, int act, void* stream);
+/* y = x . w^T + bias + res   (residual connection fused in the epilogue; fast.py:24-25) */
+int isd_linear_residual_forward(const float* x, const float* w, const float* bias, const float* res, float* y,
+                                int64_t M, int K, int N, void* stream);
 int64_t isd_linear_workspace_bytes(int64_t M, int K, int N);
-/* dx nullable; db nullable; N <= 64 */
+/* dx nullable; db nullable */
 int isd_linear_backward(const float* x, const float* w, const float* dy, const float* pre, float* dx,
                         float* dw, float* db, void* workspace, int64_t M, int K, int N, int act,
                         void* stream);
@@ -205,6 +208,27 @@ int isd_eegnet_forward(const isd_eegnet_plan* plan, const float* x, const float*
 int isd_eegnet_backward(const isd_eegnet_plan* plan, const float* x, const float* params, const float* dout,
                         float* dparams, void* workspace, int64_t B, float dropout_p, uint64_t seed,
                         void* stream);
+
+/* ------------------------------------------------------------------------
+ * Transformer tail of FAST (src/fast/models/fast.py:10-29 AttentionBlock, :260-268 forward_transformer).
+ * The dense projections are isd_linear_* launches over the [B*S, D] token matrix; these are the pieces around them.
+ *   embed:      tok[b,0] = cls + pos[0];  tok[b,1+n] = x[b,n] + pos[1+n]                 (fast.py:263-265)
+ *   layernorm:  nn.LayerNorm(D), D <= 64; stats [M][2] = (mean, rstd) saved for backward (fast.py:11,13)
+ *   attention:  nn.MultiheadAttention core, batch_first: qkv [B][S][3D] (q|k|v) -> ctx [B][S][D], probs [B][H][S][S];
+ *               S <= 8 tokens, head_dim <= 8; attention dropout through a counter-based mask (seed)   (fast.py:12,23)
+ * ---------------------------------------------------------------------- */
+int isd_embed_forward(const float* x, const float* cls, const float* pos, float* tok, int64_t B, int N, int D,
+                      void* stream);
+int isd_embed_backward(const float* dtok, float* dx, float* dcls, float* dpos, int64_t B, int N, int D,
+                       void* stream);
+int isd_layernorm_forward(const float* x, const float* w, const float* b, float* y, float* stats, int64_t M, int D,
+                          float eps, void* stream);
+int isd_layernorm_backward(const float* x, const float* w, const float* dy, const float* stats, float* dx,
+                           float* dw, float* db, int64_t M, int D, void* stream);
+int isd_attention_forward(const float* qkv, float* ctx, float* probs, int64_t B, int S, int H, int head_dim,
+                          float dropout_p, uint64_t seed, void* stream);
+int isd_attention_backward(const float* qkv, const float* probs, const float* dctx, float* dqkv, int64_t B, int S,
+                           int H, int head_dim, float dropout_p, uint64_t seed, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@ A from-scratch restatement in functional PyTorch (CPU, fp32 or fp64) of
 * ``Head``             src/fast/models/fast.py:199-210   (zone gather + stack)
 * ``forward_head``     src/fast/models/fast.py:242-252   (unfold windows)
 * ``train_head`` mode  src/fast/models/fast.py:273-278   (FC 256->32 GELU, 32->5, mean)
+* ``AttentionBlock`` / ``forward_transformer`` / 'default' mode   src/fast/models/fast.py:10-29,260-272
 * CE loss / argmax     src/fast/train/trainer.py:37,59,89
 * ``cosine_scheduler`` src/fast/train/trainer.py:15-27 and the LambdaLR quirk :52
 * dataset constants    src/fast/data/preprocess.py:20-42 (label / zone order)
@@ -123,6 +124,38 @@ def train_head_logits(x, p, zone_names, zone_idx, window_len=250, slide_step=125
     tok = F.gelu(F.linear(feat.reshape(B, N, Z * Fd), p["input_layer.0.weight"],
                           p["input_layer.0.bias"]))
     return F.linear(tok, p["last_layer.weight"], p["last_layer.bias"]).mean(dim=1)
+
+
+def attention_block(x, p, prefix, num_heads):
+    """fast.py:10-29 (AttentionBlock, dropout disabled): pre-LN MHA + pre-LN MLP with residuals.  x [B, S, D]."""
+    D = x.shape[-1]
+    h = F.layer_norm(x, (D,), p[prefix + "layer_norm_1.weight"], p[prefix + "layer_norm_1.bias"], 1e-5)
+    qkv = F.linear(h, p[prefix + "attn.in_proj_weight"], p[prefix + "attn.in_proj_bias"])
+    q, k, v = qkv.chunk(3, dim=-1)
+    B, S, _ = x.shape
+    dh = D // num_heads
+
+    def heads(t):
+        return t.reshape(B, S, num_heads, dh).transpose(1, 2)                # B H S dh
+    att = torch.softmax(heads(q) @ heads(k).transpose(-1, -2) / math.sqrt(dh), dim=-1)
+    ctx = (att @ heads(v)).transpose(1, 2).reshape(B, S, D)
+    x = x + F.linear(ctx, p[prefix + "attn.out_proj.weight"], p[prefix + "attn.out_proj.bias"])
+    h = F.layer_norm(x, (D,), p[prefix + "layer_norm_2.weight"], p[prefix + "layer_norm_2.bias"], 1e-5)
+    h = F.gelu(F.linear(h, p[prefix + "linear.0.weight"], p[prefix + "linear.0.bias"]))
+    return x + F.linear(h, p[prefix + "linear.3.weight"], p[prefix + "linear.3.bias"])
+
+
+def default_logits(x, p, zone_names, zone_idx, num_heads, num_layers, window_len=250, slide_step=125, **kw):
+    """fast.py:260-272 (``forward_mode='default'``, dropout disabled): CNN head -> input_layer -> cls token +
+    positional embedding -> ``num_layers`` AttentionBlocks -> last_layer on the cls token."""
+    feat = forward_head(x, p, zone_names, zone_idx, window_len, slide_step, **kw)
+    B, N, Z, Fd = feat.shape
+    tok = F.gelu(F.linear(feat.reshape(B, N, Z * Fd), p["input_layer.0.weight"], p["input_layer.0.bias"]))
+    tok = torch.cat((p["cls_token"].expand(B, -1, -1), tok), dim=1)
+    tok = tok + p["pos_embedding"][:, :N + 1]
+    for i in range(num_layers):
+        tok = attention_block(tok, p, f"transformer.{i}.", num_heads)
+    return F.linear(tok[:, 0], p["last_layer.weight"], p["last_layer.bias"])
 
 
 def feature_cnn_logits(feats, p, n_layers=4):

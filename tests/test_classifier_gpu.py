@@ -41,10 +41,11 @@ def test_fast_adamw_trajectory_matches_reference_golden(isd):
     g5, g9 = load_golden("g5_fast_small.npz"), load_golden("g9_adamw.npz")
     electrodes = ["Fp1", "Fp2", "F3", "F4", "C3", "C4", "O1", "O2"]
     zones = {"Frontal": ["Fp1", "Fp2", "F3", "F4"], "Central": ["C3", "C4"], "Occipital": ["O1", "O2"]}
-    cfg = inn.fast_config(electrodes, zones, dim_cnn=16, dim_token=16, seq_len=500, n_classes=3)
+    cfg = inn.fast_config(electrodes, zones, dim_cnn=16, dim_token=16, seq_len=500, n_classes=3, num_layers=1,
+                          num_heads=4, dropout=0.0)
     m = _FastModel(cfg).cuda()
     sd = {k[3:]: torch.from_numpy(g5[k]) for k in g5.files if k.startswith("sd.")}
-    assert not m.net.load_state_dict(sd, strict=False)[0]
+    m.net.load_state_dict(sd)
     tr = isd.Trainer(m, lr=5e-4, weight_decay=1e-2, schedule=None)
     x = torch.from_numpy(g5["x"]).cuda()
     y = torch.from_numpy(g5["labels"]).cuda()

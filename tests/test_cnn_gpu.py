@@ -67,9 +67,7 @@ def _small_cfg(inn):
 def test_fast_small_train_head_matches_reference_golden(inn):
     g = load_golden("g5_fast_small.npz")
     m = inn.FAST(_small_cfg(inn)).cuda()
-    missing, unexpected = m.load_state_dict(_sd(g, "sd."), strict=False)
-    assert not missing, missing                              # every parameter of the hot path is provided
-    assert all(k.startswith(("transformer.", "pos_embedding", "cls_token")) for k in unexpected)
+    m.load_state_dict(_sd(g, "sd."))                         # strict: names/shapes equal the reference's
     assert m.n_tokens == 3
     x = torch.from_numpy(g["x"]).cuda()
     feat = m.forward_head(x)
@@ -78,27 +76,44 @@ def test_fast_small_train_head_matches_reference_golden(inn):
     lt = m.token_logits(x)
     loss = inn.token_mean_cross_entropy(lt, torch.from_numpy(g["labels"]).cuda())
     loss.backward()
-    assert rel_err(m(x).detach().cpu(), g["train_head.logits"]) < TOL
+    assert rel_err(m(x, forward_mode="train_head").detach().cpu(), g["train_head.logits"]) < TOL
     assert abs(float(loss) - float(g["train_head.loss"])) < 1e-5
     for k, p in m.named_parameters():
-        assert rel_err(p.grad.cpu(), g[f"train_head.grad.{k}"]) < 2e-4, k
+        if f"train_head.grad.{k}" in g.files:
+            assert rel_err(p.grad.cpu(), g[f"train_head.grad.{k}"]) < 2e-4, k
+    # forward_mode='default': the mode the reference trains (trainer.py:58) -- transformer tail included
+    m.zero_grad(set_to_none=True)
+    logits = m(x)
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(g["labels"]).long().cuda())
+    loss.backward()
+    assert rel_err(logits.detach().cpu(), g["default.logits"]) < TOL
+    assert abs(float(loss.detach()) - float(g["default.loss"])) < 1e-5
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad.cpu(), g[f"default.grad.{k}"]) < 5e-4, k
+    # 'train_transformer': the CNN head is frozen (no gradient reaches it)
+    m.zero_grad(set_to_none=True)
+    m(x, forward_mode="train_transformer").sum().backward()
+    assert all(p.grad is None for k, p in m.named_parameters() if k.startswith("head."))
+    assert m.transformer[0].attn.in_proj_weight.grad is not None
 
 
 def test_fast_prod_eval_logits_bitexact_argmax(inn):
     g = load_golden("g6_fast_prod.npz")
     m = inn.FAST(inn.fast_config()).cuda().eval()
-    missing, _ = m.load_state_dict(_sd(g, "sd."), strict=False)
-    assert not missing
+    m.load_state_dict(_sd(g, "sd."))
     x = torch.from_numpy(np.random.default_rng(6).standard_normal((4, 64, 800)).astype(np.float32)).cuda()
     with torch.no_grad():
         feat = m.forward_head(x)
-        logits = m(x)
+        logits = m(x, forward_mode="train_head")
         lm, pred = inn.token_mean_predict(m.token_logits(x))
+        logits_default = m(x)                                             # forward_mode='default' (transformer tail)
     assert feat.shape == (4, 5, 8, 32)
     assert rel_err(feat.cpu(), g["features"]) < TOL
     assert rel_err(logits.cpu(), g["train_head_logits"]) < TOL
     assert np.array_equal(pred.cpu().numpy(), g["train_head_pred"])       # class indices bit-exact
     assert pred.dtype == torch.int64
+    assert rel_err(logits_default.cpu(), g["default_logits"]) < TOL
+    assert np.array_equal(logits_default.argmax(1).cpu().numpy(), g["default_pred"])
     with pytest.raises(NotImplementedError):
         m(x, forward_mode="nonexistent")
 

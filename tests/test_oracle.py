@@ -95,6 +95,31 @@ def test_fast_small_train_head_matches_reference_golden():
             assert rel_err(p[name].grad, g[k]) < 2e-5, name
 
 
+def test_fast_small_default_mode_matches_reference_golden():
+    g = load_golden("g5_fast_small.npz")
+    names, idx = _small_zones()
+    p = {k: v.requires_grad_() for k, v in _t(g, "sd.").items()}
+    logits = ocnn.default_logits(torch.from_numpy(g["x"]), p, names, idx, num_heads=4, num_layers=1)
+    loss = ocnn.cross_entropy(logits, g["labels"])
+    loss.backward()
+    assert rel_err(logits.detach(), g["default.logits"]) < 1e-5
+    assert abs(float(loss.detach()) - float(g["default.loss"])) < 1e-6
+    for k in g.files:
+        if k.startswith("default.grad."):
+            name = k[len("default.grad."):]
+            assert rel_err(p[name].grad, g[k]) < 5e-5, name
+
+
+def test_fast_prod_default_mode_eval_matches_reference_golden():
+    g = load_golden("g6_fast_prod.npz")
+    p = _t(g, "sd.")
+    x = torch.from_numpy(np.random.default_rng(6).standard_normal((4, 64, 800)).astype(np.float32))
+    with torch.no_grad():
+        logits = ocnn.default_logits(x, p, list(ocnn.ZONES), ocnn.zone_index_lists(), num_heads=8, num_layers=4)
+    assert rel_err(logits, g["default_logits"]) < 1e-5
+    assert np.array_equal(ocnn.predict(logits).numpy(), g["default_pred"])
+
+
 def test_fast_prod_eval_logits_and_argmax_match_reference_golden():
     g = load_golden("g6_fast_prod.npz")
     p = _t(g, "sd.")
