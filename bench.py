@@ -45,7 +45,7 @@ def synth_trials(B, C, T, fs, seed):
     return X, y
 
 
-def cpu_baseline(C, T, fs, n_trials=128, steps=3):
+def cpu_baseline(C, T, fs, n_trials=128, steps=5):
     """The oracle (CPU restatement of the same pipeline) timed on this box's host cores, bounded sample."""
     from oracle import cnn as ocnn, dsp as odsp
     # the GPU box grants a 16-CPU share per GPU (cpu_count reports the whole host)
@@ -62,7 +62,7 @@ def cpu_baseline(C, T, fs, n_trials=128, steps=3):
     t_feat = t_cnn = 0.0
     for _ in range(steps):
         t0 = time.perf_counter()
-        feats = torch.from_numpy(odsp.extract_features(X, fs=fs, bands=odsp.BANDS_9))
+        feats = torch.from_numpy(odsp.extract_features_scipy(X, fs=fs, bands=odsp.BANDS_9))
         t1 = time.perf_counter()
         opt.zero_grad()
         ocnn.cross_entropy(ocnn.feature_cnn_logits(feats, p), yt).backward()
@@ -72,9 +72,9 @@ def cpu_baseline(C, T, fs, n_trials=128, steps=3):
         t_cnn += t2 - t1
     total = t_feat + t_cnn
     return {"value": round(n_trials * steps / total, 2), "unit": "trials/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} steps x {n_trials} trials of the same workload through oracle/ (NumPy fp64 DSP on 1 "
-                      f"thread: {t_feat / steps:.2f} s/step; torch-CPU CNN fwd+bwd+AdamW on {threads} threads: "
-                      f"{t_cnn / steps:.2f} s/step)"}
+            "sample": f"{steps} steps x {n_trials} trials of the same workload through oracle/ (scipy butter/sosfilt/"
+                      f"stft fp64 on 1 thread: {t_feat / steps:.2f} s/step; torch-CPU CNN fwd+bwd+AdamW on {threads} "
+                      f"threads: {t_cnn / steps:.2f} s/step)"}
 
 
 def main():

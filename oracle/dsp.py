@@ -167,6 +167,23 @@ def extract_features(trials, *, fs, bands, order=4, nperseg=64, noverlap=None,
     return out
 
 
+def extract_features_scipy(trials, *, fs, bands, order=4, nperseg=64, noverlap=None, eps=1e-10):
+    """Spec S through scipy's own C routines (``butter`` / ``sosfilt`` / ``stft``): the reference-equivalent CPU
+    path of BASELINE.md section 2, used by bench.py's ``cpu_baseline`` (the NumPy restatement above is the checker;
+    tests pin the two against each other)."""
+    import scipy.signal as ss
+    x = np.asarray(trials, dtype=np.float64)
+    if noverlap is None:
+        noverlap = nperseg // 2
+    outs = []
+    for (lo, hi), (klo, khi) in zip(band_edges(bands), band_bins(fs, nperseg, bands)):
+        y = ss.sosfilt(ss.butter(order, (lo, hi), "bandpass", fs=fs, output="sos"), x, axis=-1)
+        _, _, Z = ss.stft(y, fs=fs, nperseg=nperseg, noverlap=noverlap)
+        P = (np.abs(Z[..., klo:khi + 1, :]) ** 2).mean(axis=-2) if khi >= klo else np.zeros(Z.shape[:-2] + Z.shape[-1:])
+        outs.append(np.log(P + eps))
+    return np.stack(outs, axis=1).astype(np.float32)
+
+
 def synth_trials(B, C=64, T=512, fs=256.0, seed=0, zones=None):
     """Synthetic EEG of SURVEY.md 8d: white noise + class-dependent tone.
 

@@ -52,6 +52,13 @@ def test_spec_s_features_match_scipy_golden(tag, bands):
     np.testing.assert_allclose(feat, g[f"{tag}_feat"][:2], rtol=0, atol=2e-5)
 
 
+def test_scipy_backed_features_equal_the_numpy_restatement():
+    x = np.random.default_rng(9).standard_normal((2, 3, 512)).astype(np.float32)
+    a = odsp.extract_features(x, fs=256.0, bands=odsp.BANDS_9)
+    b = odsp.extract_features_scipy(x, fs=256.0, bands=odsp.BANDS_9)
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-5)
+
+
 # ------------------------------------------------------------------ CNN (reference-pinned)
 def _t(g, prefix):
     return {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
