@@ -460,10 +460,12 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
     __syncthreads();
     if (wave_live) {
       const int row_b = c_real ? (ct * 16 + jl) : 0;
-      for (int ii = grp; ii < n_it; ii += n_grp) {
+      // wave groups split the reduction (time) range of every item, so one staged item keeps all waves busy
+      for (int ii = 0; ii < n_it; ++ii) {
         const float* dro = do_tile + (ii * a.F + gsel * 16 + jl) * a.RSo;
         const float* iro = in_tile + (ii * a.CW + row_b) * a.RSi;
-        for (int t0 = 0; t0 < Tk; t0 += 4) {
+#pragma unroll 2
+        for (int t0 = grp * 4; t0 < Tk; t0 += 4 * n_grp) {
           const int ta = t0 + q;
           const bool a_ok = ta < a.Tout;
           const int tac = a_ok ? ta : 0;
@@ -862,6 +864,7 @@ static int launch_wgrad(int mode, int bf16, WgradArgs& a, int n_zones, int cin_m
   const int64_t per_item = (int64_t)a.F * a.RSo + (int64_t)a.CW * a.RSi;
   int ips = (int)((96 * 1024 / 4 - 4) / per_item);
   ISD_CHECK_ARG(ips >= 1, "conv4 wgrad: window too long for the LDS tile");
+  if (ips > 1 && per_item * 4 > 32 * 1024) ips = 1;           // big items: one per stage, 2-3 workgroups per CU
   const int ips_occ = (int)((32 * 1024 / 4) / per_item);      // prefer <= 32 KiB so several workgroups share a CU
   if (ips_occ >= 1 && ips > ips_occ) ips = ips_occ;
   if (ips > 16) ips = 16;
