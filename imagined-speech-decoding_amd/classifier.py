@@ -195,16 +195,30 @@ class GradientBucket:
     def rank(self):
         return self.dist.get_rank(self.group) if self.dist else 0
 
+    def _sum(self, t):
+        if t.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # gloo (CPU rehearsals, single-GPU multi-process tests): stage through host memory
+            h = t.detach().cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
     def all_reduce_(self, flat_grad, extra=None):
         if self.dist is None or self.world_size == 1:
             return
-        self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._sum(flat_grad)
         if extra is not None:
-            self.dist.all_reduce(extra, op=self.dist.ReduceOp.SUM, group=self.group)
+            self._sum(extra)
 
     def broadcast_(self, flat_params, src=0):
         if self.dist is not None and self.world_size > 1:
-            self.dist.broadcast(flat_params, src=src, group=self.group)
+            if flat_params.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                h = flat_params.detach().cpu()
+                self.dist.broadcast(h, src=src, group=self.group)
+                flat_params.copy_(h)
+            else:
+                self.dist.broadcast(flat_params, src=src, group=self.group)
 
     def shard(self, n):
         """Contiguous shard [lo, hi) of n items owned by this rank (equal shards, remainder to the first ranks)."""
