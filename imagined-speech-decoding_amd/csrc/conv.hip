@@ -294,6 +294,209 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Fused forward of one (window, zone) item for the reference-native shape (F = 32, <= 16 channels per zone,
+// <= 256 time steps): cnn1.cnn2 -> cnn3 -> cnn4 -> GELU -> mean, activations handed over in LDS.
+// Persistent workgroups (one per CU): the weight fragments of the zone (Weff, W3, W4: 200 A-fragments,
+// 50 KB) stay in LDS for the whole launch next to the x rows and the two activation tiles.
+// A2/A3/A4 are still written to HBM (coalesced float4 from the LDS tile) when `store` is set, because the
+// backward kernels consume them; inference skips the stores.
+// ---------------------------------------------------------------------------------------
+struct FusedFwdArgs {
+  const float* x;            // raw trials [B][Ctot][Tx]
+  const float* weff;         // frag-ordered Weff per zone (ZoneDesc::eff_off)
+  const float* beff;         // [Z][F]
+  const float* w3;           // frag-ordered cnn3 / cnn4 weights, [Z][conv_zstride]
+  const float* w4;
+  float* a2;                 // [items][Z][F][T1] (may be null when !store)
+  float* a3;
+  float* a4;
+  float* feat;               // [items][Z][F]
+  const ZoneDesc* zones;
+  const int* chan_idx;
+  int64_t wz_stride, items;
+  int Z, W, T1, TT, store;
+  int Ctot, Tx, N, S;
+};
+
+template <int NW>
+__device__ __forceinline__ void fused_layer_store(const f32x4 (&acc)[16 / NW][2], const float* __restrict__ bias,
+                                                  float* __restrict__ tile, int T1, int TT, int wave, int q, int jl) {
+#pragma unroll
+  for (int j = 0; j < 16 / NW; ++j) {
+    const int tt = j * NW + wave;
+    if (tt >= TT) continue;
+    const int t = tt * 16 + jl;
+    if (t >= T1) continue;
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int g = gt * 16 + 4 * q + r;
+        tile[g * T1 + t] = acc[j][gt][r] + (bias ? bias[g] : 0.f);
+      }
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int F = 32;
+  const int z = blockIdx.y;
+  const ZoneDesc zd = a.zones[z];
+  const int cz = zd.cin, ncg = (cz + 3) / 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
+  const int T1 = a.T1, W = a.W, TT = a.TT;
+  float* xz = smem;                                  // [16][W]
+  float* t2 = smem + ((16 * W + 3) & ~3);            // [32][T1]
+  float* t3 = t2 + ((F * T1 + 3) & ~3);              // [32][T1]
+  float* red = t3 + ((F * T1 + 3) & ~3);             // [8][32]
+  float* we = red + NW * F;                           // [4][5][2][64]   frag-ordered Weff of the zone
+  float* w3s = we + 4 * kTaps * 2 * 64;              // [8][5][2][64]
+  float* w4s = w3s + 8 * kTaps * 2 * 64;
+  // ---- weight fragments into LDS once per (persistent) workgroup
+  for (int e = threadIdx.x; e < 4 * kTaps * 2 * 64; e += NW * 64) we[e] = (e < ncg * kTaps * 2 * 64) ? a.weff[zd.eff_off + e] : 0.f;
+  for (int e = threadIdx.x; e < 8 * kTaps * 2 * 64; e += NW * 64) {
+    w3s[e] = a.w3[(int64_t)z * a.wz_stride + e];
+    w4s[e] = a.w4[(int64_t)z * a.wz_stride + e];
+  }
+  const float* bias = a.beff + z * F;
+
+  for (int64_t item = blockIdx.x; item < a.items; item += gridDim.x) {
+    const int64_t b = item / a.N;
+    const int n = (int)(item - b * a.N);
+    __syncthreads();                                   // previous item's tiles are no longer read
+    for (int r = wave; r < cz; r += NW) {               // gather the zone's rows of this window
+      const float* src = a.x + (b * a.Ctot + a.chan_idx[zd.idx_off + r]) * (int64_t)a.Tx + (int64_t)n * a.S;
+      for (int t = lane; t < W; t += 64) xz[r * W + t] = src[t];
+    }
+    __syncthreads();
+    f32x4 acc[16 / NW][2];
+    // ---------------- cnn1 o cnn2 (valid, Cz x 5 taps)
+#pragma unroll
+    for (int j = 0; j < 16 / NW; ++j)
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cg = 0; cg < ncg; ++cg) {
+      const int crow = cg * 4 + q;
+      const bool c_ok = crow < cz;
+      const float* xr = xz + (c_ok ? crow : 0) * W;
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k) {
+        const float a0 = we[((cg * kTaps + k) * 2 + 0) * 64 + lane], a1 = we[((cg * kTaps + k) * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 16 / NW; ++j) {
+          const int tt = j * NW + wave;
+          if (tt >= TT) continue;
+          const int idx = tt * 16 + jl + k;
+          float bf = xr[idx < W ? idx : W - 1];
+          bf = (c_ok && idx < W) ? bf : 0.f;
+          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc[j][0], 0, 0, 0);
+          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc[j][1], 0, 0, 0);
+        }
+      }
+    }
+    fused_layer_store<NW>(acc, bias, t2, T1, TT, wave, q, jl);
+    __syncthreads();
+    if (a.store) {
+      float4* dst = reinterpret_cast<float4*>(a.a2 + (item * a.Z + z) * (int64_t)(F * T1));
+      const float4* src = reinterpret_cast<const float4*>(t2);
+      for (int e = threadIdx.x; e < (F * T1) / 4; e += NW * 64) dst[e] = src[e];
+    }
+    // ---------------- cnn3 (pad 2)
+#pragma unroll
+    for (int j = 0; j < 16 / NW; ++j)
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cg = 0; cg < 8; ++cg) {
+      const float* xr = t2 + (cg * 4 + q) * T1;
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k) {
+        const float a0 = w3s[((cg * kTaps + k) * 2 + 0) * 64 + lane], a1 = w3s[((cg * kTaps + k) * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 16 / NW; ++j) {
+          const int tt = j * NW + wave;
+          if (tt >= TT) continue;
+          const int idx = tt * 16 + jl + k - 2;
+          const bool ok = idx >= 0 && idx < T1;
+          float bf = xr[ok ? idx : 0];
+          bf = ok ? bf : 0.f;
+          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc[j][0], 0, 0, 0);
+          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc[j][1], 0, 0, 0);
+        }
+      }
+    }
+    fused_layer_store<NW>(acc, nullptr, t3, T1, TT, wave, q, jl);
+    __syncthreads();                                   // t3 complete; every read of t2 is done
+    if (a.store) {
+      float4* dst = reinterpret_cast<float4*>(a.a3 + (item * a.Z + z) * (int64_t)(F * T1));
+      const float4* src = reinterpret_cast<const float4*>(t3);
+      for (int e = threadIdx.x; e < (F * T1) / 4; e += NW * 64) dst[e] = src[e];
+    }
+    // ---------------- cnn4 (pad 2) -> GELU -> mean
+#pragma unroll
+    for (int j = 0; j < 16 / NW; ++j)
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cg = 0; cg < 8; ++cg) {
+      const float* xr = t3 + (cg * 4 + q) * T1;
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k) {
+        const float a0 = w4s[((cg * kTaps + k) * 2 + 0) * 64 + lane], a1 = w4s[((cg * kTaps + k) * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 16 / NW; ++j) {
+          const int tt = j * NW + wave;
+          if (tt >= TT) continue;
+          const int idx = tt * 16 + jl + k - 2;
+          const bool ok = idx >= 0 && idx < T1;
+          float bf = xr[ok ? idx : 0];
+          bf = ok ? bf : 0.f;
+          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc[j][0], 0, 0, 0);
+          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc[j][1], 0, 0, 0);
+        }
+      }
+    }
+    if (a.store) fused_layer_store<NW>(acc, nullptr, t2, T1, TT, wave, q, jl);   // t2 is free: stage A4 for the store
+    float part[2][4];
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16 / NW; ++j) {
+          const int tt = j * NW + wave;
+          if (tt < TT && tt * 16 + jl < T1) sacc += gelu_f(acc[j][gt][r]);
+        }
+        sacc += row_shr<8>(sacc);
+        sacc += row_shr<4>(sacc);
+        sacc += row_shr<2>(sacc);
+        sacc += row_shr<1>(sacc);
+        part[gt][r] = sacc;                            // lane 15 of each 16-lane row holds the row sum
+      }
+    if (jl == 15) {
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * F + gt * 16 + 4 * q + r] = part[gt][r];
+    }
+    __syncthreads();
+    if (threadIdx.x < F)
+      a.feat[(item * a.Z + z) * F + threadIdx.x] =
+          [&] {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += red[w * F + threadIdx.x];
+            return tot;
+          }() / (float)T1;
+    if (a.store) {
+      float4* dst = reinterpret_cast<float4*>(a.a4 + (item * a.Z + z) * (int64_t)(F * T1));
+      const float4* src = reinterpret_cast<const float4*>(t2);
+      for (int e = threadIdx.x; e < (F * T1) / 4; e += NW * 64) dst[e] = src[e];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // GELU + mean over time (fast.py:117-118) and its backward (in place on the activation).
 // one 16-lane row per (item, zone, filter) row of length T
 // ---------------------------------------------------------------------------------------
@@ -818,6 +1021,29 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
     hipLaunchKernelGGL(prep_conv_kernel, dim3(4, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_w4,
                        ws + g.o_w4t, F, 1, p->conv_zstride, p->act_bf16);
     ISD_LAUNCH_CHECK();
+  }
+  if (p->n_layers == 4 && F == 32 && !p->act_bf16 && p->max_cz <= 16 && g.TT <= 16 && (F * g.T1) % 4 == 0 &&
+      g.TT >= 4) {
+    // reference-native shape: one persistent fused kernel (register-resident weights, activations through LDS)
+    FusedFwdArgs fa = {};
+    fa.x = x; fa.weff = ws + g.o_eff; fa.beff = ws + g.o_beff; fa.w3 = ws + g.o_w3; fa.w4 = ws + g.o_w4;
+    fa.a2 = ws + g.o_a2; fa.a3 = ws + g.o_a3; fa.a4 = ws + g.o_a4; fa.feat = feat;
+    fa.zones = p->d_zones; fa.chan_idx = p->d_idx; fa.wz_stride = p->conv_zstride; fa.items = g.items;
+    fa.Z = p->Z; fa.W = p->W; fa.T1 = g.T1; fa.TT = g.TT; fa.store = 1;
+    fa.Ctot = p->Ctot; fa.Tx = (int)T; fa.N = g.N; fa.S = p->S;
+    constexpr int NW = 8;   // measured: 8 waves per item 37.2 ms/step, 16 waves 39.7, 4 waves 43.5 (B=4096, T=512)
+    const size_t lds = sizeof(float) * (size_t)(((16 * p->W + 3) & ~3) + 2 * ((F * g.T1 + 3) & ~3) + NW * F +
+                                                 (4 + 8 + 8) * kTaps * 2 * 64);
+    if (lds <= 150 * 1024) {
+      int per_zone = 256 / p->Z;
+      if (per_zone < 1) per_zone = 1;
+      if (per_zone > g.items) per_zone = (int)g.items;
+      ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv4_fused_fwd_kernel<NW>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((conv4_fused_fwd_kernel<NW>), dim3(per_zone, p->Z), dim3(NW * 64), lds, st, fa);
+      ISD_LAUNCH_CHECK();
+      return ISD_OK;
+    }
   }
   ConvArgs a = {};
   a.zones = p->d_zones; a.chan_idx = p->d_idx; a.items = g.items; a.Z = p->Z; a.F = F;
