@@ -172,8 +172,9 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
   const int64_t item0 = (int64_t)blockIdx.x * a.IPW;
   const int n_items = (int)((a.items - item0) < a.IPW ? (a.items - item0) : a.IPW);
   const int n_ct = n_items * a.TT;
-  float* in_tile = smem;                                   // [IPW][kCK][RS]
-  float* w_tile = smem + ((a.IPW * kCK * a.RS + 3) & ~3);  // [kCK/4][5][GT][64], 16-byte aligned
+  float* in_tile = smem + 4;                               // [IPW][kCK][RS]; 4 floats of slack: masked reads may
+                                                           // address up to `pad` elements before row 0
+  float* w_tile = smem + 4 + ((a.IPW * kCK * a.RS + 3) & ~3);  // [kCK/4][5][GT][64], 16-byte aligned
   const float* wbase = a.wfrag + ((MODE == 0) ? zd.eff_off : (int64_t)z * a.wz_stride);
   const int n_chunks = (cin + kCK - 1) / kCK;
   const int q = lane >> 4, jl = lane & 15;
@@ -186,6 +187,8 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
       for (int g = 0; g < 2; ++g) acc[j][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int t_ii[4], t_t0[4];
     bool t_ok[4];
+    int boff[4];                                           // per-tile LDS offset of (row 0, t0 + jl - pad)
+    bool okk[4][kTaps];                                    // per-tile, per-tap validity of the B element
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ct = base + j * 4 + wave;                  // round-robin: few tiles still use every wave
@@ -193,6 +196,12 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
       const int ctc = t_ok[j] ? ct : 0;
       t_ii[j] = ctc / a.TT;
       t_t0[j] = (ctc - t_ii[j] * a.TT) * 16;
+      boff[j] = t_ii[j] * kCK * a.RS + t_t0[j] + jl - a.pad;
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k) {
+        const int idx = t_t0[j] + jl + k - a.pad;
+        okk[j][k] = idx >= 0 && idx < a.Tin;
+      }
     }
     for (int ch = 0; ch < n_chunks; ++ch) {
       const int c_lo = ch * kCK;
@@ -241,6 +250,12 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
           for (int t = lane; t < a.Tin; t += 64) dst[t] = Act<AT>::rnd(Act<IT>::ld(a.in, soff + t));
         }
       }
+      if (ckc4 != ckc) {                                   // channel round-up rows read as zero
+        for (int e = threadIdx.x; e < n_items * (ckc4 - ckc) * a.RS; e += 256) {
+          const int ii = e / ((ckc4 - ckc) * a.RS), r = e - ii * (ckc4 - ckc) * a.RS;
+          in_tile[(ii * kCK + ckc) * a.RS + r] = 0.f;
+        }
+      }
       {
         const int wlen4 = (ckc4 / 4) * kTaps * GT * 16;
         const float4* wsrc = reinterpret_cast<const float4*>(wbase + (int64_t)ch * (kCK / 4) * kTaps * GT * 64);
@@ -248,10 +263,9 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
         for (int e = threadIdx.x; e < wlen4; e += 256) wdst[e] = wsrc[e];
       }
       __syncthreads();
+      // addresses and masks were hoisted out of this loop (boff / okk); the channel round-up rows are zero
       for (int cg = 0; cg < ckc4 / 4; ++cg) {
-        const int crow = cg * 4 + q;
-        const bool c_ok = crow < ckc;
-        const int crow_c = c_ok ? crow : 0;
+        const float* rowp = in_tile + (cg * 4 + q) * a.RS;
 #pragma unroll
         for (int k = 0; k < kTaps; ++k) {
           float af[2];
@@ -260,11 +274,8 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (!t_ok[j]) continue;                          // wave-uniform: unused tile slots issue nothing
-            const int idx = t_t0[j] + jl + k - a.pad;
-            const bool ok = c_ok && idx >= 0 && idx < a.Tin;
-            const int idc = idx < 0 ? 0 : (idx >= a.Tin ? a.Tin - 1 : idx);
-            float bf = in_tile[(t_ii[j] * kCK + crow_c) * a.RS + idc];
-            bf = ok ? bf : 0.f;
+            float bf = rowp[boff[j] + k];                    // may touch a neighbouring row: masked below
+            bf = okk[j][k] ? bf : 0.f;
             acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf, acc[j][0], 0, 0, 0);
             if (GT > 1) acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf, acc[j][1], 0, 0, 0);
           }
@@ -986,7 +997,7 @@ static int launch_conv(int mode, int bf16, const ConvArgs& a, int n_zones, hipSt
   const int64_t blocks = cdiv(a.items, a.IPW);
   ISD_CHECK_ARG(blocks <= 0x7fffffffLL, "conv4: too many items");
   const int GT = a.F / 16;
-  const size_t lds = sizeof(float) * ((((size_t)a.IPW * kCK * a.RS + 3) & ~(size_t)3) + (size_t)(kCK / 4) * kTaps * GT * 64);
+  const size_t lds = sizeof(float) * (4 + (((size_t)a.IPW * kCK * a.RS + 3) & ~(size_t)3) + (size_t)(kCK / 4) * kTaps * GT * 64 + 32);
   ISD_CHECK_ARG(lds <= 64 * 1024, "conv4: LDS tile of %zu bytes exceeds 64 KiB (window too long)", lds);
   const dim3 grid((unsigned)blocks, n_zones);
   if (mode == 0 && !bf16) hipLaunchKernelGGL((conv5_fwd_kernel<0, float>), grid, dim3(256), lds, st, a);
