@@ -357,7 +357,7 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
   const int cz = zd.cin, ncg = (cz + 3) / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
   const int T1 = a.T1, W = a.W, TT = a.TT;
-  float* xz = smem;                                  // [16][W]
+  float* xz = smem + 4;                              // [16][W]  (4 floats of slack before every tile)
   float* t2 = smem + ((16 * W + 3) & ~3);            // [32][T1]
   float* t3 = t2 + ((F * T1 + 3) & ~3);              // [32][T1]
   float* red = t3 + ((F * T1 + 3) & ~3);             // [8][32]
@@ -371,6 +371,21 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
     w4s[e] = a.w4[(int64_t)z * a.wz_stride + e];
   }
   const float* bias = a.beff + z * F;
+  constexpr int NJ = 16 / NW;
+  int off0[NJ], off2[NJ];                             // tile column offsets for pad 0 / pad 2 reads
+  bool tlive[NJ], ok0[NJ][kTaps], ok2[NJ][kTaps];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int tt = j * NW + wave;
+    tlive[j] = tt < TT;
+    off0[j] = tt * 16 + jl;
+    off2[j] = tt * 16 + jl - 2;
+#pragma unroll
+    for (int kk = 0; kk < kTaps; ++kk) {
+      ok0[j][kk] = off0[j] + kk < W;
+      ok2[j][kk] = off2[j] + kk >= 0 && off2[j] + kk < T1;
+    }
+  }
 
   for (int64_t item = blockIdx.x; item < a.items; item += gridDim.x) {
     const int64_t b = item / a.N;
@@ -395,12 +410,10 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
       for (int k = 0; k < kTaps; ++k) {
         const float a0 = we[((cg * kTaps + k) * 2 + 0) * 64 + lane], a1 = we[((cg * kTaps + k) * 2 + 1) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < 16 / NW; ++j) {
-          const int tt = j * NW + wave;
-          if (tt >= TT) continue;
-          const int idx = tt * 16 + jl + k;
-          float bf = xr[idx < W ? idx : W - 1];
-          bf = (c_ok && idx < W) ? bf : 0.f;
+        for (int j = 0; j < NJ; ++j) {
+          if (!tlive[j]) continue;
+          float bf = xr[off0[j] + k];                        // beyond W: lands in the next row / tile, masked
+          bf = (c_ok && ok0[j][k]) ? bf : 0.f;
           acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc[j][0], 0, 0, 0);
           acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc[j][1], 0, 0, 0);
         }
@@ -424,13 +437,10 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
       for (int k = 0; k < kTaps; ++k) {
         const float a0 = w3s[((cg * kTaps + k) * 2 + 0) * 64 + lane], a1 = w3s[((cg * kTaps + k) * 2 + 1) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < 16 / NW; ++j) {
-          const int tt = j * NW + wave;
-          if (tt >= TT) continue;
-          const int idx = tt * 16 + jl + k - 2;
-          const bool ok = idx >= 0 && idx < T1;
-          float bf = xr[ok ? idx : 0];
-          bf = ok ? bf : 0.f;
+        for (int j = 0; j < NJ; ++j) {
+          if (!tlive[j]) continue;
+          float bf = xr[off2[j] + k];                        // may touch the neighbouring row: masked
+          bf = ok2[j][k] ? bf : 0.f;
           acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc[j][0], 0, 0, 0);
           acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc[j][1], 0, 0, 0);
         }
@@ -454,13 +464,10 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
       for (int k = 0; k < kTaps; ++k) {
         const float a0 = w4s[((cg * kTaps + k) * 2 + 0) * 64 + lane], a1 = w4s[((cg * kTaps + k) * 2 + 1) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < 16 / NW; ++j) {
-          const int tt = j * NW + wave;
-          if (tt >= TT) continue;
-          const int idx = tt * 16 + jl + k - 2;
-          const bool ok = idx >= 0 && idx < T1;
-          float bf = xr[ok ? idx : 0];
-          bf = ok ? bf : 0.f;
+        for (int j = 0; j < NJ; ++j) {
+          if (!tlive[j]) continue;
+          float bf = xr[off2[j] + k];                        // may touch the neighbouring row: masked
+          bf = ok2[j][k] ? bf : 0.f;
           acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc[j][0], 0, 0, 0);
           acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc[j][1], 0, 0, 0);
         }
@@ -1043,8 +1050,8 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
     fa.Z = p->Z; fa.W = p->W; fa.T1 = g.T1; fa.TT = g.TT; fa.store = 1;
     fa.Ctot = p->Ctot; fa.Tx = (int)T; fa.N = g.N; fa.S = p->S;
     constexpr int NW = 8;   // measured: 8 waves per item 37.2 ms/step, 16 waves 39.7, 4 waves 43.5 (B=4096, T=512)
-    const size_t lds = sizeof(float) * (size_t)(((16 * p->W + 3) & ~3) + 2 * ((F * g.T1 + 3) & ~3) + NW * F +
-                                                 (4 + 8 + 8) * kTaps * 2 * 64);
+    const size_t lds = sizeof(float) * (size_t)(4 + ((16 * p->W + 3) & ~3) + 2 * ((F * g.T1 + 3) & ~3) + NW * F +
+                                                 (4 + 8 + 8) * kTaps * 2 * 64 + 64);
     if (lds <= 150 * 1024) {
       int per_zone = 256 / p->Z;
       if (per_zone < 1) per_zone = 1;
