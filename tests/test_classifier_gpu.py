@@ -107,3 +107,28 @@ def test_estimator_accepts_device_tensors_and_uint8_labels(isd):
     assert clf.fit(x, y) is clf
     assert clf.predict(x).shape == (16,)
     assert clf.extractor_.fb.precision == "f64"
+
+
+def test_experiment_driver_writes_reference_artifacts(isd, tmp_path):
+    """Per-subject K-fold fine-tuning in the reference's trained mode ('default') on tiny synthetic data."""
+    from isd_amd import experiment as E
+    import isd_amd.nn as inn
+    rng = np.random.default_rng(0)
+    electrodes = ["Fp1", "Fp2", "F3", "F4", "C3", "C4", "O1", "O2"]
+    zones = {"Frontal": ["Fp1", "Fp2", "F3", "F4"], "Central": ["C3", "C4"], "Occipital": ["O1", "O2"]}
+    cfg = inn.fast_config(electrodes, zones, dim_cnn=16, dim_token=16, seq_len=500, n_classes=3, num_layers=1,
+                          num_heads=4, dropout=0.1)
+    tv = {sid: (rng.standard_normal((12, 8, 500)).astype(np.float32), rng.integers(0, 3, 12).astype(np.uint8))
+          for sid in ("01", "02")}
+    te = {"01": (rng.standard_normal((5, 8, 500)).astype(np.float32), rng.integers(0, 3, 5).astype(np.uint8))}
+    rows = E.finetune_per_subject_cv(tv, te, str(tmp_path), cfg, n_folds=2, max_epochs=2, batch_size=4, seed=1)
+    assert [r[0] for r in rows] == ["01", "02"] and all(0.0 <= r[1] <= 1.0 for r in rows)
+    base = tmp_path / "FAST"
+    for f in ("sub-01/fold_metrics.csv", "sub-01/best_subject.pth", "sub-01/test_predictions.csv",
+              "summary_per_subject.csv", "global_test_predictions.csv", "sub-02/best_subject.pth"):
+        assert (base / f).exists(), f
+    assert open(base / "sub-01" / "test_predictions.csv").readline().strip() == "# Predicted,True"
+    sd = torch.load(base / "sub-01" / "best_subject.pth")
+    assert "head.encoders.Frontal.cnn2.weight" in sd and "transformer.0.attn.in_proj_weight" in sd
+    per, summary = E.process_results(str(tmp_path))
+    assert summary["N_subjects"] == 1 and per[0]["N_samples"] == 5

@@ -83,3 +83,52 @@ def test_band_bins_inclusive_edges():
     assert band_bins(256.0, 64, odsp.BANDS_9)[0] == (1, 2)           # 4 and 8 Hz bins, both edges included
     assert band_bins(250.0, 64, odsp.BANDS_5) == odsp.band_bins(250.0, 64, odsp.BANDS_5)
     assert band_bins(256.0, 64, [("x", 1.0, 3.0)]) == [(1, 0)]       # empty band
+
+
+def test_mat_ingestion_and_standardized_cache_roundtrip(tmp_path):
+    import scipy.io
+    from isd_amd import data as D
+    rng = np.random.default_rng(0)
+    for sub, key in (("Training set", "epo_train"), ("Validation set", "epo_validation")):
+        os.makedirs(tmp_path / sub)
+        for sid in ("01", "02"):
+            n = 7 if key == "epo_train" else 3
+            x = rng.standard_normal((795, 64, n)).astype(np.float32)             # [T, C, n] as in the .mat files
+            lab = rng.integers(0, 5, n)
+            onehot = np.eye(5)[lab].T                                             # [5, n]
+            scipy.io.savemat(tmp_path / sub / f"Data_Sample{sid}.mat", {key: {"x": x, "y": onehot}})
+    X, Y = D.load_subject_train_val(str(tmp_path), "01")
+    assert X.shape == (10, 64, 800) and X.dtype == np.float32 and Y.dtype == np.uint8 and Y.shape == (10,)
+    assert np.array_equal(X[:, :, 795:], np.repeat(X[:, :, 794:795], 5, axis=2))  # edge padding 795 -> 800
+    Xa, Ya = D.load_training_set(str(tmp_path), ["01", "02"])
+    assert Xa.shape == (14, 64, 800)
+    path = D.save_standardized(str(tmp_path / "cache.npz"), {"01": (X, Y)})
+    back = D.load_standardized(path)
+    assert np.array_equal(back["01"][0], X) and np.array_equal(back["01"][1], Y)
+    ds = D.BasicDataset(X.reshape(2, 5, 64, 800), Y)
+    assert len(ds) == 10 and ds[3][0].shape == (64, 800) and ds.labels.dtype == np.uint8
+
+
+def test_report_aggregation_matches_known_metrics(tmp_path):
+    from isd_amd import experiment as E
+    folder = tmp_path / "FAST"
+    truth = np.array([0, 1, 2, 3, 4] * 10)
+    for sid, flip in ((1, 0), (2, 10)):
+        os.makedirs(folder / f"sub-{sid:02d}")
+        pred = truth.copy()
+        pred[:flip] = (pred[:flip] + 1) % 5
+        E._save_predictions(str(folder / f"sub-{sid:02d}" / "test_predictions.csv"), pred, truth)
+    per, summary = E.process_results(str(tmp_path))
+    assert [r["Subject"] for r in per] == [1, 2]
+    assert per[0]["Accuracy"] == 1.0 and abs(per[1]["Accuracy"] - 0.8) < 1e-12
+    from sklearn.metrics import f1_score, precision_score
+    pred2 = truth.copy()
+    pred2[:10] = (pred2[:10] + 1) % 5
+    assert abs(per[1]["F1"] - f1_score(truth, pred2, average="macro")) < 1e-12
+    assert abs(per[1]["Precision"] - precision_score(truth, pred2, average="macro")) < 1e-12
+    assert summary["N_subjects"] == 2 and abs(summary["Acc_Mean"] - 0.9) < 1e-12
+    folds = E.kfold_indices(23, 5, seed=42)
+    assert sorted(np.concatenate([v for _, v in folds]).tolist()) == list(range(23))
+    from sklearn.model_selection import KFold
+    ref = [v for _, v in KFold(5, shuffle=True, random_state=42).split(np.arange(23))]
+    assert all(sorted(a.tolist()) == sorted(b.tolist()) for (_, a), b in zip(folds, ref))
