@@ -326,19 +326,18 @@ __global__ void eeg_finalize2_kernel(const float* __restrict__ params, float* __
   co->B2[g] = (float)(b2 + g2 * ((double)c1 - mu2) / sig2);
 }
 
-// p2[b,g,v] = mean_{r<4} ELU(A2 u[b,g,4v+r] + B2)
+// p2[b,g,v] = mean_{r<P1} ELU(A2 u[b,g,P1 v+r] + B2)   (P1 = 4 EEGNet, 8 CVBlock)
 __global__ __launch_bounds__(256) void eeg_pool2_kernel(const float* __restrict__ u, const EegCoef* __restrict__ co,
-                                                        float* __restrict__ p2, int Tp, int T2, float dp,
+                                                        float* __restrict__ p2, int Tp, int T2, int P1, float dp,
                                                         uint64_t seed) {
   const int bg = blockIdx.y, g = bg & (kF2 - 1);
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v >= T2) return;
   const float A = co->A2[g], Bc = co->B2[g];
-  const float* ur = u + (int64_t)bg * Tp + 4 * v;
+  const float* ur = u + (int64_t)bg * Tp + P1 * v;
   float s = 0.f;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) s += elu_f(fmaf(A, ur[r], Bc));
-  p2[(int64_t)bg * T2 + v] = 0.25f * s * drop_scale(seed, (uint64_t)bg * T2 + v, dp);
+  for (int r = 0; r < P1; ++r) s += elu_f(fmaf(A, ur[r], Bc));
+  p2[(int64_t)bg * T2 + v] = s / (float)P1 * drop_scale(seed, (uint64_t)bg * T2 + v, dp);
 }
 
 // a3[b,g,w] = sum_k Wd[g,k] p2pad[b,g,w+k];  a4[b,h,w] = sum_g Wp[h,g] a3[b,g,w];  BN3 sums.
@@ -545,24 +544,28 @@ __global__ __launch_bounds__(256) void eeg_bwd_sepw_kernel(const float* __restri
 __global__ __launch_bounds__(256) void eeg_bwd_pool2_kernel(const float* __restrict__ da3, const float* __restrict__ Wd,
                                                             const float* __restrict__ u, const EegCoef* __restrict__ co,
                                                             float* __restrict__ dy2, EegStats* __restrict__ st, int Tp,
-                                                            int T2, int T2p, float dpr, uint64_t seed) {
+                                                            int T2, int T2p, int P1, float dpr, uint64_t seed) {
   __shared__ float red[4];
   const int bg = blockIdx.y, g = bg & (kF2 - 1);
   const int tp = blockIdx.x * 256 + threadIdx.x;
   float dy = 0.f, xh = 0.f;
   if (tp < Tp) {
-    const int v = tp >> 2;
+    const int v = tp / P1;
     if (v < T2) {
       float dp = 0.f;                                   // dp2[v] = sum_k Wd[g,k] da3[v - k + 8]
+      if (Wd) {
 #pragma unroll
-      for (int k = 0; k < kK2; ++k) {
-        const int w = v - k + kP2;
-        if (w >= 0 && w < T2p) dp = fmaf(Wd[g * kK2 + k], da3[(int64_t)bg * T2p + w], dp);
+        for (int k = 0; k < kK2; ++k) {
+          const int w = v - k + kP2;
+          if (w >= 0 && w < T2p) dp = fmaf(Wd[g * kK2 + k], da3[(int64_t)bg * T2p + w], dp);
+        }
+      } else {
+        dp = da3[(int64_t)bg * T2 + v];                 // CVBlock: dp2 already formed by cv_bwd_dp2_kernel
       }
       dp *= drop_scale(seed, (uint64_t)bg * T2 + v, dpr);
       const float uv = u[(int64_t)bg * Tp + tp];
       const float y2 = fmaf(co->A2[g], uv, co->B2[g]);
-      dy = 0.25f * dp * elu_grad_f(y2);
+      dy = dp / (float)P1 * elu_grad_f(y2);
       // xhat2 = (a2 - mu2)/sig2 with a2 = s1 u + c1  ==  (y2 - beta2)/gamma2 ; use the direct form
       xh = (co->s1[g >> 1] * uv + co->o1[g >> 1] * co->wsum[g] - co->mu2[g]) / co->sig2[g];
     }
@@ -709,10 +712,12 @@ __global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restr
                                                             float* __restrict__ dparams,
                                                             const EegStats* __restrict__ st,
                                                             const EegCoef* __restrict__ co, EegOff off, int C, int K,
-                                                            double N1) {
+                                                            double N1, int separable) {
   const float* Wt = params + off.Wt;
-  for (int e = threadIdx.x; e < kF2 * kF2; e += 256) dparams[off.Wp + e] = (float)st->dWp[e / kF2][e % kF2];
-  for (int e = threadIdx.x; e < kF2 * kK2; e += 256) dparams[off.Wd + e] = (float)st->dWd[e / kK2][e % kK2];
+  if (separable) {
+    for (int e = threadIdx.x; e < kF2 * kF2; e += 256) dparams[off.Wp + e] = (float)st->dWp[e / kF2][e % kF2];
+    for (int e = threadIdx.x; e < kF2 * kK2; e += 256) dparams[off.Wd + e] = (float)st->dWd[e / kK2][e % kK2];
+  }
   __shared__ double SD[kF1], SU[kF1];
   if (threadIdx.x < kF1) {
     const int f = threadIdx.x;
@@ -739,32 +744,237 @@ __global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// CVBlock (reference: src/fast/models/fast.py:32-100).  Stage 1 (temporal conv, BN1, depthwise spatial
+// conv, BN2, ELU) is the EEGNet one with AvgPool 8; stage 2 is a full 16->16 (1,16) convolution, BN3,
+// ELU, AvgPool 2, and the projector is Linear(16*T3 -> F) over the flattened [16, T3] map.
+// ------------------------------------------------------------------------------------------------
+// W3 [h][g][k] -> fwd layout [g][k][h] and data-gradient layout [h][k][g] (16 contiguous scalars per tap)
+__global__ __launch_bounds__(256) void cv_prep_kernel(const float* __restrict__ W3, float* __restrict__ Wf,
+                                                      float* __restrict__ Wb) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= kF2 * kF2 * kK2) return;
+  const int h = e >> 8, g = (e >> 4) & 15, k = e & 15;
+  const float w = W3[e];
+  Wf[(g * kK2 + k) * kF2 + h] = w;
+  Wb[(h * kK2 + k) * kF2 + g] = w;
+}
+
+// a4[b,h,w] = sum_{g,k} W3[h,g,k] p2pad[b,g,w+k];  BN3 sums.  One thread per (b,w), 16 outputs in registers.
+__global__ __launch_bounds__(256) void cv_conv3_kernel(const float* __restrict__ p2, const float* __restrict__ Wf,
+                                                       float* __restrict__ a4, EegStats* __restrict__ st, int64_t B,
+                                                       int T2, int T2p, int want_stats) {
+  __shared__ float red[4];
+  __shared__ float tot[2 * kF2];
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = e < B * T2p;
+  const int64_t b = live ? e / T2p : 0;
+  const int w = live ? (int)(e - b * T2p) : 0;
+  float o[kF2];
+#pragma unroll
+  for (int h = 0; h < kF2; ++h) o[h] = 0.f;
+  if (live) {
+    for (int g = 0; g < kF2; ++g) {
+      const float* pr = p2 + (b * kF2 + g) * T2;
+#pragma unroll
+      for (int k = 0; k < kK2; ++k) {
+        const int v = w + k - kP2;
+        const float pv = (v >= 0 && v < T2) ? pr[v] : 0.f;
+        const float* wv = Wf + (g * kK2 + k) * kF2;
+#pragma unroll
+        for (int h = 0; h < kF2; ++h) o[h] = fmaf(wv[h], pv, o[h]);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < kF2; ++h) a4[(b * kF2 + h) * T2p + w] = o[h];
+  }
+  if (want_stats) {
+#pragma unroll
+    for (int h = 0; h < kF2; ++h) {
+      const float s1 = block_sum(o[h], red);
+      const float s2 = block_sum(o[h] * o[h], red);
+      if (threadIdx.x == 0) { tot[h] = s1; tot[kF2 + h] = s2; }
+    }
+    __syncthreads();
+    if (threadIdx.x < kF2) atomicAdd(&st->a1[threadIdx.x], (double)tot[threadIdx.x]);
+    else if (threadIdx.x < 2 * kF2) atomicAdd(&st->a2[threadIdx.x - kF2], (double)tot[threadIdx.x]);
+  }
+}
+
+// p3[b,h,v] = mean_{r<P2} ELU(A3 a4[b,h,P2 v+r] + B3) * dropout      ([B,16,T3] == the flattened projector input)
+__global__ __launch_bounds__(256) void cv_pool3_kernel(const float* __restrict__ a4, const EegCoef* __restrict__ co,
+                                                       float* __restrict__ p3, int64_t n, int T2p, int T3, int P2,
+                                                       float dp, uint64_t seed) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int64_t row = e / T3;
+  const int v = (int)(e - row * T3), h = (int)(row & (kF2 - 1));
+  const float A = co->A3[h], Bc = co->B3[h];
+  const float* ar = a4 + row * T2p + P2 * v;
+  float s = 0.f;
+  for (int r = 0; r < P2; ++r) s += elu_f(fmaf(A, ar[r], Bc));
+  p3[e] = s / (float)P2 * drop_scale(seed ^ 0x5bd1e995u, (uint64_t)e, dp);
+}
+
+__device__ __forceinline__ float cv_dy3(const float* __restrict__ dp3, const EegCoef* __restrict__ co, int64_t row,
+                                        int h, int w, float av, int T3, int P2, float dp, uint64_t seed) {
+  if (w >= P2 * T3) return 0.f;
+  const int64_t e = row * T3 + w / P2;
+  const float de = dp3[e] / (float)P2 * drop_scale(seed ^ 0x5bd1e995u, (uint64_t)e, dp);
+  return de * elu_grad_f(fmaf(co->A3[h], av, co->B3[h]));
+}
+
+// BN3 backward sums: one wave per (b,h) row
+__global__ __launch_bounds__(256) void cv_bwd3_sums_kernel(const float* __restrict__ a4, const float* __restrict__ dp3,
+                                                           const EegCoef* __restrict__ co, EegStats* __restrict__ st,
+                                                           int64_t rows, int T2p, int T3, int P2, float dp,
+                                                           uint64_t seed) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int h = (int)(row & (kF2 - 1));
+  const float mu = co->mu3[h], isg = 1.f / co->sig3[h];
+  float s1 = 0.f, s2 = 0.f;
+  for (int w = lane; w < P2 * T3; w += 64) {
+    const float av = a4[row * T2p + w];
+    const float dy = cv_dy3(dp3, co, row, h, w, av, T3, P2, dp, seed);
+    s1 += dy;
+    s2 += dy * (av - mu) * isg;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    atomicAdd(&st->dy3s[h], (double)s1);
+    atomicAdd(&st->dy3x[h], (double)s2);
+  }
+}
+
+// da4 = cA3 (dy3 - cB3 - xhat3 cC3), elementwise over [B,16,T2p]
+__global__ __launch_bounds__(256) void cv_bwd_da4_kernel(const float* __restrict__ a4, const float* __restrict__ dp3,
+                                                         const EegCoef* __restrict__ co, float* __restrict__ da4,
+                                                         int64_t n, int T2p, int T3, int P2, float dp, uint64_t seed) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int64_t row = e / T2p;
+  const int w = (int)(e - row * T2p), h = (int)(row & (kF2 - 1));
+  const float av = a4[e];
+  const float dy = cv_dy3(dp3, co, row, h, w, av, T3, P2, dp, seed);
+  const float xh = (av - co->mu3[h]) / co->sig3[h];
+  da4[e] = co->cA3[h] * (dy - co->cB3[h] - xh * co->cC3[h]);
+}
+
+// dp2[b,g,v] = sum_{h,k} W3[h,g,k] da4[b,h,v-k+8].  One thread per (b,v), 16 outputs in registers.
+__global__ __launch_bounds__(256) void cv_bwd_dp2_kernel(const float* __restrict__ da4, const float* __restrict__ Wb,
+                                                         float* __restrict__ dp2, int64_t B, int T2, int T2p) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * T2) return;
+  const int64_t b = e / T2;
+  const int v = (int)(e - b * T2);
+  float o[kF2];
+#pragma unroll
+  for (int g = 0; g < kF2; ++g) o[g] = 0.f;
+  for (int h = 0; h < kF2; ++h) {
+    const float* dr = da4 + (b * kF2 + h) * T2p;
+#pragma unroll
+    for (int k = 0; k < kK2; ++k) {
+      const int w = v - k + kP2;
+      const float dv = (w >= 0 && w < T2p) ? dr[w] : 0.f;
+      const float* wv = Wb + (h * kK2 + k) * kF2;
+#pragma unroll
+      for (int g = 0; g < kF2; ++g) o[g] = fmaf(wv[g], dv, o[g]);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < kF2; ++g) dp2[(b * kF2 + g) * T2 + v] = o[g];
+}
+
+// dW3[h,g,k] = sum_{b,w} da4[b,h,w] p2pad[b,g,w+k] on the matrix cores: M = h, N = k (tap), K = w, one
+// 16x16 accumulator tile per input channel g.  Persistent waves over trials, partial slabs [h][g][k].
+__global__ __launch_bounds__(64) void cv_bwd_w3_kernel(const float* __restrict__ da4, const float* __restrict__ p2,
+                                                       float* __restrict__ part, int64_t B, int T2, int T2p) {
+  const int lane = threadIdx.x, q = lane >> 4, jl = lane & 15;
+  f32x4 acc[kF2];
+#pragma unroll
+  for (int g = 0; g < kF2; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const float* dr = da4 + (b * kF2 + jl) * T2p;
+    const float* pb = p2 + b * kF2 * T2;
+    for (int w0 = 0; w0 < T2p; w0 += 4) {
+      const int w = w0 + q;
+      const float af = w < T2p ? dr[w] : 0.f;
+      const int v = w + jl - kP2;
+      const bool ok = w < T2p && v >= 0 && v < T2;
+#pragma unroll
+      for (int g = 0; g < kF2; ++g) {
+        const float bf = ok ? pb[g * T2 + v] : 0.f;
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[g], 0, 0, 0);
+      }
+    }
+  }
+  float* slab = part + (int64_t)blockIdx.x * (kF2 * kF2 * kK2);
+#pragma unroll
+  for (int g = 0; g < kF2; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slab[(4 * q + r) * (kF2 * kK2) + g * kK2 + jl] = acc[g][r];
+}
+
+__global__ __launch_bounds__(256) void cv_w3_reduce_kernel(const float* __restrict__ part, int n_slabs,
+                                                           float* __restrict__ dW3) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= kF2 * kF2 * kK2) return;
+  float s0 = 0.f, s1 = 0.f;
+  int k = 0;
+  for (; k + 1 < n_slabs; k += 2) {
+    s0 += part[(int64_t)k * (kF2 * kF2 * kK2) + e];
+    s1 += part[(int64_t)(k + 1) * (kF2 * kF2 * kK2) + e];
+  }
+  if (k < n_slabs) s0 += part[(int64_t)k * (kF2 * kF2 * kK2) + e];
+  dW3[e] = s0 + s1;
+}
+
 }  // namespace isd
 
 using namespace isd;
 
 struct isd_eegnet_plan {
   int C, F, K, T, Tp, T2, T2p, T3;
+  int cv;          // 0: EEGNet_Encoder, 1: CVBlock
+  int P1, P2;      // AvgPool widths of the two stages
   EegOff off;
 };
 
 static inline int64_t al64(int64_t v) { return (v + 63) / 64 * 64; }
 
+static int eeg_plan_create(isd_eegnet_plan** out, int in_channels, int feature_dim, int kernel_length, int T, int cv);
+
 extern "C" int isd_eegnet_plan_create(isd_eegnet_plan** out, int in_channels, int feature_dim, int kernel_length,
                                       int T) {
+  return eeg_plan_create(out, in_channels, feature_dim, kernel_length, T, 0);
+}
+extern "C" int isd_cvblock_plan_create(isd_eegnet_plan** out, int in_channels, int dim_token, int T) {
+  return eeg_plan_create(out, in_channels, dim_token, kMaxK, T, 1);
+}
+extern "C" int64_t isd_cvblock_flat_dim(const isd_eegnet_plan* p) {
+  return (p && p->cv) ? (int64_t)kF2 * p->T3 : ISD_ERR_INVALID;
+}
+
+static int eeg_plan_create(isd_eegnet_plan** out, int in_channels, int feature_dim, int kernel_length, int T, int cv) {
   ISD_CHECK_ARG(out, "isd_eegnet_plan_create: null argument");
   ISD_CHECK_ARG(in_channels >= 1 && in_channels <= 16384, "isd_eegnet_plan_create: in_channels=%d", in_channels);
-  ISD_CHECK_ARG(feature_dim >= 1 && feature_dim <= 64, "isd_eegnet_plan_create: feature_dim=%d not in [1,64]", feature_dim);
+  ISD_CHECK_ARG(feature_dim >= 1 && feature_dim <= 1024, "isd_eegnet_plan_create: feature_dim=%d not in [1,1024]", feature_dim);
   ISD_CHECK_ARG(kernel_length >= 2 && kernel_length <= kMaxK && (kernel_length & 1) == 0,
                 "isd_eegnet_plan_create: kernel_length=%d must be even and <= %d", kernel_length, kMaxK);
   isd_eegnet_plan* p = new isd_eegnet_plan();
   p->C = in_channels; p->F = feature_dim; p->K = kernel_length; p->T = T;
+  p->cv = cv;
+  p->P1 = cv ? 8 : 4;
+  p->P2 = cv ? 2 : 8;
   p->Tp = T + 2 * (kernel_length / 2) - kernel_length + 1;
-  p->T2 = p->Tp / 4;
+  p->T2 = p->Tp / p->P1;
   p->T2p = p->T2 + 2 * kP2 - kK2 + 1;
-  p->T3 = p->T2p / 8;
-  if (T < 1 || p->T3 < 1) {
-    set_error("isd_eegnet_plan_create: T=%d is too short (the second AvgPool needs >= 8 samples: T >= 28)", T);
+  p->T3 = p->T2p / p->P2;
+  if (T < 1 || p->T2 < 1 || p->T3 < 1) {
+    set_error("isd_eegnet_plan_create: T=%d is too short for the two pooling stages", T);
     delete p;
     return ISD_ERR_INVALID;
   }
@@ -776,11 +986,11 @@ extern "C" int isd_eegnet_plan_create(isd_eegnet_plan** out, int in_channels, in
   f.Ws = o; o += kF2 * in_channels;
   f.g2 = o; o += kF2;
   f.b2 = o; o += kF2;
-  f.Wd = o; o += kF2 * kK2;
-  f.Wp = o; o += kF2 * kF2;
+  f.Wd = o; o += cv ? kF2 * kF2 * kK2 : kF2 * kK2;      // CVBlock: the full conv3 weight [16,16,16] sits here
+  f.Wp = o; o += cv ? 0 : kF2 * kF2;
   f.g3 = o; o += kF2;
   f.b3 = o; o += kF2;
-  f.Wl = o; o += feature_dim * kF2;
+  f.Wl = o; o += feature_dim * kF2 * (cv ? p->T3 : 1);
   f.bl = o; o += feature_dim;
   f.total = o;
   *out = p;
@@ -796,7 +1006,7 @@ extern "C" int64_t isd_eegnet_buffer_count(const isd_eegnet_plan* p) { return p 
 
 namespace {
 struct EegWs {          // float offsets into the workspace
-  int64_t stats, coef, z, u, p2, a4, pooled, dpooled, a3, da4, da3, dy2, v, part, lin, total;
+  int64_t stats, coef, z, u, p2, a4, pooled, dpooled, a3, da4, da3, dy2, v, part, lin, w3f, w3b, total;
   int n_slabs;
 };
 EegWs eeg_layout(const isd_eegnet_plan* p, int64_t B) {
@@ -808,16 +1018,20 @@ EegWs eeg_layout(const isd_eegnet_plan* p, int64_t B) {
   w.u = o; o += al64(B * kF2 * p->Tp);
   w.p2 = o; o += al64(B * kF2 * p->T2);
   w.a4 = o; o += al64(B * kF2 * p->T2p);
-  w.pooled = o; o += al64(B * kF2);
-  w.dpooled = o; o += al64(B * kF2);
+  const int64_t npool = B * kF2 * (p->cv ? p->T3 : 1);
+  w.pooled = o; o += al64(npool);
+  w.dpooled = o; o += al64(npool);
   w.a3 = o; o += al64(B * kF2 * p->T2p);
   w.da4 = o; o += al64(B * kF2 * p->T2p);
   w.da3 = o; o += al64(B * kF2 * p->T2p);
   w.dy2 = o; o += al64(B * kF2 * p->Tp);
   w.v = o; o += al64(B * kF2 * p->T);
   w.n_slabs = 1024;
-  w.part = o; o += al64((int64_t)w.n_slabs * kF2 * p->C);
-  w.lin = o; o += al64(isd_linear_workspace_bytes(B, kF2, p->F) / 4 + 64);
+  const int64_t slab = p->cv && kF2 * kK2 > p->C ? kF2 * kF2 * kK2 : kF2 * p->C;
+  w.part = o; o += al64((int64_t)w.n_slabs * slab);
+  w.lin = o; o += al64(isd_linear_workspace_bytes(B, kF2 * (p->cv ? p->T3 : 1), p->F) / 4 + 64);
+  w.w3f = o; o += p->cv ? kF2 * kF2 * kK2 : 0;
+  w.w3b = o; o += p->cv ? kF2 * kF2 * kK2 : 0;
   w.total = o;
   return w;
 }
@@ -860,7 +1074,21 @@ extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, cons
   hipLaunchKernelGGL(eeg_finalize2_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
                      (double)B * (double)Tp, training, momentum, eps);
   hipLaunchKernelGGL(eeg_pool2_kernel, dim3((unsigned)cdiv(T2, 256), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.u,
-                     Cf, ws + w.p2, Tp, T2, dp, seed);
+                     Cf, ws + w.p2, Tp, T2, p->P1, dp, seed);
+  if (p->cv) {
+    hipLaunchKernelGGL(cv_prep_kernel, dim3(kF2 * kF2 * kK2 / 256), dim3(256), 0, st, params + p->off.Wd, ws + w.w3f,
+                       ws + w.w3b);
+    hipLaunchKernelGGL(cv_conv3_kernel, dim3((unsigned)cdiv(B * T2p, 256)), dim3(256), 0, st, ws + w.p2, ws + w.w3f,
+                       ws + w.a4, S, B, T2, T2p, training);
+    hipLaunchKernelGGL(eeg_finalize3_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
+                       (double)B * (double)T2p, training, momentum, eps);
+    const int64_t n3 = B * kF2 * T3;
+    hipLaunchKernelGGL(cv_pool3_kernel, dim3((unsigned)cdiv(n3, 256)), dim3(256), 0, st, ws + w.a4, Cf, ws + w.pooled, n3,
+                       T2p, T3, p->P2, dp, seed);
+    ISD_LAUNCH_CHECK();
+    return isd_linear_forward(ws + w.pooled, params + p->off.Wl, params + p->off.bl, out, nullptr, B, kF2 * T3, p->F, 0,
+                              stream);
+  }
   hipLaunchKernelGGL(eeg_sep_kernel, dim3((unsigned)cdiv(T2p, 256), (unsigned)B), dim3(256), 0, st, ws + w.p2,
                      params + p->off.Wd, params + p->off.Wp, training ? ws + w.a3 : nullptr, ws + w.a4, S, T2, T2p,
                      training);
@@ -888,8 +1116,25 @@ extern "C" int isd_eegnet_backward(const isd_eegnet_plan* p, const float* x, con
   const int64_t rows16 = B * kF2;
   ISD_HIP_TRY(hipMemsetAsync((char*)S + offsetof(EegStats, dy3s), 0, sizeof(EegStats) - offsetof(EegStats, dy3s), st));
   int rc = isd_linear_backward(ws + w.pooled, params + p->off.Wl, dout, nullptr, ws + w.dpooled, dparams + p->off.Wl,
-                               dparams + p->off.bl, ws + w.lin, B, kF2, p->F, 0, stream);
+                               dparams + p->off.bl, ws + w.lin, B, kF2 * (p->cv ? T3 : 1), p->F, 0, stream);
   if (rc) return rc;
+  if (p->cv) {
+    hipLaunchKernelGGL(cv_bwd3_sums_kernel, dim3((unsigned)cdiv(rows16, 4)), dim3(256), 0, st, ws + w.a4, ws + w.dpooled,
+                       Cf, S, rows16, T2p, T3, p->P2, dropout_p, seed);
+    hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
+                       (double)B * (double)T2p, 3);
+    hipLaunchKernelGGL(cv_bwd_da4_kernel, dim3((unsigned)cdiv(rows16 * T2p, 256)), dim3(256), 0, st, ws + w.a4,
+                       ws + w.dpooled, Cf, ws + w.da4, rows16 * T2p, T2p, T3, p->P2, dropout_p, seed);
+    const int slabs3 = B < w.n_slabs ? (int)B : w.n_slabs;
+    hipLaunchKernelGGL(cv_bwd_w3_kernel, dim3(slabs3), dim3(64), 0, st, ws + w.da4, ws + w.p2, ws + w.part, B, T2, T2p);
+    hipLaunchKernelGGL(cv_w3_reduce_kernel, dim3(kF2 * kF2 * kK2 / 256), dim3(256), 0, st, ws + w.part, slabs3,
+                       dparams + p->off.Wd);
+    hipLaunchKernelGGL(cv_bwd_dp2_kernel, dim3((unsigned)cdiv(B * T2, 256)), dim3(256), 0, st, ws + w.da4, ws + w.w3b,
+                       ws + w.da3, B, T2, T2p);
+    hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3((unsigned)cdiv(Tp, 256), (unsigned)rows16), dim3(256), 0, st,
+                       ws + w.da3, (const float*)nullptr, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, p->P1, dropout_p,
+                       seed);
+  } else {
   hipLaunchKernelGGL(eeg_bwd3_sums_kernel, dim3((unsigned)cdiv(rows16, 4)), dim3(256), 0, st, ws + w.a4, ws + w.dpooled,
                      Cf, S, rows16, T2p, T3, dropout_p, seed);
   hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
@@ -899,7 +1144,8 @@ extern "C" int isd_eegnet_backward(const isd_eegnet_plan* p, const float* x, con
   hipLaunchKernelGGL(eeg_bwd_sepw_kernel, dim3(kF2 * kF2 + kF2 * kK2), dim3(256), 0, st, ws + w.da4, ws + w.a3,
                      ws + w.da3, ws + w.p2, S, (int)B, T2, T2p);
   hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3((unsigned)cdiv(Tp, 256), (unsigned)rows16), dim3(256), 0, st,
-                     ws + w.da3, params + p->off.Wd, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, dropout_p, seed);
+                     ws + w.da3, params + p->off.Wd, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, p->P1, dropout_p, seed);
+  }
   hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
                      (double)B * (double)Tp, 2);
   hipLaunchKernelGGL(eeg_bwd_bn2_kernel, dim3((unsigned)cdiv(Tp, 256), (unsigned)rows16), dim3(256), 0, st, ws + w.dy2,
@@ -917,7 +1163,7 @@ extern "C" int isd_eegnet_backward(const isd_eegnet_plan* p, const float* x, con
   hipLaunchKernelGGL(eeg_bwd_dws_reduce_kernel, dim3((unsigned)cdiv((int64_t)kF2 * C, 256)), dim3(256), 0, st,
                      ws + w.part, slabs, S, Cf, dparams + p->off.Ws, C);
   hipLaunchKernelGGL(eeg_bwd_final_kernel, dim3(1), dim3(256), 0, st, params, dparams, S, Cf, p->off, C, K,
-                     (double)(B * C) * (double)Tp);
+                     (double)(B * C) * (double)Tp, !p->cv);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }

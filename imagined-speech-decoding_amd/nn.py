@@ -178,10 +178,14 @@ class _SoftmaxCEFn(torch.autograd.Function):
 
 
 class EEGNetPlan:
-    def __init__(self, in_channels, feature_dim, kernel_length, T):
+    def __init__(self, in_channels, feature_dim, kernel_length, T, cvblock=False):
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().isd_eegnet_plan_create(C.byref(self._h), int(in_channels), int(feature_dim),
-                                                     int(kernel_length), int(T)))
+        if cvblock:
+            _lib.check(_lib.lib().isd_cvblock_plan_create(C.byref(self._h), int(in_channels), int(feature_dim), int(T)))
+            self.flat_dim = int(_lib.lib().isd_cvblock_flat_dim(self._h))
+        else:
+            _lib.check(_lib.lib().isd_eegnet_plan_create(C.byref(self._h), int(in_channels), int(feature_dim),
+                                                         int(kernel_length), int(T)))
         self.n_params = int(_lib.lib().isd_eegnet_param_count(self._h))
         self.F = int(feature_dim)
 
@@ -485,7 +489,40 @@ class Conv4Layers(_Conv4Params, _FlatParamMixin):
         return _ConvStackFn.apply(x, theta, self._plan(x.shape[-1])).squeeze(1)
 
 
-class EEGNet_Encoder(nn.Module, _FlatParamMixin):
+class _BNStackMixin(_FlatParamMixin):
+    """Shared plumbing of the BatchNorm heads: packed running buffers, per-length plans, the autograd call."""
+
+    def flat_buffers(self):
+        bufs = [t for bn in self._bns() for t in (bn.running_mean, bn.running_var)]
+        flat = self._as_flat(bufs)
+        if flat is None:
+            flat = torch.cat([t.detach().reshape(-1).float() for t in bufs]).contiguous()
+            off = 0
+            for bn in self._bns():
+                for name in ("running_mean", "running_var"):
+                    n = bn._buffers[name].numel()
+                    bn._buffers[name] = flat[off:off + n]
+                    off += n
+        return flat
+
+    def _run(self, x):
+        T = x.shape[-1]
+        plan = self._plans.get(T)
+        if plan is None:
+            plan = self._plans[T] = self._make_plan(T)
+        flat = self.flat_params()
+        theta = torch.cat([p.reshape(-1) for p in self._ordered_params()]) if torch.is_grad_enabled() else flat
+        bn = self._bns()[0]
+        self._calls += 1
+        if self.training:
+            for b in self._bns():
+                b.num_batches_tracked += 1
+        return _EEGNetFn.apply(x, theta, self.flat_buffers(), plan, self.training,
+                               0.1 if bn.momentum is None else bn.momentum, bn.eps, self.p if self.training else 0.0,
+                               (torch.initial_seed() + self._calls) & 0x7FFFFFFFFFFFFFFF)
+
+
+class EEGNet_Encoder(nn.Module, _BNStackMixin):
     """Drop-in for the reference's ``EEGNet_Encoder(in_channels, feature_dim, kernel_length=64, dropout=0.25)``
     (fast.py:122-167); same sub-module / parameter / buffer names, ``forward(x[B', C, T]) -> [B', feature_dim]``.
     Train-mode dropout uses the library's own counter-based stream (statistically nn.Dropout)."""
@@ -515,36 +552,55 @@ class EEGNet_Encoder(nn.Module, _FlatParamMixin):
                 self.separable_conv[0].weight, self.separable_conv[1].weight, b3.weight, b3.bias,
                 self.projector[2].weight, self.projector[2].bias]
 
-    def flat_buffers(self):
-        bufs = [t for bn in self._bns() for t in (bn.running_mean, bn.running_var)]
-        flat = self._as_flat(bufs)
-        if flat is None:
-            flat = torch.cat([t.detach().reshape(-1).float() for t in bufs]).contiguous()
-            off = 0
-            for bn in self._bns():
-                for name in ("running_mean", "running_var"):
-                    n = bn._buffers[name].numel()
-                    bn._buffers[name] = flat[off:off + n]
-                    off += n
-        return flat
+    def _make_plan(self, T):
+        return EEGNetPlan(self.in_channels, self.feature_dim, self.kernel_length, T)
 
     def forward(self, x):
         if x.dim() != 3:
             raise ValueError("expected [batch, channels, time]")
-        T = x.shape[-1]
-        plan = self._plans.get(T)
-        if plan is None:
-            plan = self._plans[T] = EEGNetPlan(self.in_channels, self.feature_dim, self.kernel_length, T)
-        flat = self.flat_params()
-        theta = torch.cat([p.reshape(-1) for p in self._ordered_params()]) if torch.is_grad_enabled() else flat
-        bn = self._bns()[0]
-        self._calls += 1
-        if self.training:
-            for b in self._bns():
-                b.num_batches_tracked += 1
-        return _EEGNetFn.apply(x, theta, self.flat_buffers(), plan, self.training,
-                               0.1 if bn.momentum is None else bn.momentum, bn.eps, self.p if self.training else 0.0,
-                               (torch.initial_seed() + self._calls) & 0x7FFFFFFFFFFFFFFF)
+        return self._run(x)
+
+
+class CVBlock(nn.Module, _BNStackMixin):
+    """Drop-in for the reference's ``CVBlock(n_channels, dim_token, dropout=0.5)`` (fast.py:32-100); same parameter /
+    buffer names.  The projector width is fixed by a 250-sample window exactly as in the reference (fast.py:66-74),
+    so other window lengths raise like the reference's shape mismatch does.  3-D or 4-D ([B', 1, C, T]) input."""
+
+    def __init__(self, n_channels, dim_token, dropout=0.5):
+        super().__init__()
+        self.C, self.F1, self.D, self.F2, self.Kc, self.Kc2 = n_channels, 8, 2, 16, 64, 16
+        self.in_channels, self.feature_dim, self.p = n_channels, dim_token, dropout
+        self.conv1 = nn.Conv2d(1, 8, (1, 64), padding=(0, 32), bias=False)
+        self.bn1 = nn.BatchNorm2d(8)
+        self.conv2 = nn.Conv2d(8, 16, (n_channels, 1), groups=8, bias=False)
+        self.bn2 = nn.BatchNorm2d(16)
+        self.conv3 = nn.Conv2d(16, 16, (1, 16), padding=(0, 8), bias=False)
+        self.bn3 = nn.BatchNorm2d(16)
+        self.flat_dim = 16 * ((((250 + 1) // 8) + 1) // 2)             # the reference's 250-sample dummy pass
+        self.projector = nn.Linear(self.flat_dim, dim_token)
+        self._plans = {}
+        self._calls = 0
+
+    def _bns(self):
+        return [self.bn1, self.bn2, self.bn3]
+
+    def _ordered_params(self):
+        return [self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
+                self.conv3.weight, self.bn3.weight, self.bn3.bias, self.projector.weight, self.projector.bias]
+
+    def _make_plan(self, T):
+        plan = EEGNetPlan(self.in_channels, self.feature_dim, 64, T, cvblock=True)
+        if plan.flat_dim != self.flat_dim:
+            raise RuntimeError(f"CVBlock: a {T}-sample window flattens to {plan.flat_dim} features but the projector "
+                               f"expects {self.flat_dim} (fixed by the 250-sample window, fast.py:66-74)")
+        return plan
+
+    def forward(self, x):
+        if x.dim() == 4 and x.shape[1] == 1:
+            x = x[:, 0]
+        if x.dim() != 3:
+            raise ValueError("expected [batch, channels, time] or [batch, 1, channels, time]")
+        return self._run(x)
 
 
 class Head(nn.Module, _FlatParamMixin):

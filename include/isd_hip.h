@@ -198,6 +198,14 @@ int isd_softmax_ce(const float* logits_tok, const void* labels, int label_bytes,
  * ---------------------------------------------------------------------- */
 typedef struct isd_eegnet_plan isd_eegnet_plan;
 int isd_eegnet_plan_create(isd_eegnet_plan** out, int in_channels, int feature_dim, int kernel_length, int T);
+/* CVBlock (src/fast/models/fast.py:32-100): the same plan type and the same isd_eegnet_* entry points below, with
+ * stage 1 pooled by 8, a full 16->16 (1,16) convolution in stage 2 pooled by 2, and Linear(16*T3 -> dim_token) over
+ * the flattened map (T3 = 16 for the reference's 250-sample window; isd_cvblock_flat_dim returns 16*T3).
+ * Flat parameter block: conv1.weight [8,1,1,64] | bn1.weight [8] | bn1.bias [8] | conv2.weight [16,1,C,1] |
+ *   bn2.weight [16] | bn2.bias [16] | conv3.weight [16,16,1,16] | bn3.weight [16] | bn3.bias [16] |
+ *   projector.weight [F, 16*T3] | projector.bias [F];  buffer block as above (bn1, bn2, bn3). */
+int isd_cvblock_plan_create(isd_eegnet_plan** out, int in_channels, int dim_token, int T);
+int64_t isd_cvblock_flat_dim(const isd_eegnet_plan* plan);
 int isd_eegnet_plan_destroy(isd_eegnet_plan* plan);
 int64_t isd_eegnet_param_count(const isd_eegnet_plan* plan);
 int64_t isd_eegnet_buffer_count(const isd_eegnet_plan* plan);

@@ -4,6 +4,8 @@ A from-scratch restatement in functional PyTorch (CPU, fp32 or fp64) of
 
 * ``Conv4Layers``      src/fast/models/fast.py:103-119
 * ``EEGNet_Encoder``   src/fast/models/fast.py:122-167
+* ``CVBlock``          src/fast/models/fast.py:32-100
+* ``HeadConv_Paper_Version``  src/fast/models/fast.py:170-196
 * ``Head``             src/fast/models/fast.py:199-210   (zone gather + stack)
 * ``forward_head``     src/fast/models/fast.py:242-252   (unfold windows)
 * ``train_head`` mode  src/fast/models/fast.py:273-278   (FC 256->32 GELU, 32->5, mean)
@@ -15,7 +17,7 @@ A from-scratch restatement in functional PyTorch (CPU, fp32 or fp64) of
 Parameters are passed as plain dicts keyed with the reference's state_dict
 names (``head.encoders.<Zone>.cnn1.weight`` ...), so golden state dicts
 captured from the real reference load directly.  Gradients come from autograd
-over these functional ops.  Pinned by tests/golden/g4..g9 (captured from the
+over these functional ops.  Pinned by tests/golden/g4..g11 (captured from the
 importable reference by tests/golden/make_golden.py).
 """
 import math
@@ -96,6 +98,38 @@ def eegnet_encoder(x, p, prefix="", training=False, eps=1e-5, momentum=0.1,
     h = F.avg_pool2d(h, (1, 8))
     h = h.mean(dim=(-2, -1))                                  # AdaptiveAvgPool(1,1)+Flatten
     return F.linear(h, p[prefix + "projector.2.weight"], p[prefix + "projector.2.bias"])
+
+
+def _bn(h, p, name, training, momentum, eps):
+    return F.batch_norm(h, p[name + ".running_mean"], p[name + ".running_var"], p[name + ".weight"],
+                        p[name + ".bias"], training, momentum, eps)
+
+
+def cvblock(x, p, prefix="", training=False, eps=1e-5, momentum=0.1):
+    """fast.py:78-100 with dropout disabled.  x [B', C, T] (or [B', 1, C, T]) -> [B', dim_token].
+    The projector's input width is fixed by the 250-sample dummy of fast.py:66-74, so T must pool to that width."""
+    h = x.unsqueeze(1) if x.dim() == 3 else x
+    w1 = p[prefix + "conv1.weight"]
+    h = _bn(F.conv2d(h, w1, padding=(0, w1.shape[-1] // 2)), p, prefix + "bn1", training, momentum, eps)
+    h = F.conv2d(h, p[prefix + "conv2.weight"], groups=w1.shape[0])
+    h = F.avg_pool2d(F.elu(_bn(h, p, prefix + "bn2", training, momentum, eps)), (1, 8))
+    w3 = p[prefix + "conv3.weight"]
+    h = F.conv2d(h, w3, padding=(0, w3.shape[-1] // 2))
+    h = F.avg_pool2d(F.elu(_bn(h, p, prefix + "bn3", training, momentum, eps)), (1, 2))
+    return F.linear(h.flatten(start_dim=1), p[prefix + "projector.weight"], p[prefix + "projector.bias"])
+
+
+def headconv_paper(x, p, prefix="", training=False, eps=1e-5, momentum=0.1):
+    """fast.py:185-196.  x [B', C, T] -> [B', feature_dim]: (1,3) conv + spatial conv, then three (1,3) convs, each
+    followed by BatchNorm -> exact GELU -> MaxPool(1,2); mean over the remaining time steps."""
+    h = x.unsqueeze(1)
+    h = F.conv2d(h, p[prefix + "cnn1_t.weight"], p[prefix + "cnn1_t.bias"])
+    h = F.conv2d(h, p[prefix + "cnn1_s.weight"])
+    h = F.max_pool2d(F.gelu(_bn(h, p, prefix + "norm1", training, momentum, eps)), (1, 2), stride=(1, 2))
+    for i in (2, 3, 4):
+        h = F.conv2d(h, p[prefix + f"cnn{i}.weight"])
+        h = F.max_pool2d(F.gelu(_bn(h, p, prefix + f"norm{i}", training, momentum, eps)), (1, 2), stride=(1, 2))
+    return h.mean(dim=-1).squeeze(-1)
 
 
 def head_forward(xw, p, zone_names, zone_idx, encoder=conv4layers, **kw):

@@ -22,7 +22,8 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, os.path.join(REF, "src"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from fast.models.fast import FAST, Conv4Layers, EEGNet_Encoder  # noqa: E402  (the reference)
+from fast.models.fast import (FAST, Conv4Layers, CVBlock, EEGNet_Encoder,  # noqa: E402  (the reference)
+                              HeadConv_Paper_Version)
 from oracle import cnn as ocnn, dsp as odsp  # noqa: E402  (constants / band tables only)
 
 
@@ -217,6 +218,44 @@ def g7():
     save("g7_eegnet.npz", **out)
 
 
+def _bn_module_goldens(make, cases, fname):
+    out = {}
+    for tag, (C, T, B) in cases.items():
+        torch.manual_seed(0)
+        m = make(C)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.running_mean.uniform_(-0.2, 0.2)
+                    mod.running_var.uniform_(0.5, 1.5)
+                    mod.weight.uniform_(0.5, 1.5)
+                    mod.bias.uniform_(-0.3, 0.3)
+        out.update(sd_np(m, f"{tag}.sd."))
+        x = torch.randn(B, C, T, requires_grad=True)
+        m.eval()
+        with torch.no_grad():
+            out[f"{tag}.y_eval"] = m(x).numpy()
+        m.train()
+        y = m(x)
+        y.square().sum().backward()
+        out[f"{tag}.x"], out[f"{tag}.y_train"], out[f"{tag}.dx"] = x.detach().numpy(), y.detach().numpy(), x.grad.numpy()
+        out.update(grads_np(m, f"{tag}.grad."))
+        out.update(sd_np(m, f"{tag}.sd_after."))
+    save(fname, **out)
+
+
+# ---------------------------------------------------------------- G10: CVBlock eval + train (dropout 0)
+def g10():
+    _bn_module_goldens(lambda C: CVBlock(C, 32, dropout=0.0), {"z6": (6, 250, 5), "z15": (15, 250, 3)},
+                       "g10_cvblock.npz")
+
+
+# ---------------------------------------------------------------- G11: HeadConv_Paper_Version eval + train
+def g11():
+    _bn_module_goldens(lambda C: HeadConv_Paper_Version(C, 32), {"z6": (6, 250, 5), "z15": (15, 250, 3)},
+                       "g11_paperhead.npz")
+
+
 # ---------------------------------------------------------------- G8: cosine schedule
 def g8():
     # src/fast/train/trainer.py is not importable (lightning absent): the 12-line function is
@@ -229,4 +268,7 @@ def g8():
 
 
 if __name__ == "__main__":
-    g1(); g2(); g3(); g4(); g5_g9(); g6(); g7(); g8()
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5_g9, g6, g7, g8, g10, g11):
+        if not only or fn.__name__ in only:
+            fn()

@@ -1,0 +1,103 @@
+"""GPU parity of the BatchNorm heads of the reference's head registry -- CVBlock (fast.py:32-100) and
+HeadConv_Paper_Version (fast.py:170-196) -- against golden vectors captured from the reference and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import cnn as ocnn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def inn():
+    import isd_amd.nn as m
+    assert torch.cuda.is_available()
+    return m
+
+
+def _sd(g, prefix):
+    return {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+
+
+def _check_against_golden(m, g, tag, grad_tol=1e-4, cancel=()):
+    """``cancel``: parameters whose gradient vanishes analytically (BN gamma/beta directly followed by another
+    BatchNorm); the reference's own values are fp32 cancellation residue, so they are compared on the gradient scale."""
+    m.load_state_dict(_sd(g, f"{tag}.sd."))
+    x = torch.from_numpy(g[f"{tag}.x"]).cuda()
+    m.eval()
+    with torch.no_grad():
+        y_eval = m(x)
+    assert y_eval.shape == (x.shape[0], 32)
+    assert rel_err(y_eval.cpu(), g[f"{tag}.y_eval"]) < 1e-4
+    m.train()
+    y = m(x)
+    assert rel_err(y.detach().cpu(), g[f"{tag}.y_train"]) < 1e-4
+    y.square().sum().backward()
+    scale = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith(f"{tag}.grad."))
+    for k, p in m.named_parameters():
+        want = g[f"{tag}.grad.{k}"]
+        tol = grad_tol * max(float(np.abs(want).max()), (5e-2 if k.startswith(cancel) else 1e-3) * scale)
+        assert np.abs(p.grad.cpu().numpy() - want).max() < tol + 1e-7, k
+    sd_after = _sd(g, f"{tag}.sd_after.")
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert rel_err(v.cpu(), sd_after[k]) < 1e-4, k
+        if "num_batches_tracked" in k:
+            assert int(v) == int(sd_after[k])
+
+
+@pytest.mark.parametrize("tag,C", [("z6", 6), ("z15", 15)])
+def test_cvblock_matches_reference_golden(inn, tag, C):
+    _check_against_golden(inn.CVBlock(C, 32, dropout=0.0).cuda(), load_golden("g10_cvblock.npz"), tag, cancel=("bn1.",))
+
+
+def _vs_oracle(m, fn, x, F, bn_floor_prefix=()):
+    p = {k: v.detach().cpu().clone().double() for k, v in m.state_dict().items()}
+    for k, v in p.items():
+        if "running" not in k and "num_batches" not in k:
+            v.requires_grad_()
+    w = torch.randn(x.shape[0], F)
+    m.train()
+    y = m(x.cuda())
+    (y * w.cuda()).sum().backward()
+    yr = fn(x.double(), p, training=True)
+    (yr * w.double()).sum().backward()
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-4
+    scale = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
+    for k, q in m.named_parameters():
+        want = p[k].grad
+        floor = 5e-2 if k.startswith(bn_floor_prefix) else 1e-3
+        tol = 1e-4 * max(float(want.abs().max()), floor * scale)
+        assert float((q.grad.cpu().double() - want).abs().max()) < tol + 1e-7, k
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert rel_err(v.cpu(), p[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("C,B,F", [(4, 3, 16), (10, 70, 32), (64, 4, 8)])
+def test_cvblock_vs_oracle(inn, C, B, F):
+    torch.manual_seed(C)
+    m = inn.CVBlock(C, F, dropout=0.0).cuda()
+    with torch.no_grad():
+        for bn in m._bns():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    _vs_oracle(m, ocnn.cvblock, torch.randn(B, C, 250), F, bn_floor_prefix=("bn1.",))
+
+
+def test_cvblock_contract(inn):
+    m = inn.CVBlock(6, 32).cuda().eval()
+    x = torch.randn(3, 6, 250, device="cuda")
+    with torch.no_grad():
+        assert torch.equal(m(x), m(x.unsqueeze(1)))                 # 4-D input accepted (fast.py:79-80)
+        with pytest.raises(RuntimeError):
+            m(torch.randn(3, 6, 500, device="cuda"))                # projector width is tied to 250 samples
+    assert m.flat_dim == 256 and m.projector.weight.shape == (32, 256)
+    m.train()
+    m.p = 0.0
+    ref = m(x).detach()
+    m.p = 0.5
+    a, b = m(x).detach(), m(x).detach()
+    assert not torch.equal(a, b) and not torch.equal(a, ref)        # train-mode dropout draws a fresh mask per call

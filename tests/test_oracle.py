@@ -163,6 +163,31 @@ def test_eegnet_matches_reference_golden(tag):
             assert rel_err(p[f"{name}.{buf}"], g[f"{tag}.sd_after.{name}.{buf}"]) < 1e-6
 
 
+@pytest.mark.parametrize("fname,fn,bns", [
+    ("g10_cvblock.npz", ocnn.cvblock, ("bn1", "bn2", "bn3")),
+    ("g11_paperhead.npz", ocnn.headconv_paper, ("norm1", "norm2", "norm3", "norm4"))])
+@pytest.mark.parametrize("tag", ["z6", "z15"])
+def test_bn_heads_match_reference_golden(fname, fn, bns, tag):
+    g = load_golden(fname)
+    p = _t(g, f"{tag}.sd.")
+    for k, v in p.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_()
+    x = torch.from_numpy(g[f"{tag}.x"]).requires_grad_()
+    with torch.no_grad():
+        assert rel_err(fn(x, p, training=False), g[f"{tag}.y_eval"]) < 1e-5
+    y = fn(x, p, training=True)
+    y.square().sum().backward()
+    assert rel_err(y.detach(), g[f"{tag}.y_train"]) < 1e-5
+    assert rel_err(x.grad, g[f"{tag}.dx"]) < 1e-4
+    for k in g.files:
+        if k.startswith(f"{tag}.grad."):
+            assert rel_err(p[k[len(tag) + 6:]].grad, g[k]) < 1e-4, k
+    for name in bns:
+        for buf in ("running_mean", "running_var"):
+            assert rel_err(p[f"{name}.{buf}"], g[f"{tag}.sd_after.{name}.{buf}"]) < 1e-6
+
+
 def test_cosine_schedule_matches_golden_and_quirk():
     g = load_golden("g8_cosine.npz")
     s = ocnn.cosine_scheduler(1, 0.1, 200, 5, warmup_epochs=10)
