@@ -1,0 +1,544 @@
+// HeadConv_Paper_Version (reference: src/fast/models/fast.py:170-196) forward + backward on gfx950.
+//
+//   cnn1_t Conv2d(1->F1,(1,3),bias) -> cnn1_s Conv2d(F1->F1,(C,1)) -> BN -> GELU -> MaxPool(1,2)
+//   3 x [ Conv2d((1,3), valid, no bias) -> BN -> GELU -> MaxPool(1,2) ]  widths F2 = F3 = F/3, F4 = F
+//   mean over the remaining time steps.                                   F1 = F/2
+//
+// cnn1_t and cnn1_s are both linear with nothing between them, so layer 1 runs as one C -> F1 three-tap
+// convolution with Weff[o,c,k] = sum_f Ws[o,f,c] Wt[f,k], beff[o] = sum_{f,c} Ws[o,f,c] bt[f]; the
+// [B,F1,C,T-2] intermediate of the reference is never formed and the gradients of Wt, bt, Ws are assembled
+// from dWeff / dbeff.  Every layer keeps its pre-BN output y_l (the batch statistics need a grid-wide
+// reduction between the convolution and the normalisation), the pooled activations a_l are the next
+// layer's input.  Convolutions: one thread per (trial, time step), 16 output channels in registers, weights
+// through scalar loads; weight gradients: MFMA 16x16x4 (M = out channel, N = in channel, K = time), one
+// accumulator per tap, persistent waves and per-wave partial slabs reduced in a fixed order.
+// Statistics and cross-batch sums accumulate in fp64.
+#include "common.h"
+#include <math.h>
+#include <stddef.h>
+
+namespace isd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPhMaxF = 64;      // widest layer supported (feature_dim <= 64)
+constexpr int kPhSlabs = 1024;
+
+struct PhGeo {
+  int C, T, F;
+  int Fo[4], Ci[4], Ti[4], To[4], Tp[4], Fp[4], Cp[4];   // per layer: out/in channels, in/out/pooled length, paddings
+  int wt, bt, ws, w[4], g[4], b[4], n_params;            // parameter offsets (w[0] unused)
+  int rm[4], rv[4], n_bufs;                              // buffer offsets
+};
+
+struct PhStats {
+  double s1[4][kPhMaxF], s2[4][kPhMaxF];    // sum y, sum y^2
+  double d1[4][kPhMaxF], d2[4][kPhMaxF];    // sum dyhat, sum dyhat*xhat
+};
+struct PhCoef {
+  float A[4][kPhMaxF], Bc[4][kPhMaxF], mu[4][kPhMaxF], isg[4][kPhMaxF];
+  float cA[4][kPhMaxF], cB[4][kPhMaxF], cC[4][kPhMaxF];
+};
+
+__device__ __forceinline__ float ph_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float ph_gelu_grad(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float ph_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float ph_block_sum(float v, float* red) {
+  v = ph_wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+
+// Weff / beff, and the two scalar-load layouts of every layer's weight:
+//   Wf[l][c][k][Fp]  (forward: 16 consecutive output channels per tap)
+//   Wb[l][o][k][Cp]  (data gradient: 16 consecutive input channels per tap)
+__global__ __launch_bounds__(256) void ph_prep_kernel(const float* __restrict__ params, float* __restrict__ Wf,
+                                                      float* __restrict__ Wb, float* __restrict__ beff, PhGeo g,
+                                                      int l, int64_t wf_off, int64_t wb_off) {
+  const int Fo = g.Fo[l], Ci = g.Ci[l], Fp = g.Fp[l], Cp = g.Cp[l];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int n = (Fp > Fo ? Fp : Fo) * (Cp > Ci ? Cp : Ci) * 3;
+  if (l == 0 && e < Fo) {
+    float s = 0.f;
+    for (int f = 0; f < Fo; ++f) {
+      float ws = 0.f;
+      for (int c = 0; c < Ci; ++c) ws += params[g.ws + (e * Fo + f) * Ci + c];
+      s = fmaf(ws, params[g.bt + f], s);
+    }
+    beff[e] = s;
+  }
+  if (l == 0 && e >= Fo && e < g.Fp[0]) beff[e] = 0.f;
+  if (e >= n) return;
+  const int k = e % 3, c = (e / 3) % (Cp > Ci ? Cp : Ci), o = e / (3 * (Cp > Ci ? Cp : Ci));
+  float w = 0.f;
+  if (o < Fo && c < Ci) {
+    if (l == 0) {
+      for (int f = 0; f < Fo; ++f) w = fmaf(params[g.ws + (o * Fo + f) * Ci + c], params[g.wt + f * 3 + k], w);
+    } else {
+      w = params[g.w[l] + (o * Ci + c) * 3 + k];
+    }
+  }
+  if (c < Ci && o < Fp) Wf[wf_off + ((int64_t)c * 3 + k) * Fp + o] = w;
+  if (o < Fo && c < Cp) Wb[wb_off + ((int64_t)o * 3 + k) * Cp + c] = w;
+}
+
+// y[b,o,t] = bias[o] + sum_{c,k} W[o,c,k] in[b,c,t+k];  per-channel sums of y and y^2.
+// Persistent blocks over (b,t); blockIdx.y selects a tile of 16 output channels.
+__global__ __launch_bounds__(256) void ph_conv_kernel(const float* __restrict__ in, const float* __restrict__ Wf,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      double* __restrict__ s1, double* __restrict__ s2, int64_t B,
+                                                      int Ci, int Ti, int To, int Fo, int Fp, int want_stats) {
+  __shared__ float red[4];
+  __shared__ float tot[32];
+  const int o0 = blockIdx.y * 16;
+  float a1[16], a2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a1[i] = a2[i] = 0.f;
+  const int64_t n = B * To;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / To;
+    const int t = (int)(e - b * To);
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = bias ? bias[o0 + i] : 0.f;
+    const float* ip = in + b * Ci * Ti + t;
+    for (int c = 0; c < Ci; ++c) {
+      const float v0 = ip[c * Ti], v1 = ip[c * Ti + 1], v2 = ip[c * Ti + 2];
+      const float* w = Wf + (int64_t)c * 3 * Fp + o0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = fmaf(w[i], v0, fmaf(w[Fp + i], v1, fmaf(w[2 * Fp + i], v2, acc[i])));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (o0 + i < Fo) y[(b * Fo + o0 + i) * To + t] = acc[i];
+      a1[i] += acc[i];
+      a2[i] = fmaf(acc[i], acc[i], a2[i]);
+    }
+  }
+  if (want_stats) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float r1 = ph_block_sum(a1[i], red);
+      const float r2 = ph_block_sum(a2[i], red);
+      if (threadIdx.x == 0) { tot[i] = r1; tot[16 + i] = r2; }
+    }
+    __syncthreads();
+    const int i = threadIdx.x & 15;
+    if (threadIdx.x < 16 && o0 + i < Fo) atomicAdd(&s1[o0 + i], (double)tot[i]);
+    else if (threadIdx.x >= 16 && threadIdx.x < 32 && o0 + i < Fo) atomicAdd(&s2[o0 + i], (double)tot[16 + i]);
+  }
+}
+
+// BN coefficients of layer l: bn(y) = A y + Bc.  training: batch statistics (+ running update); eval: running buffers.
+__global__ void ph_finalize_kernel(const float* __restrict__ params, float* __restrict__ bufs,
+                                   const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N,
+                                   int training, float momentum, float eps) {
+  const int o = threadIdx.x;
+  if (o >= g.Fo[l]) return;
+  double mu, var;
+  if (training) {
+    mu = st->s1[l][o] / N;
+    var = st->s2[l][o] / N - mu * mu;
+    if (var < 0.0) var = 0.0;
+    bufs[g.rm[l] + o] = (1.f - momentum) * bufs[g.rm[l] + o] + momentum * (float)mu;
+    bufs[g.rv[l] + o] = (1.f - momentum) * bufs[g.rv[l] + o] + momentum * (float)(var * N / (N > 1.0 ? N - 1.0 : 1.0));
+  } else {
+    mu = bufs[g.rm[l] + o];
+    var = bufs[g.rv[l] + o];
+  }
+  const double isg = 1.0 / sqrt(var + (double)eps);
+  const double gm = params[g.g[l] + o], bt = params[g.b[l] + o];
+  co->A[l][o] = (float)(gm * isg);
+  co->Bc[l][o] = (float)(bt - gm * mu * isg);
+  co->mu[l][o] = (float)mu;
+  co->isg[l][o] = (float)isg;
+}
+
+// a[b,o,p] = max(GELU(bn(y[2p])), GELU(bn(y[2p+1])))
+__global__ __launch_bounds__(256) void ph_pool_kernel(const float* __restrict__ y, const PhCoef* __restrict__ co,
+                                                      float* __restrict__ a, int64_t n, int l, int Fo, int To, int Tp) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int64_t row = e / Tp;
+  const int p = (int)(e - row * Tp), o = (int)(row % Fo);
+  const float A = co->A[l][o], Bc = co->Bc[l][o];
+  const float* yr = y + row * To + 2 * p;
+  a[e] = fmaxf(ph_gelu(fmaf(A, yr[0], Bc)), ph_gelu(fmaf(A, yr[1], Bc)));
+}
+
+// out[b,o] = mean_p a4[b,o,p]
+__global__ __launch_bounds__(256) void ph_mean_kernel(const float* __restrict__ a, float* __restrict__ out, int64_t rows,
+                                                      int Tp) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int p = 0; p < Tp; ++p) s += a[r * Tp + p];
+  out[r] = s / (float)Tp;
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// Max-pool routing + GELU':  dyh[b,o,t] (gradient w.r.t. the BN output) from da[b,o,p] (or dout[b,o]/Tp for the
+// last layer), and the BN backward sums.  blockIdx.y = channel; persistent over (b,p).
+__global__ __launch_bounds__(256) void ph_bwd_pool_kernel(const float* __restrict__ y, const float* __restrict__ da,
+                                                          const float* __restrict__ dout,
+                                                          const PhCoef* __restrict__ co, float* __restrict__ dyh,
+                                                          PhStats* __restrict__ st, int64_t B, int l, int Fo, int To,
+                                                          int Tp) {
+  __shared__ float red[4];
+  const int o = blockIdx.y;
+  const float A = co->A[l][o], Bc = co->Bc[l][o], mu = co->mu[l][o], isg = co->isg[l][o];
+  float s1 = 0.f, s2 = 0.f;
+  const int64_t n = B * Tp;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / Tp;
+    const int p = (int)(e - b * Tp);
+    const int64_t row = b * Fo + o;
+    const float up = dout ? dout[row] / (float)Tp : da[row * Tp + p];
+    const float y0 = y[row * To + 2 * p], y1 = y[row * To + 2 * p + 1];
+    const float v0 = fmaf(A, y0, Bc), v1 = fmaf(A, y1, Bc);
+    const bool second = ph_gelu(v1) > ph_gelu(v0);                  // ties -> first element, like max_pool2d
+    const float d = up * ph_gelu_grad(second ? v1 : v0);
+    dyh[row * To + 2 * p] = second ? 0.f : d;
+    dyh[row * To + 2 * p + 1] = second ? d : 0.f;
+    if ((To & 1) && p == Tp - 1) dyh[row * To + To - 1] = 0.f;      // the sample MaxPool drops
+    s1 += d;
+    s2 = fmaf(d, ((second ? y1 : y0) - mu) * isg, s2);
+  }
+  const float r1 = ph_block_sum(s1, red);
+  const float r2 = ph_block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&st->d1[l][o], (double)r1);
+    atomicAdd(&st->d2[l][o], (double)r2);
+  }
+}
+
+__global__ void ph_bwd_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
+                                   const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N) {
+  const int o = threadIdx.x;
+  if (o >= g.Fo[l]) return;
+  dparams[g.g[l] + o] = (float)st->d2[l][o];
+  dparams[g.b[l] + o] = (float)st->d1[l][o];
+  co->cA[l][o] = params[g.g[l] + o] * co->isg[l][o];
+  co->cB[l][o] = (float)(st->d1[l][o] / N);
+  co->cC[l][o] = (float)(st->d2[l][o] / N);
+}
+
+// dy = cA (dyh - cB - xhat cC) in place
+__global__ __launch_bounds__(256) void ph_bwd_bn_kernel(float* __restrict__ dyh, const float* __restrict__ y,
+                                                        const PhCoef* __restrict__ co, int64_t n, int l, int Fo,
+                                                        int To) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int o = (int)((e / To) % Fo);
+  const float xh = (y[e] - co->mu[l][o]) * co->isg[l][o];
+  dyh[e] = co->cA[l][o] * (dyh[e] - co->cB[l][o] - xh * co->cC[l][o]);
+}
+
+// da[b,c,s] = sum_{o,k} W[o,c,k] dy[b,o,s-k]   (gradient w.r.t. the layer input = the previous pooled activation)
+__global__ __launch_bounds__(256) void ph_bwd_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ Wb,
+                                                           float* __restrict__ da, int64_t B, int Ci, int Cp, int Ti,
+                                                           int To, int Fo) {
+  const int c0 = blockIdx.y * 16;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * Ti) return;
+  const int64_t b = e / Ti;
+  const int s = (int)(e - b * Ti);
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int o = 0; o < Fo; ++o) {
+    const float* dr = dy + (b * Fo + o) * To;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int t = s - k;
+      const float dv = (t >= 0 && t < To) ? dr[t] : 0.f;
+      const float* w = Wb + ((int64_t)o * 3 + k) * Cp + c0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = fmaf(w[i], dv, acc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (c0 + i < Ci) da[(b * Ci + c0 + i) * Ti + s] = acc[i];
+}
+
+// dW[o,c,k] = sum_{b,t} dy[b,o,t] in[b,c,t+k] on the matrix cores (A = dy tile [16 o][4 t], B = in tile [4 t][16 c],
+// one accumulator per tap) + the bias column sum_{b,t} dy[b,o,t].  blockIdx.y = (o tile, c tile); persistent over b.
+// Partial slabs: part[block][o][c][k] and pbias[block][o].
+__global__ __launch_bounds__(64) void ph_bwd_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ in,
+                                                          float* __restrict__ part, float* __restrict__ pbias,
+                                                          int64_t B, int Ci, int Ti, int To, int Fo, int n_ctile) {
+  const int lane = threadIdx.x, q = lane >> 4, jl = lane & 15;
+  const int ot = blockIdx.y / n_ctile, ct = blockIdx.y - ot * n_ctile;
+  const int o = ot * 16 + jl, c = ct * 16 + jl;
+  f32x4 acc[3], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const float* dr = dy + (b * Fo + (o < Fo ? o : 0)) * To;
+    const float* ir = in + (b * Ci + (c < Ci ? c : 0)) * Ti;
+    for (int t0 = 0; t0 < To; t0 += 4) {
+      const int t = t0 + q;
+      const bool tv = t < To;
+      const float af = (tv && o < Fo) ? dr[t] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float bf = (tv && c < Ci) ? ir[t + k] : 0.f;
+        acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[k], 0, 0, 0);
+      }
+      if (pbias && ct == 0) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(af, tv ? 1.f : 0.f, accb, 0, 0, 0);
+    }
+  }
+  float* slab = part + (int64_t)blockIdx.x * Fo * Ci * 3;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int oo = ot * 16 + 4 * q + r;
+    if (oo < Fo && c < Ci) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) slab[((int64_t)oo * Ci + c) * 3 + k] = acc[k][r];
+    }
+    if (pbias && ct == 0 && jl == 0 && oo < Fo) pbias[(int64_t)blockIdx.x * Fo + oo] = accb[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void ph_reduce_kernel(const float* __restrict__ part, int n_slabs, int64_t n,
+                                                        float* __restrict__ dst) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float s0 = 0.f, s1 = 0.f;
+  int k = 0;
+  for (; k + 1 < n_slabs; k += 2) {
+    s0 += part[(int64_t)k * n + e];
+    s1 += part[(int64_t)(k + 1) * n + e];
+  }
+  if (k < n_slabs) s0 += part[(int64_t)k * n + e];
+  dst[e] = s0 + s1;
+}
+
+// dWeff [F1][C][3], dbeff [F1] -> gradients of cnn1_t.weight, cnn1_t.bias, cnn1_s.weight.  One block.
+__global__ __launch_bounds__(256) void ph_bwd_l1_kernel(const float* __restrict__ params, float* __restrict__ dparams,
+                                                        const float* __restrict__ dWeff, const float* __restrict__ dbeff,
+                                                        PhGeo g) {
+  const int F1 = g.Fo[0], C = g.C;
+  const float* Wt = params + g.wt;
+  const float* bt = params + g.bt;
+  const float* Ws = params + g.ws;
+  for (int e = threadIdx.x; e < F1 * F1 * C; e += 256) {          // dWs[o,f,c]
+    const int c = e % C, f = (e / C) % F1, o = e / (C * F1);
+    float s = dbeff[o] * bt[f];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s = fmaf(dWeff[(o * C + c) * 3 + k], Wt[f * 3 + k], s);
+    dparams[g.ws + e] = s;
+  }
+  for (int e = threadIdx.x; e < F1 * 3; e += 256) {               // dWt[f,k]
+    const int f = e / 3, k = e - f * 3;
+    float s = 0.f;
+    for (int o = 0; o < F1; ++o)
+      for (int c = 0; c < C; ++c) s = fmaf(dWeff[(o * C + c) * 3 + k], Ws[(o * F1 + f) * C + c], s);
+    dparams[g.wt + e] = s;
+  }
+  for (int f = threadIdx.x; f < F1; f += 256) {                   // dbt[f]
+    float s = 0.f;
+    for (int o = 0; o < F1; ++o) {
+      float ws = 0.f;
+      for (int c = 0; c < C; ++c) ws += Ws[(o * F1 + f) * C + c];
+      s = fmaf(dbeff[o], ws, s);
+    }
+    dparams[g.bt + f] = s;
+  }
+}
+
+}  // namespace isd
+
+using namespace isd;
+
+struct isd_paperhead_plan {
+  PhGeo g;
+};
+
+static inline int64_t ph_al64(int64_t v) { return (v + 63) / 64 * 64; }
+
+extern "C" int isd_paperhead_plan_create(isd_paperhead_plan** out, int in_channels, int feature_dim, int T) {
+  ISD_CHECK_ARG(out, "isd_paperhead_plan_create: null argument");
+  ISD_CHECK_ARG(in_channels >= 1 && in_channels <= 4096, "isd_paperhead_plan_create: in_channels=%d", in_channels);
+  ISD_CHECK_ARG(feature_dim >= 3 && feature_dim <= kPhMaxF, "isd_paperhead_plan_create: feature_dim=%d not in [3,%d]",
+                feature_dim, kPhMaxF);
+  isd_paperhead_plan* p = new isd_paperhead_plan();
+  PhGeo& g = p->g;
+  g.C = in_channels; g.T = T; g.F = feature_dim;
+  g.Fo[0] = feature_dim / 2; g.Fo[1] = feature_dim / 3; g.Fo[2] = feature_dim / 3; g.Fo[3] = feature_dim;
+  int Ti = T;
+  for (int l = 0; l < 4; ++l) {
+    g.Ci[l] = l == 0 ? in_channels : g.Fo[l - 1];
+    g.Ti[l] = Ti;
+    g.To[l] = Ti - 2;
+    g.Tp[l] = g.To[l] / 2;
+    g.Fp[l] = (g.Fo[l] + 15) / 16 * 16;
+    g.Cp[l] = (g.Ci[l] + 15) / 16 * 16;
+    Ti = g.Tp[l];
+    if (g.To[l] < 2 || g.Tp[l] < 1) {
+      set_error("isd_paperhead_plan_create: T=%d is too short for four conv(3)+MaxPool(2) stages (T >= 46)", T);
+      delete p;
+      return ISD_ERR_INVALID;
+    }
+  }
+  int o = 0;
+  const int F1 = g.Fo[0];
+  g.wt = o; o += F1 * 3;
+  g.bt = o; o += F1;
+  g.ws = o; o += F1 * F1 * in_channels;
+  g.w[0] = -1;
+  g.g[0] = o; o += F1;
+  g.b[0] = o; o += F1;
+  for (int l = 1; l < 4; ++l) {
+    g.w[l] = o; o += g.Fo[l] * g.Ci[l] * 3;
+    g.g[l] = o; o += g.Fo[l];
+    g.b[l] = o; o += g.Fo[l];
+  }
+  g.n_params = o;
+  o = 0;
+  for (int l = 0; l < 4; ++l) {
+    g.rm[l] = o; o += g.Fo[l];
+    g.rv[l] = o; o += g.Fo[l];
+  }
+  g.n_bufs = o;
+  *out = p;
+  return ISD_OK;
+}
+
+extern "C" int isd_paperhead_plan_destroy(isd_paperhead_plan* p) {
+  delete p;
+  return ISD_OK;
+}
+extern "C" int64_t isd_paperhead_param_count(const isd_paperhead_plan* p) { return p ? p->g.n_params : ISD_ERR_INVALID; }
+extern "C" int64_t isd_paperhead_buffer_count(const isd_paperhead_plan* p) { return p ? p->g.n_bufs : ISD_ERR_INVALID; }
+
+namespace {
+struct PhWs {
+  int64_t stats, coef, beff, wf[4], wb[4], y[4], a[4], dy[4], da[4], part, pbias, dweff, dbeff, total;
+};
+PhWs ph_layout(const PhGeo& g, int64_t B) {
+  PhWs w;
+  int64_t o = 0;
+  w.stats = o; o += ph_al64((int64_t)(sizeof(PhStats) + 3) / 4);
+  w.coef = o; o += ph_al64((int64_t)(sizeof(PhCoef) + 3) / 4);
+  w.beff = o; o += 64;
+  int64_t max_w = 0;
+  for (int l = 0; l < 4; ++l) {
+    w.wf[l] = o; o += ph_al64((int64_t)g.Ci[l] * 3 * g.Fp[l]);
+    w.wb[l] = o; o += ph_al64((int64_t)g.Fo[l] * 3 * g.Cp[l]);
+    w.y[l] = o; o += ph_al64(B * g.Fo[l] * g.To[l]);
+    w.a[l] = o; o += ph_al64(B * g.Fo[l] * g.Tp[l]);
+    w.dy[l] = o; o += ph_al64(B * g.Fo[l] * g.To[l]);
+    w.da[l] = o; o += ph_al64(B * g.Fo[l] * g.Tp[l]);
+    const int64_t nw = (int64_t)g.Fo[l] * g.Ci[l] * 3;
+    if (nw > max_w) max_w = nw;
+  }
+  w.part = o; o += ph_al64((int64_t)kPhSlabs * max_w);
+  w.pbias = o; o += ph_al64((int64_t)kPhSlabs * kPhMaxF);
+  w.dweff = o; o += ph_al64((int64_t)g.Fo[0] * g.C * 3);
+  w.dbeff = o; o += 64;
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+extern "C" int64_t isd_paperhead_workspace_bytes(const isd_paperhead_plan* p, int64_t B) {
+  if (!p || B < 0) return ISD_ERR_INVALID;
+  return ph_layout(p->g, B).total * 4;
+}
+
+extern "C" int isd_paperhead_forward(const isd_paperhead_plan* p, const float* x, const float* params, float* buffers,
+                                     float* out, void* workspace, int64_t B, int training, float momentum, float eps,
+                                     void* stream) {
+  ISD_CHECK_ARG(p, "isd_paperhead_forward: null plan");
+  ISD_CHECK_ARG(B >= 0 && B <= (int64_t)1 << 26, "isd_paperhead_forward: B=%lld", (long long)B);
+  if (B == 0) return ISD_OK;
+  ISD_CHECK_ARG(x && params && buffers && out && workspace, "isd_paperhead_forward: null argument");
+  const PhGeo& g = p->g;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const PhWs w = ph_layout(g, B);
+  PhStats* S = (PhStats*)(ws + w.stats);
+  PhCoef* Cf = (PhCoef*)(ws + w.coef);
+  ISD_HIP_TRY(hipMemsetAsync(S, 0, sizeof(PhStats), st));
+  for (int l = 0; l < 4; ++l) {
+    const int nmax = (g.Fp[l] > g.Fo[l] ? g.Fp[l] : g.Fo[l]) * g.Cp[l] * 3;
+    hipLaunchKernelGGL(ph_prep_kernel, dim3((unsigned)cdiv(nmax, 256)), dim3(256), 0, st, params, ws, ws, ws + w.beff, g,
+                       l, w.wf[l], w.wb[l]);
+  }
+  const float* in = x;
+  for (int l = 0; l < 4; ++l) {
+    const int64_t n = B * g.To[l];
+    const unsigned gx = (unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
+    hipLaunchKernelGGL(ph_conv_kernel, dim3(gx, (unsigned)(g.Fp[l] / 16)), dim3(256), 0, st, in, ws + w.wf[l],
+                       l == 0 ? ws + w.beff : (const float*)nullptr, ws + w.y[l], S->s1[l], S->s2[l], B, g.Ci[l], g.Ti[l],
+                       g.To[l], g.Fo[l], g.Fp[l], training);
+    hipLaunchKernelGGL(ph_finalize_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, g, l,
+                       (double)B * (double)g.To[l], training, momentum, eps);
+    const int64_t np = B * g.Fo[l] * g.Tp[l];
+    hipLaunchKernelGGL(ph_pool_kernel, dim3((unsigned)cdiv(np, 256)), dim3(256), 0, st, ws + w.y[l], Cf, ws + w.a[l], np,
+                       l, g.Fo[l], g.To[l], g.Tp[l]);
+    in = ws + w.a[l];
+  }
+  hipLaunchKernelGGL(ph_mean_kernel, dim3((unsigned)cdiv(B * g.F, 256)), dim3(256), 0, st, ws + w.a[3], out, B * g.F,
+                     g.Tp[3]);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+extern "C" int isd_paperhead_backward(const isd_paperhead_plan* p, const float* x, const float* params,
+                                      const float* dout, float* dparams, void* workspace, int64_t B, void* stream) {
+  ISD_CHECK_ARG(p, "isd_paperhead_backward: null plan");
+  ISD_CHECK_ARG(B >= 1, "isd_paperhead_backward: B=%lld", (long long)B);
+  ISD_CHECK_ARG(x && params && dout && dparams && workspace, "isd_paperhead_backward: null argument");
+  const PhGeo& g = p->g;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const PhWs w = ph_layout(g, B);
+  PhStats* S = (PhStats*)(ws + w.stats);
+  PhCoef* Cf = (PhCoef*)(ws + w.coef);
+  ISD_HIP_TRY(hipMemsetAsync((char*)S + offsetof(PhStats, d1), 0, sizeof(PhStats) - offsetof(PhStats, d1), st));
+  const int slabs = B < kPhSlabs ? (int)B : kPhSlabs;
+  for (int l = 3; l >= 0; --l) {
+    const int64_t np = B * g.Tp[l];
+    const unsigned gx = (unsigned)(cdiv(np, 256) < 256 ? cdiv(np, 256) : 256);
+    hipLaunchKernelGGL(ph_bwd_pool_kernel, dim3(gx, (unsigned)g.Fo[l]), dim3(256), 0, st, ws + w.y[l],
+                       l == 3 ? (const float*)nullptr : ws + w.da[l], l == 3 ? dout : (const float*)nullptr, Cf,
+                       ws + w.dy[l], S, B, l, g.Fo[l], g.To[l], g.Tp[l]);
+    hipLaunchKernelGGL(ph_bwd_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, g, l,
+                       (double)B * (double)g.To[l]);
+    const int64_t ny = B * g.Fo[l] * g.To[l];
+    hipLaunchKernelGGL(ph_bwd_bn_kernel, dim3((unsigned)cdiv(ny, 256)), dim3(256), 0, st, ws + w.dy[l], ws + w.y[l], Cf,
+                       ny, l, g.Fo[l], g.To[l]);
+    const float* in = l == 0 ? x : ws + w.a[l - 1];
+    const int n_ctile = g.Cp[l] / 16, n_otile = g.Fp[l] / 16;
+    const int64_t nw = (int64_t)g.Fo[l] * g.Ci[l] * 3;
+    hipLaunchKernelGGL(ph_bwd_wgrad_kernel, dim3(slabs, (unsigned)(n_ctile * n_otile)), dim3(64), 0, st, ws + w.dy[l], in,
+                       ws + w.part, l == 0 ? ws + w.pbias : (float*)nullptr, B, g.Ci[l], g.Ti[l], g.To[l], g.Fo[l],
+                       n_ctile);
+    hipLaunchKernelGGL(ph_reduce_kernel, dim3((unsigned)cdiv(nw, 256)), dim3(256), 0, st, ws + w.part, slabs, nw,
+                       l == 0 ? ws + w.dweff : dparams + g.w[l]);
+    if (l == 0) {
+      hipLaunchKernelGGL(ph_reduce_kernel, dim3(1), dim3(256), 0, st, ws + w.pbias, slabs, (int64_t)g.Fo[0],
+                         ws + w.dbeff);
+      hipLaunchKernelGGL(ph_bwd_l1_kernel, dim3(1), dim3(256), 0, st, params, dparams, ws + w.dweff, ws + w.dbeff, g);
+    } else {
+      hipLaunchKernelGGL(ph_bwd_dgrad_kernel, dim3((unsigned)cdiv(B * g.Ti[l], 256), (unsigned)n_ctile), dim3(256), 0, st,
+                         ws + w.dy[l], ws + w.wb[l], ws + w.da[l - 1], B, g.Ci[l], g.Cp[l], g.Ti[l], g.To[l], g.Fo[l]);
+    }
+  }
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}

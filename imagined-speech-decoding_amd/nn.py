@@ -231,6 +231,54 @@ class _EEGNetFn(torch.autograd.Function):
         return None, dflat, None, None, None, None, None, None, None
 
 
+class PaperHeadPlan:
+    def __init__(self, in_channels, feature_dim, T):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().isd_paperhead_plan_create(C.byref(self._h), int(in_channels), int(feature_dim), int(T)))
+        self.n_params = int(_lib.lib().isd_paperhead_param_count(self._h))
+        self.F = int(feature_dim)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().isd_paperhead_plan_destroy(h)
+            except Exception:
+                pass
+
+
+class _PaperHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flat, bufs, plan, training, momentum, eps):
+        x, flat = _f32c(x, "x"), _f32c(flat, "params")
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient w.r.t. the EEG input is not provided by the HIP HeadConv_Paper_Version")
+        B = x.shape[0]
+        out = torch.empty((B, plan.F), dtype=torch.float32, device=x.device)
+        ws = torch.empty(max(int(_lib.lib().isd_paperhead_workspace_bytes(plan._h, B)) // 4, 1), dtype=torch.float32,
+                         device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_paperhead_forward(plan._h, x.data_ptr(), flat.data_ptr(), bufs.data_ptr(),
+                                                        out.data_ptr(), ws.data_ptr(), B, int(training),
+                                                        float(momentum), float(eps), _stream()))
+        ctx.plan, ctx.ws, ctx.training = plan, ws, training
+        ctx.save_for_backward(x, flat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, flat = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("HeadConv_Paper_Version backward needs a train-mode forward (batch statistics)")
+        dflat = torch.empty_like(flat)
+        dout = _f32c(dout, "dout")
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().isd_paperhead_backward(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dout.data_ptr(),
+                                                         dflat.data_ptr(), ctx.ws.data_ptr(), x.shape[0], _stream()))
+        ctx.ws = None
+        return None, dflat, None, None, None, None, None
+
+
 class _LinearResFn(torch.autograd.Function):
     """y = x @ w.T + b + res (residual fused in the epilogue)."""
 
@@ -601,6 +649,50 @@ class CVBlock(nn.Module, _BNStackMixin):
         if x.dim() != 3:
             raise ValueError("expected [batch, channels, time] or [batch, 1, channels, time]")
         return self._run(x)
+
+
+class HeadConv_Paper_Version(nn.Module, _BNStackMixin):
+    """Drop-in for the reference's ``HeadConv_Paper_Version(in_channels, feature_dim=32)`` (fast.py:170-196); same
+    parameter / buffer names, ``forward(x[B', C, T]) -> [B', feature_dim]``."""
+
+    def __init__(self, in_channels, feature_dim=32):
+        super().__init__()
+        F1, F2, F3, F4 = feature_dim // 2, feature_dim // 3, feature_dim // 3, feature_dim
+        self.in_channels, self.feature_dim = in_channels, feature_dim
+        self.cnn1_t = nn.Conv2d(1, F1, (1, 3), bias=True)
+        self.cnn1_s = nn.Conv2d(F1, F1, (in_channels, 1), padding=0, bias=False)
+        self.norm1 = nn.BatchNorm2d(F1)
+        self.cnn2 = nn.Conv2d(F1, F2, (1, 3), bias=False)
+        self.norm2 = nn.BatchNorm2d(F2)
+        self.cnn3 = nn.Conv2d(F2, F3, (1, 3), bias=False)
+        self.norm3 = nn.BatchNorm2d(F3)
+        self.cnn4 = nn.Conv2d(F3, F4, (1, 3), bias=False)
+        self.norm4 = nn.BatchNorm2d(F4)
+        self._plans = {}
+
+    def _bns(self):
+        return [self.norm1, self.norm2, self.norm3, self.norm4]
+
+    def _ordered_params(self):
+        return [self.cnn1_t.weight, self.cnn1_t.bias, self.cnn1_s.weight, self.norm1.weight, self.norm1.bias,
+                self.cnn2.weight, self.norm2.weight, self.norm2.bias, self.cnn3.weight, self.norm3.weight,
+                self.norm3.bias, self.cnn4.weight, self.norm4.weight, self.norm4.bias]
+
+    def forward(self, x):
+        if x.dim() != 3:
+            raise ValueError("expected [batch, channels, time]")
+        T = x.shape[-1]
+        plan = self._plans.get(T)
+        if plan is None:
+            plan = self._plans[T] = PaperHeadPlan(self.in_channels, self.feature_dim, T)
+        flat = self.flat_params()
+        theta = torch.cat([p.reshape(-1) for p in self._ordered_params()]) if torch.is_grad_enabled() else flat
+        if self.training:
+            for b in self._bns():
+                b.num_batches_tracked += 1
+        bn = self.norm1
+        return _PaperHeadFn.apply(x, theta, self.flat_buffers(), plan, self.training,
+                                  0.1 if bn.momentum is None else bn.momentum, bn.eps)
 
 
 class Head(nn.Module, _FlatParamMixin):

@@ -238,6 +238,29 @@ int isd_attention_forward(const float* qkv, float* ctx, float* probs, int64_t B,
 int isd_attention_backward(const float* qkv, const float* probs, const float* dctx, float* dqkv, int64_t B, int S,
                            int H, int head_dim, float dropout_p, uint64_t seed, void* stream);
 
+/* ----------------------------------------------------------------------
+ * HeadConv_Paper_Version  (replaces src/fast/models/fast.py:170-196 behind the head contract :203-210)
+ *   x [B][C][T] f32 -> out [B][feature_dim];  feature_dim in [3,64] (F1 = F/2, F2 = F3 = F/3, F4 = F), T >= 46.
+ * Flat parameter block (reference state_dict order, trainable tensors only):
+ *   cnn1_t.weight [F1,1,1,3] | cnn1_t.bias [F1] | cnn1_s.weight [F1,F1,C,1] | norm1.weight [F1] | norm1.bias [F1] |
+ *   cnn2.weight [F2,F1,1,3] | norm2.weight | norm2.bias | cnn3.weight [F3,F2,1,3] | norm3.* | cnn4.weight [F4,F3,1,3] |
+ *   norm4.weight | norm4.bias
+ * Buffer block: running_mean / running_var of norm1..norm4 (F1,F1,F2,F2,F3,F3,F4,F4 floats), updated when training.
+ * training != 0: batch statistics (biased variance to normalise, unbiased for the running update).  MaxPool ties
+ * route the gradient to the first element, as torch does.  backward: parameter gradients only (x is data); one
+ * backward per train-mode forward, same workspace.
+ * ---------------------------------------------------------------------- */
+typedef struct isd_paperhead_plan isd_paperhead_plan;
+int isd_paperhead_plan_create(isd_paperhead_plan** out, int in_channels, int feature_dim, int T);
+int isd_paperhead_plan_destroy(isd_paperhead_plan* plan);
+int64_t isd_paperhead_param_count(const isd_paperhead_plan* plan);
+int64_t isd_paperhead_buffer_count(const isd_paperhead_plan* plan);
+int64_t isd_paperhead_workspace_bytes(const isd_paperhead_plan* plan, int64_t B);
+int isd_paperhead_forward(const isd_paperhead_plan* plan, const float* x, const float* params, float* buffers,
+                          float* out, void* workspace, int64_t B, int training, float momentum, float eps, void* stream);
+int isd_paperhead_backward(const isd_paperhead_plan* plan, const float* x, const float* params, const float* dout,
+                           float* dparams, void* workspace, int64_t B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,3 +101,23 @@ def test_cvblock_contract(inn):
     m.p = 0.5
     a, b = m(x).detach(), m(x).detach()
     assert not torch.equal(a, b) and not torch.equal(a, ref)        # train-mode dropout draws a fresh mask per call
+
+
+@pytest.mark.parametrize("tag,C", [("z6", 6), ("z15", 15)])
+def test_paperhead_matches_reference_golden(inn, tag, C):
+    # the conv bias in front of BatchNorm has an analytically zero gradient (rounding residue in the reference)
+    _check_against_golden(inn.HeadConv_Paper_Version(C, 32).cuda(), load_golden("g11_paperhead.npz"), tag,
+                          cancel=("cnn1_t.bias",))
+
+
+@pytest.mark.parametrize("C,T,B,F", [(4, 250, 3, 32), (10, 125, 70, 16), (64, 250, 4, 48), (20, 46, 5, 9)])
+def test_paperhead_vs_oracle(inn, C, T, B, F):
+    torch.manual_seed(C + T)
+    m = inn.HeadConv_Paper_Version(C, F).cuda()
+    with torch.no_grad():
+        for bn in m._bns():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    _vs_oracle(m, ocnn.headconv_paper, torch.randn(B, C, T), F, bn_floor_prefix=("cnn1_t.bias",))
+    with pytest.raises(Exception):
+        inn.HeadConv_Paper_Version(C, F).cuda()(torch.randn(2, C, 40, device="cuda"))    # too short for four stages
