@@ -706,18 +706,23 @@ class Head(nn.Module, _FlatParamMixin):
     def __init__(self, head, electrodes, zone_dict, feature_dim, act_dtype="f32"):
         super().__init__()
         self.act_dtype = act_dtype
-        if head != "Conv4Layers":
-            raise NotImplementedError(f"head '{head}' is not provided by the HIP path yet (Conv4Layers is)")
+        if head not in HEAD_REGISTRY:
+            raise KeyError(f"head '{head}' is not in the head registry {sorted(HEAD_REGISTRY)}")    # globals()[head]
+        self.head_name = head
+        self.fused = head == "Conv4Layers"
         self.electrodes = list(electrodes)
         self.index_dict = {}
         self.encoders = nn.ModuleDict()
         for area, ch_names in zone_dict.items():
             self.index_dict[area] = torch.tensor([self.electrodes.index(ch) for ch in ch_names])
-            self.encoders[area] = _Conv4Params(len(ch_names), feature_dim)
+            self.encoders[area] = (_Conv4Params(len(ch_names), feature_dim) if self.fused
+                                   else HEAD_REGISTRY[head](len(ch_names), feature_dim))
         self.feature_dim = feature_dim
         self._plans = {}
 
     def _ordered_params(self):
+        if not self.fused:
+            return [p for enc in self.encoders.values() for p in enc._ordered_params()]
         return [p for enc in self.encoders.values() for p in enc.ordered()]
 
     def _plan(self, window_len, slide_step):
@@ -735,12 +740,38 @@ class Head(nn.Module, _FlatParamMixin):
             return torch.cat([p.reshape(-1) for p in self._ordered_params()])
         return flat
 
+    def _per_zone(self, xw):
+        """Registry heads other than Conv4Layers: one encoder call per zone on its gathered channels (fast.py:210)."""
+        outs = []
+        for area, enc in self.encoders.items():
+            idx = self.index_dict[area]
+            if idx.device != xw.device:
+                idx = self.index_dict[area] = idx.to(xw.device)
+            outs.append(enc(xw.index_select(1, idx)))
+        return torch.stack(outs, dim=1)
+
     def forward_windows(self, x, window_len, slide_step):
         """x [B, C, T] -> [B*N, Z, F] with N sliding windows per trial (fast.py:247-251)."""
+        if not self.fused:
+            xw = x.unfold(-1, int(window_len), int(slide_step))                       # B C N T (view)
+            B, Cc, N, T = xw.shape
+            return self._per_zone(xw.permute(0, 2, 1, 3).reshape(B * N, Cc, T))
         return _ConvStackFn.apply(x, self._theta(), self._plan(int(window_len), int(slide_step)))
 
     def forward(self, x):
+        if not self.fused:
+            return self._per_zone(x)
         return _ConvStackFn.apply(x, self._theta(), self._plan(int(x.shape[-1]), 1))
+
+
+# the reference resolves ``globals()[config.head]`` in fast.models.fast (fast.py:203); this is that namespace
+HEAD_REGISTRY = {"Conv4Layers": Conv4Layers, "EEGNet_Encoder": EEGNet_Encoder, "CVBlock": CVBlock,
+                 "HeadConv_Paper_Version": HeadConv_Paper_Version}
+
+
+def register_head(name, cls):
+    """Add a head class honouring ``cls(n_zone_channels, feature_dim)`` / ``forward(x[B', Cz, T]) -> [B', F]``."""
+    HEAD_REGISTRY[name] = cls
 
 
 class AttentionBlock(nn.Module):

@@ -121,3 +121,38 @@ def test_paperhead_vs_oracle(inn, C, T, B, F):
     _vs_oracle(m, ocnn.headconv_paper, torch.randn(B, C, T), F, bn_floor_prefix=("cnn1_t.bias",))
     with pytest.raises(Exception):
         inn.HeadConv_Paper_Version(C, F).cuda()(torch.randn(2, C, 40, device="cuda"))    # too short for four stages
+
+
+@pytest.mark.parametrize("head,enc", [("HeadConv_Paper_Version", "headconv_paper"), ("CVBlock", "cvblock"),
+                                      ("EEGNet_Encoder", "eegnet_encoder")])
+def test_fast_with_registry_heads_vs_oracle(inn, head, enc):
+    """The head registry of fast.py:203: FAST(config.head=<name>) in the trained mode, forward + every gradient."""
+    electrodes = ["Fp1", "Fp2", "F3", "F4", "C3", "C4", "O1", "O2", "Pz"]
+    zones = {"Frontal": ["Fp1", "Fp2", "F3", "F4"], "Central": ["C4", "C3", "Pz"], "Occipital": ["O2", "O1"]}
+    cfg = inn.fast_config(electrodes, zones, dim_cnn=16, dim_token=16, seq_len=500, n_classes=3, num_layers=1,
+                          num_heads=4, dropout=0.0, head=head)
+    torch.manual_seed(3)
+    m = inn.FAST(cfg).cuda()
+    for e in m.head.encoders.values():
+        if hasattr(e, "p"):
+            e.p = 0.0                                               # the oracle has no dropout stream
+    p = {k: v.detach().cpu().clone().double() for k, v in m.state_dict().items()}
+    for k, v in p.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_()
+    x = torch.randn(6, len(electrodes), 500)
+    names = list(zones)
+    idx = [[electrodes.index(c) for c in zones[z]] for z in names]
+    m.train()
+    lg = m(x.cuda())
+    lg.square().sum().backward()
+    ref = ocnn.default_logits(x.double(), p, names, idx, 4, 1, encoder=getattr(ocnn, enc), training=True)
+    ref.square().sum().backward()
+    assert lg.shape == (6, 3) and rel_err(lg.detach().cpu(), ref.detach()) < 1e-4
+    scale = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
+    for k, q in m.named_parameters():
+        want = p[k].grad
+        tol = 2e-4 * max(float(want.abs().max()), 5e-2 * scale)
+        assert float((q.grad.cpu().double() - want).abs().max()) < tol + 1e-7, k
+    with pytest.raises(KeyError):
+        inn.FAST(inn.fast_config(electrodes, zones, head="NoSuchHead"))
