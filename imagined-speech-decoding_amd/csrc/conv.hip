@@ -305,6 +305,144 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// First-layer forward for wide inputs (spec-S features: hundreds of channels, a handful of time steps):
+// same tiling as conv5_fwd_kernel<0, float> on contiguous rows, but the input and weight chunks are
+// double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4), so the copy of chunk c+1 runs under
+// the MFMAs of chunk c.  One workgroup per CU (1 wave per SIMD, 4 column tiles x 2 filter tiles of
+// accumulators per wave); one barrier per chunk: it retires this wave's DMA (vmcnt(0)) for chunk c and, being
+// passed by every wave, frees the buffer chunk c-1 was read from.
+// Preconditions (checked on the host): fp32, contiguous zone channels, whole-row windows, cin % 4 == 0,
+// 16-byte aligned rows blocks.
+// ---------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void glds_copy16(const float* __restrict__ src, float* dst, int n4, int lane) {
+  // wave-cooperative copy of n4 float4 (contiguous both sides); dst must be the wave-uniform base
+  for (int e0 = 0; e0 < n4; e0 += 64) {
+    if (e0 + lane < n4)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (int64_t)(e0 + lane) * 4), (lds_ptr_t)(dst + e0 * 4), 16, 0, 0);
+  }
+}
+
+template <int GT>
+__global__ __launch_bounds__(256) void conv5_fwd_glds_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int z = blockIdx.y;
+  const ZoneDesc zd = a.zones[z];
+  const int cin = zd.cin;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t item0 = (int64_t)blockIdx.x * a.IPW;
+  const int n_items = (int)((a.items - item0) < a.IPW ? (a.items - item0) : a.IPW);
+  const int n_ct = n_items * a.TT;
+  const int in_len = (a.IPW * kCK * a.RS + 3) & ~3;
+  constexpr int w_len = (kCK / 4) * kTaps * GT * 64;
+  const int buf_len = in_len + w_len + 32;                  // 32 floats of slack: junk columns read past the last row
+  const float* wbase = a.wfrag + zd.eff_off;
+  const int n_chunks = (cin + kCK - 1) / kCK;
+  const int q = lane >> 4, jl = lane & 15;
+  const int chan0 = a.chan_idx[zd.idx_off];
+
+  auto stage = [&](int ch, int s) {
+    float* in_tile = smem + 4 + s * buf_len;
+    float* w_tile = in_tile + in_len;
+    const int c_lo = ch * kCK;
+    const int ckc = (cin - c_lo) < kCK ? (cin - c_lo) : kCK;
+    const int cnt4 = (ckc * a.Tin) >> 2;
+    for (int ii = wave; ii < n_items; ii += 4) {
+      const int64_t soff = ((item0 + ii) * a.Ctot + chan0 + c_lo) * (int64_t)a.Tx;
+      glds_copy16((const float*)a.in + soff, in_tile + ii * kCK * a.RS, cnt4, lane);
+    }
+    const int wlen4 = (ckc / 4) * kTaps * GT * 16;
+    const int per = (((wlen4 + 3) / 4 + 63) / 64) * 64;     // the weight chunk is split over the 4 waves in 1 KiB pieces
+    const int w0 = per * wave;
+    const int w1 = w0 + per < wlen4 ? w0 + per : wlen4;
+    if (w0 < wlen4)
+      glds_copy16(wbase + (int64_t)ch * (kCK / 4) * kTaps * GT * 64 + (int64_t)w0 * 4, w_tile + w0 * 4, w1 - w0, lane);
+  };
+
+  // Every wave always carries 4 column tiles (no branches around the MFMAs); tiles past the end compute on
+  // whatever the LDS holds and are not stored.  The first layer is a valid convolution (pad 0): columns
+  // beyond Tout are junk by construction and never stored, so the B operand needs no mask.
+  f32x4 acc[4][GT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int g = 0; g < GT; ++g) acc[j][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int t_ii[4], t_t0[4], boff[4];
+  bool t_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ct = j * 4 + wave;
+    t_ok[j] = ct < n_ct;
+    const int ctc = t_ok[j] ? ct : 0;
+    t_ii[j] = ctc / a.TT;
+    t_t0[j] = (ctc - t_ii[j] * a.TT) * 16;
+    boff[j] = t_ii[j] * kCK * a.RS + t_t0[j] + jl + q * a.RS;
+  }
+  struct Frag {
+    float af[kTaps][GT];
+    float bf[4][kTaps];
+  };
+  stage(0, 0);
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    __syncthreads();                                        // drains this wave's DMA of chunk ch; all waves left chunk ch-1
+    if (ch + 1 < n_chunks) stage(ch + 1, (ch + 1) & 1);
+    const float* in_tile = smem + 4 + (ch & 1) * buf_len;
+    const float* w_tile = in_tile + in_len + lane;
+    const int c_lo = ch * kCK;
+    const int ncg = ((cin - c_lo) < kCK ? (cin - c_lo) : kCK) / 4;
+    auto load = [&](int cg, Frag& f) {
+      const float* rowp = in_tile + cg * 4 * a.RS;
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k)
+#pragma unroll
+        for (int g = 0; g < GT; ++g) f.af[k][g] = w_tile[((cg * kTaps + k) * GT + g) * 64];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) f.bf[jj][k] = rowp[boff[jj] + k];
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int g = 0; g < GT; ++g)
+            acc[jj][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[k][g], f.bf[jj][k], acc[jj][g], 0, 0, 0);
+    };
+    Frag f0, f1;
+    load(0, f0);
+    for (int cg = 0; cg < ncg; cg += 2) {
+      if (cg + 1 < ncg) load(cg + 1, f1);
+      mma(f0);
+      if (cg + 1 < ncg) {
+        if (cg + 2 < ncg) load(cg + 2, f0);
+        mma(f1);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!t_ok[j]) continue;
+    const int64_t item = item0 + t_ii[j];
+    const int t = t_t0[j] + jl;
+    if (t >= a.Tout) continue;
+#pragma unroll
+    for (int gt = 0; gt < GT; ++gt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int g = gt * 16 + 4 * q + r;
+        float v = acc[j][gt][r];
+        if (a.bias) v += a.bias[z * a.F + g];
+        ((float*)a.out)[((item * a.Z + z) * a.F + g) * (int64_t)a.Tout + t] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Fused forward of one (window, zone) item for the reference-native shape (F = 32, <= 16 channels per zone,
 // <= 256 time steps): cnn1.cnn2 -> cnn3 -> cnn4 -> GELU -> mean, activations handed over in LDS.
 // Persistent workgroups (one per CU): the weight fragments of the zone (Weff, W3, W4: 200 A-fragments,
@@ -815,6 +953,7 @@ struct isd_conv4_plan {
   int64_t wg_size;         // floats of all dWeff blocks
   int max_cz;
   int contiguous;          // every zone's channel list is consecutive -> rows of a zone are adjacent in memory
+  int dma_ok;              // additionally every zone starts on, and spans, a multiple of 4 channels (16-byte row blocks)
   int act_bf16;            // activations / activation gradients stored as bf16 (config 3)
   ZoneDesc* d_zones;
   int* d_idx;
@@ -871,6 +1010,9 @@ extern "C" int isd_conv4_plan_create(isd_conv4_plan** out, int c_total, int n_zo
   for (int z = 0; z < n_zones; ++z)
     for (int c = 1; c < zone_sizes[z]; ++c)
       if (idx[zd[z].idx_off + c] != idx[zd[z].idx_off + c - 1] + 1) p->contiguous = 0;
+  p->dma_ok = p->contiguous && (c_total % 4 == 0);
+  for (int z = 0; z < n_zones; ++z)
+    if (zone_sizes[z] % 4 != 0 || idx[zd[z].idx_off] % 4 != 0) p->dma_ok = 0;
   p->conv_zstride = (int64_t)(F / 4) * kTaps * GT * 64;
   hipError_t e = hipMalloc(&p->d_zones, sizeof(ZoneDesc) * n_zones);
   if (e == hipSuccess) e = hipMalloc(&p->d_idx, sizeof(int) * idx.size());
@@ -1070,7 +1212,33 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
   // cnn1 o cnn2
   a.in = x; a.out = ws + g.o_a2; a.wfrag = ws + g.o_eff; a.bias = ws + g.o_beff; a.Tin = p->W; a.pad = 0; a.RS = g.RS_a;
   a.lin = g.lin0;
-  rc = launch_conv(0, p->act_bf16, a, p->Z, st);
+  {
+    // wide inputs (>= 2 channel chunks): double-buffered LDS-DMA variant, one workgroup of 16 column tiles per CU
+    int ipw = 16 / g.TT;
+    const int64_t per_cu = cdiv(g.items * p->Z, 256);
+    if (ipw > per_cu) ipw = (int)per_cu;
+    const int GT = F / 16;
+    const size_t buf = (size_t)(((ipw * kCK * p->W + 3) & ~3) + (kCK / 4) * kTaps * GT * 64 + 32);
+    const size_t lds = sizeof(float) * (4 + 2 * buf);
+    if (g.lin0 && p->dma_ok && !p->act_bf16 && p->max_cz > kCK && g.TT <= 16 && ipw >= 1 && lds <= 150 * 1024 &&
+        ((uintptr_t)x & 15) == 0) {
+      a.IPW = ipw; a.RS = p->W;
+      if (GT == 2) {
+        ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_fwd_glds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+        hipLaunchKernelGGL(conv5_fwd_glds_kernel<2>, dim3((unsigned)cdiv(g.items, ipw), p->Z), dim3(256), lds, st, a);
+      } else {
+        ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_fwd_glds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+        hipLaunchKernelGGL(conv5_fwd_glds_kernel<1>, dim3((unsigned)cdiv(g.items, ipw), p->Z), dim3(256), lds, st, a);
+      }
+      ISD_LAUNCH_CHECK();
+      a.IPW = g.IPW;
+      rc = ISD_OK;
+    } else {
+      rc = launch_conv(0, p->act_bf16, a, p->Z, st);
+    }
+  }
   if (rc) return rc;
   const float* last = ws + g.o_a2;
   if (p->n_layers == 4) {
