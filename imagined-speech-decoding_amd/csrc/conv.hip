@@ -861,25 +861,161 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// First-layer weight gradient for wide inputs (companion of conv5_fwd_glds_kernel; same preconditions).
+// A workgroup owns 64 input channels (one 16-channel tile per wave, all GT filter tiles) and a range of items;
+// dOut [F][Tout] and the 64 input rows of IPS items are double-buffered in LDS by LDS-DMA; the MFMA loop is
+// branch-free with register-prefetched fragments (K = 4 time steps, one accumulator per tap).  The dbias
+// column (virtual all-ones channel `cin`) rides along in wave 0 of channel group 0.
+template <int GT>
+__global__ __launch_bounds__(256) void conv5_wgrad_wide_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int z = blockIdx.y;
+  const ZoneDesc zd = a.zones[z];
+  const int cin = zd.cin, cin1 = zd.cin + 1;
+  const int c_base = blockIdx.z * 64;
+  if (c_base >= cin) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, jl = lane & 15;
+  const int cw = (cin - c_base) < 64 ? (cin - c_base) : 64;         // real rows of this channel group (multiple of 4)
+  const int c_mine = c_base + wave * 16 + jl;
+  const bool wave_live = c_base + wave * 16 < cin;
+  const bool with_bias = blockIdx.z == 0 && wave == 0;
+  const int do_len = a.F * a.Tout, in_len = 64 * a.Tin;             // per item (in_len: stride; cw*Tin are filled)
+  const int item_len = (do_len + in_len + 3) & ~3;
+  const int buf_len = a.IPS * item_len + 32;
+  const int64_t i_lo = (int64_t)blockIdx.x * a.items_per_wg;
+  const int64_t i_hi = (i_lo + a.items_per_wg) < a.items ? (i_lo + a.items_per_wg) : a.items;
+  const int chan0 = a.chan_idx[zd.idx_off];
+  const int nks = (a.Tout + 3) >> 2;
+  // the tail of both buffers is read (masked) by the last rows' junk columns: keep it finite
+  for (int e = threadIdx.x; e < 2 * buf_len + 8; e += 256) smem[e] = 0.f;
+  __syncthreads();
+
+  auto stage = [&](int64_t is, int s) {
+    float* buf = smem + s * buf_len;
+    const int n_it = (int)((i_hi - is) < a.IPS ? (i_hi - is) : a.IPS);
+    for (int ii = wave; ii < n_it; ii += 4) {
+      float* dst = buf + ii * item_len;
+      glds_copy16((const float*)a.dout + ((is + ii) * a.Z + z) * (int64_t)do_len, dst, do_len >> 2, lane);
+      glds_copy16((const float*)a.in + ((is + ii) * a.Ctot + chan0 + c_base) * (int64_t)a.Tx, dst + do_len,
+                  (cw * a.Tin) >> 2, lane);
+    }
+  };
+
+  f32x4 acc[GT][kTaps], accb[GT];
+#pragma unroll
+  for (int g = 0; g < GT; ++g) {
+    accb[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) acc[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  struct Frag {
+    float af[GT];
+    float bf[kTaps];
+    float one;
+  };
+  const int a_off = jl * a.Tout + q;                                   // dOut[g = jl (+16 gt)][t0 + q]
+  const int b_off = do_len + (wave * 16 + jl) * a.Tin + q;             // In[c][t0 + q + k]
+  int s = 0;
+  if (i_lo < i_hi) stage(i_lo, 0);
+  for (int64_t is = i_lo; is < i_hi; is += a.IPS, s ^= 1) {
+    __syncthreads();                                                   // DMA of this stage retired; previous stage consumed
+    if (is + a.IPS < i_hi) stage(is + a.IPS, s ^ 1);
+    if (!wave_live) continue;
+    const float* buf = smem + s * buf_len;
+    const int n_it = (int)((i_hi - is) < a.IPS ? (i_hi - is) : a.IPS);
+    const int n_step = n_it * nks;
+    auto load = [&](int st, Frag& f) {
+      const int ii = st / nks, t0 = (st - ii * nks) * 4;
+      const float* ib = buf + ii * item_len + t0;
+      const bool ok = t0 + q < a.Tout;
+#pragma unroll
+      for (int g = 0; g < GT; ++g) {
+        const float v = ib[a_off + g * 16 * a.Tout];
+        f.af[g] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k) {
+        const float v = ib[b_off + k];
+        f.bf[k] = ok ? v : 0.f;
+      }
+      f.one = ok ? 1.f : 0.f;
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k)
+#pragma unroll
+        for (int g = 0; g < GT; ++g) acc[g][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[g], f.bf[k], acc[g][k], 0, 0, 0);
+      if (with_bias) {
+#pragma unroll
+        for (int g = 0; g < GT; ++g) accb[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[g], f.one, accb[g], 0, 0, 0);
+      }
+    };
+    Frag f0, f1;
+    load(0, f0);
+    for (int st = 0; st < n_step; st += 2) {
+      if (st + 1 < n_step) load(st + 1, f1);
+      mma(f0);
+      if (st + 1 < n_step) {
+        if (st + 2 < n_step) load(st + 2, f0);
+        mma(f1);
+      }
+    }
+  }
+  if (!wave_live) return;
+  float* slab = a.part + (int64_t)blockIdx.x * a.slab_size + zd.wg_off;
+#pragma unroll
+  for (int g = 0; g < GT; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gg = g * 16 + 4 * q + r;
+      if (c_mine < cin) {
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) slab[((int64_t)gg * cin1 + c_mine) * kTaps + k] = acc[g][k][r];
+      }
+      if (with_bias && jl < kTaps) slab[((int64_t)gg * cin1 + cin) * kTaps + jl] = jl == 0 ? accb[g][r] : 0.f;
+    }
+}
+
 // sum the per-workgroup slabs: out[e] = sum_s part[s][e].  Block = 64 elements x 4 slab groups
-// (coalesced 256-B rows, 4 independent load streams per element, LDS combine).
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                           int64_t n, int n_slabs) {
+// (coalesced 256-B rows, 4 independent load streams per element, LDS combine).  blockIdx.y selects a run of
+// L slabs (slab index = k * stride); with gridDim.y > 1 the run's sum is written over its own first slab, and
+// a second launch (stride = L) adds the run sums -- a fixed order, so the result is deterministic.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ part, float* __restrict__ out,
+                                                           int64_t n, int n_slabs, int L, int stride) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+  const int k0 = blockIdx.y * L;
+  const int k1 = k0 + L < n_slabs ? k0 + L : n_slabs;
   float s0 = 0.f, s1 = 0.f;
   if (e < n) {
-    int k = grp;
-    for (; k + 4 < n_slabs; k += 8) {
-      s0 += part[(int64_t)k * n + e];
-      s1 += part[(int64_t)(k + 4) * n + e];
+    int k = k0 + grp;
+    for (; k + 4 < k1; k += 8) {
+      s0 += part[(int64_t)k * stride * n + e];
+      s1 += part[(int64_t)(k + 4) * stride * n + e];
     }
-    if (k < n_slabs) s0 += part[(int64_t)k * n + e];
+    if (k < k1) s0 += part[(int64_t)k * stride * n + e];
   }
   red[grp][lane] = s0 + s1;
   __syncthreads();
-  if (grp == 0 && e < n) out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (grp == 0 && e < n) {
+    float* dst = gridDim.y > 1 ? part + (int64_t)k0 * stride * n : out;
+    dst[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  }
+}
+
+static inline void launch_reduce_slabs(float* part, float* out, int64_t n, int n_slabs, hipStream_t st) {
+  const unsigned bx = (unsigned)cdiv(n, 64);
+  if (n_slabs >= 64 && bx < 1024) {            // few elements, many slabs: two levels so the whole chip takes part
+    int L = 8;
+    while (L * L < n_slabs) L *= 2;
+    const int S = (int)cdiv(n_slabs, L);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(bx, S), dim3(256), 0, st, part, out, n, n_slabs, L, 1);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(bx, 1), dim3(256), 0, st, part, out, n, S, S, L);
+  } else {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(bx, 1), dim3(256), 0, st, part, out, n, n_slabs, n_slabs, 1);
+  }
 }
 
 // Chain dWeff / dbeff back to cnn1.weight, cnn1.bias, cnn2.weight.  grid = (blocks, zones):
@@ -1340,7 +1476,7 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
     w.slab_size = g.slab1; w.wz_stride = (int64_t)F * F * kTaps; w.items_per_wg = g.ipw1; w.CW = g.cw1;
     rc = launch_wgrad(1, p->act_bf16, w, p->Z, F, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdiv(g.slab1, 64)), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg34, g.slab1, g.ns1);
+    launch_reduce_slabs(ws + g.o_part, ws + g.o_wg34, g.slab1, g.ns1, st);
     hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 1);
     ISD_LAUNCH_CHECK();
     a.in = ws + g.o_a4; a.out = ws + g.o_s; a.wfrag = ws + g.o_w4t;
@@ -1350,7 +1486,7 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
     w.dout = ws + g.o_s; w.in = ws + g.o_a2;
     rc = launch_wgrad(1, p->act_bf16, w, p->Z, F, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdiv(g.slab1, 64)), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg34, g.slab1, g.ns1);
+    launch_reduce_slabs(ws + g.o_part, ws + g.o_wg34, g.slab1, g.ns1, st);
     hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 0);
     ISD_LAUNCH_CHECK();
     a.in = ws + g.o_s; a.out = ws + g.o_a4; a.wfrag = ws + g.o_w3t;
@@ -1363,9 +1499,34 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
   w.RSo = g.T1; w.lin = g.lin0;
   w.RSi = g.lin0 ? p->W : (p->W | 1);
   w.slab_size = g.slab0; w.wz_stride = 0; w.items_per_wg = g.ipw0; w.CW = g.cw0;
-  rc = launch_wgrad(0, p->act_bf16, w, p->Z, p->max_cz + 1, st);
+  int n_slabs0 = g.ns0;
+  {
+    // wide inputs: LDS-DMA double-buffered variant, ~3 workgroups per CU
+    const int zg = (p->max_cz + 63) / 64;
+    int64_t r_target = (256 * 3) / ((int64_t)zg * p->Z);
+    if (r_target < 1) r_target = 1;
+    if (r_target > g.ns0) r_target = g.ns0;
+    const int ipw = (int)cdiv(g.items, r_target);
+    const int R = (int)cdiv(g.items, ipw);
+    const int item_len = (F * g.T1 + 64 * p->W + 3) & ~3;
+    int ips = 4;
+    while (ips > 1 && (size_t)(2 * (ips * item_len + 32) + 8) * 4 > 48 * 1024) --ips;
+    const size_t lds = sizeof(float) * (size_t)(2 * (ips * item_len + 32) + 8);
+    if (g.lin0 && p->dma_ok && !p->act_bf16 && p->max_cz >= 64 && (F * g.T1) % 4 == 0 && lds <= 64 * 1024 &&
+        ((uintptr_t)x & 15) == 0 && ((uintptr_t)g2 & 15) == 0) {
+      w.items_per_wg = ipw; w.IPS = ips;
+      const dim3 grid((unsigned)R, p->Z, zg);
+      if (F == 32) hipLaunchKernelGGL(conv5_wgrad_wide_kernel<2>, grid, dim3(256), lds, st, w);
+      else hipLaunchKernelGGL(conv5_wgrad_wide_kernel<1>, grid, dim3(256), lds, st, w);
+      ISD_LAUNCH_CHECK();
+      n_slabs0 = R;
+      rc = ISD_OK;
+    } else {
+      rc = launch_wgrad(0, p->act_bf16, w, p->Z, p->max_cz + 1, st);
+    }
+  }
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)cdiv(g.slab0, 64)), dim3(256), 0, st, ws + g.o_part, ws + g.o_wg, g.slab0, g.ns0);
+  launch_reduce_slabs(ws + g.o_part, ws + g.o_wg, g.slab0, n_slabs0, st);
   {
     const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
     hipLaunchKernelGGL(fused_bwd_kernel, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,

@@ -129,12 +129,26 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     }
 }
 
-__global__ void linear_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                           float* __restrict__ db, int K, int Nout, int n_slabs) {
+// Slab sums in a fixed order.  blockIdx.y selects a run of L slabs (index k * stride); with gridDim.y > 1 the
+// run's sum replaces its first slab and a second launch (stride = L) adds the run sums and scatters to dw / db.
+__global__ void linear_wgrad_reduce_kernel(float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                           int K, int Nout, int n_slabs, int L, int stride) {
   const int n = Nout * (K + 1);
+  const int k0 = blockIdx.y * L;
+  const int k1 = k0 + L < n_slabs ? k0 + L : n_slabs;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < n_slabs; ++k) s += part[(int64_t)k * n + e];
+    float s0 = 0.f, s1 = 0.f;
+    int k = k0;
+    for (; k + 1 < k1; k += 2) {
+      s0 += part[(int64_t)k * stride * n + e];
+      s1 += part[(int64_t)(k + 1) * stride * n + e];
+    }
+    if (k < k1) s0 += part[(int64_t)k * stride * n + e];
+    const float s = s0 + s1;
+    if (gridDim.y > 1) {
+      part[(int64_t)k0 * stride * n + e] = s;
+      continue;
+    }
     const int o = e / (K + 1), i = e - o * (K + 1);
     if (i < K) dw[o * K + i] = s;
     else if (db) db[o] = s;
@@ -283,8 +297,18 @@ extern "C" int isd_linear_backward(const float* x, const float* w, const float* 
   const int slabs = wgrad_slabs(M, &mp);
   hipLaunchKernelGGL(linear_wgrad_kernel, dim3(slabs, (unsigned)cdiv(K + 1, 64), (unsigned)cdiv(N, 64)), dim3(256), 0,
                      st, dsrc, x, part, M, K, N, mp);
-  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)cdiv((int64_t)N * (K + 1), 256)), dim3(256), 0, st, part,
-                     dw, db, K, N, slabs);
+  {
+    const unsigned bx = (unsigned)cdiv((int64_t)N * (K + 1), 256);
+    if (slabs >= 64 && bx < 256) {
+      int L = 8;
+      while (L * L < slabs) L *= 2;
+      const int S = (int)cdiv(slabs, L);
+      hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3(bx, S), dim3(256), 0, st, part, dw, db, K, N, slabs, L, 1);
+      hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, part, dw, db, K, N, S, S, L);
+    } else {
+      hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, part, dw, db, K, N, slabs, slabs, 1);
+    }
+  }
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
