@@ -138,6 +138,27 @@ __global__ void prep_conv_kernel(const float* __restrict__ params, const ZoneDes
   }
 }
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void glds_copy16(const float* __restrict__ src, float* dst, int n4, int lane) {
+  // wave-cooperative copy of n4 float4 (contiguous both sides); dst must be the wave-uniform base
+  for (int e0 = 0; e0 < n4; e0 += 64) {
+    if (e0 + lane < n4)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (int64_t)(e0 + lane) * 4), (lds_ptr_t)(dst + e0 * 4), 16, 0, 0);
+  }
+}
+
+// Same copy shared by `step/64` waves: a wave takes the 1 KiB pieces first, first + step, ... (first = 64 * wave
+// index within the copying group).  All pieces are in flight at once; the next __syncthreads() retires them.
+__device__ __forceinline__ void glds_copy16_strided(const float* __restrict__ src, float* dst, int n4, int first,
+                                                    int step, int lane) {
+  for (int e0 = first; e0 < n4; e0 += step) {
+    if (e0 + lane < n4)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (int64_t)(e0 + lane) * 4), (lds_ptr_t)(dst + e0 * 4), 16, 0, 0);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Forward convolution (also used as dgrad with transposed weights).
 // ---------------------------------------------------------------------------------------
@@ -160,14 +181,13 @@ struct ConvArgs {
 // LDS rows are unpadded copies of the source rows (stride RS >= Tin); zero padding, the ragged last
 // time tile and the channel round-up are handled by masking the B fragment, so staging moves only
 // real data (float4 when the block is contiguous and aligned).
-template <int MODE, typename AT>
+template <int MODE, typename AT, int GT, int NT>
 __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
   using IT = typename std::conditional<MODE == 0, float, AT>::type;   // storage type of the input
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int z = blockIdx.y;
   const ZoneDesc zd = a.zones[z];
   const int cin = (MODE == 0) ? zd.cin : a.F;
-  const int GT = a.F / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t item0 = (int64_t)blockIdx.x * a.IPW;
   const int n_items = (int)((a.items - item0) < a.IPW ? (a.items - item0) : a.IPW);
@@ -179,24 +199,30 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
   const int n_chunks = (cin + kCK - 1) / kCK;
   const int q = lane >> 4, jl = lane & 15;
 
-  for (int base = 0; base < n_ct; base += 16) {
-    f32x4 acc[4][2];
+  for (int base = 0; base < n_ct; base += 4 * NT) {
+    // every wave always carries NT column tiles: no branch stands between the MFMAs, slots past the end
+    // recompute tile 0 and are not stored
+    f32x4 acc[NT][GT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int g = 0; g < 2; ++g) acc[j][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int t_ii[4], t_t0[4];
-    bool t_ok[4];
-    int boff[4];                                           // per-tile LDS offset of (row 0, t0 + jl - pad)
-    bool okk[4][kTaps];                                    // per-tile, per-tap validity of the B element
+      for (int g = 0; g < GT; ++g) acc[j][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    struct Frag {
+      float af[kTaps][GT];
+      float bf[NT][kTaps];
+    };
+    int t_ii[NT], t_t0[NT];
+    bool t_ok[NT];
+    int boff[NT];                                          // per-tile LDS offset of (row q, t0 + jl - pad)
+    bool okk[NT][kTaps];                                   // per-tile, per-tap validity of the B element
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NT; ++j) {
       const int ct = base + j * 4 + wave;                  // round-robin: few tiles still use every wave
       t_ok[j] = ct < n_ct;
       const int ctc = t_ok[j] ? ct : 0;
       t_ii[j] = ctc / a.TT;
       t_t0[j] = (ctc - t_ii[j] * a.TT) * 16;
-      boff[j] = t_ii[j] * kCK * a.RS + t_t0[j] + jl - a.pad;
+      boff[j] = t_ii[j] * kCK * a.RS + t_t0[j] + jl - a.pad + q * a.RS;
 #pragma unroll
       for (int k = 0; k < kTaps; ++k) {
         const int idx = t_t0[j] + jl + k - a.pad;
@@ -222,9 +248,7 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
           if constexpr (std::is_same<IT, float>::value && !Act<AT>::kBf16) {
             const float* src = (const float*)a.in + soff;
             if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
-              const float4* s4 = reinterpret_cast<const float4*>(src);
-              float4* d4 = reinterpret_cast<float4*>(dst);
-              for (int e = tid0; e < (cnt >> 2); e += tstep) d4[e] = s4[e];
+              glds_copy16_strided(src, dst, cnt >> 2, tid0 - lane, tstep, lane);   // LDS-DMA: every piece in flight at once
             } else {
               for (int e = tid0; e < cnt; e += tstep) dst[e] = src[e];
             }
@@ -258,40 +282,56 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
       }
       {
         const int wlen4 = (ckc4 / 4) * kTaps * GT * 16;
-        const float4* wsrc = reinterpret_cast<const float4*>(wbase + (int64_t)ch * (kCK / 4) * kTaps * GT * 64);
-        float4* wdst = reinterpret_cast<float4*>(w_tile);
-        for (int e = threadIdx.x; e < wlen4; e += 256) wdst[e] = wsrc[e];
+        glds_copy16_strided(wbase + (int64_t)ch * (kCK / 4) * kTaps * GT * 64, w_tile, wlen4, wave * 64, 256, lane);
       }
       __syncthreads();
-      // addresses and masks were hoisted out of this loop (boff / okk); the channel round-up rows are zero
-      for (int cg = 0; cg < ckc4 / 4; ++cg) {
-        const float* rowp = in_tile + (cg * 4 + q) * a.RS;
+      // addresses and masks were hoisted out of this loop (boff / okk); the channel round-up rows are zero.
+      // Fragments of channel group cg+1 are fetched from LDS while the MFMAs of group cg run.
+      const float* wl = w_tile + lane;
+      auto load = [&](int cg, Frag& f) {
+        const float* rowp = in_tile + cg * 4 * a.RS;
 #pragma unroll
-        for (int k = 0; k < kTaps; ++k) {
-          float af[2];
-          af[0] = w_tile[((cg * kTaps + k) * GT + 0) * 64 + lane];
-          af[1] = (GT > 1) ? w_tile[((cg * kTaps + k) * GT + 1) * 64 + lane] : 0.f;
+        for (int k = 0; k < kTaps; ++k)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (!t_ok[j]) continue;                          // wave-uniform: unused tile slots issue nothing
-            float bf = rowp[boff[j] + k];                    // may touch a neighbouring row: masked below
-            bf = okk[j][k] ? bf : 0.f;
-            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf, acc[j][0], 0, 0, 0);
-            if (GT > 1) acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf, acc[j][1], 0, 0, 0);
+          for (int g = 0; g < GT; ++g) f.af[k][g] = wl[((cg * kTaps + k) * GT + g) * 64];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int k = 0; k < kTaps; ++k) {
+            const float v = rowp[boff[j] + k];                 // may touch a neighbouring row: masked
+            f.bf[j][k] = okk[j][k] ? v : 0.f;
           }
+      };
+      auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < GT; ++g)
+              acc[j][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[k][g], f.bf[j][k], acc[j][g], 0, 0, 0);
+      };
+      const int ncg = ckc4 / 4;
+      Frag f0, f1;
+      load(0, f0);
+      for (int cg = 0; cg < ncg; cg += 2) {
+        if (cg + 1 < ncg) load(cg + 1, f1);
+        mma(f0);
+        if (cg + 1 < ncg) {
+          if (cg + 2 < ncg) load(cg + 2, f0);
+          mma(f1);
         }
       }
     }
     // epilogue: D[row g = 4*(lane>>4)+r][col t = lane&15]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NT; ++j) {
       if (!t_ok[j]) continue;
       const int64_t item = item0 + t_ii[j];
       const int t = t_t0[j] + jl;
       if (t >= a.Tout) continue;
 #pragma unroll
-      for (int gt = 0; gt < 2; ++gt) {
-        if (gt >= GT) break;
+      for (int gt = 0; gt < GT; ++gt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int g = gt * 16 + 4 * q + r;
@@ -314,17 +354,6 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
 // Preconditions (checked on the host): fp32, contiguous zone channels, whole-row windows, cin % 4 == 0,
 // 16-byte aligned rows blocks.
 // ---------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-__device__ __forceinline__ void glds_copy16(const float* __restrict__ src, float* dst, int n4, int lane) {
-  // wave-cooperative copy of n4 float4 (contiguous both sides); dst must be the wave-uniform base
-  for (int e0 = 0; e0 < n4; e0 += 64) {
-    if (e0 + lane < n4)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (int64_t)(e0 + lane) * 4), (lds_ptr_t)(dst + e0 * 4), 16, 0, 0);
-  }
-}
-
 template <int GT>
 __global__ __launch_bounds__(256) void conv5_fwd_glds_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -708,7 +737,7 @@ struct WgradArgs {
 //                and write separate slabs (summed by reduce_slabs_kernel);
 //   roles == 8 : a wave owns one c-tile and both g-tiles.
 // LDS rows are unpadded copies (RSo >= Tout, RSi >= Tin); range / padding handled by masks.
-template <int MODE, typename AT>
+template <int MODE, typename AT, bool BOTH>
 __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
   using IT = typename std::conditional<MODE == 0, float, AT>::type;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -722,7 +751,7 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
   const int q = lane >> 4, jl = lane & 15;
   const int n_ct = a.CW / 16;
   const int roles = n_ct * GT;
-  const bool both = roles > 4;
+  constexpr bool both = BOTH;                              // host: BOTH == (roles > 4)
   const int n_grp = both ? 1 : 4 / roles;
   const int ct = both ? wave : wave % n_ct;
   const int gsel = both ? 0 : (wave / n_ct) % GT;
@@ -763,9 +792,7 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
         if constexpr (!Act<AT>::kBf16) {
           const float* src = (const float*)a.dout + soff;
           if (a.RSo == a.Tout && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
-            const float4* s4 = reinterpret_cast<const float4*>(src);
-            float4* d4 = reinterpret_cast<float4*>(dst);
-            for (int e = tid0; e < (cnt >> 2); e += tstep) d4[e] = s4[e];
+            glds_copy16_strided(src, dst, cnt >> 2, tid0 - lane, tstep, lane);     // LDS-DMA: every piece in flight at once
             continue;
           }
         }
@@ -788,9 +815,7 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
           if constexpr (std::is_same<IT, float>::value && !Act<AT>::kBf16) {
             const float* src = (const float*)a.in + soff;
             if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
-              const float4* s4 = reinterpret_cast<const float4*>(src);
-              float4* d4 = reinterpret_cast<float4*>(dst);
-              for (int e = tid0; e < (cnt >> 2); e += tstep) d4[e] = s4[e];
+              glds_copy16_strided(src, dst, cnt >> 2, tid0 - lane, tstep, lane);   // LDS-DMA: every piece in flight at once
             } else {
               for (int e = tid0; e < cnt; e += tstep) dst[e] = src[e];
             }
@@ -819,29 +844,51 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
     __syncthreads();
     if (wave_live) {
       const int row_b = c_real ? (ct * 16 + jl) : 0;
-      // wave groups split the reduction (time) range of every item, so one staged item keeps all waves busy
-      for (int ii = 0; ii < n_it; ++ii) {
+      // wave groups split the reduction (time) range of every item, so one staged item keeps all waves busy.
+      // The (item, K-step) pairs of the stage form one flat sequence; the fragments of step s+1 are fetched from
+      // LDS while the MFMAs of step s run, and no branch stands between the MFMAs.
+      const int nk = (Tk / 4 - grp + n_grp - 1) / n_grp;       // K-steps of this wave group per item
+      const int n_step = n_it * nk;
+      struct Frag {
+        float a0, a1;
+        float b[kTaps];
+      };
+      auto load = [&](int st, Frag& f) {
+        const int ii = st / nk;
+        const int ta = (grp + (st - ii * nk) * n_grp) * 4 + q;
         const float* dro = do_tile + (ii * a.F + gsel * 16 + jl) * a.RSo;
         const float* iro = in_tile + (ii * a.CW + row_b) * a.RSi;
-#pragma unroll 2
-        for (int t0 = grp * 4; t0 < Tk; t0 += 4 * n_grp) {
-          const int ta = t0 + q;
-          const bool a_ok = ta < a.Tout;
-          const int tac = a_ok ? ta : 0;
-          float a0 = dro[tac];
-          float a1 = both ? dro[16 * a.RSo + tac] : 0.f;
-          a0 = a_ok ? a0 : 0.f;
-          a1 = a_ok ? a1 : 0.f;
+        const bool a_ok = ta < a.Tout;
+        const int tac = a_ok ? ta : 0;
+        const float v0 = dro[tac];
+        f.a0 = a_ok ? v0 : 0.f;
+        if (BOTH) {
+          const float v1 = dro[16 * a.RSo + tac];
+          f.a1 = a_ok ? v1 : 0.f;
+        }
 #pragma unroll
-          for (int k = 0; k < kTaps; ++k) {
-            const int idx = ta + k - a.pad;
-            const bool in_rng = idx >= 0 && idx < a.Tin;
-            const int idc = in_rng ? idx : 0;
-            float bf = iro[idc];
-            bf = (c_real && in_rng) ? bf : ((c_ones && idx >= 0 && idx < a.Tout) ? 1.f : 0.f);
-            acc0[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc0[k], 0, 0, 0);
-            if (both) acc1[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc1[k], 0, 0, 0);
-          }
+        for (int k = 0; k < kTaps; ++k) {
+          const int idx = ta + k - a.pad;
+          const bool in_rng = idx >= 0 && idx < a.Tin;
+          const float bf = iro[in_rng ? idx : 0];
+          f.b[k] = (c_real && in_rng) ? bf : ((c_ones && idx >= 0 && idx < a.Tout) ? 1.f : 0.f);
+        }
+      };
+      auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) {
+          acc0[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a0, f.b[k], acc0[k], 0, 0, 0);
+          if (BOTH) acc1[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a1, f.b[k], acc1[k], 0, 0, 0);
+        }
+      };
+      Frag f0, f1;
+      if (n_step > 0) load(0, f0);
+      for (int st = 0; st < n_step; st += 2) {
+        if (st + 1 < n_step) load(st + 1, f1);
+        mma(f0);
+        if (st + 1 < n_step) {
+          if (st + 2 < n_step) load(st + 2, f0);
+          mma(f1);
         }
       }
     }
@@ -1285,10 +1332,25 @@ static int launch_conv(int mode, int bf16, const ConvArgs& a, int n_zones, hipSt
   const size_t lds = sizeof(float) * (4 + (((size_t)a.IPW * kCK * a.RS + 3) & ~(size_t)3) + (size_t)(kCK / 4) * kTaps * GT * 64 + 32);
   ISD_CHECK_ARG(lds <= 64 * 1024, "conv4: LDS tile of %zu bytes exceeds 64 KiB (window too long)", lds);
   const dim3 grid((unsigned)blocks, n_zones);
-  if (mode == 0 && !bf16) hipLaunchKernelGGL((conv5_fwd_kernel<0, float>), grid, dim3(256), lds, st, a);
-  else if (mode == 0) hipLaunchKernelGGL((conv5_fwd_kernel<0, bf16_t>), grid, dim3(256), lds, st, a);
-  else if (!bf16) hipLaunchKernelGGL((conv5_fwd_kernel<1, float>), grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((conv5_fwd_kernel<1, bf16_t>), grid, dim3(256), lds, st, a);
+  const int tiles = a.IPW * a.TT;                     // column tiles per workgroup -> tiles per wave (1, 2 or 4)
+  const int NT = tiles > 8 ? 4 : tiles > 4 ? 2 : 1;
+#define ISD_CONV_LAUNCH_N(M, T, G)                                                                   \
+  do {                                                                                               \
+    if (NT == 4) hipLaunchKernelGGL((conv5_fwd_kernel<M, T, G, 4>), grid, dim3(256), lds, st, a);    \
+    else if (NT == 2) hipLaunchKernelGGL((conv5_fwd_kernel<M, T, G, 2>), grid, dim3(256), lds, st, a); \
+    else hipLaunchKernelGGL((conv5_fwd_kernel<M, T, G, 1>), grid, dim3(256), lds, st, a);            \
+  } while (0)
+#define ISD_CONV_LAUNCH(M, T)                                                                         \
+  do {                                                                                               \
+    if (GT == 2) ISD_CONV_LAUNCH_N(M, T, 2);                                                         \
+    else ISD_CONV_LAUNCH_N(M, T, 1);                                                                 \
+  } while (0)
+  if (mode == 0 && !bf16) ISD_CONV_LAUNCH(0, float);
+  else if (mode == 0) ISD_CONV_LAUNCH(0, bf16_t);
+  else if (!bf16) ISD_CONV_LAUNCH(1, float);
+  else ISD_CONV_LAUNCH(1, bf16_t);
+#undef ISD_CONV_LAUNCH
+#undef ISD_CONV_LAUNCH_N
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
@@ -1398,14 +1460,19 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
   return ISD_OK;
 }
 
-template <int MODE, typename AT>
-static int launch_wgrad_t(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+template <int MODE, typename AT, bool BOTH>
+static int launch_wgrad_b(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   if (lds > 48 * 1024)
-    ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_wgrad_kernel<MODE, AT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-  hipLaunchKernelGGL((conv5_wgrad_kernel<MODE, AT>), grid, dim3(256), lds, st, a);
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_wgrad_kernel<MODE, AT, BOTH>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((conv5_wgrad_kernel<MODE, AT, BOTH>), grid, dim3(256), lds, st, a);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
+}
+template <int MODE, typename AT>
+static int launch_wgrad_t(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  const int roles = (a.CW / 16) * (a.F / 16);              // a wave owns both filter tiles when roles > 4
+  return roles > 4 ? launch_wgrad_b<MODE, AT, true>(a, grid, lds, st) : launch_wgrad_b<MODE, AT, false>(a, grid, lds, st);
 }
 
 static int launch_wgrad(int mode, int bf16, WgradArgs& a, int n_zones, int cin_max, hipStream_t st) {
