@@ -732,10 +732,9 @@ struct WgradArgs {
   int Ctot, Tx, N, S;
 };
 
-// Wave roles: with n_ct = CW/16 channel tiles and GT filter tiles, roles = n_ct*GT.
-//   roles <= 4 : a wave owns ONE (c-tile, g-tile); the 4/roles wave groups split the items
-//                and write separate slabs (summed by reduce_slabs_kernel);
-//   roles == 8 : a wave owns one c-tile and both g-tiles.
+// Wave roles: a wave owns one of the n_ct = CW/16 channel tiles and every filter tile (the B fragments are
+// shared by both); the 4/n_ct wave groups split the time range of each item and write separate slabs
+// (summed by reduce_slabs_kernel).
 // LDS rows are unpadded copies (RSo >= Tout, RSi >= Tin); range / padding handled by masks.
 template <int MODE, typename AT, bool BOTH>
 __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
@@ -749,13 +748,12 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
   const int GT = a.F / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, jl = lane & 15;
-  const int n_ct = a.CW / 16;
-  const int roles = n_ct * GT;
-  constexpr bool both = BOTH;                              // host: BOTH == (roles > 4)
-  const int n_grp = both ? 1 : 4 / roles;
-  const int ct = both ? wave : wave % n_ct;
-  const int gsel = both ? 0 : (wave / n_ct) % GT;
-  const int grp = both ? 0 : wave / roles;
+  const int n_ct = a.CW / 16;                              // 1, 2 or 4 channel tiles
+  constexpr bool both = BOTH;                              // host: BOTH == (F == 32): a wave owns both filter tiles
+  const int n_grp = 4 / n_ct;                              // wave groups split the time range, one slab each
+  const int ct = wave % n_ct;
+  const int gsel = 0;
+  const int grp = wave / n_ct;
   const int c_tile = c_base + ct * 16;
   const bool wave_live = c_tile < cin && grp < n_grp;
   const int n_real = (MODE == 0) ? cin - 1 : cin;           // channels that exist in memory
@@ -776,6 +774,61 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
     acc1[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const int cw_real = (n_real - c_base) < a.CW ? (n_real - c_base) : a.CW;   // real rows to stage (may be <= 0)
+
+  auto compute = [&](const float* do_tile, const float* in_tile, int n_it) {
+    if (wave_live) {
+      const int row_b = c_real ? (ct * 16 + jl) : 0;
+      // wave groups split the reduction (time) range of every item, so one staged item keeps all waves busy.
+      // The (item, K-step) pairs of the stage form one flat sequence; the fragments of step s+1 are fetched from
+      // LDS while the MFMAs of step s run, and no branch stands between the MFMAs.
+      const int nk = (Tk / 4 - grp + n_grp - 1) / n_grp;       // K-steps of this wave group per item
+      const int n_step = n_it * nk;
+      struct Frag {
+        float a0, a1;
+        float b[kTaps];
+      };
+      int l_ii = 0, l_kk = 0;                                  // loads are issued in step order: running (item, K-step)
+      auto load = [&](int, Frag& f) {
+        const int ii = l_ii;
+        const int ta = (grp + l_kk * n_grp) * 4 + q;
+        if (++l_kk == nk) { l_kk = 0; ++l_ii; }
+        const float* dro = do_tile + (ii * a.F + gsel * 16 + jl) * a.RSo;
+        const float* iro = in_tile + (ii * a.CW + row_b) * a.RSi;
+        const bool a_ok = ta < a.Tout;
+        const int tac = a_ok ? ta : 0;
+        const float v0 = dro[tac];
+        f.a0 = a_ok ? v0 : 0.f;
+        if (BOTH) {
+          const float v1 = dro[16 * a.RSo + tac];
+          f.a1 = a_ok ? v1 : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) {
+          const int idx = ta + k - a.pad;
+          const bool in_rng = idx >= 0 && idx < a.Tin;
+          const float bf = iro[in_rng ? idx : 0];
+          f.b[k] = (c_real && in_rng) ? bf : ((c_ones && idx >= 0 && idx < a.Tout) ? 1.f : 0.f);
+        }
+      };
+      auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) {
+          acc0[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a0, f.b[k], acc0[k], 0, 0, 0);
+          if (BOTH) acc1[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a1, f.b[k], acc1[k], 0, 0, 0);
+        }
+      };
+      Frag f0, f1;
+      if (n_step > 0) load(0, f0);
+      for (int st = 0; st < n_step; st += 2) {
+        if (st + 1 < n_step) load(st + 1, f1);
+        mma(f0);
+        if (st + 1 < n_step) {
+          if (st + 2 < n_step) load(st + 2, f0);
+          mma(f1);
+        }
+      }
+    }
+  };
 
   for (int64_t is = i_lo; is < i_hi; is += a.IPS) {
     const int n_it = (int)((i_hi - is) < a.IPS ? (i_hi - is) : a.IPS);
@@ -842,56 +895,7 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
       }
     }
     __syncthreads();
-    if (wave_live) {
-      const int row_b = c_real ? (ct * 16 + jl) : 0;
-      // wave groups split the reduction (time) range of every item, so one staged item keeps all waves busy.
-      // The (item, K-step) pairs of the stage form one flat sequence; the fragments of step s+1 are fetched from
-      // LDS while the MFMAs of step s run, and no branch stands between the MFMAs.
-      const int nk = (Tk / 4 - grp + n_grp - 1) / n_grp;       // K-steps of this wave group per item
-      const int n_step = n_it * nk;
-      struct Frag {
-        float a0, a1;
-        float b[kTaps];
-      };
-      auto load = [&](int st, Frag& f) {
-        const int ii = st / nk;
-        const int ta = (grp + (st - ii * nk) * n_grp) * 4 + q;
-        const float* dro = do_tile + (ii * a.F + gsel * 16 + jl) * a.RSo;
-        const float* iro = in_tile + (ii * a.CW + row_b) * a.RSi;
-        const bool a_ok = ta < a.Tout;
-        const int tac = a_ok ? ta : 0;
-        const float v0 = dro[tac];
-        f.a0 = a_ok ? v0 : 0.f;
-        if (BOTH) {
-          const float v1 = dro[16 * a.RSo + tac];
-          f.a1 = a_ok ? v1 : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < kTaps; ++k) {
-          const int idx = ta + k - a.pad;
-          const bool in_rng = idx >= 0 && idx < a.Tin;
-          const float bf = iro[in_rng ? idx : 0];
-          f.b[k] = (c_real && in_rng) ? bf : ((c_ones && idx >= 0 && idx < a.Tout) ? 1.f : 0.f);
-        }
-      };
-      auto mma = [&](const Frag& f) {
-#pragma unroll
-        for (int k = 0; k < kTaps; ++k) {
-          acc0[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a0, f.b[k], acc0[k], 0, 0, 0);
-          if (BOTH) acc1[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a1, f.b[k], acc1[k], 0, 0, 0);
-        }
-      };
-      Frag f0, f1;
-      if (n_step > 0) load(0, f0);
-      for (int st = 0; st < n_step; st += 2) {
-        if (st + 1 < n_step) load(st + 1, f1);
-        mma(f0);
-        if (st + 1 < n_step) {
-          if (st + 2 < n_step) load(st + 2, f0);
-          mma(f1);
-        }
-      }
-    }
+    compute(do_tile, in_tile, n_it);
   }
   if (!wave_live) return;
   float* slab = a.part + ((int64_t)blockIdx.x * n_grp + grp) * a.slab_size +
@@ -1298,8 +1302,7 @@ int make_geo(const isd_conv4_plan* p, int64_t B, int64_t T, Geo& g) {
   const int GT = p->F / 16;
   auto plan_wg = [&](int cin_max, int& cw, int& ipw, int& ns, int& grp) {
     cw = cin_max >= 64 ? 64 : (int)align_up(cin_max, 16);
-    const int roles = (cw / 16) * GT;
-    grp = roles > 4 ? 1 : 4 / roles;
+    grp = 4 / (cw / 16);                                    // wave groups of the kernel (cw is 16, 32 or 64)
     const int zg = (cin_max + cw - 1) / cw;
     int64_t want = 1024 / ((int64_t)p->Z * zg);
     if (want < 1) want = 1;
@@ -1471,8 +1474,7 @@ static int launch_wgrad_b(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t
 }
 template <int MODE, typename AT>
 static int launch_wgrad_t(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  const int roles = (a.CW / 16) * (a.F / 16);              // a wave owns both filter tiles when roles > 4
-  return roles > 4 ? launch_wgrad_b<MODE, AT, true>(a, grid, lds, st) : launch_wgrad_b<MODE, AT, false>(a, grid, lds, st);
+  return a.F == 32 ? launch_wgrad_b<MODE, AT, true>(a, grid, lds, st) : launch_wgrad_b<MODE, AT, false>(a, grid, lds, st);
 }
 
 static int launch_wgrad(int mode, int bf16, WgradArgs& a, int n_zones, int cin_max, hipStream_t st) {
@@ -1485,6 +1487,8 @@ static int launch_wgrad(int mode, int bf16, WgradArgs& a, int n_zones, int cin_m
   if (ips > 16) ips = 16;
   if (ips > a.items_per_wg) ips = a.items_per_wg;
   a.IPS = ips;
+  // (two LDS stages filled by LDS-DMA were measured here: 28.9 vs 28.4 ms/step on FAST B=4096 -- one stage and two
+  // co-resident workgroups per CU hide the copy better than one workgroup with two stages)
   const size_t lds = sizeof(float) * ((size_t)ips * per_item + 4);
   const int64_t wgs = cdiv(a.items, a.items_per_wg);
   const int zgroups = (cin_max + a.CW - 1) / a.CW;
