@@ -496,6 +496,54 @@ struct FusedFwdArgs {
   int Ctot, Tx, N, S;
 };
 
+// One convolution layer of the fused forward for a wave's NJ column tiles: acc[j][gt] += W[gt] (x) in, over ncg
+// groups of 4 input channels.  `wl` = frag-ordered weights + lane, `in` = LDS tile + q * RS (row of this lane's
+// K index), off/ok = per-tile column offset and per-tap validity.  Fragments of group cg+1 are fetched while
+// the MFMAs of group cg run; no branch stands between the MFMAs (dead tiles compute and are not stored).
+template <int NJ>
+__device__ __forceinline__ void fused_conv_mma(const float* __restrict__ wl, const float* __restrict__ in, int RS,
+                                               int ncg, const int (&off)[NJ], const bool (&ok)[NJ][kTaps],
+                                               f32x4 (&acc)[NJ][2]) {
+  struct Frag {
+    float af[kTaps][2];
+    float bf[NJ][kTaps];
+  };
+  auto load = [&](int cg, Frag& f) {
+    const float* rowp = in + cg * 4 * RS;
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+      f.af[k][0] = wl[((cg * kTaps + k) * 2 + 0) * 64];
+      f.af[k][1] = wl[((cg * kTaps + k) * 2 + 1) * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k) {
+        const float v = rowp[off[j] + k];                    // may touch a neighbouring row: masked
+        f.bf[j][k] = ok[j][k] ? v : 0.f;
+      }
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[k][0], f.bf[j][k], acc[j][0], 0, 0, 0);
+        acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[k][1], f.bf[j][k], acc[j][1], 0, 0, 0);
+      }
+  };
+  Frag f0, f1;
+  load(0, f0);
+  for (int cg = 0; cg < ncg; cg += 2) {
+    if (cg + 1 < ncg) load(cg + 1, f1);
+    mma(f0);
+    if (cg + 1 < ncg) {
+      if (cg + 2 < ncg) load(cg + 2, f0);
+      mma(f1);
+    }
+  }
+}
+
 template <int NW>
 __device__ __forceinline__ void fused_layer_store(const f32x4 (&acc)[16 / NW][2], const float* __restrict__ bias,
                                                   float* __restrict__ tile, int T1, int TT, int wave, int q, int jl) {
@@ -537,14 +585,14 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
     w3s[e] = a.w3[(int64_t)z * a.wz_stride + e];
     w4s[e] = a.w4[(int64_t)z * a.wz_stride + e];
   }
+  for (int e = cz * W + threadIdx.x; e < 16 * W; e += NW * 64) xz[e] = 0.f;   // channel round-up rows stay zero
   const float* bias = a.beff + z * F;
   constexpr int NJ = 16 / NW;
   int off0[NJ], off2[NJ];                             // tile column offsets for pad 0 / pad 2 reads
-  bool tlive[NJ], ok0[NJ][kTaps], ok2[NJ][kTaps];
+  bool ok0[NJ][kTaps], ok2[NJ][kTaps];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int tt = j * NW + wave;
-    tlive[j] = tt < TT;
+    const int tt = (j * NW + wave) < TT ? (j * NW + wave) : 0;   // dead slots recompute tile 0 (never stored)
     off0[j] = tt * 16 + jl;
     off2[j] = tt * 16 + jl - 2;
 #pragma unroll
@@ -560,7 +608,9 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
     __syncthreads();                                   // previous item's tiles are no longer read
     for (int r = wave; r < cz; r += NW) {               // gather the zone's rows of this window
       const float* src = a.x + (b * a.Ctot + a.chan_idx[zd.idx_off + r]) * (int64_t)a.Tx + (int64_t)n * a.S;
-      for (int t = lane; t < W; t += 64) xz[r * W + t] = src[t];
+      for (int t0 = 0; t0 < W; t0 += 64)                  // dword LDS-DMA: the whole row is in flight at once
+        if (t0 + lane < W)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + t0 + lane), (lds_ptr_t)(xz + r * W + t0), 4, 0, 0);
     }
     __syncthreads();
     f32x4 acc[16 / NW][2];
@@ -569,23 +619,7 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
     for (int j = 0; j < 16 / NW; ++j)
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int cg = 0; cg < ncg; ++cg) {
-      const int crow = cg * 4 + q;
-      const bool c_ok = crow < cz;
-      const float* xr = xz + (c_ok ? crow : 0) * W;
-#pragma unroll
-      for (int k = 0; k < kTaps; ++k) {
-        const float a0 = we[((cg * kTaps + k) * 2 + 0) * 64 + lane], a1 = we[((cg * kTaps + k) * 2 + 1) * 64 + lane];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (!tlive[j]) continue;
-          float bf = xr[off0[j] + k];                        // beyond W: lands in the next row / tile, masked
-          bf = (c_ok && ok0[j][k]) ? bf : 0.f;
-          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc[j][0], 0, 0, 0);
-          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc[j][1], 0, 0, 0);
-        }
-      }
-    }
+    fused_conv_mma<NJ>(we + lane, xz + q * W, W, ncg, off0, ok0, acc);   // rows cz..4*ncg-1 of xz are zero
     fused_layer_store<NW>(acc, bias, t2, T1, TT, wave, q, jl);
     __syncthreads();
     if (a.store) {
@@ -598,21 +632,7 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
     for (int j = 0; j < 16 / NW; ++j)
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int cg = 0; cg < 8; ++cg) {
-      const float* xr = t2 + (cg * 4 + q) * T1;
-#pragma unroll
-      for (int k = 0; k < kTaps; ++k) {
-        const float a0 = w3s[((cg * kTaps + k) * 2 + 0) * 64 + lane], a1 = w3s[((cg * kTaps + k) * 2 + 1) * 64 + lane];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (!tlive[j]) continue;
-          float bf = xr[off2[j] + k];                        // may touch the neighbouring row: masked
-          bf = ok2[j][k] ? bf : 0.f;
-          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc[j][0], 0, 0, 0);
-          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc[j][1], 0, 0, 0);
-        }
-      }
-    }
+    fused_conv_mma<NJ>(w3s + lane, t2 + q * T1, T1, 8, off2, ok2, acc);
     fused_layer_store<NW>(acc, nullptr, t3, T1, TT, wave, q, jl);
     __syncthreads();                                   // t3 complete; every read of t2 is done
     if (a.store) {
@@ -625,21 +645,7 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
     for (int j = 0; j < 16 / NW; ++j)
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int cg = 0; cg < 8; ++cg) {
-      const float* xr = t3 + (cg * 4 + q) * T1;
-#pragma unroll
-      for (int k = 0; k < kTaps; ++k) {
-        const float a0 = w4s[((cg * kTaps + k) * 2 + 0) * 64 + lane], a1 = w4s[((cg * kTaps + k) * 2 + 1) * 64 + lane];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (!tlive[j]) continue;
-          float bf = xr[off2[j] + k];                        // may touch the neighbouring row: masked
-          bf = ok2[j][k] ? bf : 0.f;
-          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf, acc[j][0], 0, 0, 0);
-          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf, acc[j][1], 0, 0, 0);
-        }
-      }
-    }
+    fused_conv_mma<NJ>(w4s + lane, t3 + q * T1, T1, 8, off2, ok2, acc);
     if (a.store) fused_layer_store<NW>(acc, nullptr, t2, T1, TT, wave, q, jl);   // t2 is free: stage A4 for the store
     float part[2][4];
 #pragma unroll
