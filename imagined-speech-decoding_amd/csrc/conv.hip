@@ -1398,7 +1398,7 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
     fa.zones = p->d_zones; fa.chan_idx = p->d_idx; fa.wz_stride = p->conv_zstride; fa.items = g.items;
     fa.Z = p->Z; fa.W = p->W; fa.T1 = g.T1; fa.TT = g.TT; fa.store = 1;
     fa.Ctot = p->Ctot; fa.Tx = (int)T; fa.N = g.N; fa.S = p->S;
-    constexpr int NW = 8;   // measured: 8 waves per item 37.2 ms/step, 16 waves 39.7, 4 waves 43.5 (B=4096, T=512)
+    constexpr int NW = 8;   // measured after the prefetch restructure (B=4096, T=512): 8 waves 25.6 ms/step, 16 waves 25.6, 4 waves 28.3
     const size_t lds = sizeof(float) * (size_t)(4 + ((16 * p->W + 3) & ~3) + 2 * ((F * g.T1 + 3) & ~3) + NW * F +
                                                  (4 + 8 + 8) * kTaps * 2 * 64 + 64);
     if (lds <= 150 * 1024) {
