@@ -36,23 +36,24 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ------------------------------------------------------------------ device side
 #if defined(__HIPCC__)
 
-// DPP row shift right by N inside each 16-lane row; lanes with no source get 0.
+// DPP row shift right by N inside each 16-lane row; lanes with no source get 0 (bound_ctrl: no `old` operand to
+// initialise, and the shift can fold into a consuming VOP2).
 template <int N>
 __device__ __forceinline__ float row_shr(float v) {
-  int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xf, 0xf, false);
+  int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xf, 0xf, true);
   return __int_as_float(r);
 }
 template <int N>
 __device__ __forceinline__ double row_shr(double v) {
   long long b = __double_as_longlong(v);
-  int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x110 + N, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x110 + N, 0xf, 0xf, false);
+  int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x110 + N, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x110 + N, 0xf, 0xf, true);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // DPP row shift left by N (lane i reads lane i+N of its 16-lane row; 0 past the end).
 template <int N>
 __device__ __forceinline__ float row_shl(float v) {
-  int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, false);
+  int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true);
   return __int_as_float(r);
 }
 // value of lane `src` (wave-uniform index) broadcast to every lane

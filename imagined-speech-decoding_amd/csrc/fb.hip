@@ -185,7 +185,10 @@ __device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& 
     O::set(t2, r, (typename O::S)i2[r]);
   }
   if constexpr (std::is_same<VT, float>::value) {
-    // adjacent samples share one v_pk_fma_f32 (unpacked v_fma_f32 issues at half the fp32 peak)
+    // adjacent samples share one v_pk_fma_f32 (unpacked v_fma_f32 issues at half the fp32 peak).
+    // The 64 table scalars are fetched here, after the scan released its 32 matrix SGPRs: hoisted to the top of
+    // the section they do not fit beside them and the compiler spills SGPRs into VGPR lanes.
+    __builtin_amdgcn_sched_barrier(0);
     const f2 T1 = {t1, t1}, T2 = {t2, t2};
 #pragma unroll
     for (int j = 0; j < kL / 2; ++j)
@@ -381,6 +384,8 @@ __device__ __forceinline__ void band_reduce_pairs(const f2 (&vf)[kL / 2], const 
     f2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < kL / 2; ++j) {
+      // the 128 table scalars of a bin do not fit the SGPR file at once: fetch them in two batches of 64
+      if (j == kL / 4) __builtin_amdgcn_sched_barrier(0);
       const f2 pr = vf[j];                                              // samples 2j, 2j+1
       const f2 x0 = __builtin_shufflevector(pr, pr, 0, 0), x1 = __builtin_shufflevector(pr, pr, 1, 1);
       const float2 ca0 = tb[2 * j], cb0 = tb[kL + 2 * j], ca1 = tb[2 * j + 1], cb1 = tb[kL + 2 * j + 1];
