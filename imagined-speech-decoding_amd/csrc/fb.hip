@@ -35,7 +35,8 @@ struct FbSec {                  // constants of one (band, section); wave-unifor
   double hd[kL][2];             // zero-input response seen at the output: row 0 of A^n
   float a1f, a2f;
   float hf[kL][2];
-  float hp[2][kL];              // same table, structure-of-arrays: (h[n], h[n+1]) pairs feed v_pk_fma_f32
+  float hq[2][kL / 2];          // first half of the table, structure-of-arrays (the packed fp32 cascade, below)
+  double N16[4];                // A^16: joins the two 16-sample halves a lane runs side by side in one register pair
 };
 
 struct FbBand {
@@ -67,10 +68,12 @@ template <typename VT> struct VOps;
 template <> struct VOps<float> {
   using S = float;
   static constexpr int NR = 1;
-  // chunk container: 16 register PAIRS, so adjacent samples feed v_pk_fma_f32 without shuffling
+  // chunk container: 16 register PAIRS {sample j, sample j + 16}.  The two 16-sample halves of the chunk are
+  // independent recurrences (zero state each), so the whole cascade runs on v_pk_add/v_pk_fma_f32; the halves
+  // are joined afterwards through A^16 (section<>, below).
   typedef f2 Arr[kL / 2];
-  static __device__ __forceinline__ float at(const Arr& a, int n) { return (n & 1) ? a[n >> 1].y : a[n >> 1].x; }
-  static __device__ __forceinline__ void put(Arr& a, int n, float s) { if (n & 1) a[n >> 1].y = s; else a[n >> 1].x = s; }
+  static __device__ __forceinline__ float at(const Arr& a, int n) { return (n & 16) ? a[n & 15].y : a[n & 15].x; }
+  static __device__ __forceinline__ void put(Arr& a, int n, float s) { if (n & 16) a[n & 15].y = s; else a[n & 15].x = s; }
   static __device__ __forceinline__ float splat(float s) { return s; }
   static __device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
   static __device__ __forceinline__ float get(float v, int) { return v; }
@@ -127,13 +130,31 @@ __device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& 
   constexpr int NR = O::NR;
   const VT na1 = O::splat(-O::a1(sc)), na2 = O::splat(-O::a2(sc));
   VT s1 = O::splat(0), s2 = O::splat(0);
+  [[maybe_unused]] float sA1 = 0.f, sA2 = 0.f;            // fp32 path: final state of the first half (zero start)
+  if constexpr (std::is_same<VT, float>::value) {
+    const f2 NA1 = {na1, na1}, NA2 = {na2, na2};
+    f2 S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
 #pragma unroll
-  for (int n = 0; n < kL; ++n) {
-    const VT x = O::at(v, n);
-    const VT y = x + s1;
-    s1 = O::fma_(na1, y, s2);
-    s2 = O::fma_(na2, y, -x);
-    O::put(v, n, y);
+    for (int j = 0; j < kL / 2; ++j) {
+      const f2 x = v[j];
+      const f2 y = x + S1;
+      S1 = __builtin_elementwise_fma(NA1, y, S2);
+      S2 = __builtin_elementwise_fma(NA2, y, -x);
+      v[j] = y;
+    }
+    sA1 = S1.x; sA2 = S2.x;
+    // state after the whole chunk from a zero start: A^16 sA + sB
+    s1 = (float)fma(sc.N16[0], (double)S1.x, fma(sc.N16[1], (double)S2.x, (double)S1.y));
+    s2 = (float)fma(sc.N16[2], (double)S1.x, fma(sc.N16[3], (double)S2.x, (double)S2.y));
+  } else {
+#pragma unroll
+    for (int n = 0; n < kL; ++n) {
+      const VT x = O::at(v, n);
+      const VT y = x + s1;
+      s1 = O::fma_(na1, y, s2);
+      s2 = O::fma_(na2, y, -x);
+      O::put(v, n, y);
+    }
   }
   double i1[NR], i2[NR];
 #pragma unroll
@@ -185,15 +206,17 @@ __device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& 
     O::set(t2, r, (typename O::S)i2[r]);
   }
   if constexpr (std::is_same<VT, float>::value) {
-    // adjacent samples share one v_pk_fma_f32 (unpacked v_fma_f32 issues at half the fp32 peak).
-    // The 64 table scalars are fetched here, after the scan released its 32 matrix SGPRs: hoisted to the top of
-    // the section they do not fit beside them and the compiler spills SGPRs into VGPR lanes.
+    // incoming state of the second half: A^16 t + sA; both halves then take the same 16-entry table.
+    // The table scalars are fetched here, after the scan released its matrix SGPRs: hoisted to the top of the
+    // section they do not fit beside them and the compiler spills SGPRs into VGPR lanes.
     __builtin_amdgcn_sched_barrier(0);
-    const f2 T1 = {t1, t1}, T2 = {t2, t2};
+    const float u1 = (float)fma(sc.N16[0], i1[0], fma(sc.N16[1], i2[0], (double)sA1));
+    const float u2 = (float)fma(sc.N16[2], i1[0], fma(sc.N16[3], i2[0], (double)sA2));
+    const f2 T1 = {t1, u1}, T2 = {t2, u2};
 #pragma unroll
     for (int j = 0; j < kL / 2; ++j)
-      v[j] = __builtin_elementwise_fma((f2){sc.hp[0][2 * j], sc.hp[0][2 * j + 1]}, T1,
-                                       __builtin_elementwise_fma((f2){sc.hp[1][2 * j], sc.hp[1][2 * j + 1]}, T2, v[j]));
+      v[j] = __builtin_elementwise_fma((f2){sc.hq[0][j], sc.hq[0][j]}, T1,
+                                       __builtin_elementwise_fma((f2){sc.hq[1][j], sc.hq[1][j]}, T2, v[j]));
   } else {
 #pragma unroll
     for (int n = 0; n < kL; ++n)
@@ -386,9 +409,9 @@ __device__ __forceinline__ void band_reduce_pairs(const f2 (&vf)[kL / 2], const 
     for (int j = 0; j < kL / 2; ++j) {
       // the 128 table scalars of a bin do not fit the SGPR file at once: fetch them in two batches of 64
       if (j == kL / 4) __builtin_amdgcn_sched_barrier(0);
-      const f2 pr = vf[j];                                              // samples 2j, 2j+1
+      const f2 pr = vf[j];                                              // samples j, j + 16
       const f2 x0 = __builtin_shufflevector(pr, pr, 0, 0), x1 = __builtin_shufflevector(pr, pr, 1, 1);
-      const float2 ca0 = tb[2 * j], cb0 = tb[kL + 2 * j], ca1 = tb[2 * j + 1], cb1 = tb[kL + 2 * j + 1];
+      const float2 ca0 = tb[j], cb0 = tb[kL + j], ca1 = tb[j + 16], cb1 = tb[kL + j + 16];
       p1 = __builtin_elementwise_fma(x0, (f2){ca0.x, ca0.y}, p1);
       p2 = __builtin_elementwise_fma(x0, (f2){cb0.x, cb0.y}, p2);
       p1 = __builtin_elementwise_fma(x1, (f2){ca1.x, ca1.y}, p1);
@@ -598,8 +621,11 @@ extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections
         sc.hd[k][1] = An[1];
         sc.hf[k][0] = (float)An[0];
         sc.hf[k][1] = (float)An[1];
-        sc.hp[0][k] = (float)An[0];
-        sc.hp[1][k] = (float)An[1];
+        if (k < kL / 2) {
+          sc.hq[0][k] = (float)An[0];
+          sc.hq[1][k] = (float)An[1];
+        }
+        if (k == kL / 2) memcpy(sc.N16, An, sizeof(sc.N16));
         mat2_mul(A, An, An);
       }
       double Mk[4];
