@@ -36,7 +36,7 @@ struct FbSec {                  // constants of one (band, section); wave-unifor
   float a1f, a2f;
   float hf[kL][2];
   float hq[2][kL / 2];          // first half of the table, structure-of-arrays (the packed fp32 cascade, below)
-  double N16[4];                // A^16: joins the two 16-sample halves a lane runs side by side in one register pair
+  float N16f[4];                // A^16: joins the two 16-sample halves a lane runs side by side in one register pair
 };
 
 struct FbBand {
@@ -144,8 +144,8 @@ __device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& 
     }
     sA1 = S1.x; sA2 = S2.x;
     // state after the whole chunk from a zero start: A^16 sA + sB
-    s1 = (float)fma(sc.N16[0], (double)S1.x, fma(sc.N16[1], (double)S2.x, (double)S1.y));
-    s2 = (float)fma(sc.N16[2], (double)S1.x, fma(sc.N16[3], (double)S2.x, (double)S2.y));
+    s1 = fmaf(sc.N16f[0], S1.x, fmaf(sc.N16f[1], S2.x, S1.y));
+    s2 = fmaf(sc.N16f[2], S1.x, fmaf(sc.N16f[3], S2.x, S2.y));
   } else {
 #pragma unroll
     for (int n = 0; n < kL; ++n) {
@@ -210,8 +210,8 @@ __device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& 
     // The table scalars are fetched here, after the scan released its matrix SGPRs: hoisted to the top of the
     // section they do not fit beside them and the compiler spills SGPRs into VGPR lanes.
     __builtin_amdgcn_sched_barrier(0);
-    const float u1 = (float)fma(sc.N16[0], i1[0], fma(sc.N16[1], i2[0], (double)sA1));
-    const float u2 = (float)fma(sc.N16[2], i1[0], fma(sc.N16[3], i2[0], (double)sA2));
+    const float u1 = fmaf(sc.N16f[0], t1, fmaf(sc.N16f[1], t2, sA1));
+    const float u2 = fmaf(sc.N16f[2], t1, fmaf(sc.N16f[3], t2, sA2));
     const f2 T1 = {t1, u1}, T2 = {t2, u2};
 #pragma unroll
     for (int j = 0; j < kL / 2; ++j)
@@ -625,7 +625,8 @@ extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections
           sc.hq[0][k] = (float)An[0];
           sc.hq[1][k] = (float)An[1];
         }
-        if (k == kL / 2) memcpy(sc.N16, An, sizeof(sc.N16));
+        if (k == kL / 2)
+          for (int e = 0; e < 4; ++e) sc.N16f[e] = (float)An[e];
         mat2_mul(A, An, An);
       }
       double Mk[4];
