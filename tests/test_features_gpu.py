@@ -137,6 +137,24 @@ def test_extract_features_matches_scipy_golden(isd, tag, bands, fused):
     np.testing.assert_allclose(feat.cpu().numpy(), g[f"{tag}_feat"], rtol=0, atol=TOL_FEAT)
 
 
+@pytest.mark.parametrize("T,fs", [(250, 250.0), (512, 256.0)])
+def test_features_relative_tolerance_on_near_silent_frames(isd, T, fs):
+    """North-star gate: features within 1e-4 relative.  Frames that hold almost no in-band power (the last frames of
+    a short trial: P six orders below the row's typical power) are where the fp32 cascade's absolute noise shows in
+    the log domain; the relative bound must hold there too, and the plain 1e-4 log-domain bound wherever the power
+    is within four orders of typical."""
+    X, _ = odsp.synth_trials(6, 64, T, fs, seed=3)
+    ref = odsp.extract_features_scipy(X, fs=fs, bands=odsp.BANDS_9).astype(np.float64)
+    got = isd.extract_features(dev(X), fs=fs, bands=odsp.BANDS_9).cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref)
+    assert (err <= 1e-4 * np.maximum(1.0, np.abs(ref))).all()
+    typical = np.median(ref, axis=-1, keepdims=True)
+    loud = ref > typical - np.log(1e4)
+    assert err[loud].max() < TOL_FEAT
+    got64 = isd.extract_features(dev(X), fs=fs, bands=odsp.BANDS_9, precision="f64").cpu().numpy()
+    assert np.abs(got64 - ref).max() < 3e-5                      # fp64 cascade: fp32 DFT noise only
+
+
 def test_extract_features_numpy_in_numpy_out(isd):
     x = np.random.default_rng(5).standard_normal((2, 4, 512)).astype(np.float32)
     f = isd.extract_features(x, fs=256.0, bands=odsp.BANDS_9)

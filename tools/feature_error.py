@@ -19,5 +19,22 @@ def main():
                 err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
                 print(f"{name:14s} precision={prec:4s} fused={fused!s:5s} max|dlog|={err.max():.3e} mean={err.mean():.3e}")
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def worst(T=250, fs=250.0, bands=isd_amd.BANDS_9, prec="f32"):
+    """Where the largest log-domain differences sit (band, frame, reference value)."""
+    X, _ = dsp.synth_trials(6, 64, T, fs, seed=3)
+    ref = dsp.extract_features_scipy(X, fs=fs, bands=bands).astype(np.float64)
+    got = isd_amd.FeatureExtractor(T, fs, bands, precision=prec)(torch.from_numpy(X).cuda(), fused=True).cpu().numpy()
+    err = np.abs(got - ref)
+    for flat in np.argsort(err.ravel())[::-1][:8]:
+        b, band, ch, j = np.unravel_index(flat, err.shape)
+        print(f"trial {b} band {band} ch {ch} frame {j}/{err.shape[-1]}: ref log P = {ref[b, band, ch, j]:.4f} "
+              f"(typical {np.median(ref[b, band, ch]):.2f}), |dlog| = {err[b, band, ch, j]:.2e}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "worst":
+    worst()
+    worst(512, 256.0)
