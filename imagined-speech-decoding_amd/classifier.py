@@ -237,11 +237,13 @@ class Trainer:
         flat = model.flat_params()
         gflat = model.flat_grads()
         self.flat, self.flat_grad = flat, gflat
-        # The optimizer sees the flat block as 8 equal views (AdamW is elementwise with uniform hyper-parameters,
-        # so this equals per-tensor AdamW).  Measured with torch's fused multi-tensor AdamW on 111 k floats
-        # (tools/adamw_probe.py): 1 view 59 us/step, 8 views 35 us, 16 views 43 us, 64 views 98 us (host-bound).
+        # The optimizer sees the flat block as ~64 equal views (AdamW is elementwise with uniform
+        # hyper-parameters, so this equals per-tensor AdamW); more views = more blocks in torch's
+        # fused multi-tensor kernel than one 100k-element tensor would get.  Measured inside the step (rocprofv3):
+        # 64 views = 2 launches x 18 us of GPU time; 8 views = one launch of 96 us (8 blocks).  The host side of
+        # opt.step() (~100 us with 64 views, tools/adamw_probe.py) runs under the previous kernels.
         n = flat.numel()
-        step = max(1024, -(-n // 8))
+        step = max(1024, -(-n // 64))
         self.chunks = []
         for lo in range(0, n, step):
             p = nn.Parameter(flat[lo:lo + step])

@@ -83,21 +83,31 @@ __global__ __launch_bounds__(256) void prep_fused_kernel(const float* __restrict
   const float* W1 = params + zd.p_off;                 // [F][5]
   const float* b1 = W1 + F * kTaps;                    // [F]
   const float* W2 = b1 + F;                            // [F][F][Cz]
-  const int total = ncg * kTaps * GT * 64;
-  if ((int)blockIdx.x < nbw) {                         // one thread per fragment element
+  if ((int)blockIdx.x < nbw) {
+    // one thread per (filter g, channel c), lanes along c: every W2 load of a wave is one coalesced row segment;
+    // the thread forms all 5 taps and scatters them into the fragment order
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const int lane = e & 63;
-    const int blk = e >> 6;
-    const int gt = blk % GT;
-    const int k = (blk / GT) % kTaps;
-    const int cg = blk / (GT * kTaps);
-    const int g = gt * 16 + (lane & 15);
-    const int c = cg * 4 + (lane >> 4);
-    float acc = 0.f;
-    if (c < zd.cin)
-      for (int f = 0; f < F; ++f) acc = fmaf(W2[(g * F + f) * zd.cin + c], W1[f * kTaps + k], acc);
-    wfrag[zd.eff_off + e] = bf16 ? bf16_round(acc) : acc;
+    const int c4 = ncg * 4;
+    if (e >= F * c4) return;
+    const int g = e / c4, c = e - g * c4;
+    float acc[kTaps];
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) acc[k] = 0.f;
+    if (c < zd.cin) {
+      const float* w2 = W2 + (int64_t)g * F * zd.cin + c;
+#pragma unroll 16
+      for (int f = 0; f < F; ++f) {
+        const float w = w2[(int64_t)f * zd.cin];
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) acc[k] = fmaf(w, W1[f * kTaps + k], acc[k]);
+      }
+    }
+    const int cg = c >> 2, lane = (c & 3) * 16 + (g & 15), gt = g >> 4;
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+      const float v = acc[k];
+      wfrag[zd.eff_off + ((int64_t)(cg * kTaps + k) * GT + gt) * 64 + lane] = bf16 ? bf16_round(v) : v;
+    }
     return;
   }
   const int g = blockIdx.x - nbw;                      // one block per beff[g]
@@ -1377,7 +1387,7 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
   float* ws = (float*)workspace;
   const int F = p->F;
   {
-    const int nbw = (int)cdiv(((int64_t)(p->max_cz + 3) / 4) * kTaps * (F / 16) * 64, 256);
+    const int nbw = (int)cdiv(((int64_t)(p->max_cz + 3) / 4) * 4 * F, 256);
     hipLaunchKernelGGL(prep_fused_kernel, dim3(nbw + F, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_eff,
                        ws + g.o_beff, F, nbw, p->act_bf16);
     ISD_LAUNCH_CHECK();
