@@ -113,7 +113,13 @@ __global__ __launch_bounds__(256) void prep_fused_kernel(const float* __restrict
   const int g = blockIdx.x - nbw;                      // one block per beff[g]
   if (g >= F) return;
   float s = 0.f;
-  for (int e = threadIdx.x; e < F * zd.cin; e += 256) s = fmaf(W2[(int64_t)g * F * zd.cin + e], b1[e / zd.cin], s);
+  {
+    const float* w2 = W2 + (int64_t)g * F * zd.cin;
+    for (int c = threadIdx.x; c < zd.cin; c += 256) {      // independent loads, no division: they pipeline
+#pragma unroll 8
+      for (int f = 0; f < F; ++f) s = fmaf(w2[(int64_t)f * zd.cin + c], b1[f], s);
+    }
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
@@ -1119,15 +1125,15 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
   float s = 0.f;
   if (o < F * kTaps) {
     const int f = o / kTaps, k = o - f * kTaps;
-    for (int e = threadIdx.x; e < F * cz; e += 256) {
-      const int g = e / cz, c = e - g * cz;
-      s = fmaf(dWe[(g * cin1 + c) * kTaps + k], W2[(g * F + f) * cz + c], s);
+    for (int c = threadIdx.x; c < cz; c += 256) {            // independent loads, no division: they pipeline
+#pragma unroll 8
+      for (int g = 0; g < F; ++g) s = fmaf(dWe[(g * cin1 + c) * kTaps + k], W2[((int64_t)g * F + f) * cz + c], s);
     }
   } else {
     const int f = o - F * kTaps;
-    for (int e = threadIdx.x; e < F * cz; e += 256) {
-      const int g = e / cz, c = e - g * cz;
-      s = fmaf(dWe[(g * cin1 + cz) * kTaps], W2[(g * F + f) * cz + c], s);
+    for (int c = threadIdx.x; c < cz; c += 256) {
+#pragma unroll 8
+      for (int g = 0; g < F; ++g) s = fmaf(dWe[(g * cin1 + cz) * kTaps], W2[((int64_t)g * F + f) * cz + c], s);
     }
   }
   red[threadIdx.x] = s;
