@@ -704,6 +704,219 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
 }
 
 // ---------------------------------------------------------------------------------------
+// Fused backward of one (window, zone) item for the reference-native shape (companion of conv4_fused_fwd_kernel):
+//   G4 = dfeat/T1 * GELU'(A4);  dW4 += G4 (*) A3;  G3 = W4^T (*) G4;  dW3 += G3 (*) A2;  G2 = W3^T (*) G3;
+//   dWeff += G2 (*) x,  dbeff += sum_t G2.
+// The gradient tiles G4/G3/G2 live only in LDS (two alternating [32][T1] tiles), A3 / A2 are staged by LDS-DMA
+// into a third tile, A4 is consumed straight from global memory, and the transposed cnn3/cnn4 fragments stay in
+// LDS for the whole (persistent) launch.  HBM traffic per item: three activation reads + the zone's x rows
+// (the layer-wise backward moved 11 tile-sized reads / writes).  Every weight gradient accumulates in registers
+// across all items of the workgroup (a wave owns one 16-channel tile x both filter tiles x 5 taps and a share
+// of the time steps) and leaves as one partial slab per wave at the end.
+// ---------------------------------------------------------------------------------------
+struct FusedBwdArgs {
+  const float* x;            // raw trials [B][Ctot][Tx]
+  const float* dfeat;        // [items][Z][F]
+  const float* a2;           // saved activations [items][Z][F][T1]
+  const float* a3;
+  const float* a4;
+  const float* w3t;          // frag-ordered transposed + flipped cnn3 / cnn4 weights, [Z][conv_zstride]
+  const float* w4t;
+  float* part4;              // [gridDim.x * 4][slab1]   slab1 = Z*F*F*5, zone block at z*F*F*5, natural [g][c][k]
+  float* part3;
+  float* part0;              // [gridDim.x * NW][slab0]  dWeff blocks at ZoneDesc::wg_off, [g][cz+1][k]
+  const ZoneDesc* zones;
+  const int* chan_idx;
+  int64_t wz_stride, items, slab1, slab0;
+  int Z, W, T1, TT;
+  int Ctot, Tx, N, S;
+};
+
+// acc[gt][k] += sum over this wave's time steps of G[gt*16 + row][t] * In[col][t + k - pad]   (MFMA: M = filter,
+// N = channel, K = 4 time steps).  Steps first, first + stride, ... < nks; fragments of the next step are fetched
+// from LDS while the MFMAs of the current one run.  `accb` (optional) takes an all-ones B operand: sum_t G.
+template <bool BIAS>
+__device__ __forceinline__ void fused_wgrad_mma(const float* __restrict__ G, const float* __restrict__ In, int T1,
+                                                int RSi, int Tin, int pad, int first, int stride, int nks, int q,
+                                                int jl, f32x4 (&acc)[2][kTaps], f32x4 (&accb)[2]) {
+  struct Frag {
+    float a[2];
+    float b[kTaps];
+    float one;
+  };
+  const float* gr = G + jl * T1 + q;
+  const float* ir = In + jl * RSi + q - pad;
+  auto load = [&](int s, Frag& f) {
+    const int t0 = s * 4, t = t0 + q;
+    const bool ok = t < T1;
+    const float v0 = gr[ok ? t0 : 0], v1 = gr[16 * T1 + (ok ? t0 : 0)];
+    f.a[0] = ok ? v0 : 0.f;
+    f.a[1] = ok ? v1 : 0.f;
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+      const int idx = t + k - pad;
+      const bool in = ok && idx >= 0 && idx < Tin;
+      const float v = ir[in ? t0 + k : pad];
+      f.b[k] = in ? v : 0.f;
+    }
+    f.one = ok ? 1.f : 0.f;
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+      acc[0][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[0], f.b[k], acc[0][k], 0, 0, 0);
+      acc[1][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[1], f.b[k], acc[1][k], 0, 0, 0);
+    }
+    if (BIAS) {
+      accb[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[0], f.one, accb[0], 0, 0, 0);
+      accb[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[1], f.one, accb[1], 0, 0, 0);
+    }
+  };
+  Frag f0, f1;
+  if (first < nks) load(first, f0);
+  for (int s = first; s < nks; s += 2 * stride) {
+    if (s + stride < nks) load(s + stride, f1);
+    mma(f0);
+    if (s + stride < nks) {
+      if (s + 2 * stride < nks) load(s + 2 * stride, f0);
+      mma(f1);
+    }
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a) {
+  static_assert(NW == 8, "wave roles below assume 8 waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int F = 32;
+  const int z = blockIdx.y;
+  const ZoneDesc zd = a.zones[z];
+  const int cz = zd.cin, cin1 = cz + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
+  const int T1 = a.T1, W = a.W, TT = a.TT;
+  const int tile = (F * T1 + 3) & ~3;
+  float* xz = smem + 4;                              // [16][W]
+  float* ga = smem + ((4 + 16 * W + 3) & ~3) + 4;    // [32][T1]  (4 floats of slack before each tile: pad-2 reads)
+  float* gb = ga + tile + 4;                         // [32][T1]
+  float* at = gb + tile + 4;                         // [32][T1]  staged activation (A3, then A2)
+  float* w4s = at + tile + 4;                        // [8][5][2][64] transposed + flipped cnn4 fragments
+  float* w3s = w4s + 8 * kTaps * 2 * 64;
+  float* dfs = w3s + 8 * kTaps * 2 * 64;             // [32] dfeat of the item / T1
+  for (int e = threadIdx.x; e < 8 * kTaps * 2 * 64; e += NW * 64) {
+    w4s[e] = a.w4t[(int64_t)z * a.wz_stride + e];
+    w3s[e] = a.w3t[(int64_t)z * a.wz_stride + e];
+  }
+  for (int e = cz * W + threadIdx.x; e < 16 * W; e += NW * 64) xz[e] = 0.f;   // channel round-up rows stay zero
+  constexpr int NJ = 16 / NW;
+  int off2[NJ];
+  bool ok2[NJ][kTaps];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int tt = (j * NW + wave) < TT ? (j * NW + wave) : 0;
+    off2[j] = tt * 16 + jl - 2;
+#pragma unroll
+    for (int kk = 0; kk < kTaps; ++kk) ok2[j][kk] = off2[j] + kk >= 0 && off2[j] + kk < T1;
+  }
+  // weight-gradient roles: cnn3/cnn4: channel tile = wave & 1, time share = wave >> 1 (of 4); Weff: time share = wave (of 8)
+  const int ct = wave & 1, ks = wave >> 1;
+  const int nks = (T1 + 3) >> 2;
+  f32x4 acc4[2][kTaps], acc3[2][kTaps], acc0[2][kTaps], accb[2], nob[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    accb[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    nob[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+      acc4[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc3[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc0[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const int n4 = (F * T1) >> 2;
+
+  for (int64_t item = blockIdx.x; item < a.items; item += gridDim.x) {
+    const int64_t b = item / a.N;
+    const int n = (int)(item - b * a.N);
+    const int64_t abase = (item * a.Z + z) * (int64_t)(F * T1);
+    __syncthreads();                                   // the previous item's tiles are no longer read
+    glds_copy16_strided(a.a3 + abase, at, n4, wave * 64, NW * 64, lane);
+    for (int r = wave; r < cz; r += NW) {
+      const float* src = a.x + (b * a.Ctot + a.chan_idx[zd.idx_off + r]) * (int64_t)a.Tx + (int64_t)n * a.S;
+      for (int t0 = 0; t0 < W; t0 += 64)
+        if (t0 + lane < W)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + t0 + lane), (lds_ptr_t)(xz + r * W + t0), 4, 0, 0);
+    }
+    if (threadIdx.x < F) dfs[threadIdx.x] = a.dfeat[(item * a.Z + z) * F + threadIdx.x] / (float)T1;
+    __syncthreads();                                   // dfs visible (also retires the DMA issued above)
+    {
+      // G4 = dfeat/T1 * GELU'(A4), straight from global memory into the first gradient tile
+      const float4* a4 = reinterpret_cast<const float4*>(a.a4 + abase);
+      float4* dst = reinterpret_cast<float4*>(ga);
+      for (int e = threadIdx.x; e < n4; e += NW * 64) {
+        const float4 v = a4[e];
+        const int g0 = (e * 4) / T1, g3 = (e * 4 + 3) / T1;
+        float4 o;
+        if (g0 == g3) {
+          const float d = dfs[g0];
+          o = make_float4(d * gelu_grad_f(v.x), d * gelu_grad_f(v.y), d * gelu_grad_f(v.z), d * gelu_grad_f(v.w));
+        } else {
+          o = make_float4(dfs[(e * 4) / T1] * gelu_grad_f(v.x), dfs[(e * 4 + 1) / T1] * gelu_grad_f(v.y),
+                          dfs[(e * 4 + 2) / T1] * gelu_grad_f(v.z), dfs[g3] * gelu_grad_f(v.w));
+        }
+        dst[e] = o;
+      }
+    }
+    __syncthreads();                                   // G4, A3 and the x rows are in LDS
+    // ---------------- cnn4: dW4 += G4 (*) A3 ; G3 = W4^T (*) G4 -> gb
+    fused_wgrad_mma<false>(ga, at + ct * 16 * T1, T1, T1, T1, 2, ks, 4, nks, q, jl, acc4, nob);
+    {
+      f32x4 acc[NJ][2];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      fused_conv_mma<NJ>(w4s + lane, ga + q * T1, T1, 8, off2, ok2, acc);
+      fused_layer_store<NW>(acc, nullptr, gb, T1, TT, wave, q, jl);
+    }
+    __syncthreads();                                   // G3 complete; A3 and G4 are dead
+    glds_copy16_strided(a.a2 + abase, at, n4, wave * 64, NW * 64, lane);
+    // ---------------- cnn3 data gradient first (does not need A2): G2 = W3^T (*) G3 -> ga
+    {
+      f32x4 acc[NJ][2];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      fused_conv_mma<NJ>(w3s + lane, gb + q * T1, T1, 8, off2, ok2, acc);
+      fused_layer_store<NW>(acc, nullptr, ga, T1, TT, wave, q, jl);
+    }
+    __syncthreads();                                   // G2 complete, A2 landed
+    fused_wgrad_mma<false>(gb, at + ct * 16 * T1, T1, T1, T1, 2, ks, 4, nks, q, jl, acc3, nob);
+    // ---------------- cnn1 o cnn2: dWeff += G2 (*) x (valid convolution), dbeff += sum_t G2
+    fused_wgrad_mma<true>(ga, xz, T1, W, W, 0, wave, NW, nks, q, jl, acc0, accb);
+  }
+  // ---------------- partial slabs
+  {
+    float* s4 = a.part4 + ((int64_t)blockIdx.x * 4 + ks) * a.slab1 + (int64_t)z * F * F * kTaps;
+    float* s3 = a.part3 + ((int64_t)blockIdx.x * 4 + ks) * a.slab1 + (int64_t)z * F * F * kTaps;
+    float* s0 = a.part0 + ((int64_t)blockIdx.x * NW + wave) * a.slab0 + zd.wg_off;
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int g = gt * 16 + 4 * q + r, c = ct * 16 + jl;
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) {
+          s4[((int64_t)g * F + c) * kTaps + k] = acc4[gt][k][r];
+          s3[((int64_t)g * F + c) * kTaps + k] = acc3[gt][k][r];
+          if (jl < cz) s0[((int64_t)g * cin1 + jl) * kTaps + k] = acc0[gt][k][r];
+        }
+        if (jl < kTaps) s0[((int64_t)g * cin1 + cz) * kTaps + jl] = jl == 0 ? accb[gt][r] : 0.f;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // GELU + mean over time (fast.py:117-118) and its backward (in place on the activation).
 // one 16-lane row per (item, zone, filter) row of length T
 // ---------------------------------------------------------------------------------------
@@ -1337,7 +1550,11 @@ int make_geo(const isd_conv4_plan* p, int64_t B, int64_t T, Geo& g) {
   plan_wg(p->F, g.cw1, g.ipw1, g.ns1, g.grp1);
   g.slab0 = p->wg_size;
   const int64_t pa = (int64_t)g.ns0 * g.slab0, pb = (p->n_layers == 4) ? (int64_t)g.ns1 * g.slab1 : 0;
-  g.o_part = o; o += align_up(pa > pb ? pa : pb, 64);
+  // fused backward (reference-native shape): one workgroup row of max(1, 256/Z) per zone, 4 + 4 + 8 slabs each
+  const int64_t rz = 256 / p->Z > 1 ? 256 / p->Z : 1;
+  const int64_t pf = (p->n_layers == 4) ? rz * (8 * g.slab1 + 8 * g.slab0) : 0;
+  const int64_t pmax = pa > pb ? pa : pb;
+  g.o_part = o; o += align_up(pmax > pf ? pmax : pf, 64);
   g.total = o;
   return ISD_OK;
 }
@@ -1546,6 +1763,42 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
   float* ws = (float*)workspace;
   const int F = p->F;
   const int64_t rows = g.items * p->Z * F;
+  if (p->n_layers == 4 && F == 32 && !p->act_bf16 && p->max_cz <= 16 && g.TT <= 16 && (F * g.T1) % 4 == 0 &&
+      g.TT >= 4) {
+    // reference-native shape: one persistent fused kernel; gradient tiles stay in LDS, weight gradients in registers
+    constexpr int NW = 8;
+    const int tile = ((F * g.T1 + 3) & ~3) + 4;
+    const size_t lds = sizeof(float) * (size_t)(((4 + 16 * p->W + 3) & ~3) + 4 + 3 * tile + 2 * 8 * kTaps * 2 * 64 + 32 + 16);
+    if (lds <= 160 * 1024) {
+      int per_zone = 256 / p->Z;
+      if (per_zone < 1) per_zone = 1;
+      if (per_zone > g.items) per_zone = (int)g.items;
+      FusedBwdArgs fb = {};
+      fb.x = x; fb.dfeat = dfeat; fb.a2 = ws + g.o_a2; fb.a3 = ws + g.o_a3; fb.a4 = ws + g.o_a4;
+      fb.w3t = ws + g.o_w3t; fb.w4t = ws + g.o_w4t;
+      fb.part4 = ws + g.o_part;
+      fb.part3 = fb.part4 + (int64_t)per_zone * 4 * g.slab1;
+      fb.part0 = fb.part3 + (int64_t)per_zone * 4 * g.slab1;
+      fb.zones = p->d_zones; fb.chan_idx = p->d_idx; fb.wz_stride = p->conv_zstride; fb.items = g.items;
+      fb.slab1 = g.slab1; fb.slab0 = g.slab0;
+      fb.Z = p->Z; fb.W = p->W; fb.T1 = g.T1; fb.TT = g.TT;
+      fb.Ctot = p->Ctot; fb.Tx = (int)T; fb.N = g.N; fb.S = p->S;
+      ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv4_fused_bwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+      hipLaunchKernelGGL((conv4_fused_bwd_kernel<NW>), dim3(per_zone, p->Z), dim3(NW * 64), lds, st, fb);
+      ISD_LAUNCH_CHECK();
+      launch_reduce_slabs(fb.part4, ws + g.o_wg34, g.slab1, per_zone * 4, st);
+      hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 1);
+      launch_reduce_slabs(fb.part3, ws + g.o_wg34, g.slab1, per_zone * 4, st);
+      hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 0);
+      launch_reduce_slabs(fb.part0, ws + g.o_wg, g.slab0, per_zone * NW, st);
+      const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
+      hipLaunchKernelGGL(fused_bwd_kernel, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,
+                         ws + g.o_wg, dparams, F, nb2);
+      ISD_LAUNCH_CHECK();
+      return ISD_OK;
+    }
+  }
   float* top = ws + (p->n_layers == 4 ? g.o_a4 : g.o_a2);        // activation that fed GELU
   if (p->act_bf16)
     hipLaunchKernelGGL((gelu_mean_bwd_kernel<bf16_t>), dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, top,
