@@ -508,7 +508,7 @@ struct FusedFwdArgs {
   const ZoneDesc* zones;
   const int* chan_idx;
   int64_t wz_stride, items;
-  int Z, W, T1, TT, store;
+  int Z, W, T1, TT, store;   // store: 0 inference, 1 keep A2/A3/A4, 2 keep A2/A3 and GELU'(A4) (fused backward)
   int Ctot, Tx, N, S;
 };
 
@@ -560,7 +560,7 @@ __device__ __forceinline__ void fused_conv_mma(const float* __restrict__ wl, con
   }
 }
 
-template <int NW>
+template <int NW, bool DGELU = false>
 __device__ __forceinline__ void fused_layer_store(const f32x4 (&acc)[16 / NW][2], const float* __restrict__ bias,
                                                   float* __restrict__ tile, int T1, int TT, int wave, int q, int jl) {
 #pragma unroll
@@ -574,7 +574,8 @@ __device__ __forceinline__ void fused_layer_store(const f32x4 (&acc)[16 / NW][2]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int g = gt * 16 + 4 * q + r;
-        tile[g * T1 + t] = acc[j][gt][r] + (bias ? bias[g] : 0.f);
+        const float v = acc[j][gt][r] + (bias ? bias[g] : 0.f);
+        tile[g * T1 + t] = DGELU ? gelu_grad_f(v) : v;
       }
   }
 }
@@ -662,7 +663,9 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     fused_conv_mma<NJ>(w4s + lane, t3 + q * T1, T1, 8, off2, ok2, acc);
-    if (a.store) fused_layer_store<NW>(acc, nullptr, t2, T1, TT, wave, q, jl);   // t2 is free: stage A4 for the store
+    // t2 is free: stage A4 for the store -- or GELU'(A4), all the fused backward needs of it (store == 2)
+    if (a.store == 2) fused_layer_store<NW, true>(acc, nullptr, t2, T1, TT, wave, q, jl);
+    else if (a.store) fused_layer_store<NW>(acc, nullptr, t2, T1, TT, wave, q, jl);
     float part[2][4];
 #pragma unroll
     for (int gt = 0; gt < 2; ++gt)
@@ -719,7 +722,7 @@ struct FusedBwdArgs {
   const float* dfeat;        // [items][Z][F]
   const float* a2;           // saved activations [items][Z][F][T1]
   const float* a3;
-  const float* a4;
+  const float* a4;           // GELU'(A4) (the forward ran with store == 2)
   const float* w3t;          // frag-ordered transposed + flipped cnn3 / cnn4 weights, [Z][conv_zstride]
   const float* w4t;
   float* part4;              // [gridDim.x * 4][slab1]   slab1 = Z*F*F*5, zone block at z*F*F*5, natural [g][c][k]
@@ -746,8 +749,22 @@ __device__ __forceinline__ void fused_wgrad_mma(const float* __restrict__ G, con
   };
   const float* gr = G + jl * T1 + q;
   const float* ir = In + jl * RSi + q - pad;
+  // interior steps touch only valid samples for every lane and tap: plain reads at immediate offsets; the
+  // (at most three) edge steps take the masked path.  The choice is wave-uniform and sits in the load phase.
+  const int s_lo = (pad + 3) >> 2;                                   // first step with 4s - pad >= 0
+  const int t_hi = (T1 < Tin + pad - kTaps + 1 ? T1 : Tin + pad - kTaps + 1);   // t + 4 - pad < Tin and t < T1
+  const int s_hi = t_hi >> 2;                                        // steps s < s_hi have 4s + 3 < t_hi
   auto load = [&](int s, Frag& f) {
-    const int t0 = s * 4, t = t0 + q;
+    const int t0 = s * 4;
+    if (s >= s_lo && s < s_hi) {
+      f.a[0] = gr[t0];
+      f.a[1] = gr[16 * T1 + t0];
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k) f.b[k] = ir[t0 + k];
+      f.one = 1.f;
+      return;
+    }
+    const int t = t0 + q;
     const bool ok = t < T1;
     const float v0 = gr[ok ? t0 : 0], v1 = gr[16 * T1 + (ok ? t0 : 0)];
     f.a[0] = ok ? v0 : 0.f;
@@ -839,6 +856,7 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a
     const int n = (int)(item - b * a.N);
     const int64_t abase = (item * a.Z + z) * (int64_t)(F * T1);
     __syncthreads();                                   // the previous item's tiles are no longer read
+    glds_copy16_strided(a.a4 + abase, ga, n4, wave * 64, NW * 64, lane);      // GELU'(A4), stored by the forward
     glds_copy16_strided(a.a3 + abase, at, n4, wave * 64, NW * 64, lane);
     for (int r = wave; r < cz; r += NW) {
       const float* src = a.x + (b * a.Ctot + a.chan_idx[zd.idx_off + r]) * (int64_t)a.Tx + (int64_t)n * a.S;
@@ -847,23 +865,20 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a
           __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + t0 + lane), (lds_ptr_t)(xz + r * W + t0), 4, 0, 0);
     }
     if (threadIdx.x < F) dfs[threadIdx.x] = a.dfeat[(item * a.Z + z) * F + threadIdx.x] / (float)T1;
-    __syncthreads();                                   // dfs visible (also retires the DMA issued above)
+    __syncthreads();                                   // the three copies have landed, dfs is visible
     {
-      // G4 = dfeat/T1 * GELU'(A4), straight from global memory into the first gradient tile
-      const float4* a4 = reinterpret_cast<const float4*>(a.a4 + abase);
-      float4* dst = reinterpret_cast<float4*>(ga);
+      // G4 = dfeat/T1 * GELU'(A4): scale the rows of the tile in place
+      float4* gt4 = reinterpret_cast<float4*>(ga);
       for (int e = threadIdx.x; e < n4; e += NW * 64) {
-        const float4 v = a4[e];
+        float4 v = gt4[e];
         const int g0 = (e * 4) / T1, g3 = (e * 4 + 3) / T1;
-        float4 o;
         if (g0 == g3) {
           const float d = dfs[g0];
-          o = make_float4(d * gelu_grad_f(v.x), d * gelu_grad_f(v.y), d * gelu_grad_f(v.z), d * gelu_grad_f(v.w));
+          v.x *= d; v.y *= d; v.z *= d; v.w *= d;
         } else {
-          o = make_float4(dfs[(e * 4) / T1] * gelu_grad_f(v.x), dfs[(e * 4 + 1) / T1] * gelu_grad_f(v.y),
-                          dfs[(e * 4 + 2) / T1] * gelu_grad_f(v.z), dfs[g3] * gelu_grad_f(v.w));
+          v.x *= dfs[g0]; v.y *= dfs[(e * 4 + 1) / T1]; v.z *= dfs[(e * 4 + 2) / T1]; v.w *= dfs[g3];
         }
-        dst[e] = o;
+        gt4[e] = v;
       }
     }
     __syncthreads();                                   // G4, A3 and the x rows are in LDS
@@ -1597,6 +1612,12 @@ static int launch_conv(int mode, int bf16, const ConvArgs& a, int n_zones, hipSt
   return ISD_OK;
 }
 
+// LDS bytes of conv4_fused_bwd_kernel<8>; the forward keeps GELU'(A4) instead of A4 exactly when this fits
+static size_t fused_bwd_lds(const isd_conv4_plan* p, const Geo& g) {
+  const int tile = ((p->F * g.T1 + 3) & ~3) + 4;
+  return sizeof(float) * (size_t)(((4 + 16 * p->W + 3) & ~3) + 4 + 3 * tile + 2 * 8 * kTaps * 2 * 64 + 32 + 16);
+}
+
 extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const float* params, float* feat,
                                  void* workspace, int64_t B, int64_t T, void* stream) {
   ISD_CHECK_ARG(p, "isd_conv4_forward: null plan");
@@ -1629,7 +1650,7 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
     fa.x = x; fa.weff = ws + g.o_eff; fa.beff = ws + g.o_beff; fa.w3 = ws + g.o_w3; fa.w4 = ws + g.o_w4;
     fa.a2 = ws + g.o_a2; fa.a3 = ws + g.o_a3; fa.a4 = ws + g.o_a4; fa.feat = feat;
     fa.zones = p->d_zones; fa.chan_idx = p->d_idx; fa.wz_stride = p->conv_zstride; fa.items = g.items;
-    fa.Z = p->Z; fa.W = p->W; fa.T1 = g.T1; fa.TT = g.TT; fa.store = 1;
+    fa.Z = p->Z; fa.W = p->W; fa.T1 = g.T1; fa.TT = g.TT; fa.store = fused_bwd_lds(p, g) <= 160 * 1024 ? 2 : 1;
     fa.Ctot = p->Ctot; fa.Tx = (int)T; fa.N = g.N; fa.S = p->S;
     constexpr int NW = 8;   // measured after the prefetch restructure (B=4096, T=512): 8 waves 25.6 ms/step, 16 waves 25.6, 4 waves 28.3
     const size_t lds = sizeof(float) * (size_t)(4 + ((16 * p->W + 3) & ~3) + 2 * ((F * g.T1 + 3) & ~3) + NW * F +
@@ -1767,9 +1788,10 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
       g.TT >= 4) {
     // reference-native shape: one persistent fused kernel; gradient tiles stay in LDS, weight gradients in registers
     constexpr int NW = 8;
-    const int tile = ((F * g.T1 + 3) & ~3) + 4;
-    const size_t lds = sizeof(float) * (size_t)(((4 + 16 * p->W + 3) & ~3) + 4 + 3 * tile + 2 * 8 * kTaps * 2 * 64 + 32 + 16);
-    if (lds <= 160 * 1024) {
+    const size_t lds = fused_bwd_lds(p, g);
+    const size_t lds_fwd = sizeof(float) * (size_t)(4 + ((16 * p->W + 3) & ~3) + 2 * ((F * g.T1 + 3) & ~3) + 8 * F +
+                                                     (4 + 8 + 8) * kTaps * 2 * 64 + 64);
+    if (lds <= 160 * 1024 && lds_fwd <= 150 * 1024) {     // the forward of this step ran fused and kept GELU'(A4)
       int per_zone = 256 / p->Z;
       if (per_zone < 1) per_zone = 1;
       if (per_zone > g.items) per_zone = (int)g.items;

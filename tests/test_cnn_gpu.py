@@ -134,6 +134,24 @@ def test_head_matches_oracle_on_reference_zones(inn):
     assert [v.tolist() for v in h.index_dict.values()] == ocnn.zone_index_lists()
 
 
+def test_head_production_shape_gradients_vs_oracle(inn):
+    """Reference zones, F = 32, 250-sample windows sliding by 125: the shape the fused forward / fused backward
+    kernels serve.  Features and every parameter gradient against fp64 autograd over the oracle."""
+    import isd_amd
+    torch.manual_seed(11)
+    h = inn.Head("Conv4Layers", isd_amd.ELECTRODES, isd_amd.ZONES, 32).cuda()
+    x = torch.randn(3, 64, 512)
+    w = torch.randn(3 * 3, 8, 32)
+    feat = h.forward_windows(x.cuda(), 250, 125)
+    (feat * w.cuda()).sum().backward()
+    p = {"head." + k: v.detach().cpu().double().requires_grad_() for k, v in h.state_dict().items()}
+    ref = ocnn.forward_head(x.double(), p, list(ocnn.ZONES), ocnn.zone_index_lists(), 250, 125)
+    (ref.reshape(9, 8, 32) * w.double()).sum().backward()
+    assert feat.shape == (9, 8, 32) and rel_err(feat.detach().cpu(), ref.reshape(9, 8, 32).detach()) < TOL
+    for k, q in h.named_parameters():
+        assert rel_err(q.grad.cpu(), p["head." + k].grad) < TOL, k
+
+
 # ------------------------------------------------------------------ FC head and loss
 @pytest.mark.parametrize("M,K,N,act", [(37, 256, 32, True), (4096 * 3, 256, 32, True), (100, 32, 5, False),
                                        (1, 7, 3, False), (130, 70, 64, True)])
