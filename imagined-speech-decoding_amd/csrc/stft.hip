@@ -103,6 +103,118 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ x, 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Band power for heavily overlapped frames (stress configuration: nperseg 1024, hop 64, 4096 samples): one wave
+// per (trial, band, channel) row, lane m owns block m of `hop` samples.  With a Hann window
+//   Z_k[j] = (-1)^k w^{kj} [ R_k[j]/2 + (w^j R_{k+1}[j] + w^{-j} R_{k-1}[j])/4 ] / sum(window),   w = e^{2 pi i hop/n},
+//   R_k[j] = sum over the n/hop blocks m of frame j of S_k[m],   S_k[m] = sum_{t in block m} y[t] e^{-2 pi i k t/n},
+// so a row costs one 64-sample DFT sum per lane for the band's bins and their two neighbours, two sliding-window
+// sums over lanes (log2(n/hop) shuffles each) and a few complex multiplies per frame -- not a 1024-point FFT per
+// frame (513 bins computed, 3 used).  Reads each row once, coalesced; the block layout is transposed through LDS.
+// ---------------------------------------------------------------------------------------
+template <int H, int KB>
+__global__ __launch_bounds__(64) void bandpower_blocksum_kernel(const float2* __restrict__ tab,
+                                                                const float* __restrict__ y, float* __restrict__ feat,
+                                                                int64_t R, int C, int T, int nb, int J, int n,
+                                                                int log2_nblk, float scale2, BandArgs ba, int mode,
+                                                                float eps) {
+  constexpr int RS = H + 4;                                   // padded block stride: conflict-free ds_read_b128
+  __shared__ __attribute__((aligned(16))) float tile[64 * RS];
+  __shared__ float2 tw[64];                                   // e^{-2 pi i u / nblk}
+  const int lane = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const int band = (int)((row / C) % nb);
+  const int klo = ba.klo[band], khi = ba.khi[band];
+  const int nbin = khi - klo + 1, k0 = klo - 1;
+  const int nblk = 1 << log2_nblk, half = nblk >> 1;
+  const float* src = y + row * (int64_t)T;
+  const bool vec = (T & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+#pragma unroll
+  for (int it = 0; it < H / 4; ++it) {
+    const int e = (it * 64 + lane) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec && e + 3 < T) {
+      v = *reinterpret_cast<const float4*>(src + e);
+    } else {
+      if (e + 0 < T) v.x = src[e];
+      if (e + 1 < T) v.y = src[e + 1];
+      if (e + 2 < T) v.z = src[e + 2];
+      if (e + 3 < T) v.w = src[e + 3];
+    }
+    *reinterpret_cast<float4*>(tile + (e / H) * RS + (e % H)) = v;
+  }
+  if (lane < nblk) {
+    float sn, cs;
+    sincospif(2.f * (float)lane / (float)nblk, &sn, &cs);
+    tw[lane] = make_float2(cs, -sn);
+  }
+  __syncthreads();
+  float2 S[KB];
+#pragma unroll
+  for (int kk = 0; kk < KB; ++kk) S[kk] = make_float2(0.f, 0.f);
+  const float* sp = tile + lane * RS;
+  const int kmax = n / 2;
+  for (int i0 = 0; i0 < H; i0 += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(sp + i0);
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+      const int k = k0 + kk < kmax ? k0 + kk : kmax;              // unused slots repeat a valid table row
+      const float2* tb = tab + (int64_t)k * H + i0;               // wave-uniform -> scalar loads
+      S[kk].x = fmaf(v.x, tb[0].x, fmaf(v.y, tb[1].x, fmaf(v.z, tb[2].x, fmaf(v.w, tb[3].x, S[kk].x))));
+      S[kk].y = fmaf(v.x, tb[0].y, fmaf(v.y, tb[1].y, fmaf(v.z, tb[2].y, fmaf(v.w, tb[3].y, S[kk].y))));
+    }
+  }
+  // absolute phase of the block, then the two sliding-window sums over lanes (zero fill outside [0, 64))
+  float2 Cw[KB], Bw[KB];
+#pragma unroll
+  for (int kk = 0; kk < KB; ++kk) {
+    const float2 w = tw[((k0 + kk) * lane) & (nblk - 1)];
+    const float2 s = make_float2(S[kk].x * w.x - S[kk].y * w.y, S[kk].x * w.y + S[kk].y * w.x);
+    Cw[kk] = s;
+    Bw[kk] = s;
+  }
+  for (int d = 1; d < nblk; d <<= 1) {
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+      const float cx = __shfl_down(Cw[kk].x, d, 64), cy = __shfl_down(Cw[kk].y, d, 64);
+      const float bx = __shfl_up(Bw[kk].x, d, 64), by = __shfl_up(Bw[kk].y, d, 64);
+      if (lane + d < 64) { Cw[kk].x += cx; Cw[kk].y += cy; }
+      if (lane >= d) { Bw[kk].x += bx; Bw[kk].y += by; }
+    }
+  }
+  // frame j = lane; a second, wave-uniform pass serves frames 64.. (frame 64 on lane 0 when the row has 65 frames):
+  // every lane takes part in the shuffles of both passes
+  const int n_pass = J > 64 ? 2 : 1;
+  for (int f = 0; f < n_pass; ++f) {
+    const int j = lane + 64 * f;
+    const int from_c = j - half;                                  // leading window starting at block j - half
+    float2 Rk[KB];
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+      const float cx = __shfl(Cw[kk].x, from_c & 63, 64), cy = __shfl(Cw[kk].y, from_c & 63, 64);
+      const float bx = __shfl(Bw[kk].x, (j + half - 1) & 63, 64), by = __shfl(Bw[kk].y, (j + half - 1) & 63, 64);
+      Rk[kk] = j >= half ? make_float2(cx, cy) : make_float2(bx, by);
+    }
+    const float2 wn = tw[j & (nblk - 1)];                         // e^{-2 pi i j/nblk};  w^j = conj(wn)
+    float acc = 0.f;
+#pragma unroll
+    for (int bq = 0; bq < KB - 2; ++bq) {
+      if (bq < nbin) {
+        const float2 lo = Rk[bq], mid = Rk[bq + 1], hi = Rk[bq + 2];
+        // w^j * hi + w^{-j} * lo
+        const float sx = hi.x * wn.x + hi.y * wn.y + lo.x * wn.x - lo.y * wn.y;
+        const float sy = hi.y * wn.x - hi.x * wn.y + lo.y * wn.x + lo.x * wn.y;
+        const float vx = 0.5f * mid.x + 0.25f * sx, vy = 0.5f * mid.y + 0.25f * sy;
+        const float pw = (vx * vx + vy * vy) * scale2;
+        acc += mode == ISD_BP_MAGNITUDE ? sqrtf(pw) : pw;
+      }
+    }
+    float r = nbin > 0 ? acc / (float)nbin : 0.f;
+    if (mode == ISD_BP_LOGPOWER) r = logf(r + eps);
+    if (j < J) feat[row * (int64_t)J + j] = r;
+  }
+}
+
 }  // namespace isd
 
 using namespace isd;
@@ -143,7 +255,21 @@ extern "C" int isd_stft_plan_create(isd_stft_plan** out, int T, int nperseg, int
         dft[k * 64 + i] = make_float2((float)((double)win[i] * cos(ph)), (float)(-(double)win[i] * sin(ph)));
       }
   }
-  p->d_win = nullptr; p->d_tw = nullptr; p->d_dft = nullptr;
+  // block-sum table for heavily overlapped frames
+  std::vector<float2> blk;
+  {
+    const int hop = p->hop, nblk = nperseg / hop;
+    if ((hop == 32 || hop == 64) && nperseg % hop == 0 && nblk >= 4 && nblk <= 64 && (nblk & (nblk - 1)) == 0 &&
+        T <= 64 * hop) {
+      blk.resize((size_t)(nperseg / 2 + 1) * hop);
+      for (int k = 0; k <= nperseg / 2; ++k)
+        for (int i = 0; i < hop; ++i) {
+          const double ph = 2.0 * M_PI * (double)(((int64_t)k * i) % nperseg) / nperseg;
+          blk[(size_t)k * hop + i] = make_float2((float)cos(ph), (float)(-sin(ph)));
+        }
+    }
+  }
+  p->d_win = nullptr; p->d_tw = nullptr; p->d_dft = nullptr; p->d_blk = nullptr;
   hipError_t e = hipMalloc(&p->d_win, sizeof(float) * nperseg);
   if (e == hipSuccess) e = hipMalloc(&p->d_tw, sizeof(float2) * (nperseg / 2));
   if (e == hipSuccess) e = hipMemcpy(p->d_win, win.data(), sizeof(float) * nperseg, hipMemcpyHostToDevice);
@@ -151,6 +277,10 @@ extern "C" int isd_stft_plan_create(isd_stft_plan** out, int T, int nperseg, int
   if (e == hipSuccess && !dft.empty()) {
     e = hipMalloc(&p->d_dft, sizeof(float2) * dft.size());
     if (e == hipSuccess) e = hipMemcpy(p->d_dft, dft.data(), sizeof(float2) * dft.size(), hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess && !blk.empty()) {
+    e = hipMalloc(&p->d_blk, sizeof(float2) * blk.size());
+    if (e == hipSuccess) e = hipMemcpy(p->d_blk, blk.data(), sizeof(float2) * blk.size(), hipMemcpyHostToDevice);
   }
   if (e != hipSuccess) {
     set_error("isd_stft_plan_create: %s", hipGetErrorString(e));
@@ -166,6 +296,7 @@ extern "C" int isd_stft_plan_destroy(isd_stft_plan* p) {
   if (p->d_win) (void)hipFree(p->d_win);
   if (p->d_tw) (void)hipFree(p->d_tw);
   if (p->d_dft) (void)hipFree(p->d_dft);
+  if (p->d_blk) (void)hipFree(p->d_blk);
   delete p;
   return ISD_OK;
 }
@@ -227,6 +358,34 @@ extern "C" int isd_stft_bandpower(const isd_stft_plan* p, const float* y, float*
   if (p->n == 64 && p->hop == 32 && p->T <= 512 && p->d_dft && n_bands_in == n_bands)
     return bandpower_direct(p, y, feat, B * n_bands * C, (int)C, n_bands, ba.klo, ba.khi, mode, eps,
                             (hipStream_t)stream);
+  if (p->d_blk && n_bands_in == n_bands) {
+    // per-band rows, every band 1..6 interior bins: block sums instead of one FFT per frame
+    int nbmax = 0;
+    bool ok = true;
+    for (int b = 0; b < n_bands; ++b) {
+      const int nbin = ba.khi[b] - ba.klo[b] + 1;
+      if (nbin < 1 || nbin > 6 || ba.klo[b] < 1 || ba.khi[b] > p->n / 2 - 1) ok = false;
+      if (nbin > nbmax) nbmax = nbin;
+    }
+    const int64_t rows = B * n_bands * C;
+    if (ok && rows <= 0x7fffffffLL) {
+      int log2_nblk = 0;
+      while ((p->hop << log2_nblk) < p->n) ++log2_nblk;
+      const int KB = nbmax + 2 <= 4 ? 4 : nbmax + 2 <= 6 ? 6 : 8;
+      hipStream_t st = (hipStream_t)stream;
+#define ISD_BS_LAUNCH(H, K)                                                                                        \
+  hipLaunchKernelGGL((bandpower_blocksum_kernel<H, K>), dim3((unsigned)rows), dim3(64), 0, st, p->d_blk, y, feat, rows, \
+                     (int)C, p->T, n_bands, p->J, p->n, log2_nblk, p->scale * p->scale, ba, mode, eps)
+      if (p->hop == 64) {
+        if (KB == 4) ISD_BS_LAUNCH(64, 4); else if (KB == 6) ISD_BS_LAUNCH(64, 6); else ISD_BS_LAUNCH(64, 8);
+      } else {
+        if (KB == 4) ISD_BS_LAUNCH(32, 4); else if (KB == 6) ISD_BS_LAUNCH(32, 6); else ISD_BS_LAUNCH(32, 8);
+      }
+#undef ISD_BS_LAUNCH
+      ISD_LAUNCH_CHECK();
+      return ISD_OK;
+    }
+  }
   return stft_launch(p, 1, y, feat, B * n_bands_in * C, (int)C, n_bands_in, n_bands, ba, mode, eps,
                      (hipStream_t)stream);
 }

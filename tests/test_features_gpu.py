@@ -103,6 +103,27 @@ def test_stft_matches_scipy_golden(isd, tag):
     np.testing.assert_allclose(bm, ref_bm, rtol=2e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("T,nperseg,noverlap", [(4096, 1024, 960), (4000, 1024, 960), (1000, 1024, 960),
+                                                 (2048, 256, 224), (130, 512, 448), (4096, 256, 192)])
+@pytest.mark.parametrize("mode", ["power", "magnitude", "logpower"])
+def test_overlapped_frames_bandpower_vs_oracle(isd, T, nperseg, noverlap, mode):
+    """Heavily overlapped frames (stress configuration): the block-sum kernel against the oracle's STFT and band means."""
+    rng = np.random.default_rng(T + nperseg)
+    bins = [(1, 1), (4, 6), (nperseg // 2 - 6, nperseg // 2 - 1), (9, 10)]      # 1, 3, 6 and 2 bins per band
+    y = rng.standard_normal((2, len(bins), 3, T)).astype(np.float32)
+    st = isd.Stft(T, nperseg, noverlap)
+    got = st.bandpower(dev(y), bins, mode=mode).cpu().numpy()
+    _, _, Z = odsp.stft(y.astype(np.float64), 256.0, nperseg, noverlap)          # [2, nb, 3, nfreq, J]
+    ref = np.empty(got.shape)
+    for b, (lo, hi) in enumerate(bins):
+        P = np.abs(Z[:, b, :, lo:hi + 1, :]) ** 2
+        ref[:, b] = (np.sqrt(P) if mode == "magnitude" else P).mean(axis=-2)
+    if mode == "logpower":
+        assert np.abs(got - np.log(ref + 1e-10)).max() < TOL_FEAT
+    else:
+        assert np.abs(got - ref).max() < 2e-5 * ref.max()
+
+
 @pytest.mark.parametrize("T,nperseg,noverlap", [(512, 64, 32), (500, 64, 32), (800, 64, 48), (100, 16, 4),
                                                  (4096, 1024, 960), (37, 8, 0), (300, 256, 128)])
 def test_stft_vs_oracle_param_sweep(isd, T, nperseg, noverlap):
