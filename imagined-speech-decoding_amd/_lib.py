@@ -64,6 +64,8 @@ SIGNATURES = {
     "isd_attention_backward": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _f, C.c_uint64, _p]),
     "isd_linear_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "isd_eegnet_plan_create": (_i, [C.POINTER(_p), _i, _i, _i, _i]),
+    "isd_featcnn_supported": (_i, [_p, _i64, _i64, _i]),
+    "isd_featcnn_step": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _f, _p]),
     "isd_paperhead_plan_create": (_i, [C.POINTER(_p), _i, _i, _i]),
     "isd_paperhead_plan_destroy": (_i, [_p]),
     "isd_paperhead_param_count": (_i64, [_p]),

@@ -127,6 +127,22 @@ class HotPath:
         fp, f4 = flat.data_ptr(), 4
         ws_bytes = int(L.isd_conv4_workspace_bytes(plan._h, B, T))
         ws = self._buf("conv", ws_bytes // 4, dev)
+        if len(offs) == 1 and not m.hidden_act and L.isd_featcnn_supported(plan._h, B, T, offs[0][2]):
+            # classifier on spec-S features: the whole step is one library call (three kernels + reductions)
+            wo, bo, n_cls, _ = offs[0]
+            logits = torch.empty((B, n_cls), dtype=torch.float32, device=dev)
+            pred = torch.empty((B,), dtype=torch.int64, device=dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev) if labels is not None else None
+            gp = gflat.data_ptr() if (want_grad and labels is not None) else 0
+            _lib.check(L.isd_featcnn_step(plan._h, x.data_ptr(), fp, fp + wo * f4, fp + bo * f4,
+                                          0 if labels is None else labels.data_ptr(),
+                                          0 if labels is None else labels.element_size(), gp, gp + wo * f4 if gp else 0,
+                                          logits.data_ptr(), pred.data_ptr(), 0 if loss is None else loss.data_ptr(),
+                                          ws.data_ptr(), B, T, n_cls, 1.0 / float(global_batch or B), st))
+            out = {"logits": logits, "pred": pred}
+            if loss is not None:
+                out["loss"] = loss
+            return out
         feat = self._buf("feat", B * N * plan.n_zones * plan.F, dev)
         _lib.check(L.isd_conv4_forward(plan._h, x.data_ptr(), fp, feat.data_ptr(), ws.data_ptr(), B, T, st))
         # dense layers

@@ -932,6 +932,306 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a
 }
 
 // ---------------------------------------------------------------------------------------
+// Tail of the feature classifier (spec-S features: a handful of time steps, one zone) in ONE launch:
+//   A2 -> cnn3 -> cnn4 -> GELU -> mean -> Linear(F, n_cls) -> softmax cross-entropy / argmax
+//   and back: dLogits -> dFeat -> G4 -> (dW4, G3) -> (dW3, G2), dW_fc, db_fc, loss.
+// The layer-wise path spends 19 launches of 5-20 us on these [B, 32, 13] tensors.  Here one WAVE owns an item
+// end to end (T1 <= 16: one 16-column MFMA tile), its tiles live in a wave-private LDS region (no workgroup
+// barrier inside the item loop), the four weight fragment sets are shared by the workgroup in LDS, and the
+// weight gradients accumulate in registers over the wave's items (40 MFMA accumulators), are combined across
+// the 4 waves through LDS in wave order and leave as one slab per workgroup: [dW3 | dW4 | dW_fc | db_fc | loss].
+// ---------------------------------------------------------------------------------------
+struct TailArgs {
+  const float* a2;           // [items][F][T1]
+  float* g2;                 // [items][F][T1] gradient w.r.t. A2 (training)
+  const float* w3;           // frag-ordered cnn3 / cnn4 weights and their transposed + flipped copies (zone 0)
+  const float* w4;
+  const float* w3t;
+  const float* w4t;
+  const float* fc_w;         // [n_cls][F]
+  const float* fc_b;         // [n_cls]
+  const void* labels;        // uint8 or int64, null: inference
+  float* logits;             // [items][n_cls]
+  int64_t* pred;             // [items]
+  float* part;               // [gridDim.x][slab]   slab = 2*F*F*5 + n_cls*(F+1) + 1
+  int64_t items;
+  int T1, n_cls, label_bytes, train, slab;
+  float grad_scale;
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // wave-private LDS hand-over between lanes: LDS operations of one wave execute in order; keep the compiler
+  // from moving them across this point and wait for the outstanding ones
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// one 16-column tile: acc[gt] += W[gt] (x) in   (F = 32 input channels, pad 2)
+__device__ __forceinline__ void tail_conv(const float* __restrict__ wl, const float* __restrict__ in, int T1, int q,
+                                          int jl, f32x4 (&acc)[2]) {
+  struct Frag {
+    float af[kTaps][2];
+    float bf[kTaps];
+  };
+  bool ok[kTaps];
+  int off[kTaps];
+#pragma unroll
+  for (int k = 0; k < kTaps; ++k) {
+    const int idx = jl + k - 2;
+    ok[k] = idx >= 0 && idx < T1;
+    off[k] = ok[k] ? idx : 0;
+  }
+  auto load = [&](int cg, Frag& f) {
+    const float* rowp = in + (cg * 4 + q) * T1;
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+      f.af[k][0] = wl[((cg * kTaps + k) * 2 + 0) * 64];
+      f.af[k][1] = wl[((cg * kTaps + k) * 2 + 1) * 64];
+      const float v = rowp[off[k]];
+      f.bf[k] = ok[k] ? v : 0.f;
+    }
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[k][0], f.bf[k], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[k][1], f.bf[k], acc[1], 0, 0, 0);
+    }
+  };
+  Frag f0, f1;
+  load(0, f0);
+#pragma unroll 1
+  for (int cg = 0; cg < 8; cg += 2) {
+    load(cg + 1, f1);
+    mma(f0);
+    if (cg + 2 < 8) load(cg + 2, f0);
+    mma(f1);
+  }
+}
+
+// dW[gt][ct][k] += sum_t G[gt*16 + row][t] * In[ct*16 + col][t + k - 2]   for one item (T1 <= 16: four K-steps)
+__device__ __forceinline__ void tail_wgrad(const float* __restrict__ G, const float* __restrict__ In, int T1, int q,
+                                           int jl, f32x4 (&acc)[2][2][kTaps]) {
+#pragma unroll 1
+  for (int s = 0; s < 4; ++s) {
+    const int t = s * 4 + q;
+    const bool okA = t < T1;
+    const int tc = okA ? t : 0;
+    float a[2], b[2][kTaps];
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt) {
+      const float v = G[(gt * 16 + jl) * T1 + tc];
+      a[gt] = okA ? v : 0.f;
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k) {
+        const int idx = t + k - 2;
+        const bool in = okA && idx >= 0 && idx < T1;
+        const float v = In[(ct * 16 + jl) * T1 + (in ? idx : 0)];
+        b[ct][k] = in ? v : 0.f;
+      }
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k)
+          acc[gt][ct][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gt], b[ct][k], acc[gt][ct][k], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void tail_store_tile(const f32x4 (&acc)[2], float* __restrict__ tile, int T1, int q, int jl) {
+  if (jl < T1) {
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[(gt * 16 + 4 * q + r) * T1 + jl] = acc[gt][r];
+  }
+}
+
+constexpr int kTailMaxCls = 16;
+
+__global__ __launch_bounds__(256) void featcnn_tail_kernel(TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int F = 32, NW = 4, WF = 8 * kTaps * 2 * 64;      // 5120 floats per fragment set
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
+  const int T1 = a.T1, n_cls = a.n_cls;
+  const int tile = F * T1;
+  float* w3s = smem;                                          // fragment sets, shared by the workgroup
+  float* w4s = w3s + WF;
+  float* w3ts = w4s + WF;
+  float* w4ts = w3ts + WF;
+  float* fcs = w4ts + WF;                                     // [n_cls][F] then [n_cls]
+  float* priv = fcs + kTailMaxCls * (F + 1) + ((wave * (4 * ((tile + 3) & ~3) + 64)));
+  float* tA2 = priv;                                          // wave-private tiles
+  float* tA3 = tA2 + ((tile + 3) & ~3);
+  float* tG = tA3 + ((tile + 3) & ~3);                        // G4, later G2
+  float* tH = tG + ((tile + 3) & ~3);                         // G3
+  float* featL = tH + ((tile + 3) & ~3);                      // [32] pooled features, [16] logits, [16] dlogits
+  float* logL = featL + 32;
+  for (int e = threadIdx.x; e < WF; e += 256) {
+    w3s[e] = a.w3[e];
+    w4s[e] = a.w4[e];
+    if (a.train) { w3ts[e] = a.w3t[e]; w4ts[e] = a.w4t[e]; }
+  }
+  for (int e = threadIdx.x; e < n_cls * F; e += 256) fcs[e] = a.fc_w[e];
+  for (int e = threadIdx.x; e < n_cls; e += 256) fcs[n_cls * F + e] = a.fc_b[e];
+  __syncthreads();
+
+  f32x4 accW4[2][2][kTaps], accW3[2][2][kTaps];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k) {
+        accW4[g][c][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        accW3[g][c][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+  float accfc[kTailMaxCls * F / 64], accb = 0.f, loss_acc = 0.f;   // lane l owns flat fc elements l, l+64, ...
+#pragma unroll
+  for (int i = 0; i < kTailMaxCls * F / 64; ++i) accfc[i] = 0.f;
+  const int n4 = tile >> 2;                                   // T1 % 4 == 0 is not required: tile = 32*T1 is
+  const float inv_t = 1.f / (float)T1;
+
+  for (int64_t item = (int64_t)blockIdx.x * NW + wave; item < a.items; item += (int64_t)gridDim.x * NW) {
+    {
+      const float4* src = reinterpret_cast<const float4*>(a.a2 + item * tile);
+      float4* dst = reinterpret_cast<float4*>(tA2);
+      for (int e = lane; e < n4; e += 64) dst[e] = src[e];
+    }
+    wave_lds_sync();
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    tail_conv(w3s + lane, tA2, T1, q, jl, acc);               // A3
+    tail_store_tile(acc, tA3, T1, q, jl);
+    wave_lds_sync();
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tail_conv(w4s + lane, tA3, T1, q, jl, acc);               // A4 stays in registers
+    // GELU + mean over time: row sums inside each 16-lane row
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sacc = jl < T1 ? gelu_f(acc[gt][r]) : 0.f;
+        sacc += row_shr<8>(sacc);
+        sacc += row_shr<4>(sacc);
+        sacc += row_shr<2>(sacc);
+        sacc += row_shr<1>(sacc);
+        if (jl == 15) featL[gt * 16 + 4 * q + r] = sacc * inv_t;
+      }
+    wave_lds_sync();
+    if (lane < n_cls) {
+      float l = fcs[n_cls * F + lane];
+#pragma unroll
+      for (int g = 0; g < F; ++g) l = fmaf(fcs[lane * F + g], featL[g], l);
+      logL[lane] = l;
+      a.logits[item * n_cls + lane] = l;
+    }
+    wave_lds_sync();
+    float mx = -INFINITY;
+    int am = 0;
+    for (int c = 0; c < n_cls; ++c) {
+      const float v = logL[c];
+      if (v > mx) { mx = v; am = c; }                         // strict '>' keeps the lowest index on ties (torch.argmax)
+    }
+    if (lane == 0) a.pred[item] = am;
+    if (!a.labels) continue;
+    float se = 0.f;
+    for (int c = 0; c < n_cls; ++c) se += expf(logL[c] - mx);
+    const int y = a.label_bytes == 1 ? (int)((const unsigned char*)a.labels)[item]
+                                     : (int)((const long long*)a.labels)[item];
+    const float lse = mx + logf(se);
+    if (lane == 0) loss_acc += (lse - logL[y]) * a.grad_scale;
+    if (!a.train) continue;
+    // dlogits -> LDS; dfeat for this lane's 8 filters; G4 = dfeat/T1 * GELU'(A4)
+    if (lane < n_cls) logL[16 + lane] = (expf(logL[lane] - lse) - (lane == y ? 1.f : 0.f)) * a.grad_scale;
+    wave_lds_sync();
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int g = gt * 16 + 4 * q + r;
+        float d = 0.f;
+        for (int c = 0; c < n_cls; ++c) d = fmaf(fcs[c * F + g], logL[16 + c], d);
+        acc[gt][r] = d * inv_t * gelu_grad_f(acc[gt][r]);
+      }
+    tail_store_tile(acc, tG, T1, q, jl);
+    // FC gradients: flat element e = lane + 64 i of [n_cls][F]
+#pragma unroll
+    for (int i = 0; i < kTailMaxCls * F / 64; ++i) {
+      const int e = lane + 64 * i;
+      if (e < n_cls * F) accfc[i] = fmaf(logL[16 + (e >> 5)], featL[e & 31], accfc[i]);
+    }
+    if (lane < n_cls) accb += logL[16 + lane];
+    wave_lds_sync();
+    tail_wgrad(tG, tA3, T1, q, jl, accW4);
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tail_conv(w4ts + lane, tG, T1, q, jl, acc);               // G3
+    tail_store_tile(acc, tH, T1, q, jl);
+    wave_lds_sync();
+    tail_wgrad(tH, tA2, T1, q, jl, accW3);
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tail_conv(w3ts + lane, tH, T1, q, jl, acc);               // G2
+    wave_lds_sync();                                          // every read of tG (wgrad4, cnn4 data gradient) is done
+    tail_store_tile(acc, tG, T1, q, jl);
+    wave_lds_sync();
+    {
+      float4* dst = reinterpret_cast<float4*>(a.g2 + item * tile);
+      const float4* src = reinterpret_cast<const float4*>(tG);
+      for (int e = lane; e < n4; e += 64) dst[e] = src[e];
+    }
+    wave_lds_sync();                                          // tiles are reused by the next item
+  }
+  if (!a.labels) return;
+  // combine the 4 waves in wave order through LDS (the fragment sets are dead), then one slab per workgroup
+  __syncthreads();
+  float* comb = smem;                                         // [2*F*F*5 + n_cls*(F+1) + 1]
+  const int o_fc = 2 * F * F * kTaps, o_b = o_fc + n_cls * F, o_loss = o_b + n_cls;
+  for (int w = 0; w < NW; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int k = 0; k < kTaps; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int idx = ((gt * 16 + 4 * q + r) * F + ct * 16 + jl) * kTaps + k;
+              comb[idx] = (w == 0 ? 0.f : comb[idx]) + accW3[gt][ct][k][r];
+              comb[F * F * kTaps + idx] = (w == 0 ? 0.f : comb[F * F * kTaps + idx]) + accW4[gt][ct][k][r];
+            }
+#pragma unroll
+      for (int i = 0; i < kTailMaxCls * F / 64; ++i) {
+        const int e = lane + 64 * i;
+        if (e < n_cls * F) comb[o_fc + e] = (w == 0 ? 0.f : comb[o_fc + e]) + accfc[i];
+      }
+      if (lane < n_cls) comb[o_b + lane] = (w == 0 ? 0.f : comb[o_b + lane]) + accb;
+      if (lane == 0) comb[o_loss] = (w == 0 ? 0.f : comb[o_loss]) + loss_acc;
+    }
+    __syncthreads();
+  }
+  float* slab = a.part + (int64_t)blockIdx.x * a.slab;
+  for (int e = threadIdx.x; e < a.slab; e += 256) slab[e] = comb[e];
+}
+
+// reduced slab -> cnn3 / cnn4 gradients (adjacent in the flat block), FC gradients, loss
+__global__ __launch_bounds__(256) void featcnn_tail_scatter_kernel(const float* __restrict__ red, float* __restrict__ dw34,
+                                                                   float* __restrict__ dfc, float* __restrict__ loss,
+                                                                   int n34, int nfc) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < n34) dw34[e] = red[e];
+  else if (e < n34 + nfc) dfc[e - n34] = red[e];
+  else if (e == n34 + nfc) loss[0] = red[e];
+}
+
+// ---------------------------------------------------------------------------------------
 // GELU + mean over time (fast.py:117-118) and its backward (in place on the activation).
 // one 16-lane row per (item, zone, filter) row of length T
 // ---------------------------------------------------------------------------------------
@@ -1612,61 +1912,27 @@ static int launch_conv(int mode, int bf16, const ConvArgs& a, int n_zones, hipSt
   return ISD_OK;
 }
 
-// LDS bytes of conv4_fused_bwd_kernel<8>; the forward keeps GELU'(A4) instead of A4 exactly when this fits
-static size_t fused_bwd_lds(const isd_conv4_plan* p, const Geo& g) {
-  const int tile = ((p->F * g.T1 + 3) & ~3) + 4;
-  return sizeof(float) * (size_t)(((4 + 16 * p->W + 3) & ~3) + 4 + 3 * tile + 2 * 8 * kTaps * 2 * 64 + 32 + 16);
-}
-
-extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const float* params, float* feat,
-                                 void* workspace, int64_t B, int64_t T, void* stream) {
-  ISD_CHECK_ARG(p, "isd_conv4_forward: null plan");
-  ISD_CHECK_ARG(B >= 0, "isd_conv4_forward: B=%lld", (long long)B);
-  Geo g;
-  int rc = make_geo(p, B, T, g);
-  if (rc) return rc;
-  if (B == 0) return ISD_OK;
-  ISD_CHECK_ARG(x && params && feat && workspace, "isd_conv4_forward: null argument");
-  hipStream_t st = (hipStream_t)stream;
-  float* ws = (float*)workspace;
+static int launch_prep(const isd_conv4_plan* p, const Geo& g, const float* params, float* ws, hipStream_t st) {
   const int F = p->F;
-  {
-    const int nbw = (int)cdiv(((int64_t)(p->max_cz + 3) / 4) * 4 * F, 256);
-    hipLaunchKernelGGL(prep_fused_kernel, dim3(nbw + F, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_eff,
-                       ws + g.o_beff, F, nbw, p->act_bf16);
-    ISD_LAUNCH_CHECK();
-  }
+  const int nbw = (int)cdiv(((int64_t)(p->max_cz + 3) / 4) * 4 * F, 256);
+  hipLaunchKernelGGL(prep_fused_kernel, dim3(nbw + F, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_eff,
+                     ws + g.o_beff, F, nbw, p->act_bf16);
   if (p->n_layers == 4) {
     hipLaunchKernelGGL(prep_conv_kernel, dim3(4, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_w3,
                        ws + g.o_w3t, F, 0, p->conv_zstride, p->act_bf16);
     hipLaunchKernelGGL(prep_conv_kernel, dim3(4, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_w4,
                        ws + g.o_w4t, F, 1, p->conv_zstride, p->act_bf16);
-    ISD_LAUNCH_CHECK();
   }
-  if (p->n_layers == 4 && F == 32 && !p->act_bf16 && p->max_cz <= 16 && g.TT <= 16 && (F * g.T1) % 4 == 0 &&
-      g.TT >= 4) {
-    // reference-native shape: one persistent fused kernel (register-resident weights, activations through LDS)
-    FusedFwdArgs fa = {};
-    fa.x = x; fa.weff = ws + g.o_eff; fa.beff = ws + g.o_beff; fa.w3 = ws + g.o_w3; fa.w4 = ws + g.o_w4;
-    fa.a2 = ws + g.o_a2; fa.a3 = ws + g.o_a3; fa.a4 = ws + g.o_a4; fa.feat = feat;
-    fa.zones = p->d_zones; fa.chan_idx = p->d_idx; fa.wz_stride = p->conv_zstride; fa.items = g.items;
-    fa.Z = p->Z; fa.W = p->W; fa.T1 = g.T1; fa.TT = g.TT; fa.store = fused_bwd_lds(p, g) <= 160 * 1024 ? 2 : 1;
-    fa.Ctot = p->Ctot; fa.Tx = (int)T; fa.N = g.N; fa.S = p->S;
-    constexpr int NW = 8;   // measured after the prefetch restructure (B=4096, T=512): 8 waves 25.6 ms/step, 16 waves 25.6, 4 waves 28.3
-    const size_t lds = sizeof(float) * (size_t)(4 + ((16 * p->W + 3) & ~3) + 2 * ((F * g.T1 + 3) & ~3) + NW * F +
-                                                 (4 + 8 + 8) * kTaps * 2 * 64 + 64);
-    if (lds <= 150 * 1024) {
-      int per_zone = 256 / p->Z;
-      if (per_zone < 1) per_zone = 1;
-      if (per_zone > g.items) per_zone = (int)g.items;
-      ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv4_fused_fwd_kernel<NW>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((conv4_fused_fwd_kernel<NW>), dim3(per_zone, p->Z), dim3(NW * 64), lds, st, fa);
-      ISD_LAUNCH_CHECK();
-      return ISD_OK;
-    }
-  }
-  ConvArgs a = {};
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+// cnn1 o cnn2 forward into the A2 buffer; `a` comes back filled with the shared fields for the later layers
+static int first_layer_forward(const isd_conv4_plan* p, const Geo& g, const float* x, int64_t T, float* ws,
+                               hipStream_t st, ConvArgs& a) {
+  const int F = p->F;
+  int rc;
+  a = ConvArgs{};
   a.zones = p->d_zones; a.chan_idx = p->d_idx; a.items = g.items; a.Z = p->Z; a.F = F;
   a.TT = g.TT; a.IPW = g.IPW; a.Tout = g.T1;
   a.Ctot = p->Ctot; a.Tx = (int)T; a.N = g.N; a.S = p->S;
@@ -1700,6 +1966,54 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
       rc = launch_conv(0, p->act_bf16, a, p->Z, st);
     }
   }
+  return rc;
+}
+
+// LDS bytes of conv4_fused_bwd_kernel<8>; the forward keeps GELU'(A4) instead of A4 exactly when this fits
+static size_t fused_bwd_lds(const isd_conv4_plan* p, const Geo& g) {
+  const int tile = ((p->F * g.T1 + 3) & ~3) + 4;
+  return sizeof(float) * (size_t)(((4 + 16 * p->W + 3) & ~3) + 4 + 3 * tile + 2 * 8 * kTaps * 2 * 64 + 32 + 16);
+}
+
+extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const float* params, float* feat,
+                                 void* workspace, int64_t B, int64_t T, void* stream) {
+  ISD_CHECK_ARG(p, "isd_conv4_forward: null plan");
+  ISD_CHECK_ARG(B >= 0, "isd_conv4_forward: B=%lld", (long long)B);
+  Geo g;
+  int rc = make_geo(p, B, T, g);
+  if (rc) return rc;
+  if (B == 0) return ISD_OK;
+  ISD_CHECK_ARG(x && params && feat && workspace, "isd_conv4_forward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int F = p->F;
+  rc = launch_prep(p, g, params, ws, st);
+  if (rc) return rc;
+  if (p->n_layers == 4 && F == 32 && !p->act_bf16 && p->max_cz <= 16 && g.TT <= 16 && (F * g.T1) % 4 == 0 &&
+      g.TT >= 4) {
+    // reference-native shape: one persistent fused kernel (register-resident weights, activations through LDS)
+    FusedFwdArgs fa = {};
+    fa.x = x; fa.weff = ws + g.o_eff; fa.beff = ws + g.o_beff; fa.w3 = ws + g.o_w3; fa.w4 = ws + g.o_w4;
+    fa.a2 = ws + g.o_a2; fa.a3 = ws + g.o_a3; fa.a4 = ws + g.o_a4; fa.feat = feat;
+    fa.zones = p->d_zones; fa.chan_idx = p->d_idx; fa.wz_stride = p->conv_zstride; fa.items = g.items;
+    fa.Z = p->Z; fa.W = p->W; fa.T1 = g.T1; fa.TT = g.TT; fa.store = fused_bwd_lds(p, g) <= 160 * 1024 ? 2 : 1;
+    fa.Ctot = p->Ctot; fa.Tx = (int)T; fa.N = g.N; fa.S = p->S;
+    constexpr int NW = 8;   // measured after the prefetch restructure (B=4096, T=512): 8 waves 25.6 ms/step, 16 waves 25.6, 4 waves 28.3
+    const size_t lds = sizeof(float) * (size_t)(4 + ((16 * p->W + 3) & ~3) + 2 * ((F * g.T1 + 3) & ~3) + NW * F +
+                                                 (4 + 8 + 8) * kTaps * 2 * 64 + 64);
+    if (lds <= 150 * 1024) {
+      int per_zone = 256 / p->Z;
+      if (per_zone < 1) per_zone = 1;
+      if (per_zone > g.items) per_zone = (int)g.items;
+      ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv4_fused_fwd_kernel<NW>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((conv4_fused_fwd_kernel<NW>), dim3(per_zone, p->Z), dim3(NW * 64), lds, st, fa);
+      ISD_LAUNCH_CHECK();
+      return ISD_OK;
+    }
+  }
+  ConvArgs a = {};
+  rc = first_layer_forward(p, g, x, T, ws, st, a);
   if (rc) return rc;
   const float* last = ws + g.o_a2;
   if (p->n_layers == 4) {
@@ -1765,6 +2079,131 @@ __global__ void scatter_conv_grad_kernel(const float* __restrict__ wg, const isd
   const int n = F * F * isd::kTaps;
   float* dst = dparams + zd.p_off + F * isd::kTaps + F + (int64_t)F * F * zd.cin + (int64_t)layer * n;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) dst[e] = wg[(int64_t)z * n + e];
+}
+
+// cnn1 o cnn2 backward: dWeff (+ dbeff in the ones channel) from g2 = dL/dA2, then the chain to W1, b1, W2
+static int first_layer_backward(const isd_conv4_plan* p, const Geo& g, const float* x, int64_t T, const float* params,
+                                const float* g2, float* dparams, float* ws, hipStream_t st) {
+  const int F = p->F;
+  int rc;
+  WgradArgs w = {};
+  w.zones = p->d_zones; w.chan_idx = p->d_idx; w.items = g.items;
+  w.Z = p->Z; w.F = F; w.Tout = g.T1; w.part = ws + g.o_part;
+  w.Ctot = p->Ctot; w.Tx = (int)T; w.N = g.N; w.S = p->S;
+  w.dout = g2; w.in = x; w.Tin = p->W; w.pad = 0;
+  w.RSo = g.T1; w.lin = g.lin0;
+  w.RSi = g.lin0 ? p->W : (p->W | 1);
+  w.slab_size = g.slab0; w.wz_stride = 0; w.items_per_wg = g.ipw0; w.CW = g.cw0;
+  int n_slabs0 = g.ns0;
+  {
+    // wide inputs: LDS-DMA double-buffered variant, ~3 workgroups per CU
+    const int zg = (p->max_cz + 63) / 64;
+    int64_t r_target = (256 * 3) / ((int64_t)zg * p->Z);
+    if (r_target < 1) r_target = 1;
+    if (r_target > g.ns0) r_target = g.ns0;
+    const int ipw = (int)cdiv(g.items, r_target);
+    const int R = (int)cdiv(g.items, ipw);
+    const int item_len = (F * g.T1 + 64 * p->W + 3) & ~3;
+    int ips = 4;
+    while (ips > 1 && (size_t)(2 * (ips * item_len + 32) + 8) * 4 > 48 * 1024) --ips;
+    const size_t lds = sizeof(float) * (size_t)(2 * (ips * item_len + 32) + 8);
+    if (g.lin0 && p->dma_ok && !p->act_bf16 && p->max_cz >= 64 && (F * g.T1) % 4 == 0 && lds <= 64 * 1024 &&
+        ((uintptr_t)x & 15) == 0 && ((uintptr_t)g2 & 15) == 0) {
+      w.items_per_wg = ipw; w.IPS = ips;
+      const dim3 grid((unsigned)R, p->Z, zg);
+      if (F == 32) hipLaunchKernelGGL(conv5_wgrad_wide_kernel<2>, grid, dim3(256), lds, st, w);
+      else hipLaunchKernelGGL(conv5_wgrad_wide_kernel<1>, grid, dim3(256), lds, st, w);
+      ISD_LAUNCH_CHECK();
+      n_slabs0 = R;
+      rc = ISD_OK;
+    } else {
+      rc = launch_wgrad(0, p->act_bf16, w, p->Z, p->max_cz + 1, st);
+    }
+  }
+  if (rc) return rc;
+  launch_reduce_slabs(ws + g.o_part, ws + g.o_wg, g.slab0, n_slabs0, st);
+  {
+    const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
+    hipLaunchKernelGGL(fused_bwd_kernel, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,
+                       ws + g.o_wg, dparams, F, nb2);
+  }
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// One call for the whole classifier step on spec-S features: conv stack -> Linear -> softmax-CE forward and
+// backward (featcnn_tail_kernel between the two first-layer kernels).
+// ---------------------------------------------------------------------------------------
+static bool featcnn_ok(const isd_conv4_plan* p, const Geo& g, int n_cls) {
+  return p->Z == 1 && p->n_layers == 4 && p->F == 32 && !p->act_bf16 && g.TT == 1 && g.N == 1 && n_cls >= 1 &&
+         n_cls <= kTailMaxCls;
+}
+
+extern "C" int isd_featcnn_supported(const isd_conv4_plan* p, int64_t B, int64_t T, int n_cls) {
+  if (!p || B < 1) return 0;
+  Geo g;
+  if (make_geo(p, B, T, g)) return 0;
+  return featcnn_ok(p, g, n_cls) ? 1 : 0;
+}
+
+extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const float* params, const float* fc_w,
+                                const float* fc_b, const void* labels, int label_bytes, float* dparams, float* dfc,
+                                float* logits, int64_t* pred, float* loss, void* workspace, int64_t B, int64_t T,
+                                int n_cls, float grad_scale, void* stream) {
+  ISD_CHECK_ARG(p, "isd_featcnn_step: null plan");
+  ISD_CHECK_ARG(B >= 1, "isd_featcnn_step: B=%lld", (long long)B);
+  Geo g;
+  int rc = make_geo(p, B, T, g);
+  if (rc) return rc;
+  if (!featcnn_ok(p, g, n_cls)) {
+    set_error("isd_featcnn_step: needs one zone, 4 layers, 32 filters, fp32 activations, <= 16 output steps, <= %d classes",
+              kTailMaxCls);
+    return ISD_ERR_UNSUPPORTED;
+  }
+  ISD_CHECK_ARG(x && params && fc_w && fc_b && logits && pred && workspace, "isd_featcnn_step: null argument");
+  ISD_CHECK_ARG(!labels || label_bytes == 1 || label_bytes == 8, "isd_featcnn_step: labels must be uint8 or int64");
+  const bool train = labels && dparams && dfc;
+  ISD_CHECK_ARG(!labels || loss, "isd_featcnn_step: labels without a loss pointer");
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int F = p->F;
+  rc = launch_prep(p, g, params, ws, st);
+  if (rc) return rc;
+  ConvArgs a = {};
+  rc = first_layer_forward(p, g, x, T, ws, st, a);
+  if (rc) return rc;
+  TailArgs t = {};
+  t.a2 = ws + g.o_a2; t.g2 = ws + g.o_a4;
+  t.w3 = ws + g.o_w3; t.w4 = ws + g.o_w4; t.w3t = ws + g.o_w3t; t.w4t = ws + g.o_w4t;
+  t.fc_w = fc_w; t.fc_b = fc_b; t.labels = labels; t.label_bytes = label_bytes;
+  t.logits = logits; t.pred = pred; t.part = ws + g.o_part;
+  t.items = g.items; t.T1 = g.T1; t.n_cls = n_cls; t.train = train ? 1 : 0; t.grad_scale = grad_scale;
+  const int n34 = 2 * F * F * kTaps, nfc = n_cls * (F + 1);
+  t.slab = n34 + nfc + 1;
+  int blocks = (int)cdiv(g.items, 4 * 4);                         // ~4 items per wave
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  const int tile = (F * g.T1 + 3) & ~3;
+  const size_t lds = sizeof(float) * (size_t)(4 * 8 * kTaps * 2 * 64 + kTailMaxCls * (F + 1) + 4 * (4 * tile + 64) + 16);
+  ISD_CHECK_ARG(lds <= 160 * 1024 && (int64_t)blocks * t.slab <= g.total - g.o_part, "isd_featcnn_step: workspace");
+  ISD_HIP_TRY(hipFuncSetAttribute((const void*)featcnn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(featcnn_tail_kernel, dim3(blocks), dim3(256), lds, st, t);
+  ISD_LAUNCH_CHECK();
+  if (!labels) return ISD_OK;
+  float* red = ws + g.o_s;                                        // free activation-sized scratch
+  launch_reduce_slabs(ws + g.o_part, red, t.slab, blocks, st);
+  {
+    // cnn3 / cnn4 gradients sit back to back in the flat block
+    float* dw34 = train ? dparams + p->p_off[0] + F * kTaps + F + (int64_t)F * F * p->cz[0] : red;
+    hipLaunchKernelGGL(featcnn_tail_scatter_kernel, dim3((unsigned)cdiv(t.slab, 256)), dim3(256), 0, st, red,
+                       train ? dw34 : red, train ? dfc : red + n34, loss, train ? n34 : 0, train ? nfc : 0);
+    if (!train)   // loss only: element n34 + nfc of the reduced slab
+      hipLaunchKernelGGL(featcnn_tail_scatter_kernel, dim3(1), dim3(1), 0, st, red + n34 + nfc, red, red, loss, 0, 0);
+  }
+  ISD_LAUNCH_CHECK();
+  if (!train) return ISD_OK;
+  return first_layer_backward(p, g, x, T, params, ws + g.o_a4, dparams, ws, st);
 }
 
 extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const float* params, const float* dfeat,
@@ -1862,44 +2301,5 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
     if (rc) return rc;
     g2 = ws + g.o_a4;
   }
-  // cnn1 o cnn2: dWeff (+ dbeff in the ones channel), then chain to W1, b1, W2
-  w.dout = g2; w.in = x; w.Tin = p->W; w.pad = 0;
-  w.RSo = g.T1; w.lin = g.lin0;
-  w.RSi = g.lin0 ? p->W : (p->W | 1);
-  w.slab_size = g.slab0; w.wz_stride = 0; w.items_per_wg = g.ipw0; w.CW = g.cw0;
-  int n_slabs0 = g.ns0;
-  {
-    // wide inputs: LDS-DMA double-buffered variant, ~3 workgroups per CU
-    const int zg = (p->max_cz + 63) / 64;
-    int64_t r_target = (256 * 3) / ((int64_t)zg * p->Z);
-    if (r_target < 1) r_target = 1;
-    if (r_target > g.ns0) r_target = g.ns0;
-    const int ipw = (int)cdiv(g.items, r_target);
-    const int R = (int)cdiv(g.items, ipw);
-    const int item_len = (F * g.T1 + 64 * p->W + 3) & ~3;
-    int ips = 4;
-    while (ips > 1 && (size_t)(2 * (ips * item_len + 32) + 8) * 4 > 48 * 1024) --ips;
-    const size_t lds = sizeof(float) * (size_t)(2 * (ips * item_len + 32) + 8);
-    if (g.lin0 && p->dma_ok && !p->act_bf16 && p->max_cz >= 64 && (F * g.T1) % 4 == 0 && lds <= 64 * 1024 &&
-        ((uintptr_t)x & 15) == 0 && ((uintptr_t)g2 & 15) == 0) {
-      w.items_per_wg = ipw; w.IPS = ips;
-      const dim3 grid((unsigned)R, p->Z, zg);
-      if (F == 32) hipLaunchKernelGGL(conv5_wgrad_wide_kernel<2>, grid, dim3(256), lds, st, w);
-      else hipLaunchKernelGGL(conv5_wgrad_wide_kernel<1>, grid, dim3(256), lds, st, w);
-      ISD_LAUNCH_CHECK();
-      n_slabs0 = R;
-      rc = ISD_OK;
-    } else {
-      rc = launch_wgrad(0, p->act_bf16, w, p->Z, p->max_cz + 1, st);
-    }
-  }
-  if (rc) return rc;
-  launch_reduce_slabs(ws + g.o_part, ws + g.o_wg, g.slab0, n_slabs0, st);
-  {
-    const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
-    hipLaunchKernelGGL(fused_bwd_kernel, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,
-                       ws + g.o_wg, dparams, F, nb2);
-  }
-  ISD_LAUNCH_CHECK();
-  return ISD_OK;
+  return first_layer_backward(p, g, x, T, params, g2, dparams, ws, st);
 }

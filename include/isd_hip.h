@@ -239,6 +239,22 @@ int isd_attention_backward(const float* qkv, const float* probs, const float* dc
                            int H, int head_dim, float dropout_p, uint64_t seed, void* stream);
 
 /* ----------------------------------------------------------------------
+ * Whole classifier step on spec-S features in one call (the build-defined classifier of SURVEY 8d:
+ * Conv4Layers(nb*C, 32) -> Linear(32, n_cls) -> softmax cross-entropy; replaces the call sequence
+ * isd_conv4_forward / isd_linear_forward / isd_softmax_ce / isd_linear_backward / isd_conv4_backward).
+ *   x [B][c_total][T] f32 features, params = the conv4 flat block, fc_w [n_cls][32], fc_b [n_cls].
+ *   labels (uint8 / int64, may be null: inference): loss = sum_b nll_b * grad_scale, gradients scaled alike.
+ *   dparams (conv4 layout) and dfc ([n_cls][32] then [n_cls]) may be null: forward + loss only.
+ * Needs one zone, 4 layers, 32 filters, fp32 activations, T - 4 <= 16 output steps, n_cls <= 16
+ * (isd_featcnn_supported); workspace = isd_conv4_workspace_bytes(plan, B, T).
+ * ---------------------------------------------------------------------- */
+int isd_featcnn_supported(const isd_conv4_plan* plan, int64_t B, int64_t T, int n_cls);
+int isd_featcnn_step(const isd_conv4_plan* plan, const float* x, const float* params, const float* fc_w,
+                     const float* fc_b, const void* labels, int label_bytes, float* dparams, float* dfc,
+                     float* logits, int64_t* pred, float* loss, void* workspace, int64_t B, int64_t T, int n_cls,
+                     float grad_scale, void* stream);
+
+/* ----------------------------------------------------------------------
  * HeadConv_Paper_Version  (replaces src/fast/models/fast.py:170-196 behind the head contract :203-210)
  *   x [B][C][T] f32 -> out [B][feature_dim];  feature_dim in [3,64] (F1 = F/2, F2 = F3 = F/3, F4 = F), T >= 46.
  * Flat parameter block (reference state_dict order, trainable tensors only):
