@@ -960,19 +960,22 @@ struct TailArgs {
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
-  // wave-private LDS hand-over between lanes: LDS operations of one wave execute in order; keep the compiler
-  // from moving them across this point and wait for the outstanding ones
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // wave-private LDS hand-over between lanes: LDS operations of one wave execute in order, so it is enough to
+  // wait for the outstanding LDS operations (not for global stores: a fence would also drain vmcnt, ~1.5 us
+  // after every logits / gradient store) and to keep the compiler from moving accesses across this point
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// one 16-column tile: acc[gt] += W[gt] (x) in   (F = 32 input channels, pad 2)
-__device__ __forceinline__ void tail_conv(const float* __restrict__ wl, const float* __restrict__ in, int T1, int q,
-                                          int jl, f32x4 (&acc)[2]) {
+// NI items side by side (independent MFMA chains hide the LDS and MFMA latencies of a single wave per SIMD):
+// acc[i][gt] += W[gt] (x) in_i  for one 16-column tile per item (F = 32 input channels, pad 2); the A fragments
+// are shared by the items
+template <int NI>
+__device__ __forceinline__ void tail_conv(const float* __restrict__ wl, const float* const (&in)[NI], int T1, int q,
+                                          int jl, f32x4 (&acc)[NI][2]) {
   struct Frag {
     float af[kTaps][2];
-    float bf[kTaps];
+    float bf[NI][kTaps];
   };
   bool ok[kTaps];
   int off[kTaps];
@@ -983,21 +986,25 @@ __device__ __forceinline__ void tail_conv(const float* __restrict__ wl, const fl
     off[k] = ok[k] ? idx : 0;
   }
   auto load = [&](int cg, Frag& f) {
-    const float* rowp = in + (cg * 4 + q) * T1;
 #pragma unroll
     for (int k = 0; k < kTaps; ++k) {
       f.af[k][0] = wl[((cg * kTaps + k) * 2 + 0) * 64];
       f.af[k][1] = wl[((cg * kTaps + k) * 2 + 1) * 64];
-      const float v = rowp[off[k]];
-      f.bf[k] = ok[k] ? v : 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const float v = in[i][(cg * 4 + q) * T1 + off[k]];
+        f.bf[i][k] = ok[k] ? v : 0.f;
+      }
     }
   };
   auto mma = [&](const Frag& f) {
 #pragma unroll
-    for (int k = 0; k < kTaps; ++k) {
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[k][0], f.bf[k], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[k][1], f.bf[k], acc[1], 0, 0, 0);
-    }
+    for (int k = 0; k < kTaps; ++k)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[k][0], f.bf[i][k], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[k][1], f.bf[i][k], acc[i][1], 0, 0, 0);
+      }
   };
   Frag f0, f1;
   load(0, f0);
@@ -1010,36 +1017,42 @@ __device__ __forceinline__ void tail_conv(const float* __restrict__ wl, const fl
   }
 }
 
-// dW[gt][ct][k] += sum_t G[gt*16 + row][t] * In[ct*16 + col][t + k - 2]   for one item (T1 <= 16: four K-steps)
-__device__ __forceinline__ void tail_wgrad(const float* __restrict__ G, const float* __restrict__ In, int T1, int q,
+// dW[gt][ct][k] += sum_i sum_t G_i[gt*16 + row][t] * In_i[ct*16 + col][t + k - 2]   (T1 <= 16: four K-steps per item)
+template <int NI>
+__device__ __forceinline__ void tail_wgrad(const float* const (&G)[NI], const float* const (&In)[NI], int T1, int q,
                                            int jl, f32x4 (&acc)[2][2][kTaps]) {
 #pragma unroll 1
   for (int s = 0; s < 4; ++s) {
     const int t = s * 4 + q;
     const bool okA = t < T1;
     const int tc = okA ? t : 0;
-    float a[2], b[2][kTaps];
+    float a[NI][2], b[NI][2][kTaps];
 #pragma unroll
-    for (int gt = 0; gt < 2; ++gt) {
-      const float v = G[(gt * 16 + jl) * T1 + tc];
-      a[gt] = okA ? v : 0.f;
-    }
+    for (int i = 0; i < NI; ++i) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int k = 0; k < kTaps; ++k) {
-        const int idx = t + k - 2;
-        const bool in = okA && idx >= 0 && idx < T1;
-        const float v = In[(ct * 16 + jl) * T1 + (in ? idx : 0)];
-        b[ct][k] = in ? v : 0.f;
+      for (int gt = 0; gt < 2; ++gt) {
+        const float v = G[i][(gt * 16 + jl) * T1 + tc];
+        a[i][gt] = okA ? v : 0.f;
       }
-#pragma unroll
-    for (int gt = 0; gt < 2; ++gt)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int k = 0; k < kTaps; ++k)
-          acc[gt][ct][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gt], b[ct][k], acc[gt][ct][k], 0, 0, 0);
+        for (int k = 0; k < kTaps; ++k) {
+          const int idx = t + k - 2;
+          const bool in = okA && idx >= 0 && idx < T1;
+          const float v = In[i][(ct * 16 + jl) * T1 + (in ? idx : 0)];
+          b[i][ct][k] = in ? v : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int k = 0; k < kTaps; ++k)
+            acc[gt][ct][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][gt], b[i][ct][k], acc[gt][ct][k], 0, 0, 0);
   }
 }
 
@@ -1053,25 +1066,31 @@ __device__ __forceinline__ void tail_store_tile(const f32x4 (&acc)[2], float* __
 }
 
 constexpr int kTailMaxCls = 16;
+constexpr int kTailNI = 1;        // items a wave carries side by side (measured at cfg 2: 1 -> 107 us, 2 -> 116 us: 512 VGPRs + spills)
 
 __global__ __launch_bounds__(256) void featcnn_tail_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int F = 32, NW = 4, WF = 8 * kTaps * 2 * 64;      // 5120 floats per fragment set
+  constexpr int F = 32, NW = 4, NI = kTailNI, WF = 8 * kTaps * 2 * 64;      // 5120 floats per fragment set
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
   const int T1 = a.T1, n_cls = a.n_cls;
-  const int tile = F * T1;
+  const int tile = F * T1, tpad = (tile + 3) & ~3;
   float* w3s = smem;                                          // fragment sets, shared by the workgroup
   float* w4s = w3s + WF;
   float* w3ts = w4s + WF;
   float* w4ts = w3ts + WF;
   float* fcs = w4ts + WF;                                     // [n_cls][F] then [n_cls]
-  float* priv = fcs + kTailMaxCls * (F + 1) + ((wave * (4 * ((tile + 3) & ~3) + 64)));
-  float* tA2 = priv;                                          // wave-private tiles
-  float* tA3 = tA2 + ((tile + 3) & ~3);
-  float* tG = tA3 + ((tile + 3) & ~3);                        // G4, later G2
-  float* tH = tG + ((tile + 3) & ~3);                         // G3
-  float* featL = tH + ((tile + 3) & ~3);                      // [32] pooled features, [16] logits, [16] dlogits
-  float* logL = featL + 32;
+  float* priv = fcs + kTailMaxCls * (F + 1) + wave * NI * (4 * tpad + 64);
+  float *tA2[NI], *tA3[NI], *tG[NI], *tH[NI], *featL[NI], *logL[NI];   // wave-private tiles, per item slot
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    float* base = priv + i * (4 * tpad + 64);
+    tA2[i] = base;
+    tA3[i] = base + tpad;
+    tG[i] = base + 2 * tpad;                                  // G4, later G2
+    tH[i] = base + 3 * tpad;                                  // G3
+    featL[i] = base + 4 * tpad;                               // [32] pooled features, then [16] logits, [16] dlogits
+    logL[i] = featL[i] + 32;
+  }
   for (int e = threadIdx.x; e < WF; e += 256) {
     w3s[e] = a.w3[e];
     w4s[e] = a.w4[e];
@@ -1094,99 +1113,137 @@ __global__ __launch_bounds__(256) void featcnn_tail_kernel(TailArgs a) {
   float accfc[kTailMaxCls * F / 64], accb = 0.f, loss_acc = 0.f;   // lane l owns flat fc elements l, l+64, ...
 #pragma unroll
   for (int i = 0; i < kTailMaxCls * F / 64; ++i) accfc[i] = 0.f;
-  const int n4 = tile >> 2;                                   // T1 % 4 == 0 is not required: tile = 32*T1 is
+  const int n4 = tile >> 2;                                   // <= 128: two float4 per lane
   const float inv_t = 1.f / (float)T1;
+  const int64_t stride = (int64_t)gridDim.x * NW * NI;
 
-  for (int64_t item = (int64_t)blockIdx.x * NW + wave; item < a.items; item += (int64_t)gridDim.x * NW) {
-    {
-      const float4* src = reinterpret_cast<const float4*>(a.a2 + item * tile);
-      float4* dst = reinterpret_cast<float4*>(tA2);
-      for (int e = lane; e < n4; e += 64) dst[e] = src[e];
+  // item slot i of this wave walks items first + i, first + i + stride, ...; a slot past the end recomputes the
+  // last valid item (uniform control flow for the MFMAs) and contributes nothing
+  for (int64_t first = ((int64_t)blockIdx.x * NW + wave) * NI; first < a.items; first += stride) {
+    int64_t item[NI];
+    bool live[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      live[i] = first + i < a.items;
+      item[i] = live[i] ? first + i : first;
+      const float4* src = reinterpret_cast<const float4*>(a.a2 + item[i] * tile);
+      float4* dst = reinterpret_cast<float4*>(tA2[i]);
+      if (lane < n4) dst[lane] = src[lane];
+      if (lane + 64 < n4) dst[lane + 64] = src[lane + 64];
     }
     wave_lds_sync();
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    tail_conv(w3s + lane, tA2, T1, q, jl, acc);               // A3
-    tail_store_tile(acc, tA3, T1, q, jl);
+    f32x4 acc[NI][2];
+    auto clear = [&]() {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    clear();
+    tail_conv<NI>(w3s + lane, tA2, T1, q, jl, acc);           // A3
+#pragma unroll
+    for (int i = 0; i < NI; ++i) tail_store_tile(acc[i], tA3[i], T1, q, jl);
     wave_lds_sync();
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tail_conv(w4s + lane, tA3, T1, q, jl, acc);               // A4 stays in registers
+    clear();
+    tail_conv<NI>(w4s + lane, tA3, T1, q, jl, acc);           // A4 stays in registers
     // GELU + mean over time: row sums inside each 16-lane row
 #pragma unroll
-    for (int gt = 0; gt < 2; ++gt)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float sacc = jl < T1 ? gelu_f(acc[gt][r]) : 0.f;
-        sacc += row_shr<8>(sacc);
-        sacc += row_shr<4>(sacc);
-        sacc += row_shr<2>(sacc);
-        sacc += row_shr<1>(sacc);
-        if (jl == 15) featL[gt * 16 + 4 * q + r] = sacc * inv_t;
+      for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sacc = jl < T1 ? gelu_f(acc[i][gt][r]) : 0.f;
+          sacc += row_shr<8>(sacc);
+          sacc += row_shr<4>(sacc);
+          sacc += row_shr<2>(sacc);
+          sacc += row_shr<1>(sacc);
+          if (jl == 15) featL[i][gt * 16 + 4 * q + r] = sacc * inv_t;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (lane < n_cls) {
+        float l = fcs[n_cls * F + lane];
+#pragma unroll
+        for (int g = 0; g < F; ++g) l = fmaf(fcs[lane * F + g], featL[i][g], l);
+        logL[i][lane] = l;
+        if (live[i]) a.logits[item[i] * n_cls + lane] = l;
       }
     wave_lds_sync();
-    if (lane < n_cls) {
-      float l = fcs[n_cls * F + lane];
+    float lse[NI];
+    int yv[NI];
 #pragma unroll
-      for (int g = 0; g < F; ++g) l = fmaf(fcs[lane * F + g], featL[g], l);
-      logL[lane] = l;
-      a.logits[item * n_cls + lane] = l;
-    }
-    wave_lds_sync();
-    float mx = -INFINITY;
-    int am = 0;
-    for (int c = 0; c < n_cls; ++c) {
-      const float v = logL[c];
-      if (v > mx) { mx = v; am = c; }                         // strict '>' keeps the lowest index on ties (torch.argmax)
-    }
-    if (lane == 0) a.pred[item] = am;
-    if (!a.labels) continue;
-    float se = 0.f;
-    for (int c = 0; c < n_cls; ++c) se += expf(logL[c] - mx);
-    const int y = a.label_bytes == 1 ? (int)((const unsigned char*)a.labels)[item]
-                                     : (int)((const long long*)a.labels)[item];
-    const float lse = mx + logf(se);
-    if (lane == 0) loss_acc += (lse - logL[y]) * a.grad_scale;
-    if (!a.train) continue;
-    // dlogits -> LDS; dfeat for this lane's 8 filters; G4 = dfeat/T1 * GELU'(A4)
-    if (lane < n_cls) logL[16 + lane] = (expf(logL[lane] - lse) - (lane == y ? 1.f : 0.f)) * a.grad_scale;
-    wave_lds_sync();
-#pragma unroll
-    for (int gt = 0; gt < 2; ++gt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int g = gt * 16 + 4 * q + r;
-        float d = 0.f;
-        for (int c = 0; c < n_cls; ++c) d = fmaf(fcs[c * F + g], logL[16 + c], d);
-        acc[gt][r] = d * inv_t * gelu_grad_f(acc[gt][r]);
+    for (int i = 0; i < NI; ++i) {
+      float mx = -INFINITY;
+      int am = 0;
+      for (int c = 0; c < n_cls; ++c) {
+        const float v = logL[i][c];
+        if (v > mx) { mx = v; am = c; }                       // strict '>' keeps the lowest index on ties (torch.argmax)
       }
-    tail_store_tile(acc, tG, T1, q, jl);
-    // FC gradients: flat element e = lane + 64 i of [n_cls][F]
-#pragma unroll
-    for (int i = 0; i < kTailMaxCls * F / 64; ++i) {
-      const int e = lane + 64 * i;
-      if (e < n_cls * F) accfc[i] = fmaf(logL[16 + (e >> 5)], featL[e & 31], accfc[i]);
+      if (lane == 0 && live[i]) a.pred[item[i]] = am;
+      lse[i] = 0.f;
+      yv[i] = 0;
+      if (a.labels) {
+        float se = 0.f;
+        for (int c = 0; c < n_cls; ++c) se += expf(logL[i][c] - mx);
+        yv[i] = a.label_bytes == 1 ? (int)((const unsigned char*)a.labels)[item[i]]
+                                   : (int)((const long long*)a.labels)[item[i]];
+        lse[i] = mx + logf(se);
+        if (lane == 0 && live[i]) loss_acc += (lse[i] - logL[i][yv[i]]) * a.grad_scale;
+      }
     }
-    if (lane < n_cls) accb += logL[16 + lane];
+    if (!a.labels || !a.train) continue;
+    // dlogits -> LDS (zero for a dead slot); dfeat for this lane's 8 filters; G4 = dfeat/T1 * GELU'(A4)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (lane < n_cls)
+        logL[i][16 + lane] = live[i] ? (expf(logL[i][lane] - lse[i]) - (lane == yv[i] ? 1.f : 0.f)) * a.grad_scale : 0.f;
     wave_lds_sync();
-    tail_wgrad(tG, tA3, T1, q, jl, accW4);
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tail_conv(w4ts + lane, tG, T1, q, jl, acc);               // G3
-    tail_store_tile(acc, tH, T1, q, jl);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int g = gt * 16 + 4 * q + r;
+          float d = 0.f;
+          for (int c = 0; c < n_cls; ++c) d = fmaf(fcs[c * F + g], logL[i][16 + c], d);
+          acc[i][gt][r] = d * inv_t * gelu_grad_f(acc[i][gt][r]);
+        }
+      tail_store_tile(acc[i], tG[i], T1, q, jl);
+      // FC gradients: flat element e = lane + 64 j of [n_cls][F]
+#pragma unroll
+      for (int j = 0; j < kTailMaxCls * F / 64; ++j) {
+        const int e = lane + 64 * j;
+        if (e < n_cls * F) accfc[j] = fmaf(logL[i][16 + (e >> 5)], featL[i][e & 31], accfc[j]);
+      }
+      if (lane < n_cls) accb += logL[i][16 + lane];
+    }
     wave_lds_sync();
-    tail_wgrad(tH, tA2, T1, q, jl, accW3);
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tail_conv(w3ts + lane, tH, T1, q, jl, acc);               // G2
+    tail_wgrad<NI>(tG, tA3, T1, q, jl, accW4);
+    clear();
+    tail_conv<NI>(w4ts + lane, tG, T1, q, jl, acc);           // G3
+#pragma unroll
+    for (int i = 0; i < NI; ++i) tail_store_tile(acc[i], tH[i], T1, q, jl);
+    wave_lds_sync();
+    tail_wgrad<NI>(tH, tA2, T1, q, jl, accW3);
+    clear();
+    tail_conv<NI>(w3ts + lane, tH, T1, q, jl, acc);           // G2
     wave_lds_sync();                                          // every read of tG (wgrad4, cnn4 data gradient) is done
-    tail_store_tile(acc, tG, T1, q, jl);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) tail_store_tile(acc[i], tG[i], T1, q, jl);
     wave_lds_sync();
-    {
-      float4* dst = reinterpret_cast<float4*>(a.g2 + item * tile);
-      const float4* src = reinterpret_cast<const float4*>(tG);
-      for (int e = lane; e < n4; e += 64) dst[e] = src[e];
-    }
-    wave_lds_sync();                                          // tiles are reused by the next item
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (live[i]) {
+        float4* dst = reinterpret_cast<float4*>(a.g2 + item[i] * tile);
+        const float4* src = reinterpret_cast<const float4*>(tG[i]);
+        if (lane < n4) dst[lane] = src[lane];
+        if (lane + 64 < n4) dst[lane + 64] = src[lane + 64];
+      }
+    wave_lds_sync();                                          // tiles are reused by the next items
   }
   if (!a.labels) return;
   // combine the 4 waves in wave order through LDS (the fragment sets are dead), then one slab per workgroup
@@ -2181,11 +2238,11 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
   t.items = g.items; t.T1 = g.T1; t.n_cls = n_cls; t.train = train ? 1 : 0; t.grad_scale = grad_scale;
   const int n34 = 2 * F * F * kTaps, nfc = n_cls * (F + 1);
   t.slab = n34 + nfc + 1;
-  int blocks = (int)cdiv(g.items, 4 * 4);                         // ~4 items per wave
+  int blocks = (int)cdiv(g.items, 4 * kTailNI * 2);               // two rounds of NI items per wave
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   const int tile = (F * g.T1 + 3) & ~3;
-  const size_t lds = sizeof(float) * (size_t)(4 * 8 * kTaps * 2 * 64 + kTailMaxCls * (F + 1) + 4 * (4 * tile + 64) + 16);
+  const size_t lds = sizeof(float) * (size_t)(4 * 8 * kTaps * 2 * 64 + kTailMaxCls * (F + 1) + 4 * kTailNI * (4 * tile + 64) + 16);
   ISD_CHECK_ARG(lds <= 160 * 1024 && (int64_t)blocks * t.slab <= g.total - g.o_part, "isd_featcnn_step: workspace");
   ISD_HIP_TRY(hipFuncSetAttribute((const void*)featcnn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(featcnn_tail_kernel, dim3(blocks), dim3(256), lds, st, t);
