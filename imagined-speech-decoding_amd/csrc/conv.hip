@@ -2250,13 +2250,14 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
   if (!labels) return ISD_OK;
   float* red = ws + g.o_s;                                        // free activation-sized scratch
   launch_reduce_slabs(ws + g.o_part, red, t.slab, blocks, st);
-  {
+  if (train) {
     // cnn3 / cnn4 gradients sit back to back in the flat block
-    float* dw34 = train ? dparams + p->p_off[0] + F * kTaps + F + (int64_t)F * F * p->cz[0] : red;
-    hipLaunchKernelGGL(featcnn_tail_scatter_kernel, dim3((unsigned)cdiv(t.slab, 256)), dim3(256), 0, st, red,
-                       train ? dw34 : red, train ? dfc : red + n34, loss, train ? n34 : 0, train ? nfc : 0);
-    if (!train)   // loss only: element n34 + nfc of the reduced slab
-      hipLaunchKernelGGL(featcnn_tail_scatter_kernel, dim3(1), dim3(1), 0, st, red + n34 + nfc, red, red, loss, 0, 0);
+    float* dw34 = dparams + p->p_off[0] + F * kTaps + F + (int64_t)F * F * p->cz[0];
+    hipLaunchKernelGGL(featcnn_tail_scatter_kernel, dim3((unsigned)cdiv(t.slab, 256)), dim3(256), 0, st, red, dw34, dfc,
+                       loss, n34, nfc);
+  } else {
+    // evaluation with labels: only the loss (last element of the reduced slab) is wanted
+    hipLaunchKernelGGL(featcnn_tail_scatter_kernel, dim3(1), dim3(1), 0, st, red + n34 + nfc, red, red, loss, 0, 0);
   }
   ISD_LAUNCH_CHECK();
   if (!train) return ISD_OK;

@@ -132,3 +132,30 @@ def test_experiment_driver_writes_reference_artifacts(isd, tmp_path):
     assert "head.encoders.Frontal.cnn2.weight" in sd and "transformer.0.attn.in_proj_weight" in sd
     per, summary = E.process_results(str(tmp_path))
     assert summary["N_subjects"] == 1 and per[0]["N_samples"] == 5
+
+
+def test_fused_classifier_step_modes_match_layerwise_path(isd):
+    """isd_featcnn_step (one call) against the layer-wise call sequence: inference, loss-only and training modes,
+    uint8 and int64 labels, a batch that does not fill the last wave."""
+    from isd_amd.classifier import _FeatureModel
+    import isd_amd._lib as L
+    torch.manual_seed(5)
+    m = _FeatureModel(9 * 8, 32, 5, 4).cuda()
+    hp = isd.HotPath(m)
+    feats = torch.randn(37, 72, 17, device="cuda")
+    y = torch.randint(0, 5, (37,), device="cuda")
+    assert L.lib().isd_featcnn_supported(m.conv_plan(feats)._h, 37, 17, 5) == 1
+    lw = m.net.token_logits(feats.view(37, 9, 8, 17)).squeeze(1)            # autograd modules = layer-wise kernels
+    inf = hp.forward(feats)
+    assert "loss" not in inf and rel_err(inf["logits"].cpu(), lw.detach().cpu()) < 1e-6
+    assert np.array_equal(inf["pred"].cpu().numpy(), lw.argmax(1).cpu().numpy())
+    ev = hp.forward(feats, y.to(torch.uint8), global_batch=74)
+    ref_loss = torch.nn.functional.cross_entropy(lw, y, reduction="sum") / 74
+    assert abs(float(ev["loss"]) - float(ref_loss)) < 1e-6
+    m.zero_grad(set_to_none=True)
+    tr = hp.forward(feats, y, global_batch=74, want_grad=True)
+    g_fused = m.flat_grads().clone()
+    m.zero_grad(set_to_none=True)
+    ref_loss.backward()
+    g_ref = torch.cat([p.grad.reshape(-1) for p in m._ordered_params()])
+    assert abs(float(tr["loss"]) - float(ref_loss)) < 1e-6 and rel_err(g_fused.cpu(), g_ref.cpu()) < 1e-5
