@@ -1883,8 +1883,9 @@ int make_geo(const isd_conv4_plan* p, int64_t B, int64_t T, Geo& g) {
   {   // keep the staged tile (input rows + one weight chunk) inside 64 KiB of LDS
     const int64_t wfl = (int64_t)(kCK / 4) * kTaps * (p->F / 16) * 64;
     const int64_t per_item = (int64_t)kCK * (g.RS_a > g.RS_b ? g.RS_a : g.RS_b);
-    const int64_t fit = (64 * 1024 / 4 - wfl) / per_item;
-    ISD_CHECK_ARG(fit >= 1, "conv4: window_len=%d is too long for the LDS tile", p->W);
+    int64_t fit = (64 * 1024 / 4 - wfl) / per_item;
+    if (fit < 1) fit = (150 * 1024 / 4 - wfl - 64) / per_item;     // long windows: one item in the large LDS allocation
+    ISD_CHECK_ARG(fit >= 1, "conv4: window_len=%d is too long for the LDS tile (about 1000 samples)", p->W);
     if (g.IPW > fit) g.IPW = (int)fit;
     // enough workgroups to co-schedule ~4 per CU (staging of one overlaps the MFMA phase of another)
     const int64_t occ = (g.items * p->Z) / 512;
@@ -1944,15 +1945,22 @@ static int launch_conv(int mode, int bf16, const ConvArgs& a, int n_zones, hipSt
   ISD_CHECK_ARG(blocks <= 0x7fffffffLL, "conv4: too many items");
   const int GT = a.F / 16;
   const size_t lds = sizeof(float) * (4 + (((size_t)a.IPW * kCK * a.RS + 3) & ~(size_t)3) + (size_t)(kCK / 4) * kTaps * GT * 64 + 32);
-  ISD_CHECK_ARG(lds <= 64 * 1024, "conv4: LDS tile of %zu bytes exceeds 64 KiB (window too long)", lds);
+  ISD_CHECK_ARG(lds <= 150 * 1024, "conv4: LDS tile of %zu bytes exceeds 150 KiB (window too long)", lds);
   const dim3 grid((unsigned)blocks, n_zones);
   const int tiles = a.IPW * a.TT;                     // column tiles per workgroup -> tiles per wave (1, 2 or 4)
   const int NT = tiles > 8 ? 4 : tiles > 4 ? 2 : 1;
+#define ISD_CONV_LAUNCH_1(M, T, G, N)                                                                \
+  do {                                                                                               \
+    if (lds > 48 * 1024)                                                                             \
+      ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_fwd_kernel<M, T, G, N>,                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+    hipLaunchKernelGGL((conv5_fwd_kernel<M, T, G, N>), grid, dim3(256), lds, st, a);                 \
+  } while (0)
 #define ISD_CONV_LAUNCH_N(M, T, G)                                                                   \
   do {                                                                                               \
-    if (NT == 4) hipLaunchKernelGGL((conv5_fwd_kernel<M, T, G, 4>), grid, dim3(256), lds, st, a);    \
-    else if (NT == 2) hipLaunchKernelGGL((conv5_fwd_kernel<M, T, G, 2>), grid, dim3(256), lds, st, a); \
-    else hipLaunchKernelGGL((conv5_fwd_kernel<M, T, G, 1>), grid, dim3(256), lds, st, a);            \
+    if (NT == 4) ISD_CONV_LAUNCH_1(M, T, G, 4);                                                      \
+    else if (NT == 2) ISD_CONV_LAUNCH_1(M, T, G, 2);                                                 \
+    else ISD_CONV_LAUNCH_1(M, T, G, 1);                                                              \
   } while (0)
 #define ISD_CONV_LAUNCH(M, T)                                                                         \
   do {                                                                                               \
@@ -1965,6 +1973,7 @@ static int launch_conv(int mode, int bf16, const ConvArgs& a, int n_zones, hipSt
   else ISD_CONV_LAUNCH(1, bf16_t);
 #undef ISD_CONV_LAUNCH
 #undef ISD_CONV_LAUNCH_N
+#undef ISD_CONV_LAUNCH_1
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
@@ -2111,7 +2120,8 @@ static int launch_wgrad_t(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t
 static int launch_wgrad(int mode, int bf16, WgradArgs& a, int n_zones, int cin_max, hipStream_t st) {
   const int64_t per_item = (int64_t)a.F * a.RSo + (int64_t)a.CW * a.RSi;
   int ips = (int)((96 * 1024 / 4 - 4) / per_item);
-  ISD_CHECK_ARG(ips >= 1, "conv4 wgrad: window too long for the LDS tile");
+  if (ips < 1) ips = (int)((150 * 1024 / 4 - 4) / per_item);   // long windows: one item in the large LDS allocation
+  ISD_CHECK_ARG(ips >= 1, "conv4 wgrad: window too long for the LDS tile (about 600 samples)");
   if (ips > 1 && per_item * 4 > 32 * 1024) ips = 1;           // big items: one per stage, 2-3 workgroups per CU
   const int ips_occ = (int)((32 * 1024 / 4) / per_item);      // prefer <= 32 KiB so several workgroups share a CU
   if (ips_occ >= 1 && ips > ips_occ) ips = ips_occ;
