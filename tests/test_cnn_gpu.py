@@ -39,7 +39,11 @@ def test_conv4layers_matches_reference_golden(inn, cz):
 
 
 @pytest.mark.parametrize("channels,T,dim,n_layers,B", [(4, 250, 16, 4, 5), (40, 64, 32, 4, 3), (70, 21, 32, 2, 9),
-                                                      (576, 17, 32, 4, 20), (3, 300, 32, 4, 2), (1, 9, 16, 2, 1)])
+                                                      (576, 17, 32, 4, 20), (3, 300, 32, 4, 2), (1, 9, 16, 2, 1),
+                                                      # wide inputs (LDS-DMA kernels): 16 filters, partial last chunk /
+                                                      # channel group, 2-layer stack, one item, many items per workgroup
+                                                      (128, 17, 16, 4, 7), (100, 20, 32, 2, 33), (320, 9, 32, 4, 1),
+                                                      (68, 17, 16, 2, 300), (200, 40, 32, 4, 5)])
 def test_conv4layers_vs_oracle_shapes(inn, channels, T, dim, n_layers, B):
     p = ocnn.init_conv4_params(channels, dim, seed=channels + T, n_layers=n_layers)
     m = inn.Conv4Layers(channels, dim, n_layers).cuda()
