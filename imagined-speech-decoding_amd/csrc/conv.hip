@@ -188,6 +188,7 @@ struct ConvArgs {
   int64_t wz_stride;         // MODE 1: per-zone stride of wfrag
   int64_t items;             // B' = B * N
   int Z, F, Tin, Tout, pad, TT, IPW, RS;
+  int CK;                    // conv5_fwd_kernel: channels staged per chunk (multiple of 4, <= 32)
   int lin;                   // 1: a chunk's rows are one contiguous block in global memory and RS == Tin
   int Ctot, Tx, N, S;        // MODE 0 only
 };
@@ -204,15 +205,16 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
   const int z = blockIdx.y;
   const ZoneDesc zd = a.zones[z];
   const int cin = (MODE == 0) ? zd.cin : a.F;
+  const int CK = a.CK;                                     // channels staged per chunk (32, or fewer for long rows)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t item0 = (int64_t)blockIdx.x * a.IPW;
   const int n_items = (int)((a.items - item0) < a.IPW ? (a.items - item0) : a.IPW);
   const int n_ct = n_items * a.TT;
-  float* in_tile = smem + 4;                               // [IPW][kCK][RS]; 4 floats of slack: masked reads may
+  float* in_tile = smem + 4;                               // [IPW][CK][RS]; 4 floats of slack: masked reads may
                                                            // address up to `pad` elements before row 0
-  float* w_tile = smem + 4 + ((a.IPW * kCK * a.RS + 3) & ~3);  // [kCK/4][5][GT][64], 16-byte aligned
+  float* w_tile = smem + 4 + ((a.IPW * CK * a.RS + 3) & ~3);  // [CK/4][5][GT][64], 16-byte aligned
   const float* wbase = a.wfrag + ((MODE == 0) ? zd.eff_off : (int64_t)z * a.wz_stride);
-  const int n_chunks = (cin + kCK - 1) / kCK;
+  const int n_chunks = (cin + CK - 1) / CK;
   const int q = lane >> 4, jl = lane & 15;
 
   for (int base = 0; base < n_ct; base += 4 * NT) {
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
       const int ctc = t_ok[j] ? ct : 0;
       t_ii[j] = ctc / a.TT;
       t_t0[j] = (ctc - t_ii[j] * a.TT) * 16;
-      boff[j] = t_ii[j] * kCK * a.RS + t_t0[j] + jl - a.pad + q * a.RS;
+      boff[j] = t_ii[j] * CK * a.RS + t_t0[j] + jl - a.pad + q * a.RS;
 #pragma unroll
       for (int k = 0; k < kTaps; ++k) {
         const int idx = t_t0[j] + jl + k - a.pad;
@@ -246,8 +248,8 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
       }
     }
     for (int ch = 0; ch < n_chunks; ++ch) {
-      const int c_lo = ch * kCK;
-      const int ckc = (cin - c_lo) < kCK ? (cin - c_lo) : kCK;
+      const int c_lo = ch * CK;
+      const int ckc = (cin - c_lo) < CK ? (cin - c_lo) : CK;
       const int ckc4 = (ckc + 3) & ~3;
       __syncthreads();
       if (a.lin) {
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
           const int64_t item = item0 + ii;
           const int64_t soff = (MODE == 0) ? (item * a.Ctot + a.chan_idx[zd.idx_off + c_lo]) * (int64_t)a.Tx
                                            : ((item * a.Z + z) * a.F + c_lo) * (int64_t)a.Tin;
-          float* dst = in_tile + ii * kCK * a.RS;
+          float* dst = in_tile + ii * CK * a.RS;
           if constexpr (std::is_same<IT, float>::value && !Act<AT>::kBf16) {
             const float* src = (const float*)a.in + soff;
             if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && (cnt & 3) == 0) {
@@ -286,19 +288,19 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
           } else {
             soff = ((item * a.Z + z) * a.F + c_lo + cc) * (int64_t)a.Tin;
           }
-          float* dst = in_tile + (ii * kCK + cc) * a.RS;
+          float* dst = in_tile + (ii * CK + cc) * a.RS;
           for (int t = lane; t < a.Tin; t += 64) dst[t] = Act<AT>::rnd(Act<IT>::ld(a.in, soff + t));
         }
       }
       if (ckc4 != ckc) {                                   // channel round-up rows read as zero
         for (int e = threadIdx.x; e < n_items * (ckc4 - ckc) * a.RS; e += 256) {
           const int ii = e / ((ckc4 - ckc) * a.RS), r = e - ii * (ckc4 - ckc) * a.RS;
-          in_tile[(ii * kCK + ckc) * a.RS + r] = 0.f;
+          in_tile[(ii * CK + ckc) * a.RS + r] = 0.f;
         }
       }
       {
         const int wlen4 = (ckc4 / 4) * kTaps * GT * 16;
-        glds_copy16_strided(wbase + (int64_t)ch * (kCK / 4) * kTaps * GT * 64, w_tile, wlen4, wave * 64, 256, lane);
+        glds_copy16_strided(wbase + (int64_t)ch * (CK / 4) * kTaps * GT * 64, w_tile, wlen4, wave * 64, 256, lane);
       }
       __syncthreads();
       // addresses and masks were hoisted out of this loop (boff / okk); the channel round-up rows are zero.
@@ -1333,6 +1335,7 @@ struct WgradArgs {
   int64_t items, slab_size;
   int64_t wz_stride;         // MODE 1: per-zone stride inside a slab
   int items_per_wg, IPS;     // items per workgroup, items per LDS stage
+  int seg_len;               // > 0: rows are staged in time segments of this many output samples (long windows)
   int CW;                    // input channels staged per workgroup (16, 32, 48 or 64)
   int lin;                   // 1: the CW rows of an item are one contiguous block and RSi == Tin
   int Z, F, Tin, Tout, pad, RSo, RSi;
@@ -1369,7 +1372,6 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
   float* in_tile = smem + do_sz;                            // [IPS][CW][RSi]
   const int64_t i_lo = (int64_t)blockIdx.x * a.items_per_wg;
   const int64_t i_hi = (i_lo + a.items_per_wg) < a.items ? (i_lo + a.items_per_wg) : a.items;
-  const int Tk = (a.Tout + 3) & ~3;
   const int c_mine = c_tile + jl;                           // channel of this lane's B column
   const bool c_real = c_mine < n_real;
   const bool c_ones = (MODE == 0) && c_mine == cin - 1;
@@ -1382,9 +1384,12 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
   }
   const int cw_real = (n_real - c_base) < a.CW ? (n_real - c_base) : a.CW;   // real rows to stage (may be <= 0)
 
-  auto compute = [&](const float* do_tile, const float* in_tile, int n_it) {
+  // t_base / t_cnt: the staged time range of the rows (whole rows, or one segment of a row too long for the LDS
+  // tile); org = global sample index of LDS column 0 of the input rows
+  auto compute = [&](const float* do_tile, const float* in_tile, int n_it, int t_base, int t_cnt, int org) {
     if (wave_live) {
       const int row_b = c_real ? (ct * 16 + jl) : 0;
+      const int Tk = (t_cnt + 3) & ~3;
       // wave groups split the reduction (time) range of every item, so one staged item keeps all waves busy.
       // The (item, K-step) pairs of the stage form one flat sequence; the fragments of step s+1 are fetched from
       // LDS while the MFMAs of step s run, and no branch stands between the MFMAs.
@@ -1401,7 +1406,7 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
         if (++l_kk == nk) { l_kk = 0; ++l_ii; }
         const float* dro = do_tile + (ii * a.F + gsel * 16 + jl) * a.RSo;
         const float* iro = in_tile + (ii * a.CW + row_b) * a.RSi;
-        const bool a_ok = ta < a.Tout;
+        const bool a_ok = ta < t_cnt;
         const int tac = a_ok ? ta : 0;
         const float v0 = dro[tac];
         f.a0 = a_ok ? v0 : 0.f;
@@ -1411,10 +1416,10 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < kTaps; ++k) {
-          const int idx = ta + k - a.pad;
-          const bool in_rng = idx >= 0 && idx < a.Tin;
-          const float bf = iro[in_rng ? idx : 0];
-          f.b[k] = (c_real && in_rng) ? bf : ((c_ones && idx >= 0 && idx < a.Tout) ? 1.f : 0.f);
+          const int idx = t_base + ta + k - a.pad;               // global sample of the input row
+          const bool in_rng = a_ok && idx >= 0 && idx < a.Tin;
+          const float bf = iro[in_rng ? idx - org : 0];
+          f.b[k] = (c_real && in_rng) ? bf : ((c_ones && a_ok && idx >= 0 && idx < a.Tout) ? 1.f : 0.f);
         }
       };
       auto mma = [&](const Frag& f) {
@@ -1437,7 +1442,38 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
     }
   };
 
-  for (int64_t is = i_lo; is < i_hi; is += a.IPS) {
+  if (a.seg_len > 0) {
+    // rows longer than the LDS tile: one item per stage, the time range in segments of seg_len output samples
+    // (row-wise staging at the segment origin; the accumulators simply keep summing over the segments)
+    for (int64_t item = i_lo; item < i_hi; ++item) {
+      for (int t_base = 0; t_base < a.Tout; t_base += a.seg_len) {
+        const int t_cnt = (a.Tout - t_base) < a.seg_len ? (a.Tout - t_base) : a.seg_len;
+        const int org = t_base - a.pad, in_cnt = t_cnt + kTaps - 1;
+        __syncthreads();
+        for (int r = wave; r < a.F; r += 4) {
+          const int64_t soff = (((item * a.Z + z) * a.F) + r) * (int64_t)a.Tout + t_base;
+          for (int t = lane; t < t_cnt; t += 64) do_tile[r * a.RSo + t] = Act<AT>::ld(a.dout, soff + t);
+        }
+        for (int r = wave; r < cw_real; r += 4) {
+          int64_t soff;
+          if (MODE == 0) {
+            const int64_t b = item / a.N;
+            const int n = (int)(item - b * a.N);
+            soff = (b * a.Ctot + a.chan_idx[zd.idx_off + c_base + r]) * (int64_t)a.Tx + (int64_t)n * a.S;
+          } else {
+            soff = ((item * a.Z + z) * a.F + c_base + r) * (int64_t)a.Tin;
+          }
+          for (int t = lane; t < in_cnt; t += 64) {
+            const int idx = org + t;
+            in_tile[r * a.RSi + t] = (idx >= 0 && idx < a.Tin) ? Act<AT>::rnd(Act<IT>::ld(a.in, soff + idx)) : 0.f;
+          }
+        }
+        __syncthreads();
+        compute(do_tile, in_tile, 1, t_base, t_cnt, org);
+      }
+    }
+  }
+  for (int64_t is = a.seg_len > 0 ? i_hi : i_lo; is < i_hi; is += a.IPS) {
     const int n_it = (int)((i_hi - is) < a.IPS ? (i_hi - is) : a.IPS);
     __syncthreads();
     // dOut: [F][Tout] of an item is contiguous; few items -> the whole workgroup copies each block
@@ -1502,7 +1538,7 @@ __global__ __launch_bounds__(256) void conv5_wgrad_kernel(WgradArgs a) {
       }
     }
     __syncthreads();
-    compute(do_tile, in_tile, n_it);
+    compute(do_tile, in_tile, n_it, 0, a.Tout, 0);
   }
   if (!wave_live) return;
   float* slab = a.part + ((int64_t)blockIdx.x * n_grp + grp) * a.slab_size +
@@ -1852,7 +1888,7 @@ extern "C" int isd_conv4_windows(const isd_conv4_plan* p, int64_t T) {
 
 namespace {
 struct Geo {           // derived sizes for one call
-  int N, T1, TT, IPW, RS_a, RS_b, lin0;
+  int N, T1, TT, IPW, RS_a, RS_b, lin0, CK;
   int64_t items, act;  // act = floats of one activation tensor
   // workspace layout (floats)
   int64_t o_eff, o_beff, o_w3, o_w3t, o_w4, o_w4t, o_a2, o_a3, o_a4, o_s, o_wg, o_wg34, o_part, total;
@@ -1880,12 +1916,17 @@ int make_geo(const isd_conv4_plan* p, int64_t B, int64_t T, Geo& g) {
   g.lin0 = (p->contiguous && g.N == 1 && T == p->W) ? 1 : 0;
   g.RS_a = g.lin0 ? p->W : row_stride_fwd(p->W);
   g.RS_b = g.T1;
-  {   // keep the staged tile (input rows + one weight chunk) inside 64 KiB of LDS
-    const int64_t wfl = (int64_t)(kCK / 4) * kTaps * (p->F / 16) * 64;
-    const int64_t per_item = (int64_t)kCK * (g.RS_a > g.RS_b ? g.RS_a : g.RS_b);
-    int64_t fit = (64 * 1024 / 4 - wfl) / per_item;
-    if (fit < 1) fit = (150 * 1024 / 4 - wfl - 64) / per_item;     // long windows: one item in the large LDS allocation
-    ISD_CHECK_ARG(fit >= 1, "conv4: window_len=%d is too long for the LDS tile (about 1000 samples)", p->W);
+  {   // keep the staged tile (input rows + one weight chunk) inside 64 KiB of LDS; rows too long for that take the
+      // large LDS allocation, and beyond ~1000 samples fewer channels per chunk
+    const int GTf = p->F / 16;
+    const int64_t row = g.RS_a > g.RS_b ? g.RS_a : g.RS_b;
+    g.CK = kCK;
+    int64_t fit = (64 * 1024 / 4 - (int64_t)(g.CK / 4) * kTaps * GTf * 64) / (g.CK * row);
+    if (fit < 1) {
+      while (g.CK > 4 && (150 * 1024 / 4 - 64 - (int64_t)(g.CK / 4) * kTaps * GTf * 64) / (g.CK * row) < 1) g.CK -= 4;
+      fit = (150 * 1024 / 4 - 64 - (int64_t)(g.CK / 4) * kTaps * GTf * 64) / (g.CK * row);
+    }
+    ISD_CHECK_ARG(fit >= 1, "conv4: window_len=%d is too long for the LDS tile (about 9000 samples)", p->W);
     if (g.IPW > fit) g.IPW = (int)fit;
     // enough workgroups to co-schedule ~4 per CU (staging of one overlaps the MFMA phase of another)
     const int64_t occ = (g.items * p->Z) / 512;
@@ -1944,7 +1985,7 @@ static int launch_conv(int mode, int bf16, const ConvArgs& a, int n_zones, hipSt
   const int64_t blocks = cdiv(a.items, a.IPW);
   ISD_CHECK_ARG(blocks <= 0x7fffffffLL, "conv4: too many items");
   const int GT = a.F / 16;
-  const size_t lds = sizeof(float) * (4 + (((size_t)a.IPW * kCK * a.RS + 3) & ~(size_t)3) + (size_t)(kCK / 4) * kTaps * GT * 64 + 32);
+  const size_t lds = sizeof(float) * (4 + (((size_t)a.IPW * a.CK * a.RS + 3) & ~(size_t)3) + (size_t)(a.CK / 4) * kTaps * GT * 64 + 32);
   ISD_CHECK_ARG(lds <= 150 * 1024, "conv4: LDS tile of %zu bytes exceeds 150 KiB (window too long)", lds);
   const dim3 grid((unsigned)blocks, n_zones);
   const int tiles = a.IPW * a.TT;                     // column tiles per workgroup -> tiles per wave (1, 2 or 4)
@@ -2000,7 +2041,7 @@ static int first_layer_forward(const isd_conv4_plan* p, const Geo& g, const floa
   int rc;
   a = ConvArgs{};
   a.zones = p->d_zones; a.chan_idx = p->d_idx; a.items = g.items; a.Z = p->Z; a.F = F;
-  a.TT = g.TT; a.IPW = g.IPW; a.Tout = g.T1;
+  a.TT = g.TT; a.IPW = g.IPW; a.Tout = g.T1; a.CK = g.CK;
   a.Ctot = p->Ctot; a.Tx = (int)T; a.N = g.N; a.S = p->S;
   // cnn1 o cnn2
   a.in = x; a.out = ws + g.o_a2; a.wfrag = ws + g.o_eff; a.bias = ws + g.o_beff; a.Tin = p->W; a.pad = 0; a.RS = g.RS_a;
@@ -2117,11 +2158,22 @@ static int launch_wgrad_t(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t
   return a.F == 32 ? launch_wgrad_b<MODE, AT, true>(a, grid, lds, st) : launch_wgrad_b<MODE, AT, false>(a, grid, lds, st);
 }
 
-static int launch_wgrad(int mode, int bf16, WgradArgs& a, int n_zones, int cin_max, hipStream_t st) {
-  const int64_t per_item = (int64_t)a.F * a.RSo + (int64_t)a.CW * a.RSi;
+static int launch_wgrad(int mode, int bf16, WgradArgs a, int n_zones, int cin_max, hipStream_t st) {   // `a` by value: the stage geometry chosen here must not leak into the caller's next launch
+  int64_t per_item = (int64_t)a.F * a.RSo + (int64_t)a.CW * a.RSi;
   int ips = (int)((96 * 1024 / 4 - 4) / per_item);
   if (ips < 1) ips = (int)((150 * 1024 / 4 - 4) / per_item);   // long windows: one item in the large LDS allocation
-  ISD_CHECK_ARG(ips >= 1, "conv4 wgrad: window too long for the LDS tile (about 600 samples)");
+  a.seg_len = 0;
+  if (ips < 1) {
+    // longer still: time segments (the reduction dimension of the weight gradient), one item per stage
+    int seg = (int)((150 * 1024 / 4 - 64 - (int64_t)a.CW * (kTaps - 1)) / (a.F + a.CW)) & ~3;
+    ISD_CHECK_ARG(seg >= 16, "conv4 wgrad: no LDS segment fits");
+    a.seg_len = seg;
+    a.RSo = seg;
+    a.RSi = seg + kTaps - 1;
+    a.lin = 0;
+    per_item = (int64_t)a.F * a.RSo + (int64_t)a.CW * a.RSi;
+    ips = 1;
+  }
   if (ips > 1 && per_item * 4 > 32 * 1024) ips = 1;           // big items: one per stage, 2-3 workgroups per CU
   const int ips_occ = (int)((32 * 1024 / 4) / per_item);      // prefer <= 32 KiB so several workgroups share a CU
   if (ips_occ >= 1 && ips > ips_occ) ips = ips_occ;
@@ -2343,6 +2395,7 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
   ConvArgs a = {};
   a.zones = p->d_zones; a.chan_idx = p->d_idx; a.items = g.items; a.Z = p->Z; a.F = F;
   a.TT = g.TT; a.IPW = g.IPW; a.Tout = g.T1; a.Tin = g.T1; a.pad = 2; a.RS = g.RS_b; a.wz_stride = p->conv_zstride;
+  a.CK = g.CK;
   a.lin = 1;
   a.Ctot = p->Ctot; a.Tx = (int)T; a.N = g.N; a.S = p->S;
   const float* g2 = top;                                          // gradient w.r.t. the cnn2 output

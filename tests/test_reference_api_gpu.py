@@ -93,8 +93,25 @@ def test_conv4layers_long_window_vs_oracle(inn):
     assert rel_err(y.detach().cpu(), ref.detach()) < 1e-4
     for k, q in m.named_parameters():
         assert rel_err(q.grad.cpu(), p[k].grad) < 1e-4, k
-    with pytest.raises(Exception):
-        m(torch.randn(1, 7, 4000, device="cuda"))            # beyond the LDS tile: a clear error, not a wrong answer
+
+
+@pytest.mark.parametrize("C,T,dim,n_layers", [(7, 1500, 32, 4), (64, 800, 32, 4), (3, 4096, 16, 2), (40, 2100, 32, 4)])
+def test_conv4layers_very_long_windows_vs_oracle(inn, C, T, dim, n_layers):
+    """Rows beyond the LDS tile: fewer channels per forward chunk, time segments in the weight gradient."""
+    from oracle import cnn as ocnn
+    from conftest import rel_err
+    torch.manual_seed(C + T)
+    m = inn.Conv4Layers(C, dim, n_layers).cuda()
+    x = torch.randn(2, C, T)
+    w = torch.randn(2, dim)
+    y = m(x.cuda())
+    (y * w.cuda()).sum().backward()
+    p = {k: v.detach().cpu().double().requires_grad_() for k, v in m.state_dict().items()}
+    ref = ocnn.conv4layers(x.double(), p, n_layers=n_layers)
+    (ref * w.double()).sum().backward()
+    assert rel_err(y.detach().cpu(), ref.detach()) < 1e-4
+    for k, q in m.named_parameters():
+        assert rel_err(q.grad.cpu(), p[k].grad) < 1e-4, k
 
 
 @pytest.mark.parametrize("K", [64, 32])
