@@ -44,6 +44,11 @@ struct EegStats {
   double S;                     // sum of all samples
   double Hs[32];                // Hs[a] = sum_rows sum_{s<a} x[s]
   double Ts[33];                // Ts[e] = sum_rows sum_{s>T-e} x[s]
+  // raw accumulators of eeg_stats_kernel (eeg_stats_derive_kernel turns them into A, H, Tl, Hs, Ts above)
+  double D[5][256];             // D[q][i][j] = sum_rows sum_k x[16k+i] x[16k+j+16q]   (matrix cores)
+  double Qh[32][kMaxK];         // Qh[s][d] = sum_rows x[s] x[s+d],      s < 31
+  double Qt[32][kMaxK];         // Qt[i][d] = sum_rows x[T-i] x[T-i+d],  1 <= i <= 31
+  double Sh[32], St[32];        // Sh[s] = sum_rows x[s];  St[i] = sum_rows x[T-i]
   double u1[kF2], u2[kF2];      // sum u, sum u^2 per g
   double a1[kF2], a2[kF2];      // sum a4, sum a4^2 per h
   double dy3s[kF2], dy3x[kF2];  // BN3 backward sums
@@ -101,88 +106,96 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // ------------------------------------------------------------------------------------------------
 // x statistics: autocorrelation over 64 lags + the head/tail pieces the zero padding cuts off.
-// One wave per workgroup, persistent over rows; lane = sample inside a 64-sample block, the 64 lag
-// accumulators live in registers; lane = lag for the edge terms.
+// One wave per workgroup, persistent over rows.
+//  * bulk on the matrix cores: with A[i][k] = x[16k+i] and B_q[k][j] = x[16k+j+16q] one MFMA chain per q = 0..4 gives
+//    D_q[i][j] = sum_k x[16k+i] x[16k+j+16q], and the lag-d autocorrelation is sum_i D_{(i+d)>>4}[i][(i+d)&15].
+//    Both operands are plain contiguous reads of the row (lane l <-> sample 64 step + l (+16q)): 5 MFMAs per 64
+//    samples instead of 64 FMA + 64 LDS reads.
+//  * edges: per row only the products x[s] x[s+d] for the first / last 31 samples are accumulated (lane = lag d);
+//    their prefix sums over s -- what the zero padding of the temporal convolution removes -- are formed once, in
+//    eeg_stats_derive_kernel, not per row.
+// fp32 accumulation stays within one wave's share of the rows (a few hundred), then fp64 atomics.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void eeg_stats_kernel(const float* __restrict__ x, EegStats* __restrict__ st,
                                                        int64_t rows, int T) {
-  extern __shared__ float xrow[];                      // [T + 2*kMaxK] zero extended
+  __shared__ float win[2][96];                         // head x[0..94), tail x[T-31 .. T+63), zero extended
   const int lane = threadIdx.x;
-  float acc[kMaxK];
+  f32x4 Dq[5];
 #pragma unroll
-  for (int d = 0; d < kMaxK; ++d) acc[d] = 0.f;
-  double Hacc[32], Tacc[33];
+  for (int q = 0; q < 5; ++q) Dq[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float qh[31], qt[31];
 #pragma unroll
-  for (int a = 0; a < 32; ++a) Hacc[a] = 0.0;
-#pragma unroll
-  for (int e = 0; e < 33; ++e) Tacc[e] = 0.0;
-  double Ssum = 0.0, HsAcc = 0.0, TsAcc = 0.0;           // lane a: Hs[a]; lane e: Ts[e]
-  double Aacc = 0.0;                                     // lane d: A[d] (folded from the fp32 accumulators)
-  const int fold_every = T >= 8192 ? 1 : 8192 / T;       // bound the fp32 run length to ~8k products
-  int since_fold = 0;
+  for (int i = 0; i < 31; ++i) qh[i] = qt[i] = 0.f;
+  float sh = 0.f, stl = 0.f, rs = 0.f;
   for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-    __syncthreads();
     const float* src = x + r * (int64_t)T;
-    for (int t = lane; t < T + 2 * kMaxK; t += 64) xrow[t] = (t < T) ? src[t] : 0.f;
-    __syncthreads();
-    float rs = 0.f;
     for (int s0 = 0; s0 < T; s0 += 64) {
-      const float xs = xrow[s0 + lane];                  // 0 beyond T
-      rs += xs;
+      const int idx = s0 + lane;
+      const float a = idx < T ? src[idx] : 0.f;
+      rs += a;
+      Dq[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, Dq[0], 0, 0, 0);
 #pragma unroll
-      for (int d = 0; d < kMaxK; ++d) acc[d] = fmaf(xs, xrow[s0 + lane + d], acc[d]);
-    }
-    Ssum += (double)wave_sum(rs);
-    // fold the per-lane lag accumulators into fp64, lane d <- A[d]
-    if (++since_fold >= fold_every) {
-      since_fold = 0;
-#pragma unroll
-      for (int d = 0; d < kMaxK; ++d) {
-        const float tot = wave_sum(acc[d]);
-        if (lane == d) Aacc += (double)tot;
-        acc[d] = 0.f;
+      for (int q = 1; q < 5; ++q) {
+        const float b = idx + 16 * q < T ? src[idx + 16 * q] : 0.f;
+        Dq[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, Dq[q], 0, 0, 0);
       }
     }
-    // head: lane = lag d;  H[a][d] = sum_{s<a} x[s] x[s+d]
-    float pre = 0.f;
+    __syncthreads();
+    for (int u = lane; u < 96; u += 64) {
+      win[0][u] = u < T ? src[u] : 0.f;
+      const int t = T - 31 + u;
+      win[1][u] = (t >= 0 && t < T) ? src[t] : 0.f;
+    }
+    __syncthreads();
 #pragma unroll
     for (int s = 0; s < 31; ++s) {
-      pre = fmaf(xrow[s], xrow[s + lane], pre);
-      Hacc[s + 1] += (double)pre;
+      qh[s] = fmaf(win[0][s], win[0][s + lane], qh[s]);            // x[s] x[s+d]
+      qt[s] = fmaf(win[1][30 - s], win[1][30 - s + lane], qt[s]);  // i = s + 1:  x[T-i] x[T-i+d]
     }
-    // tail: Tl[e][d] = sum_{s=T-e+1}^{T-1} x[s] x[s+d]   (x is zero beyond T)
-    float suf = 0.f;
-#pragma unroll
-    for (int i2 = 1; i2 <= 31; ++i2) {
-      const int s = T - i2;
-      if (s >= 0) suf = fmaf(xrow[s], xrow[s + lane], suf);
-      Tacc[i2 + 1] += (double)suf;
-    }
-    // prefix / suffix sums of the samples themselves: lane a -> sum_{s<a} x[s]; lane e -> sum_{s>T-e} x[s]
-    if (lane < 32) {
-      float p = 0.f;
-      for (int s = 0; s < lane; ++s) p += xrow[s];
-      HsAcc += (double)p;
-    }
-    if (lane < 33) {
-      float p = 0.f;
-      for (int s = T - lane + 1; s < T; ++s) p += (s >= 0) ? xrow[s] : 0.f;
-      TsAcc += (double)p;
+    if (lane < 31) {
+      sh += win[0][lane];                                           // x[s],   s = lane
+      stl += win[1][30 - lane];                                     // x[T-i], i = lane + 1
     }
   }
 #pragma unroll
-  for (int d = 0; d < kMaxK; ++d) {
-    const float tot = wave_sum(acc[d]);
-    if (lane == d) Aacc += (double)tot;
+  for (int q = 0; q < 5; ++q)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) atomicAdd(&st->D[q][(4 * (lane >> 4) + rr) * 16 + (lane & 15)], (double)Dq[q][rr]);
+#pragma unroll
+  for (int s = 0; s < 31; ++s) {
+    atomicAdd(&st->Qh[s][lane], (double)qh[s]);
+    atomicAdd(&st->Qt[s + 1][lane], (double)qt[s]);
   }
-  atomicAdd(&st->A[lane], Aacc);
-#pragma unroll
-  for (int a = 1; a < 32; ++a) atomicAdd(&st->H[a][lane], Hacc[a]);
-#pragma unroll
-  for (int e = 2; e < 33; ++e) atomicAdd(&st->Tl[e][lane], Tacc[e]);
-  if (lane == 0) atomicAdd(&st->S, Ssum);
-  if (lane < 32) atomicAdd(&st->Hs[lane], HsAcc);
-  if (lane < 33) atomicAdd(&st->Ts[lane], TsAcc);
+  if (lane < 31) {
+    atomicAdd(&st->Sh[lane], (double)sh);
+    atomicAdd(&st->St[lane + 1], (double)stl);
+  }
+  const float tot = wave_sum(rs);
+  if (lane == 0) atomicAdd(&st->S, (double)tot);
+}
+
+// raw accumulators -> the quantities eeg_finalize1_kernel consumes.  One block of 64 threads (thread = lag d).
+__global__ __launch_bounds__(64) void eeg_stats_derive_kernel(EegStats* __restrict__ st) {
+  const int d = threadIdx.x;
+  double a = 0.0;
+  for (int i = 0; i < 16; ++i) a += st->D[(i + d) >> 4][i * 16 + ((i + d) & 15)];
+  st->A[d] = a;
+  double h = 0.0, t = 0.0;
+  for (int k = 1; k < 32; ++k) {
+    h += st->Qh[k - 1][d];                               // H[k][d] = sum_{s<k} x[s] x[s+d]
+    st->H[k][d] = h;
+  }
+  for (int e = 2; e < 33; ++e) {
+    t += st->Qt[e - 1][d];                               // Tl[e][d] = sum_{i<e} x[T-i] x[T-i+d]
+    st->Tl[e][d] = t;
+  }
+  if (d == 0) {
+    double hs = 0.0, ts = 0.0;
+    st->Hs[0] = 0.0;
+    for (int k = 1; k < 32; ++k) { hs += st->Sh[k - 1]; st->Hs[k] = hs; }
+    st->Ts[0] = st->Ts[1] = 0.0;
+    for (int e = 2; e < 33; ++e) { ts += st->St[e - 1]; st->Ts[e] = ts; }
+  }
 }
 
 // BN1 coefficients.  training: from the x statistics; eval: from the running buffers.  One block.
@@ -1060,10 +1073,9 @@ extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, cons
   const int64_t rows = B * C;
   ISD_HIP_TRY(hipMemsetAsync(S, 0, sizeof(EegStats), st));
   if (training) {
-    const size_t lds = sizeof(float) * (size_t)(T + 2 * kMaxK);
-    ISD_CHECK_ARG(lds <= 64 * 1024, "isd_eegnet_forward: T=%d too long for the statistics tile", T);
     const int grid = rows < 2048 ? (int)rows : 2048;
-    hipLaunchKernelGGL(eeg_stats_kernel, dim3(grid), dim3(64), lds, st, x, S, rows, T);
+    hipLaunchKernelGGL(eeg_stats_kernel, dim3(grid), dim3(64), 0, st, x, S, rows, T);
+    hipLaunchKernelGGL(eeg_stats_derive_kernel, dim3(1), dim3(64), 0, st, S);
   }
   hipLaunchKernelGGL(eeg_finalize1_kernel, dim3(1), dim3(256), 0, st, params, buffers, S, Cf, p->off, C, K, T, rows,
                      training, momentum, eps);
