@@ -207,9 +207,20 @@ __global__ __launch_bounds__(256) void eeg_finalize1_kernel(const float* __restr
   const double N1 = (double)rows * (double)(T + 2 * P - K + 1);
   const float* Wt = params + off.Wt;
   const float* Ws = params + off.Ws;
+  __shared__ float wpart[kF2][16];
+  __shared__ double rowdot[kF1][kMaxK];
+  {
+    // wsum[g] = sum_c Ws[g,c]: 16 threads per row, then a 16-term finish
+    const int g = threadIdx.x >> 4, j = threadIdx.x & 15;
+    float s = 0.f;
+    for (int c = j; c < C; c += 16) s += Ws[g * C + c];
+    wpart[g][j] = s;
+  }
+  __syncthreads();
   if (threadIdx.x < kF2) {
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += Ws[threadIdx.x * C + c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += wpart[threadIdx.x][j];
     co->wsum[threadIdx.x] = s;
   }
   if (training) {
@@ -232,6 +243,16 @@ __global__ __launch_bounds__(256) void eeg_finalize1_kernel(const float* __restr
     }
   }
   __syncthreads();
+  if (training) {
+    // rowdot[f][k] = sum_k2 G[k][k2] Wt[f][k2]: the 8 x K row products spread over the block
+    for (int e = threadIdx.x; e < kF1 * K; e += 256) {
+      const int f = e / K, k = e - f * K;
+      double row = 0.0;
+      for (int k2 = 0; k2 < K; ++k2) row += co->G[k][k2] * (double)Wt[f * K + k2];
+      rowdot[f][k] = row;
+    }
+  }
+  __syncthreads();
   if (threadIdx.x < kF1) {
     const int f = threadIdx.x;
     double mu, var;
@@ -240,9 +261,7 @@ __global__ __launch_bounds__(256) void eeg_finalize1_kernel(const float* __restr
       double e2 = 0.0;
       for (int k = 0; k < K; ++k) {
         mu += (double)Wt[f * K + k] * co->m[k];
-        double row = 0.0;
-        for (int k2 = 0; k2 < K; ++k2) row += co->G[k][k2] * (double)Wt[f * K + k2];
-        e2 += (double)Wt[f * K + k] * row;
+        e2 += (double)Wt[f * K + k] * rowdot[f][k];
       }
       var = e2 - mu * mu;
       if (var < 0.0) var = 0.0;
@@ -261,24 +280,39 @@ __global__ __launch_bounds__(256) void eeg_finalize1_kernel(const float* __restr
   }
 }
 
-// z[b,g,t] = sum_c Ws[g,c] x[b,c,t]   (one thread per (b,t), all 16 rows in registers)
+// z[b,g,t] = sum_c Ws[g,c] x[b,c,t] on the matrix cores: M = the 16 rows g, N = 16 time steps, K = 4 channels per
+// MFMA; one wave per (trial, time tile) walks all channels.  (The scalar version gave one thread per (b,t) a serial
+// loop over C: 2.3 ms at C = 5120, T = 65 with 65 live threads per workgroup.)
 __global__ __launch_bounds__(256) void eeg_spatial_kernel(const float* __restrict__ x, const float* __restrict__ Ws,
-                                                          float* __restrict__ z, int C, int T) {
+                                                          float* __restrict__ z, int C, int T, int n_tiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= n_tiles) return;
   const int b = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= T) return;
-  float acc[kF2];
-#pragma unroll
-  for (int g = 0; g < kF2; ++g) acc[g] = 0.f;
-  const float* xb = x + (int64_t)b * C * T + t;
-  for (int c = 0; c < C; ++c) {
-    const float xv = xb[(int64_t)c * T];
-#pragma unroll
-    for (int g = 0; g < kF2; ++g) acc[g] = fmaf(Ws[g * C + c], xv, acc[g]);
+  const int t = tile * 16 + jl;
+  const bool tv = t < T;
+  const float* xb = x + (int64_t)b * C * T + (tv ? t : 0);
+  const float* wr = Ws + jl * C;
+  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;       // two chains: consecutive MFMAs do not depend
+  int c0 = 0;
+  for (; c0 + 8 <= C; c0 += 8) {
+    const int ca = c0 + q, cb = c0 + 4 + q;
+    const float a0 = wr[ca], a1 = wr[cb];
+    const float b0 = tv ? xb[(int64_t)ca * T] : 0.f, b1 = tv ? xb[(int64_t)cb * T] : 0.f;
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
   }
-  float* zb = z + (int64_t)b * kF2 * T + t;
+  for (; c0 < C; c0 += 4) {
+    const int c = c0 + q;
+    const bool cv = c < C;
+    const float a0 = cv ? wr[c] : 0.f;
+    const float b0 = (cv && tv) ? xb[(int64_t)c * T] : 0.f;
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+  }
+  if (tv) {
 #pragma unroll
-  for (int g = 0; g < kF2; ++g) zb[(int64_t)g * T] = acc[g];
+    for (int r = 0; r < 4; ++r) z[((int64_t)b * kF2 + 4 * q + r) * T + t] = acc0[r] + acc1[r];
+  }
 }
 
 // u[b,g,t'] = sum_k Wt[f,k] zpad[b,g,t'+k]; per-g sums of u and u^2 (fp64 atomics).  grid (ceil(Tp/256), B*16)
@@ -1079,8 +1113,8 @@ extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, cons
   }
   hipLaunchKernelGGL(eeg_finalize1_kernel, dim3(1), dim3(256), 0, st, params, buffers, S, Cf, p->off, C, K, T, rows,
                      training, momentum, eps);
-  hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(T, 256), (unsigned)B), dim3(256), 0, st, x,
-                     params + p->off.Ws, ws + w.z, C, T);
+  hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(cdiv(T, 16), 4), (unsigned)B), dim3(256), 0, st, x,
+                     params + p->off.Ws, ws + w.z, C, T, (int)cdiv(T, 16));
   hipLaunchKernelGGL(eeg_tconv_kernel, dim3((unsigned)cdiv(Tp, 256), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.z,
                      params + p->off.Wt, ws + w.u, S, K, T, Tp, training);
   hipLaunchKernelGGL(eeg_finalize2_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
