@@ -11,7 +11,7 @@ from .build import LIB_PATH
 
 ISD_OK = 0
 ISD_ERR_INVALID, ISD_ERR_UNSUPPORTED, ISD_ERR_HIP, ISD_ERR_NO_DEVICE = -1, -2, -3, -4
-FB_F32, FB_F64, FB_AUTO = 0, 1, 2
+FB_F32, FB_F64, FB_AUTO, FB_MIXED = 0, 1, 2, 3
 BP_MAGNITUDE, BP_POWER, BP_LOGPOWER = 0, 1, 2
 
 

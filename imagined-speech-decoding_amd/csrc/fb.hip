@@ -47,11 +47,20 @@ struct FbBand {
 
 }  // namespace isd
 
+// The bands of a plan are split by arithmetic: set 0 runs the in-chunk recursion in fp32, set 1 in fp64
+// (ISD_FB_AUTO decides per band; ISD_FB_F32 / ISD_FB_F64 put every band in one set).  `d_map` gives the
+// position of a set's band in the caller's band order.
+struct FbSet {
+  int nb;
+  isd::FbSec* d_sec;   // [nb][n_sections]
+  isd::FbBand* d_band; // [nb]
+  double* d_Q;         // [nb][n_sections][16][4]  per-lane M^i
+  int* d_map;          // [nb] output band index
+};
 struct isd_fb_plan {
-  int n_bands, n_sections, precision;
-  isd::FbSec* d_sec;   // [n_bands][n_sections]
-  isd::FbBand* d_band; // [n_bands]
-  double* d_Q;         // [n_bands][n_sections][16][4]  per-lane M^i
+  int n_bands, n_sections, precision;   // precision: ISD_FB_F32, ISD_FB_F64 or ISD_FB_MIXED
+  FbSet set[2];
+  int* host_map[2];    // host copies of the output maps (band-bin tables are gathered through them)
 };
 
 namespace isd {
@@ -311,7 +320,7 @@ template <typename VT, int GPR>
 __global__ __launch_bounds__(64) void fb_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                                                 const double* __restrict__ Qtab, const float* __restrict__ x,
                                                 float* __restrict__ y, int64_t R, int C, int T, int nb, int ns,
-                                                int vec) {
+                                                int vec, const int* __restrict__ bmap, int nb_out) {
   using O = VOps<VT>;
   constexpr int NR = O::NR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(64) void fb_kernel(const FbSec* __restrict__ secs, 
           if (xbase[r][gq] < 0) { ybase[gq] = -1; continue; }
           const int64_t row = rowg[r][gq];
           const int64_t bt = row / C, ch = row - bt * C;
-          ybase[gq] = ((bt * nb + b) * C + ch) * (int64_t)T;
+          ybase[gq] = ((bt * nb_out + bmap[b]) * C + ch) * (int64_t)T;
         }
         tile_store(tile, y, lane, ybase, gt0, T, vec != 0);
       }
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
                                                    const float2* __restrict__ dft, const float* __restrict__ x,
                                                    float* __restrict__ feat, int64_t R, int C, int T, int nb, int ns,
                                                    int J, float scale2, FusedBands fbnd, int mode, float eps,
-                                                   int vec) {
+                                                   int vec, const int* __restrict__ bmap, int nb_out) {
   using O = VOps<VT>;
   constexpr int NR = O::NR;
   using FT = typename std::conditional<NR == 2, f2, float>::type;      // DFT arithmetic is fp32
@@ -572,7 +581,7 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
       if (row < R) {
         const int64_t bt = row / C;
         const int ch = (int)(row - bt * C);
-        float* o = feat + ((bt * nb + b) * C + ch) * (int64_t)J;
+        float* o = feat + ((bt * nb_out + bmap[b]) * C + ch) * (int64_t)J;
         if (i < J) o[i] = o0;
         if (i == 15 && J == 17) o[16] = o16;
       }
@@ -590,6 +599,8 @@ static void mat2_mul(const double* a, const double* b, double* o) {
 
 using namespace isd;
 
+extern "C" int isd_fb_plan_destroy(isd_fb_plan* p);
+
 extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections, const double* a12,
                                   const double* gain, int precision) {
   ISD_CHECK_ARG(out && a12 && gain, "isd_fb_plan_create: null argument");
@@ -602,7 +613,7 @@ extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections
   std::vector<FbSec> secs(n);
   std::vector<FbBand> bands(n_bands);
   std::vector<double> Q((size_t)n * 64);
-  double worst = 0.0;
+  std::vector<double> worst(n_bands, 0.0);
   for (int b = 0; b < n_bands; ++b) {
     bands[b].gd = gain[b];
     bands[b].gf = (float)gain[b];
@@ -649,20 +660,51 @@ extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections
         c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
         const double st = sqrt(1.0 - c * c);
         const double g = 1.0 / ((1.0 - r) * (st > 1e-9 ? st : 1e-9));
-        if (g > worst) worst = g;
+        if (g > worst[b]) worst[b] = g;
       }
     }
   }
-  if (precision == ISD_FB_AUTO) precision = worst > 2000.0 ? ISD_FB_F64 : ISD_FB_F32;
   isd_fb_plan* p = new isd_fb_plan();
-  p->n_bands = n_bands; p->n_sections = n_sections; p->precision = precision;
-  p->d_sec = nullptr; p->d_band = nullptr; p->d_Q = nullptr;
-  hipError_t e = hipMalloc(&p->d_sec, sizeof(FbSec) * n);
-  if (e == hipSuccess) e = hipMalloc(&p->d_band, sizeof(FbBand) * n_bands);
-  if (e == hipSuccess) e = hipMalloc(&p->d_Q, sizeof(double) * Q.size());
-  if (e == hipSuccess) e = hipMemcpy(p->d_sec, secs.data(), sizeof(FbSec) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p->d_band, bands.data(), sizeof(FbBand) * n_bands, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p->d_Q, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice);
+  p->n_bands = n_bands; p->n_sections = n_sections;
+  for (int k = 0; k < 2; ++k) {
+    p->set[k] = FbSet{0, nullptr, nullptr, nullptr, nullptr};
+    p->host_map[k] = nullptr;
+  }
+  // per-band arithmetic: AUTO sends a band to the fp64 set when one of its poles is too close to z = 1
+  std::vector<int> idx[2];
+  for (int b = 0; b < n_bands; ++b) {
+    const int k = precision == ISD_FB_AUTO ? (worst[b] > 2000.0 ? 1 : 0) : (precision == ISD_FB_F64 ? 1 : 0);
+    idx[k].push_back(b);
+  }
+  p->precision = idx[1].empty() ? ISD_FB_F32 : (idx[0].empty() ? ISD_FB_F64 : ISD_FB_MIXED);
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    const int nb = (int)idx[k].size();
+    if (!nb) continue;
+    std::vector<FbSec> ss((size_t)nb * n_sections);
+    std::vector<FbBand> bb(nb);
+    std::vector<double> qq((size_t)nb * n_sections * 64);
+    for (int i = 0; i < nb; ++i) {
+      const int b = idx[k][i];
+      bb[i] = bands[b];
+      for (int sct = 0; sct < n_sections; ++sct) {
+        ss[(size_t)i * n_sections + sct] = secs[(size_t)b * n_sections + sct];
+        memcpy(&qq[((size_t)i * n_sections + sct) * 64], &Q[((size_t)b * n_sections + sct) * 64], sizeof(double) * 64);
+      }
+    }
+    FbSet& fs = p->set[k];
+    fs.nb = nb;
+    p->host_map[k] = new int[nb];
+    memcpy(p->host_map[k], idx[k].data(), sizeof(int) * nb);
+    e = hipMalloc(&fs.d_sec, sizeof(FbSec) * ss.size());
+    if (e == hipSuccess) e = hipMalloc(&fs.d_band, sizeof(FbBand) * nb);
+    if (e == hipSuccess) e = hipMalloc(&fs.d_Q, sizeof(double) * qq.size());
+    if (e == hipSuccess) e = hipMalloc(&fs.d_map, sizeof(int) * nb);
+    if (e == hipSuccess) e = hipMemcpy(fs.d_sec, ss.data(), sizeof(FbSec) * ss.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(fs.d_band, bb.data(), sizeof(FbBand) * nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(fs.d_Q, qq.data(), sizeof(double) * qq.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(fs.d_map, idx[k].data(), sizeof(int) * nb, hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     set_error("isd_fb_plan_create: %s", hipGetErrorString(e));
     isd_fb_plan_destroy(p);
@@ -674,9 +716,14 @@ extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections
 
 extern "C" int isd_fb_plan_destroy(isd_fb_plan* p) {
   if (!p) return ISD_OK;
-  if (p->d_sec) (void)hipFree(p->d_sec);
-  if (p->d_band) (void)hipFree(p->d_band);
-  if (p->d_Q) (void)hipFree(p->d_Q);
+  for (int k = 0; k < 2; ++k) {
+    FbSet& fs = p->set[k];
+    if (fs.d_sec) (void)hipFree(fs.d_sec);
+    if (fs.d_band) (void)hipFree(fs.d_band);
+    if (fs.d_Q) (void)hipFree(fs.d_Q);
+    if (fs.d_map) (void)hipFree(fs.d_map);
+    delete[] p->host_map[k];
+  }
   delete p;
   return ISD_OK;
 }
@@ -684,18 +731,27 @@ extern "C" int isd_fb_plan_destroy(isd_fb_plan* p) {
 extern "C" int isd_fb_plan_precision(const isd_fb_plan* p) { return p ? p->precision : ISD_ERR_INVALID; }
 
 template <typename VT, int GPR>
-static int fb_launch(const isd_fb_plan* p, const float* x, float* y, int64_t R, int C, int T, hipStream_t st) {
+static int fb_launch(const isd_fb_plan* p, const FbSet& fs, const float* x, float* y, int64_t R, int C, int T,
+                     hipStream_t st) {
   constexpr int NR = VOps<VT>::NR;
   const int64_t items = cdiv(R, (int64_t)NR * (4 / GPR));
   ISD_CHECK_ARG(items <= 0x7fffffffLL, "isd_fb_forward: too many rows (%lld)", (long long)R);
-  const size_t lds = 4 * 16 * kPad * 4 + (GPR == 4 ? (size_t)NR * p->n_bands * p->n_sections * 2 * 8 : 0);
+  const size_t lds = 4 * 16 * kPad * 4 + (GPR == 4 ? (size_t)NR * fs.nb * p->n_sections * 2 * 8 : 0);
   ISD_CHECK_ARG(lds <= 64 * 1024, "isd_fb_forward: n_bands*n_sections too large for the carry tile");
   const int vec = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  hipLaunchKernelGGL((fb_kernel<VT, GPR>), dim3((unsigned)items), dim3(64), lds, st, p->d_sec, p->d_band, p->d_Q, x,
-                     y, R, C, T, p->n_bands, p->n_sections, vec);
+  hipLaunchKernelGGL((fb_kernel<VT, GPR>), dim3((unsigned)items), dim3(64), lds, st, fs.d_sec, fs.d_band, fs.d_Q, x, y,
+                     R, C, T, fs.nb, p->n_sections, vec, fs.d_map, p->n_bands);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
+}
+
+template <typename VT>
+static int fb_launch_t(const isd_fb_plan* p, const FbSet& fs, const float* x, float* y, int64_t R, int C, int T,
+                       hipStream_t st) {
+  if (T <= kSeg) return fb_launch<VT, 1>(p, fs, x, y, R, C, T, st);
+  if (T <= 2 * kSeg) return fb_launch<VT, 2>(p, fs, x, y, R, C, T, st);
+  return fb_launch<VT, 4>(p, fs, x, y, R, C, T, st);
 }
 
 extern "C" int isd_fb_forward(const isd_fb_plan* p, const float* x, float* y, int64_t B, int64_t C, int64_t T,
@@ -707,21 +763,21 @@ extern "C" int isd_fb_forward(const isd_fb_plan* p, const float* x, float* y, in
   ISD_CHECK_ARG(x && y, "isd_fb_forward: null argument");
   hipStream_t st = (hipStream_t)stream;
   const int64_t R = B * C;
-  const bool f64 = p->precision == ISD_FB_F64;
-  if (T <= kSeg) return f64 ? fb_launch<double, 1>(p, x, y, R, (int)C, (int)T, st) : fb_launch<float, 1>(p, x, y, R, (int)C, (int)T, st);
-  if (T <= 2 * kSeg) return f64 ? fb_launch<double, 2>(p, x, y, R, (int)C, (int)T, st) : fb_launch<float, 2>(p, x, y, R, (int)C, (int)T, st);
-  return f64 ? fb_launch<double, 4>(p, x, y, R, (int)C, (int)T, st) : fb_launch<float, 4>(p, x, y, R, (int)C, (int)T, st);
+  int rc = ISD_OK;
+  if (p->set[0].nb) rc = fb_launch_t<float>(p, p->set[0], x, y, R, (int)C, (int)T, st);
+  if (rc == ISD_OK && p->set[1].nb) rc = fb_launch_t<double>(p, p->set[1], x, y, R, (int)C, (int)T, st);
+  return rc;
 }
 
 template <typename VT>
-static int fused_launch(const isd_fb_plan* fb, const isd_stft_plan* st, const float* x, float* feat, int64_t R, int C,
-                        const FusedBands& fbnd, int mode, float eps, hipStream_t stream) {
+static int fused_launch(const isd_fb_plan* fb, const FbSet& fs, const isd_stft_plan* st, const float* x, float* feat,
+                        int64_t R, int C, const FusedBands& fbnd, int mode, float eps, hipStream_t stream) {
   const int64_t items = cdiv(R, 4 * VOps<VT>::NR);
   ISD_CHECK_ARG(items <= 0x7fffffffLL, "isd_features_fused: too many rows (%lld)", (long long)R);
   const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  hipLaunchKernelGGL((fused_kernel<VT>), dim3((unsigned)items), dim3(64), 0, stream, fb->d_sec, fb->d_band, st->d_dft,
-                     x, feat, R, C, st->T, fb->n_bands, fb->n_sections, st->J, st->scale * st->scale, fbnd, mode, eps,
-                     vec);
+  hipLaunchKernelGGL((fused_kernel<VT>), dim3((unsigned)items), dim3(64), 0, stream, fs.d_sec, fs.d_band, st->d_dft, x,
+                     feat, R, C, st->T, fs.nb, fb->n_sections, st->J, st->scale * st->scale, fbnd, mode, eps, vec,
+                     fs.d_map, fb->n_bands);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
@@ -739,13 +795,24 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
               st->hop, st->T);
     return ISD_ERR_UNSUPPORTED;
   }
-  FusedBands fbnd = {};
-  int rc = fill_band_args(st, fb->n_bands, klo, khi, fbnd.klo, fbnd.khi, "isd_features_fused");
+  FusedBands all = {};
+  int rc = fill_band_args(st, fb->n_bands, klo, khi, all.klo, all.khi, "isd_features_fused");
   if (rc) return rc;
   if (B == 0) return ISD_OK;
   hipStream_t s = (hipStream_t)stream;
-  return fb->precision == ISD_FB_F64 ? fused_launch<double>(fb, st, x, feat, B * C, (int)C, fbnd, mode, eps, s)
-                                     : fused_launch<float>(fb, st, x, feat, B * C, (int)C, fbnd, mode, eps, s);
+  for (int k = 0; k < 2; ++k) {
+    const FbSet& fs = fb->set[k];
+    if (!fs.nb) continue;
+    FusedBands fbnd = {};                                  // the set's bands, in the set's order
+    for (int i = 0; i < fs.nb; ++i) {
+      fbnd.klo[i] = all.klo[fb->host_map[k][i]];
+      fbnd.khi[i] = all.khi[fb->host_map[k][i]];
+    }
+    rc = k ? fused_launch<double>(fb, fs, st, x, feat, B * C, (int)C, fbnd, mode, eps, s)
+           : fused_launch<float>(fb, fs, st, x, feat, B * C, (int)C, fbnd, mode, eps, s);
+    if (rc) return rc;
+  }
+  return ISD_OK;
 }
 
 int isd::bandpower_direct(const isd_stft_plan* st, const float* y, float* feat, int64_t R, int C, int nb,

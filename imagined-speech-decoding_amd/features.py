@@ -51,7 +51,8 @@ class Filterbank:
         _lib.check(_lib.lib().isd_fb_plan_create(C.byref(self._h), len(self.bands), self.order,
                                                  _lib.double_array(a12.ravel()), _lib.double_array(gain),
                                                  _PREC[precision]))
-        self.precision = "f64" if _lib.lib().isd_fb_plan_precision(self._h) == _lib.FB_F64 else "f32"
+        self.precision = {_lib.FB_F32: "f32", _lib.FB_F64: "f64", _lib.FB_MIXED: "mixed"}[
+            int(_lib.lib().isd_fb_plan_precision(self._h))]          # "mixed": per-band fp32 / fp64 (auto)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

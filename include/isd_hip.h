@@ -50,17 +50,18 @@ int isd_device_count(void);
  * ---------------------------------------------------------------------- */
 typedef struct isd_fb_plan isd_fb_plan;
 
-enum { ISD_FB_F32 = 0, ISD_FB_F64 = 1, ISD_FB_AUTO = 2 };
+enum { ISD_FB_F32 = 0, ISD_FB_F64 = 1, ISD_FB_AUTO = 2, ISD_FB_MIXED = 3 /* reported only */ };
 
 /* a12  : host, [n_bands][n_sections][2] doubles (a1, a2)
  * gain : host, [n_bands] doubles
  * precision: arithmetic of the in-chunk recursion (the cross-chunk state scan
- *            is always fp64); AUTO picks F64 when a pole is too close to z=1
- *            for fp32 to keep 1e-4.  n_sections <= 8. */
+ *            is always fp64); AUTO decides PER BAND: a band whose poles are too
+ *            close to z=1 for fp32 to keep 1e-4 runs in fp64, the others in fp32
+ *            (see DESIGN.md).  n_sections <= 8. */
 int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections,
                        const double* a12, const double* gain, int precision);
 int isd_fb_plan_destroy(isd_fb_plan* plan);
-int isd_fb_plan_precision(const isd_fb_plan* plan); /* resolved ISD_FB_F32 / F64 */
+int isd_fb_plan_precision(const isd_fb_plan* plan); /* resolved ISD_FB_F32 / F64 / MIXED */
 
 /* x [B][C][T] f32  ->  y [B][n_bands][C][T] f32   (zero initial state, causal) */
 int isd_fb_forward(const isd_fb_plan* plan, const float* x, float* y,
