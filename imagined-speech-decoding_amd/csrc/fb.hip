@@ -589,6 +589,119 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
   }
 }
 
+// Fused spec-S extractor for long rows with heavily overlapped frames (stress configuration: 4096 samples,
+// nperseg 1024, hop 64): the filterbank cascade of fb_kernel<VT, 4> (one row per wave, 2048 samples per pass, the
+// section states carried across passes) followed, in registers, by the per-block DFT sums of the block-sum band
+// power (stft.hip): every lane holds half of a 64-sample block, forms the half-block sums of the band's bins and
+// their two neighbours, lane pairs are joined by one DPP shift and the 64 block sums of the row wait in LDS for
+// blocksum_finish.  The filtered rows (86 MB per trial at the stress shape) are never written.
+// The x row is staged once in LDS in the padded chunk layout and re-read for every band.
+template <typename VT, int KB>
+__global__ __launch_bounds__(64) void fused_long_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
+                                                        const double* __restrict__ Qtab, const float2* __restrict__ blk,
+                                                        const float* __restrict__ x, float* __restrict__ feat, int C,
+                                                        int T, int nb, int ns, int J, int log2_nblk, int n_bins_max,
+                                                        float scale2, FusedBands fbnd, int mode, float eps, int vec,
+                                                        const int* __restrict__ bmap, int nb_out) {
+  using O = VOps<VT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x;
+  const int n_iter = (T + 4 * kSeg - 1) / (4 * kSeg);
+  const int n_chunk = n_iter * 64;
+  float* xrow = reinterpret_cast<float*>(smem_raw);                         // [n_chunk][kPad]
+  float2* Sblk = reinterpret_cast<float2*>(xrow + n_chunk * kPad);         // [KB][64]
+  float2* tw = Sblk + KB * 64;                                             // [64]  e^{-2 pi i u / nblk}
+  double* carry = reinterpret_cast<double*>(tw + 64);                      // [ns][2]
+  const int64_t row = blockIdx.x;
+  const int64_t bt = row / C;
+  const int ch = (int)(row - bt * C);
+  const int nblk = 1 << log2_nblk;
+  const float* src = x + row * (int64_t)T;
+  for (int e = lane * 4; e < n_chunk * kL; e += 256) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec && e + 3 < T) {
+      v = *reinterpret_cast<const float4*>(src + e);
+    } else {
+      if (e + 0 < T) v.x = src[e];
+      if (e + 1 < T) v.y = src[e + 1];
+      if (e + 2 < T) v.z = src[e + 2];
+      if (e + 3 < T) v.w = src[e + 3];
+    }
+    *reinterpret_cast<float4*>(xrow + (e >> 5) * kPad + (e & 31)) = v;
+  }
+  if (lane < nblk) {
+    float sn, cs;
+    sincospif(2.f * (float)lane / (float)nblk, &sn, &cs);
+    tw[lane] = make_float2(cs, -sn);
+  }
+  __syncthreads();
+  for (int b = 0; b < nb; ++b) {
+    const int klo = fbnd.klo[b], khi = fbnd.khi[b];
+    const int k0 = klo - 1, nbin = khi - klo + 1;
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) Sblk[kk * 64 + lane] = make_float2(0.f, 0.f);
+    if (lane < ns * 2) carry[lane] = 0.0;
+    __syncthreads();
+    const auto gain = O::g(bands[b]);
+    for (int it = 0; it < n_iter; ++it) {
+      typename O::Arr v;
+      const float* cp = xrow + (it * 64 + lane) * kPad;
+#pragma unroll
+      for (int n = 0; n < kL; n += 4) {
+        const float4 f = *reinterpret_cast<const float4*>(cp + n);
+        O::put(v, n, (typename O::S)f.x * gain);
+        O::put(v, n + 1, (typename O::S)f.y * gain);
+        O::put(v, n + 2, (typename O::S)f.z * gain);
+        O::put(v, n + 3, (typename O::S)f.w * gain);
+      }
+      for (int sct = 0; sct < ns; ++sct) {
+        double c1[1] = {carry[sct * 2]}, c2[1] = {carry[sct * 2 + 1]};
+        section<VT, 4>(v, secs[b * ns + sct], Qtab + (int64_t)(b * ns + sct) * 64, lane, c1, c2);
+        __syncthreads();                                // every lane has read the incoming carry
+        if (lane == 0) {
+          carry[sct * 2] = c1[0];
+          carry[sct * 2 + 1] = c2[0];
+        }
+      }
+      __syncthreads();
+      // the STFT sees y[0..T) then zeros, not the filter's ringing
+      const int base = (it * 64 + lane) * kL;
+      float vf[kL];
+#pragma unroll
+      for (int n = 0; n < kL; ++n) vf[n] = base + n < T ? (float)O::at(v, n) : 0.f;
+      // half-block DFT sums with block-local phase (this lane's 32 samples start at offset 32*(lane&1) in the block)
+      const float2 none = make_float2(0.f, 0.f);
+      float2 P[KB];
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        __builtin_amdgcn_sched_barrier(0);              // one bin's 64 table scalars at a time in the SGPR file
+        const int k = k0 + kk < n_bins_max ? k0 + kk : n_bins_max;
+        const float2* tb = blk + (int64_t)k * 64;
+        f2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < kL; ++n) acc = __builtin_elementwise_fma((f2){vf[n], vf[n]}, (f2){tb[n].x, tb[n].y}, acc);
+        const float2 ph = tb[kL];                       // e^{-2 pi i k 32 / n}: the odd lane's offset in the block
+        P[kk] = (lane & 1) ? make_float2(acc.x * ph.x - acc.y * ph.y, acc.x * ph.y + acc.y * ph.x)
+                           : make_float2(acc.x, acc.y);
+        (void)none;
+      }
+      const int m = it * 32 + (lane >> 1);
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        const float sx = P[kk].x + row_shl<1>(P[kk].x), sy = P[kk].y + row_shl<1>(P[kk].y);
+        if (!(lane & 1)) Sblk[kk * 64 + m] = make_float2(sx, sy);
+      }
+    }
+    __syncthreads();
+    float2 S[KB];
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) S[kk] = Sblk[kk * 64 + lane];
+    blocksum_finish<KB>(S, tw, lane, k0, nbin, nblk, J, scale2, mode, eps,
+                        feat + ((bt * nb_out + bmap[b]) * C + ch) * (int64_t)J);
+    __syncthreads();
+  }
+}
+
 static void mat2_mul(const double* a, const double* b, double* o) {
   double r[4] = {a[0] * b[0] + a[1] * b[2], a[0] * b[1] + a[1] * b[3], a[2] * b[0] + a[3] * b[2],
                  a[2] * b[1] + a[3] * b[3]};
@@ -790,9 +903,11 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
   ISD_CHECK_ARG(B >= 0 && C >= 1 && C <= (1 << 20), "isd_features_fused: bad shape B=%lld C=%lld", (long long)B,
                 (long long)C);
   ISD_CHECK_ARG(mode >= ISD_BP_MAGNITUDE && mode <= ISD_BP_LOGPOWER, "isd_features_fused: bad mode %d", mode);
-  if (!(st->n == 64 && st->hop == 32 && st->T <= kSeg && st->d_dft)) {
-    set_error("isd_features_fused: needs nperseg=64, noverlap=32, T<=512 (got nperseg=%d hop=%d T=%d)", st->n,
-              st->hop, st->T);
+  const bool short_rows = st->n == 64 && st->hop == 32 && st->T <= kSeg && st->d_dft;
+  const bool long_rows = st->d_blk && st->hop == 64 && st->T <= 64 * 64;
+  if (!short_rows && !long_rows) {
+    set_error("isd_features_fused: needs nperseg=64/noverlap=32/T<=512, or hop 64 with nperseg = 2^a*64 and T<=4096 "
+              "(got nperseg=%d hop=%d T=%d)", st->n, st->hop, st->T);
     return ISD_ERR_UNSUPPORTED;
   }
   FusedBands all = {};
@@ -800,6 +915,49 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
   if (rc) return rc;
   if (B == 0) return ISD_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (!short_rows) {
+    // long rows, heavily overlapped frames: filterbank + block sums in one kernel per band set
+    int nbmax = 0;
+    for (int b = 0; b < fb->n_bands; ++b) {
+      const int nbin = all.khi[b] - all.klo[b] + 1;
+      if (nbin < 1 || nbin > 6 || all.klo[b] < 1 || all.khi[b] > st->n / 2 - 1) {
+        set_error("isd_features_fused: band %d needs 1..6 interior bins for the block-sum path (bins %d..%d)", b,
+                  all.klo[b], all.khi[b]);
+        return ISD_ERR_UNSUPPORTED;
+      }
+      if (nbin > nbmax) nbmax = nbin;
+    }
+    const int64_t rows = B * C;
+    ISD_CHECK_ARG(rows <= 0x7fffffffLL, "isd_features_fused: too many rows (%lld)", (long long)rows);
+    int log2_nblk = 0;
+    while ((64 << log2_nblk) < st->n) ++log2_nblk;
+    const int KB = nbmax + 2 <= 4 ? 4 : nbmax + 2 <= 6 ? 6 : 8;
+    const int n_iter = (st->T + 4 * kSeg - 1) / (4 * kSeg);
+    const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    for (int k = 0; k < 2; ++k) {
+      const FbSet& fs = fb->set[k];
+      if (!fs.nb) continue;
+      FusedBands fbnd = {};
+      for (int i = 0; i < fs.nb; ++i) {
+        fbnd.klo[i] = all.klo[fb->host_map[k][i]];
+        fbnd.khi[i] = all.khi[fb->host_map[k][i]];
+      }
+      const size_t lds = sizeof(float) * (size_t)n_iter * 64 * kPad + sizeof(float2) * ((size_t)KB * 64 + 64) +
+                         sizeof(double) * 2 * kMaxSec;
+#define ISD_FL_LAUNCH(VT, K)                                                                                      \
+  hipLaunchKernelGGL((fused_long_kernel<VT, K>), dim3((unsigned)rows), dim3(64), lds, s, fs.d_sec, fs.d_band, fs.d_Q, \
+                     st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections, st->J, log2_nblk, st->n / 2,         \
+                     st->scale * st->scale, fbnd, mode, eps, vec, fs.d_map, fb->n_bands)
+      if (k == 0) {
+        if (KB == 4) ISD_FL_LAUNCH(float, 4); else if (KB == 6) ISD_FL_LAUNCH(float, 6); else ISD_FL_LAUNCH(float, 8);
+      } else {
+        if (KB == 4) ISD_FL_LAUNCH(double, 4); else if (KB == 6) ISD_FL_LAUNCH(double, 6); else ISD_FL_LAUNCH(double, 8);
+      }
+#undef ISD_FL_LAUNCH
+      ISD_LAUNCH_CHECK();
+    }
+    return ISD_OK;
+  }
   for (int k = 0; k < 2; ++k) {
     const FbSet& fs = fb->set[k];
     if (!fs.nb) continue;

@@ -164,55 +164,7 @@ __global__ __launch_bounds__(64) void bandpower_blocksum_kernel(const float2* __
       S[kk].y = fmaf(v.x, tb[0].y, fmaf(v.y, tb[1].y, fmaf(v.z, tb[2].y, fmaf(v.w, tb[3].y, S[kk].y))));
     }
   }
-  // absolute phase of the block, then the two sliding-window sums over lanes (zero fill outside [0, 64))
-  float2 Cw[KB], Bw[KB];
-#pragma unroll
-  for (int kk = 0; kk < KB; ++kk) {
-    const float2 w = tw[((k0 + kk) * lane) & (nblk - 1)];
-    const float2 s = make_float2(S[kk].x * w.x - S[kk].y * w.y, S[kk].x * w.y + S[kk].y * w.x);
-    Cw[kk] = s;
-    Bw[kk] = s;
-  }
-  for (int d = 1; d < nblk; d <<= 1) {
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk) {
-      const float cx = __shfl_down(Cw[kk].x, d, 64), cy = __shfl_down(Cw[kk].y, d, 64);
-      const float bx = __shfl_up(Bw[kk].x, d, 64), by = __shfl_up(Bw[kk].y, d, 64);
-      if (lane + d < 64) { Cw[kk].x += cx; Cw[kk].y += cy; }
-      if (lane >= d) { Bw[kk].x += bx; Bw[kk].y += by; }
-    }
-  }
-  // frame j = lane; a second, wave-uniform pass serves frames 64.. (frame 64 on lane 0 when the row has 65 frames):
-  // every lane takes part in the shuffles of both passes
-  const int n_pass = J > 64 ? 2 : 1;
-  for (int f = 0; f < n_pass; ++f) {
-    const int j = lane + 64 * f;
-    const int from_c = j - half;                                  // leading window starting at block j - half
-    float2 Rk[KB];
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk) {
-      const float cx = __shfl(Cw[kk].x, from_c & 63, 64), cy = __shfl(Cw[kk].y, from_c & 63, 64);
-      const float bx = __shfl(Bw[kk].x, (j + half - 1) & 63, 64), by = __shfl(Bw[kk].y, (j + half - 1) & 63, 64);
-      Rk[kk] = j >= half ? make_float2(cx, cy) : make_float2(bx, by);
-    }
-    const float2 wn = tw[j & (nblk - 1)];                         // e^{-2 pi i j/nblk};  w^j = conj(wn)
-    float acc = 0.f;
-#pragma unroll
-    for (int bq = 0; bq < KB - 2; ++bq) {
-      if (bq < nbin) {
-        const float2 lo = Rk[bq], mid = Rk[bq + 1], hi = Rk[bq + 2];
-        // w^j * hi + w^{-j} * lo
-        const float sx = hi.x * wn.x + hi.y * wn.y + lo.x * wn.x - lo.y * wn.y;
-        const float sy = hi.y * wn.x - hi.x * wn.y + lo.y * wn.x + lo.x * wn.y;
-        const float vx = 0.5f * mid.x + 0.25f * sx, vy = 0.5f * mid.y + 0.25f * sy;
-        const float pw = (vx * vx + vy * vy) * scale2;
-        acc += mode == ISD_BP_MAGNITUDE ? sqrtf(pw) : pw;
-      }
-    }
-    float r = nbin > 0 ? acc / (float)nbin : 0.f;
-    if (mode == ISD_BP_LOGPOWER) r = logf(r + eps);
-    if (j < J) feat[row * (int64_t)J + j] = r;
-  }
+  blocksum_finish<KB>(S, tw, lane, k0, nbin, nblk, J, scale2, mode, eps, feat + row * (int64_t)J);
 }
 
 }  // namespace isd

@@ -151,8 +151,8 @@ def test_extract_features_matches_scipy_golden(isd, tag, bands, fused):
     g = load_golden("g3_features.npz")
     B, Cc, T, fs, nperseg, nov, nb = g[f"{tag}_cfg"]
     B, Cc, T, nperseg, nov = int(B), int(Cc), int(T), int(nperseg), int(nov)
-    if fused and not (nperseg == 64 and T <= 512):
-        pytest.skip("fused kernel covers nperseg 64 / hop 32 / T<=512")
+    if fused and not ((nperseg == 64 and T <= 512) or (nperseg - nov == 64 and T <= 4096)):
+        pytest.skip("fused kernels cover nperseg 64 / hop 32 / T<=512 and hop 64 / T<=4096")
     x = g[f"{tag}_x"] if f"{tag}_x" in g.files else \
         np.random.default_rng(3).standard_normal((B, Cc, T)).astype(np.float32)
     feat = isd.extract_features(dev(x), fs=float(fs), bands=bands, nperseg=nperseg, noverlap=nov, fused=fused)
@@ -184,6 +184,26 @@ def test_extract_features_numpy_in_numpy_out(isd):
     assert isinstance(f, np.ndarray) and f.shape == (2, 9, 4, 17)
     ref = odsp.extract_features(x, fs=256.0, bands=odsp.BANDS_9)
     np.testing.assert_allclose(f, ref, rtol=0, atol=TOL_FEAT)
+
+
+@pytest.mark.parametrize("T,fs,nperseg,noverlap,bands", [
+    (4096, 1024.0, 1024, 960, odsp.BANDS_40[:7]),       # stress shape; bands on both sides of the fp32 / fp64 split
+    (4096, 1024.0, 1024, 960, odsp.BANDS_40[20:24]),    # fp32 bands only
+    (3000, 1024.0, 1024, 960, odsp.BANDS_40[:3]),       # ragged row: last pass and last block partial
+    (1500, 512.0, 256, 192, [("a", 6.0, 10.0), ("b", 20.0, 24.0)]),   # one pass, 4 blocks per frame
+])
+def test_fused_long_rows_vs_oracle_and_two_kernel_path(isd, T, fs, nperseg, noverlap, bands):
+    X, _ = odsp.synth_trials(3, 5, T, fs, seed=T)
+    fx = isd.FeatureExtractor(T, fs, bands, nperseg=nperseg, noverlap=noverlap)
+    assert fx.can_fuse
+    a = fx(dev(X), fused=True).cpu().numpy().astype(np.float64)
+    b = fx(dev(X), fused=False).cpu().numpy().astype(np.float64)
+    ref = odsp.extract_features_scipy(X, fs=fs, bands=bands, nperseg=nperseg, noverlap=noverlap).astype(np.float64)
+    assert a.shape == ref.shape
+    for got in (a, b):
+        assert (np.abs(got - ref) <= 1e-4 * np.maximum(1.0, np.abs(ref))).all()     # north-star gate: 1e-4 relative
+    loud = ref > np.median(ref, axis=-1, keepdims=True) - np.log(1e4)
+    assert np.abs(a - ref)[loud].max() < TOL_FEAT and np.abs(a - b)[loud].max() < TOL_FEAT
 
 
 @pytest.mark.parametrize("T", [512, 480, 250, 33])
