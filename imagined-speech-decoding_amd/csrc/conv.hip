@@ -1070,9 +1070,10 @@ __device__ __forceinline__ void tail_store_tile(const f32x4 (&acc)[2], float* __
 constexpr int kTailMaxCls = 16;
 constexpr int kTailNI = 1;        // items a wave carries side by side (measured at cfg 2: 1 -> 107 us, 2 -> 116 us: 512 VGPRs + spills)
 
-__global__ __launch_bounds__(256) void featcnn_tail_kernel(TailArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void featcnn_tail_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int F = 32, NW = 4, NI = kTailNI, WF = 8 * kTaps * 2 * 64;      // 5120 floats per fragment set
+  constexpr int F = 32, NI = kTailNI, WF = 8 * kTaps * 2 * 64;              // 5120 floats per fragment set
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
   const int T1 = a.T1, n_cls = a.n_cls;
   const int tile = F * T1, tpad = (tile + 3) & ~3;
@@ -1093,13 +1094,13 @@ __global__ __launch_bounds__(256) void featcnn_tail_kernel(TailArgs a) {
     featL[i] = base + 4 * tpad;                               // [32] pooled features, then [16] logits, [16] dlogits
     logL[i] = featL[i] + 32;
   }
-  for (int e = threadIdx.x; e < WF; e += 256) {
+  for (int e = threadIdx.x; e < WF; e += NW * 64) {
     w3s[e] = a.w3[e];
     w4s[e] = a.w4[e];
     if (a.train) { w3ts[e] = a.w3t[e]; w4ts[e] = a.w4t[e]; }
   }
-  for (int e = threadIdx.x; e < n_cls * F; e += 256) fcs[e] = a.fc_w[e];
-  for (int e = threadIdx.x; e < n_cls; e += 256) fcs[n_cls * F + e] = a.fc_b[e];
+  for (int e = threadIdx.x; e < n_cls * F; e += NW * 64) fcs[e] = a.fc_w[e];
+  for (int e = threadIdx.x; e < n_cls; e += NW * 64) fcs[n_cls * F + e] = a.fc_b[e];
   __syncthreads();
 
   f32x4 accW4[2][2][kTaps], accW3[2][2][kTaps];
@@ -1277,7 +1278,7 @@ __global__ __launch_bounds__(256) void featcnn_tail_kernel(TailArgs a) {
     __syncthreads();
   }
   float* slab = a.part + (int64_t)blockIdx.x * a.slab;
-  for (int e = threadIdx.x; e < a.slab; e += 256) slab[e] = comb[e];
+  for (int e = threadIdx.x; e < a.slab; e += NW * 64) slab[e] = comb[e];
 }
 
 // reduced slab -> cnn3 / cnn4 gradients (adjacent in the flat block), FC gradients, loss
@@ -2300,14 +2301,15 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
   t.items = g.items; t.T1 = g.T1; t.n_cls = n_cls; t.train = train ? 1 : 0; t.grad_scale = grad_scale;
   const int n34 = 2 * F * F * kTaps, nfc = n_cls * (F + 1);
   t.slab = n34 + nfc + 1;
-  int blocks = (int)cdiv(g.items, 4 * kTailNI * 2);               // two rounds of NI items per wave
+  constexpr int TNW = 4;                                          // waves per workgroup (measured: 4 -> 107 us; 8 -> 135 us, 256 VGPRs + 133 spills)
+  int blocks = (int)cdiv(g.items, TNW * kTailNI * 2);             // two rounds of NI items per wave
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   const int tile = (F * g.T1 + 3) & ~3;
-  const size_t lds = sizeof(float) * (size_t)(4 * 8 * kTaps * 2 * 64 + kTailMaxCls * (F + 1) + 4 * kTailNI * (4 * tile + 64) + 16);
+  const size_t lds = sizeof(float) * (size_t)(4 * 8 * kTaps * 2 * 64 + kTailMaxCls * (F + 1) + TNW * kTailNI * (4 * tile + 64) + 16);
   ISD_CHECK_ARG(lds <= 160 * 1024 && (int64_t)blocks * t.slab <= g.total - g.o_part, "isd_featcnn_step: workspace");
-  ISD_HIP_TRY(hipFuncSetAttribute((const void*)featcnn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(featcnn_tail_kernel, dim3(blocks), dim3(256), lds, st, t);
+  ISD_HIP_TRY(hipFuncSetAttribute((const void*)featcnn_tail_kernel<TNW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(featcnn_tail_kernel<TNW>, dim3(blocks), dim3(TNW * 64), lds, st, t);
   ISD_LAUNCH_CHECK();
   if (!labels) return ISD_OK;
   float* red = ws + g.o_s;                                        // free activation-sized scratch
