@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void conv5_fwd_kernel(ConvArgs a) {
 // Preconditions (checked on the host): fp32, contiguous zone channels, whole-row windows, cin % 4 == 0,
 // 16-byte aligned rows blocks.
 // ---------------------------------------------------------------------------------------
-template <int GT>
+template <int GT, int NT>
 __global__ __launch_bounds__(256) void conv5_fwd_glds_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int z = blockIdx.y;
@@ -408,18 +408,18 @@ __global__ __launch_bounds__(256) void conv5_fwd_glds_kernel(ConvArgs a) {
       glds_copy16(wbase + (int64_t)ch * (kCK / 4) * kTaps * GT * 64 + (int64_t)w0 * 4, w_tile + w0 * 4, w1 - w0, lane);
   };
 
-  // Every wave always carries 4 column tiles (no branches around the MFMAs); tiles past the end compute on
+  // Every wave always carries NT column tiles (no branches around the MFMAs); tiles past the end compute on
   // whatever the LDS holds and are not stored.  The first layer is a valid convolution (pad 0): columns
   // beyond Tout are junk by construction and never stored, so the B operand needs no mask.
-  f32x4 acc[4][GT];
+  f32x4 acc[NT][GT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int g = 0; g < GT; ++g) acc[j][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int t_ii[4], t_t0[4], boff[4];
-  bool t_ok[4];
+  int t_ii[NT], t_t0[NT], boff[NT];
+  bool t_ok[NT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NT; ++j) {
     const int ct = j * 4 + wave;
     t_ok[j] = ct < n_ct;
     const int ctc = t_ok[j] ? ct : 0;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void conv5_fwd_glds_kernel(ConvArgs a) {
   }
   struct Frag {
     float af[kTaps][GT];
-    float bf[4][kTaps];
+    float bf[NT][kTaps];
   };
   stage(0, 0);
   for (int ch = 0; ch < n_chunks; ++ch) {
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void conv5_fwd_glds_kernel(ConvArgs a) {
 #pragma unroll
         for (int g = 0; g < GT; ++g) f.af[k][g] = w_tile[((cg * kTaps + k) * GT + g) * 64];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
+      for (int jj = 0; jj < NT; ++jj)
 #pragma unroll
         for (int k = 0; k < kTaps; ++k) f.bf[jj][k] = rowp[boff[jj] + k];
     };
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void conv5_fwd_glds_kernel(ConvArgs a) {
 #pragma unroll
       for (int k = 0; k < kTaps; ++k)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < NT; ++jj)
 #pragma unroll
           for (int g = 0; g < GT; ++g)
             acc[jj][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.af[k][g], f.bf[jj][k], acc[jj][g], 0, 0, 0);
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void conv5_fwd_glds_kernel(ConvArgs a) {
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NT; ++j) {
     if (!t_ok[j]) continue;
     const int64_t item = item0 + t_ii[j];
     const int t = t_t0[j] + jl;
@@ -2048,25 +2048,35 @@ static int first_layer_forward(const isd_conv4_plan* p, const Geo& g, const floa
   a.in = x; a.out = ws + g.o_a2; a.wfrag = ws + g.o_eff; a.bias = ws + g.o_beff; a.Tin = p->W; a.pad = 0; a.RS = g.RS_a;
   a.lin = g.lin0;
   {
-    // wide inputs (>= 2 channel chunks): double-buffered LDS-DMA variant, one workgroup of 16 column tiles per CU
-    int ipw = 16 / g.TT;
-    const int64_t per_cu = cdiv(g.items * p->Z, 256);
-    if (ipw > per_cu) ipw = (int)per_cu;
+    // wide inputs (>= 2 channel chunks): double-buffered LDS-DMA variant.  Two workgroups of 8 column tiles per CU
+    // when there is enough work (the barrier / DMA wait of one runs under the MFMAs of the other), else one of 16.
     const int GT = F / 16;
+    int NT = 2;
+    int ipw = (4 * NT) / g.TT;
+    const int64_t per_slot = cdiv(g.items * p->Z, 512);
+    if (ipw < 1 || per_slot < ipw) {
+      NT = 4;
+      ipw = 16 / g.TT;
+      const int64_t per_cu = cdiv(g.items * p->Z, 256);
+      if (ipw > per_cu) ipw = (int)per_cu;
+    }
     const size_t buf = (size_t)(((ipw * kCK * p->W + 3) & ~3) + (kCK / 4) * kTaps * GT * 64 + 32);
     const size_t lds = sizeof(float) * (4 + 2 * buf);
-    if (g.lin0 && p->dma_ok && !p->act_bf16 && p->max_cz > kCK && g.TT <= 16 && ipw >= 1 && lds <= 150 * 1024 &&
+    if (g.lin0 && p->dma_ok && !p->act_bf16 && p->max_cz > kCK && g.TT <= 4 * NT && ipw >= 1 && lds <= 150 * 1024 &&
         ((uintptr_t)x & 15) == 0) {
       a.IPW = ipw; a.RS = p->W;
-      if (GT == 2) {
-        ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_fwd_glds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-        hipLaunchKernelGGL(conv5_fwd_glds_kernel<2>, dim3((unsigned)cdiv(g.items, ipw), p->Z), dim3(256), lds, st, a);
-      } else {
-        ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_fwd_glds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-        hipLaunchKernelGGL(conv5_fwd_glds_kernel<1>, dim3((unsigned)cdiv(g.items, ipw), p->Z), dim3(256), lds, st, a);
-      }
+      const dim3 grid((unsigned)cdiv(g.items, ipw), p->Z);
+#define ISD_GLDS_LAUNCH(G, N)                                                                                  \
+  do {                                                                                                        \
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_fwd_glds_kernel<G, N>,                                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+    hipLaunchKernelGGL((conv5_fwd_glds_kernel<G, N>), grid, dim3(256), lds, st, a);                           \
+  } while (0)
+      if (GT == 2 && NT == 2) ISD_GLDS_LAUNCH(2, 2);
+      else if (GT == 2) ISD_GLDS_LAUNCH(2, 4);
+      else if (NT == 2) ISD_GLDS_LAUNCH(1, 2);
+      else ISD_GLDS_LAUNCH(1, 4);
+#undef ISD_GLDS_LAUNCH
       ISD_LAUNCH_CHECK();
       a.IPW = g.IPW;
       rc = ISD_OK;
