@@ -53,6 +53,7 @@ SIGNATURES = {
     "isd_conv4_workspace_bytes": (_i64, [_p, _i64, _i64]),
     "isd_conv4_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i64, _p]),
     "isd_conv4_backward": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
+    "isd_conv4_backward_x": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _p]),
     "isd_linear_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "isd_linear_residual_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _p]),
     "isd_linear_workspace_bytes": (_i64, [_i64, _i, _i]),

@@ -1311,14 +1311,54 @@ __global__ __launch_bounds__(256) void gelu_mean_fwd_kernel(const void* __restri
   if (row < rows && i == 15) feat[row] = s / (float)T;
 }
 
-template <typename AT>
+// PRE: the buffer already holds GELU'(A) (the fused forward stored it): only the scaling is left
+template <typename AT, bool PRE = false>
 __global__ __launch_bounds__(256) void gelu_mean_bwd_kernel(void* __restrict__ a, const float* __restrict__ dfeat,
                                                             int64_t rows, int T) {
   const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   const int i = threadIdx.x & 15;
   if (row >= rows) return;
   const float g = dfeat[row] / (float)T;
-  for (int t = i; t < T; t += 16) Act<AT>::st(a, row * T + t, g * gelu_grad_f(Act<AT>::ld(a, row * T + t)));
+  for (int t = i; t < T; t += 16) {
+    const float v = Act<AT>::ld(a, row * T + t);
+    Act<AT>::st(a, row * T + t, g * (PRE ? v : gelu_grad_f(v)));
+  }
+}
+
+// Gradient w.r.t. the input trials: dx[b][chan][n*S + t] += sum_{g,k} Weff[g][c][k] G2[item][g][t - k]  (full
+// correlation of the first, fused layer; zones own disjoint channels, overlapping windows add).  One workgroup per
+// (window, zone) item with the G2 tile in LDS; not a hot path (saliency / SHAP-style attributions), plain VALU.
+// With at most two windows covering a sample (slide_step >= window_len / 2) the float atomics commute exactly.
+__global__ __launch_bounds__(256) void conv5_dx_kernel(const float* __restrict__ g2, const float* __restrict__ wfrag,
+                                                       const ZoneDesc* __restrict__ zones,
+                                                       const int* __restrict__ chan_idx, float* __restrict__ dx,
+                                                       int Z, int F, int T1, int W, int Ctot, int Tx, int N, int S) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];          // [F][T1]
+  const int64_t item = blockIdx.x;
+  const int z = blockIdx.y;
+  const ZoneDesc zd = zones[z];
+  const int GT = F / 16;
+  const float* src = g2 + (item * Z + z) * (int64_t)(F * T1);
+  for (int e = threadIdx.x; e < F * T1; e += 256) smem[e] = src[e];
+  __syncthreads();
+  const int64_t b = item / N;
+  const int n = (int)(item - b * N);
+  const float* wz = wfrag + zd.eff_off;
+  for (int e = threadIdx.x; e < zd.cin * W; e += 256) {
+    const int c = e / W, t = e - c * W;
+    const int cg = c >> 2, cl = (c & 3) * 16;
+    float acc = 0.f;
+    for (int g = 0; g < F; ++g) {
+      const float* gr = smem + g * T1;
+      const int gt = g >> 4, gl = g & 15;
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k) {
+        const int tt = t - k;
+        if (tt >= 0 && tt < T1) acc = fmaf(wz[((int64_t)(cg * kTaps + k) * GT + gt) * 64 + cl + gl], gr[tt], acc);
+      }
+    }
+    atomicAdd(&dx[(b * Ctot + chan_idx[zd.idx_off + c]) * (int64_t)Tx + (int64_t)n * S + t], acc);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2338,8 +2378,8 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
   return first_layer_backward(p, g, x, T, params, ws + g.o_a4, dparams, ws, st);
 }
 
-extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const float* params, const float* dfeat,
-                                  float* dparams, void* workspace, int64_t B, int64_t T, void* stream) {
+static int conv4_backward_impl(const isd_conv4_plan* p, const float* x, const float* params, const float* dfeat,
+                               float* dparams, float* dx, void* workspace, int64_t B, int64_t T, void* stream) {
   ISD_CHECK_ARG(p, "isd_conv4_backward: null plan");
   ISD_CHECK_ARG(B >= 0, "isd_conv4_backward: B=%lld", (long long)B);
   Geo g;
@@ -2352,9 +2392,11 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
     return ISD_OK;
   }
   ISD_CHECK_ARG(x && params && dfeat && workspace, "isd_conv4_backward: null argument");
+  ISD_CHECK_ARG(!dx || !p->act_bf16, "isd_conv4_backward_x: fp32 activations only");
   float* ws = (float*)workspace;
   const int F = p->F;
   const int64_t rows = g.items * p->Z * F;
+  bool kept_dgelu = false;                                 // the forward of this step ran fused and kept GELU'(A4)
   if (p->n_layers == 4 && F == 32 && !p->act_bf16 && p->max_cz <= 16 && g.TT <= 16 && (F * g.T1) % 4 == 0 &&
       g.TT >= 4) {
     // reference-native shape: one persistent fused kernel; gradient tiles stay in LDS, weight gradients in registers
@@ -2362,7 +2404,8 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
     const size_t lds = fused_bwd_lds(p, g);
     const size_t lds_fwd = sizeof(float) * (size_t)(4 + ((16 * p->W + 3) & ~3) + 2 * ((F * g.T1 + 3) & ~3) + 8 * F +
                                                      (4 + 8 + 8) * kTaps * 2 * 64 + 64);
-    if (lds <= 160 * 1024 && lds_fwd <= 150 * 1024) {     // the forward of this step ran fused and kept GELU'(A4)
+    kept_dgelu = lds <= 160 * 1024 && lds_fwd <= 150 * 1024;
+    if (kept_dgelu && !dx) {                              // (the input gradient needs G2 in memory: layer-wise path)
       int per_zone = 256 / p->Z;
       if (per_zone < 1) per_zone = 1;
       if (per_zone > g.items) per_zone = (int)g.items;
@@ -2395,6 +2438,9 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
   float* top = ws + (p->n_layers == 4 ? g.o_a4 : g.o_a2);        // activation that fed GELU
   if (p->act_bf16)
     hipLaunchKernelGGL((gelu_mean_bwd_kernel<bf16_t>), dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, top,
+                       dfeat, rows, g.T1);
+  else if (kept_dgelu)
+    hipLaunchKernelGGL((gelu_mean_bwd_kernel<float, true>), dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, top,
                        dfeat, rows, g.T1);
   else
     hipLaunchKernelGGL((gelu_mean_bwd_kernel<float>), dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, top, dfeat,
@@ -2434,5 +2480,27 @@ extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const
     if (rc) return rc;
     g2 = ws + g.o_a4;
   }
-  return first_layer_backward(p, g, x, T, params, g2, dparams, ws, st);
+  rc = first_layer_backward(p, g, x, T, params, g2, dparams, ws, st);
+  if (rc || !dx) return rc;
+  const size_t lds = sizeof(float) * (size_t)F * g.T1;
+  ISD_CHECK_ARG(lds <= 150 * 1024, "isd_conv4_backward_x: window_len=%d is too long for the gradient tile", p->W);
+  ISD_CHECK_ARG(g.items <= 0x7fffffffLL, "isd_conv4_backward_x: too many items");
+  ISD_HIP_TRY(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * p->Ctot * T, st));
+  if (lds > 48 * 1024)
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(conv5_dx_kernel, dim3((unsigned)g.items, p->Z), dim3(256), lds, st, g2, ws + g.o_eff, p->d_zones,
+                     p->d_idx, dx, p->Z, F, g.T1, p->W, p->Ctot, (int)T, g.N, p->S);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+extern "C" int isd_conv4_backward(const isd_conv4_plan* p, const float* x, const float* params, const float* dfeat,
+                                  float* dparams, void* workspace, int64_t B, int64_t T, void* stream) {
+  return conv4_backward_impl(p, x, params, dfeat, dparams, nullptr, workspace, B, T, stream);
+}
+
+extern "C" int isd_conv4_backward_x(const isd_conv4_plan* p, const float* x, const float* params, const float* dfeat,
+                                    float* dparams, float* dx, void* workspace, int64_t B, int64_t T, void* stream) {
+  ISD_CHECK_ARG(dx || B == 0, "isd_conv4_backward_x: null dx");
+  return conv4_backward_impl(p, x, params, dfeat, dparams, dx, workspace, B, T, stream);
 }

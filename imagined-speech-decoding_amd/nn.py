@@ -100,16 +100,21 @@ class _ConvStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat):
         x, flat = ctx.saved_tensors
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("gradient w.r.t. the EEG input is not provided by the HIP conv stack yet")
         B, _, T = x.shape
         dflat = torch.empty_like(flat)
         dfeat = _f32c(dfeat, "dfeat")
+        dx = None
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().isd_conv4_backward(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dfeat.data_ptr(),
-                                                     dflat.data_ptr(), ctx.ws.data_ptr(), B, T, _stream()))
+            if ctx.needs_input_grad[0]:             # attributions: layer-wise backward + the input-gradient kernel
+                dx = torch.empty_like(x)
+                _lib.check(_lib.lib().isd_conv4_backward_x(ctx.plan._h, x.data_ptr(), flat.data_ptr(),
+                                                           dfeat.data_ptr(), dflat.data_ptr(), dx.data_ptr(),
+                                                           ctx.ws.data_ptr(), B, T, _stream()))
+            else:
+                _lib.check(_lib.lib().isd_conv4_backward(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dfeat.data_ptr(),
+                                                         dflat.data_ptr(), ctx.ws.data_ptr(), B, T, _stream()))
         ctx.ws = None
-        return None, dflat, None
+        return dx, dflat, None
 
 
 class _LinearFn(torch.autograd.Function):

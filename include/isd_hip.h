@@ -149,6 +149,12 @@ int isd_conv4_forward(const isd_conv4_plan* plan, const float* x, const float* p
 int isd_conv4_backward(const isd_conv4_plan* plan, const float* x, const float* params,
                        const float* dfeat, float* dparams, void* workspace, int64_t B, int64_t T,
                        void* stream);
+/* As isd_conv4_backward, and additionally dx [B][c_total][T] = dL/dx (zeroed here, then accumulated over zones and
+ * overlapping windows).  Takes the layer-wise backward (the fused one keeps the activation gradients in LDS); fp32
+ * activations only.  Off the hot path: it serves input attributions (scripts/explain_fast.py,
+ * scripts/global_shap_analysis.py differentiate the model w.r.t. its input). */
+int isd_conv4_backward_x(const isd_conv4_plan* plan, const float* x, const float* params, const float* dfeat,
+                         float* dparams, float* dx, void* workspace, int64_t B, int64_t T, void* stream);
 
 /* ------------------------------------------------------------------------
  * Dense head on the matrix cores (fp32-in MFMA).  nn.Linear semantics:

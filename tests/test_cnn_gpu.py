@@ -36,6 +36,36 @@ def test_conv4layers_matches_reference_golden(inn, cz):
     y.square().sum().backward()
     for k, p in m.named_parameters():
         assert rel_err(p.grad.cpu(), g[f"c{cz}.grad.{k}"]) < TOL, k
+    # the gradient w.r.t. the input (the head contract asks for an autograd-differentiable encoder, fast.py:203-210)
+    m.zero_grad(set_to_none=True)
+    xg = x.clone().requires_grad_()
+    m(xg).square().sum().backward()
+    assert rel_err(xg.grad.cpu(), g[f"c{cz}.dx"]) < TOL
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad.cpu(), g[f"c{cz}.grad.{k}"]) < TOL, k      # same parameter gradients on this path
+
+
+def test_input_gradient_through_windows_and_zones_vs_oracle(inn):
+    """dL/dx of FAST's CNN head on the reference zones: overlapping 250-sample windows add, zones own their channels."""
+    import isd_amd
+    torch.manual_seed(12)
+    h = inn.Head("Conv4Layers", isd_amd.ELECTRODES, isd_amd.ZONES, 32).cuda()
+    x = torch.randn(2, 64, 512)
+    w = torch.randn(2 * 3, 8, 32)
+    xg = x.cuda().requires_grad_()
+    (h.forward_windows(xg, 250, 125) * w.cuda()).sum().backward()
+    p = {"head." + k: v.detach().cpu().double().requires_grad_() for k, v in h.state_dict().items()}
+    xr = x.double().requires_grad_()
+    ref = ocnn.forward_head(xr, p, list(ocnn.ZONES), ocnn.zone_index_lists(), 250, 125)
+    (ref.reshape(6, 8, 32) * w.double()).sum().backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < TOL
+    for k, q in h.named_parameters():
+        assert rel_err(q.grad.cpu(), p["head." + k].grad) < TOL, k
+    # the whole model, trained mode: logits -> input
+    m = inn.FAST(inn.fast_config(dropout=0.0)).cuda().eval()
+    x8 = torch.randn(2, 64, 800, device="cuda", requires_grad=True)
+    m(x8).sum().backward()
+    assert x8.grad is not None and x8.grad.shape == x8.shape and torch.isfinite(x8.grad).all() and x8.grad.abs().sum() > 0
 
 
 @pytest.mark.parametrize("channels,T,dim,n_layers,B", [(4, 250, 16, 4, 5), (40, 64, 32, 4, 3), (70, 21, 32, 2, 9),
