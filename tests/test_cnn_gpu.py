@@ -88,6 +88,12 @@ def test_conv4layers_vs_oracle_shapes(inn, channels, T, dim, n_layers, B):
     assert rel_err(y.detach().cpu(), yr.detach()) < TOL
     for k, q in m.named_parameters():
         assert rel_err(q.grad.cpu(), pr[k].grad) < TOL, k
+    # input gradient on the same shapes (layer-wise backward + conv5_dx_kernel)
+    xg = x.cuda().requires_grad_()
+    (m(xg) * w.cuda()).sum().backward()
+    xr = x.double().requires_grad_()
+    (ocnn.conv4layers(xr, {k: v.detach() for k, v in pr.items()}, n_layers=n_layers) * w.double()).sum().backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < TOL
 
 
 # ------------------------------------------------------------------ FAST train_head (G5 / G6, from the reference)
