@@ -90,6 +90,9 @@ def main():
                     help="extract the features of the next batch on a second HIP stream while the CNN trains on the "
                          "current one (measured: no gain on MI355X -- the fused extractor already fills every wave "
                          "slot -- so the default is one stream)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N > 1 only: wait for the gradient all-reduce before extracting the next batch's features "
+                         "(default: the all-reduce of step k runs under the feature extraction of batch k+1)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -165,14 +168,29 @@ def main():
             e[2].record(main_stream)
         return out
 
+    # N > 1: the features do not depend on the parameters, so the one exchange step of the iteration (the flat
+    # gradient all-reduce, RCCL's own stream) is started right after the backward pass and waited for only after
+    # the next batch's features are queued: forward/backward(k) -> all-reduce(k) || extract(k+1) -> AdamW(k).
+    pipelined = world > 1 and not overlap and not args.no_pipeline
+
+    def pipelined_step(e=None):
+        out = trainer.step_begin(feats.view(B, nb * C, fx.n_frames), y, global_batch=global_batch)
+        extract(0, e)                                       # same stream: queued behind the backward pass that read feats
+        trainer.step_finish()
+        if e:
+            e[2].record(main_stream)
+        return out
+
     # Every step = one feature-extraction pass + one CNN fwd/bwd/optimizer pass.  With overlap the extraction
     # of the NEXT batch runs on its own stream under the CNN work of the current one (the features do not
     # depend on the parameters), exactly K of each inside the timed region.
     freed[0].record(main_stream); freed[1].record(main_stream)
-    if overlap:
+    if overlap or pipelined:
         extract(0)
     for i in range(args.warmup):
-        if overlap:
+        if pipelined:
+            pipelined_step()
+        elif overlap:
             extract((i + 1) % 2)
             train(i % 2)
         else:
@@ -184,7 +202,9 @@ def main():
     t0 = time.perf_counter()
     base = args.warmup
     for i in range(args.steps):
-        if overlap:
+        if pipelined:
+            out = pipelined_step(ev[i])
+        elif overlap:
             extract((base + i + 1) % 2, ev[i])
             out = train((base + i) % 2, ev[i])
         else:
@@ -203,7 +223,7 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         t_feat = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-        t_train = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if not overlap else float("nan")
+        t_train = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if not (overlap or pipelined) else float("nan")
         if fused:
             # dominant kernel: the fused filterbank+STFT extractor; VALU-bound on its algorithmic traffic, so the
             # compute roofline is the honest one: flops = cascade (5 flop/sample/section incl. fix-up) + band DFT
@@ -239,9 +259,11 @@ def main():
                                    "log band power -> Conv4Layers(576,32)+Linear(32,5) fwd+bwd, softmax-CE, AdamW",
                        "trials_per_gpu": B, "global_batch": global_batch, "parallelism": f"dp{world}",
                        "feature_path": "fused" if fused else "filterbank+bandpower kernels",
-                       "streams": "features of batch k+1 overlap the CNN step of batch k" if overlap else "one stream"},
+                       "streams": "features of batch k+1 overlap the CNN step of batch k" if overlap else
+                                  "one stream; gradient all-reduce of step k (RCCL stream) under the feature "
+                                  "extraction of batch k+1" if pipelined else "one stream"},
             "stages_ms": {"extract_features": round(t_feat, 4),
-                          "cnn_fwd_bwd_allreduce_adamw": None if overlap else round(t_train, 4)},
+                          "cnn_fwd_bwd_allreduce_adamw": None if (overlap or pipelined) else round(t_train, 4)},
             "final_loss": round(loss, 5),
             "roofline": roof,
         }

@@ -227,6 +227,22 @@ class GradientBucket:
         if extra is not None:
             self._sum(extra)
 
+    def all_reduce_start(self, flat_grad):
+        """Start the bucket's all-reduce and return a handle for ``all_reduce_wait`` (None: nothing pending).
+        RCCL runs it on its own stream behind the kernels already queued on the current one, so work launched
+        between start and wait that does not touch the bucket (the next batch's feature extraction) overlaps it."""
+        if self.dist is None or self.world_size == 1:
+            return None
+        if flat_grad.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            self._sum(flat_grad)
+            return None
+        return self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @staticmethod
+    def all_reduce_wait(work):
+        if work is not None:
+            work.wait()                                   # the current stream waits for the collective; the host does not
+
     def broadcast_(self, flat_params, src=0):
         if self.dist is not None and self.world_size > 1:
             if flat_params.is_cuda and self.dist.get_backend(self.group) == "gloo":
@@ -276,15 +292,31 @@ class Trainer:
 
     def step(self, x, labels, global_batch=None):
         """One optimisation step on a device-resident batch.  Returns the (local share of the) loss tensor."""
+        out = self.step_begin(x, labels, global_batch)
+        self.step_finish()
+        return out
+
+    def step_begin(self, x, labels, global_batch=None):
+        """Forward + backward, then start the gradient all-reduce.  Work queued before ``step_finish`` that does
+        not read the parameters or the gradient bucket runs under the collective."""
+        if getattr(self, "_pending", None) is not None:
+            raise RuntimeError("step_begin called twice without step_finish")
         out = self.path.forward(x, labels, global_batch=global_batch, want_grad=True)
-        self.bucket.all_reduce_(self.flat_grad)
+        self._pending = (self.bucket.all_reduce_start(self.flat_grad),)
+        return out
+
+    def step_finish(self):
+        """Wait for the all-reduce started by ``step_begin`` and apply AdamW."""
+        if getattr(self, "_pending", None) is None:
+            raise RuntimeError("step_finish without step_begin")
+        self.bucket.all_reduce_wait(self._pending[0])
+        self._pending = None
         if self.schedule is not None:
             lr = self.base_lr * lr_multiplier(self.schedule, self.global_step)
             for g in self.opt.param_groups:
                 g["lr"] = lr
         self.opt.step()
         self.global_step += 1
-        return out
 
 
 # ----------------------------------------------------------------------------- estimators

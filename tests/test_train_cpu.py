@@ -59,6 +59,10 @@ def _worker(rank, world, port, q):
     g[0] = full[lo:hi].sum() / 10.0
     g[1] = float(rank + 1)
     b.all_reduce_(g)
+    h = torch.full((2,), float(rank + 1))
+    work = b.all_reduce_start(h)                   # the split form bench.py pipelines behind the next extraction
+    b.all_reduce_wait(work)
+    assert h.tolist() == [3.0, 3.0]
     params = torch.full((3,), float(rank))
     b.broadcast_(params)
     q.put((rank, lo, hi, g.tolist(), params.tolist(), b.world_size))
