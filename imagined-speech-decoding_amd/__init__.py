@@ -8,7 +8,8 @@ Importing this package does not touch the GPU and does not load the library.
 """
 from .constants import BANDS_5, BANDS_9, BANDS_40, CLASSES, ELECTRODES, ZONES, zone_index_lists  # noqa: F401
 from .features import FeatureExtractor, Filterbank, Stft, band_bins, extract_features  # noqa: F401
-from .filter_design import butter_bandpass_resonators, butter_bandpass_sos  # noqa: F401
+from .bandpass import FirFilter, filter_data  # noqa: F401
+from .filter_design import butter_bandpass_resonators, butter_bandpass_sos, fir_design  # noqa: F401
 from . import data, experiment  # noqa: F401
 from .classifier import (FASTHeadClassifier, FilterbankCNNClassifier, GradientBucket, HotPath, Trainer,  # noqa: F401
                          cosine_scheduler, lr_multiplier, smoke_classifier)
@@ -16,4 +17,4 @@ from .classifier import (FASTHeadClassifier, FilterbankCNNClassifier, GradientBu
 __all__ = ["FilterbankCNNClassifier", "FASTHeadClassifier", "Trainer", "HotPath", "GradientBucket",
            "cosine_scheduler", "lr_multiplier", "extract_features", "FeatureExtractor", "Filterbank", "Stft", "band_bins", "butter_bandpass_sos",
            "butter_bandpass_resonators", "BANDS_5", "BANDS_9", "BANDS_40", "CLASSES", "ELECTRODES", "ZONES",
-           "zone_index_lists", "data", "experiment"]
+           "zone_index_lists", "data", "experiment", "FirFilter", "filter_data", "fir_design"]

@@ -44,6 +44,11 @@ SIGNATURES = {
     "isd_stft_forward": (_i, [_p, _p, _p, _i64, _p]),
     "isd_stft_bandpower": (_i, [_p, _p, _p, _i64, _i64, _i, _i, _pi, _pi, _i, _f, _p]),
     "isd_features_fused": (_i, [_p, _p, _p, _p, _i64, _i64, _pi, _pi, _i, _f, _p]),
+    "isd_fir_plan_create": (_i, [C.POINTER(_p), _i, _pd]),
+    "isd_fir_plan_destroy": (_i, [_p]),
+    "isd_fir_plan_taps": (_i, [_p]),
+    "isd_fir_zero_phase_f32": (_i, [_p, _p, _p, _i64, _i, _p]),
+    "isd_fir_zero_phase_f64": (_i, [_p, _p, _p, _i64, _i, _p]),
     "isd_conv4_plan_create": (_i, [C.POINTER(_p), _i, _i, _pi, _pi, _i, _i, _i, _i]),
     "isd_conv4_plan_destroy": (_i, [_p]),
     "isd_conv4_plan_set_activation_dtype": (_i, [_p, _i]),

@@ -110,6 +110,23 @@ int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st, const flo
                        int mode, float eps, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Zero-phase FIR filter.  Replaces the band-pass of the SVM baseline,
+ *   mne.filter.filter_data(X, 250, l_freq=4, h_freq=40)   notebooks/svm_baseline.ipynb:238-239, :968-969
+ * (MNE is a third-party dependency that is not vendored in the reference; its documented defaults are restated:
+ * method 'fir', fir_design 'firwin', hamming window, phase 'zero', pad 'reflect_limited').
+ * taps: host, [n_taps] doubles, n_taps odd and symmetric (linear-phase type I); the host-side design lives in
+ * isd_amd.filter_design.fir_design.  y[r][n] = sum_k taps[k] * xe[r][n - (n_taps-1)/2 + k] where xe is the row
+ * extended by odd reflection about its end points over min(n_taps, T) - 1 samples and zeros beyond.
+ * x, y [rows][T], distinct buffers.  _f32 computes in fp32, _f64 in fp64 (the notebook filters float64).
+ * ---------------------------------------------------------------------- */
+typedef struct isd_fir_plan isd_fir_plan;
+int isd_fir_plan_create(isd_fir_plan** out, int n_taps, const double* taps);
+int isd_fir_plan_destroy(isd_fir_plan* plan);
+int isd_fir_plan_taps(const isd_fir_plan* plan);
+int isd_fir_zero_phase_f32(const isd_fir_plan* plan, const float* x, float* y, int64_t rows, int T, void* stream);
+int isd_fir_zero_phase_f64(const isd_fir_plan* plan, const double* x, double* y, int64_t rows, int T, void* stream);
+
+/* ------------------------------------------------------------------------
  * Zone-wise Conv4Layers stack over sliding windows: the reference's
  *   FAST.forward_head   src/fast/models/fast.py:242-252  (unfold window_len / slide_step)
  *   Head.forward        src/fast/models/fast.py:209-210  (zone gather, one encoder per zone, stack)

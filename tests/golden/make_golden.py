@@ -267,8 +267,33 @@ def g8():
     save("g8_cosine.npz", schedule=sched, args=np.array([base, final, epochs, it, wu]))
 
 
+def g12():
+    # Row A12 (notebooks/svm_baseline.ipynb:238): MNE is absent, so this fixture is produced by SciPY ALONE, on a
+    # path independent of oracle/fir.py: taps = firwin low-pass differences, application = overlap-add convolution
+    # of the odd-reflected row (MNE's _overlap_add_filter does the same with its own FFT blocks).
+    from scipy.signal import firwin, oaconvolve
+    out = {}
+    for tag, (sf, lo, hi, T) in {"n": (250.0, 4.0, 40.0, 795), "s": (256.0, 8.0, 30.0, 512)}.items():
+        nyq = sf / 2
+        lt, ht = min(max(0.25 * lo, 2.0), lo), min(max(0.25 * hi, 2.0), nyq - hi)
+        n = int(round(3.3 * sf / min(lt, ht)))
+        n += (n - 1) % 2
+        h = np.zeros(n)
+        for sign, f0, f1 in ((1.0, hi, hi + ht), (-1.0, lo - lt, lo)):
+            m = int(round(3.3 * sf / (f1 - f0)))
+            m += 1 - m % 2
+            off = (n - m) // 2
+            h[off:n - off] += sign * firwin(m, (f0 + f1) / 2, window="hamming", fs=sf)
+        x = np.random.default_rng(12).standard_normal((2, 3, T))
+        ne = min(n, T) - 1
+        xp = np.concatenate([2 * x[..., :1] - x[..., ne:0:-1], x, 2 * x[..., -1:] - x[..., -2:-ne - 2:-1]], axis=-1)
+        y = oaconvolve(xp, h.reshape(1, 1, -1), mode="full", axes=-1)[..., (n - 1) // 2 + ne:][..., :T]
+        out.update({f"{tag}.args": np.array([sf, lo, hi]), f"{tag}.taps": h, f"{tag}.x": x, f"{tag}.y": y})
+    save("g12_fir.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5_g9, g6, g7, g8, g10, g11):
+    for fn in (g1, g2, g3, g4, g5_g9, g6, g7, g8, g10, g11, g12):
         if not only or fn.__name__ in only:
             fn()
