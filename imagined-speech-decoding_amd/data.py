@@ -3,11 +3,13 @@
 
 * ``.mat`` v5 splits (``epo_train`` / ``epo_validation``: ``x`` [T, C, n], one-hot ``y`` [5, n]) through
   ``scipy.io.loadmat``  -> X float32 [n, 64, 800] (edge-padded 795 -> 800, preprocess.py:58-62), Y uint8.
-* ``.mat`` v7.3 test split + Excel answer sheet (preprocess.py:118-121) need ``h5py`` / ``openpyxl``; they are
-  imported lazily and a clear error is raised when the image lacks them.
-* standardized cache: the reference writes HDF5 ``{SID}/X``, ``{SID}/Y`` (preprocess.py:220-223).  The same
-  hierarchy is written as HDF5 when ``h5py`` is importable and as ``.npz`` (keys ``"{SID}/X"``) otherwise;
-  ``load_standardized`` reads either.
+* ``.mat`` v7.3 test split (HDF5) + Excel answer sheet (preprocess.py:104-121): through ``h5py`` and
+  pandas + ``openpyxl`` when they are installed, otherwise through ``isd_amd.h5lite`` (ctypes over the HDF5 C
+  library) and ``isd_amd.xlsx`` (zip + XML from the standard library).
+* standardized cache: the reference writes HDF5 ``{SID}/X``, ``{SID}/Y`` (preprocess.py:220-223) and a gzip
+  flavour with file attributes (scripts/preprocess.py:83-99).  ``save_standardized`` / ``save_splits`` write the
+  same hierarchies (HDF5 for ``.h5`` / ``.hdf5`` paths, ``.npz`` with keys ``"{SID}/X"`` otherwise);
+  ``load_standardized`` / ``load_splits`` read them.
 """
 import os
 
@@ -68,14 +70,35 @@ def load_subject_train_val(base_folder, sid):
     return np.concatenate([p[0] for p in parts], axis=0), np.concatenate([p[1] for p in parts], axis=0)
 
 
-def load_test_set_per_subject(base_folder, excel_path, subjects=SUBJECTS):
-    """{SID: (X, Y)} from the v7.3 test files and the Excel answer sheet (columns 2(i+1), rows 3:53, 1-based labels)."""
+def _h5():
+    """``h5py`` when installed, else the ctypes binding of the HDF5 C library (same call surface for this module)."""
     try:
         import h5py
+        return h5py
+    except ImportError:
+        from . import h5lite
+        if not h5lite.available():
+            raise ImportError("HDF5 files need h5py or a loadable libhdf5 (set ISD_HDF5_LIB)") from None
+        return h5lite
+
+
+def read_answer_sheet(excel_path):
+    """``col -> float[50]``: the numeric cells ``iloc[3:53, col]`` of the competition's answer sheet."""
+    try:
+        import openpyxl  # noqa: F401
         import pandas as pd
-    except ImportError as e:                                   # not in this image
-        raise ImportError("the official test split needs h5py (MATLAB v7.3) and pandas+openpyxl (answer sheet)") from e
-    labels = pd.read_excel(excel_path, header=None)
+        frame = pd.read_excel(excel_path, header=None)
+        return lambda col: pd.to_numeric(frame.iloc[3:53, col], errors="coerce").values
+    except ImportError:
+        from .xlsx import numeric_column, read_sheet
+        grid = read_sheet(excel_path)
+        return lambda col: numeric_column(grid, col, 3, 53)
+
+
+def load_test_set_per_subject(base_folder, excel_path, subjects=SUBJECTS):
+    """{SID: (X, Y)} from the v7.3 test files and the Excel answer sheet (columns 2(i+1), rows 3:53, 1-based labels)."""
+    h5py = _h5()
+    column = read_answer_sheet(excel_path)
     out = {}
     for i, sid in enumerate(subjects):
         path = os.path.join(base_folder, "Test set", f"Data_Sample{sid}.mat")
@@ -85,16 +108,53 @@ def load_test_set_per_subject(base_folder, excel_path, subjects=SUBJECTS):
             if "epo_test" not in f:
                 continue
             x = pad_time(np.array(f["epo_test"]["x"]).astype(np.float32))
-        raw = pd.to_numeric(labels.iloc[3:53, 2 * (i + 1)], errors="coerce").values
+        raw = column(2 * (i + 1))
         out[sid] = (x, (raw - 1).astype(np.uint8))
     return out
+
+
+def load_test_set(base_folder, excel_path, subjects=SUBJECTS):
+    """All test subjects concatenated -> (X, Y) (preprocess.py:96-129)."""
+    per = load_test_set_per_subject(base_folder, excel_path, subjects)
+    if not per:
+        raise FileNotFoundError(f"no test data under {os.path.join(base_folder, 'Test set')}")
+    return (np.concatenate([per[s][0] for s in per], axis=0), np.concatenate([per[s][1] for s in per], axis=0))
+
+
+SPLIT_ATTRS = ("n_subjects", "n_classes", "classes", "electrodes", "sfreq")
+
+
+def save_splits(path, splits, attrs=None):
+    """scripts/preprocess.py:83-99: ``X_train``/``Y_train``/``X_valid``/... gzip datasets + file attributes."""
+    from .constants import CLASSES, ELECTRODES
+    meta = {"n_subjects": len(SUBJECTS), "n_classes": len(CLASSES), "classes": str(list(CLASSES)),
+            "electrodes": str(list(ELECTRODES)), "sfreq": 250}
+    meta.update(attrs or {})
+    with _h5().File(path, "w") as f:
+        for name, (x, y) in splits.items():
+            f.create_dataset(f"X_{name}", data=np.asarray(x, np.float32), compression="gzip")
+            f.create_dataset(f"Y_{name}", data=np.asarray(y, np.uint8), compression="gzip")
+        for k, v in meta.items():
+            f.attrs[k] = v
+    return path
+
+
+def load_splits(path):
+    """-> ({'train': (X, Y), ...}, attrs dict) from a ``save_splits`` / scripts/preprocess.py file."""
+    out, meta = {}, {}
+    with _h5().File(path, "r") as f:
+        for key in f.keys():
+            if key.startswith("X_") and f"Y_{key[2:]}" in f:
+                out[key[2:]] = (np.array(f[key], dtype=np.float32), np.array(f[f"Y_{key[2:]}"], dtype=np.uint8))
+        for k in f.attrs.keys():
+            meta[k] = f.attrs[k]
+    return out, meta
 
 
 def save_standardized(path, per_subject):
     """Write {SID: (X, Y)} as the reference's ``{SID}/X``, ``{SID}/Y`` hierarchy (HDF5 if possible, else .npz)."""
     if path.endswith((".h5", ".hdf5")):
-        import h5py                                           # explicit request for HDF5: let the ImportError through
-        with h5py.File(path, "w") as f:
+        with _h5().File(path, "w") as f:
             for sid, (x, y) in per_subject.items():
                 f.create_dataset(f"{sid}/X", data=np.asarray(x, np.float32))
                 f.create_dataset(f"{sid}/Y", data=np.asarray(y, np.uint8))
@@ -111,8 +171,7 @@ def load_standardized(path, subjects=None):
     """Read a standardized cache -> {SID: (X float32, Y uint8)} (loaders.py:27-45 for the HDF5 flavour)."""
     out = {}
     if path.endswith((".h5", ".hdf5")):
-        import h5py
-        with h5py.File(path, "r") as f:
+        with _h5().File(path, "r") as f:
             for sid in (subjects or list(f.keys())):
                 out[sid] = (np.array(f[f"{sid}/X"], dtype=np.float32), np.array(f[f"{sid}/Y"], dtype=np.uint8))
         return out
