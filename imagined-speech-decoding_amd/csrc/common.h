@@ -64,5 +64,13 @@ __device__ __forceinline__ double read_lane(double v, int src) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// LDS hand-over between the lanes of ONE wave (workgroups of 64 threads): LDS operations of a wave execute in
+// order, so it is enough to wait for the outstanding LDS operations and to keep the compiler from moving accesses
+// across this point.  Unlike __syncthreads() this does not drain vmcnt: global stores and loads stay in flight.
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 #endif  // __HIPCC__
 }  // namespace isd

@@ -961,14 +961,6 @@ struct TailArgs {
   float grad_scale;
 };
 
-__device__ __forceinline__ void wave_lds_sync() {
-  // wave-private LDS hand-over between lanes: LDS operations of one wave execute in order, so it is enough to
-  // wait for the outstanding LDS operations (not for global stores: a fence would also drain vmcnt, ~1.5 us
-  // after every logits / gradient store) and to keep the compiler from moving accesses across this point
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // NI items side by side (independent MFMA chains hide the LDS and MFMA latencies of a single wave per SIMD):
 // acc[i][gt] += W[gt] (x) in_i  for one 16-column tile per item (F = 32 input channels, pad 2); the A fragments
 // are shared by the items

@@ -292,9 +292,9 @@ __device__ __forceinline__ void load_chunks(typename VOps<VT>::Arr& v, float* ti
   using O = VOps<VT>;
 #pragma unroll
   for (int r = 0; r < O::NR; ++r) {
-    __syncthreads();
+    wave_lds_sync();
     tile_load(tile, x, lane, xbase[r], gt0, T, vec);
-    __syncthreads();
+    wave_lds_sync();
     const float* src = tile + lane * kPad;            // (q*16 + i) == lane
 #pragma unroll
     for (int n = 0; n < kL; n += 4) {
@@ -376,14 +376,14 @@ __global__ __launch_bounds__(64) void fb_kernel(const FbSec* __restrict__ secs, 
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        __syncthreads();                              // earlier readers of the tile are done
+        wave_lds_sync();                              // earlier readers of the tile are done
         float* dst = tile + lane * kPad;
 #pragma unroll
         for (int n = 0; n < kL; n += 4)
           *reinterpret_cast<float4*>(dst + n) =
               make_float4((float)O::get(O::at(v, n), r), (float)O::get(O::at(v, n + 1), r),
                           (float)O::get(O::at(v, n + 2), r), (float)O::get(O::at(v, n + 3), r));
-        __syncthreads();
+        wave_lds_sync();
         int64_t ybase[4];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -634,14 +634,14 @@ __global__ __launch_bounds__(64) void fused_long_kernel(const FbSec* __restrict_
     sincospif(2.f * (float)lane / (float)nblk, &sn, &cs);
     tw[lane] = make_float2(cs, -sn);
   }
-  __syncthreads();
+  wave_lds_sync();
   for (int b = 0; b < nb; ++b) {
     const int klo = fbnd.klo[b], khi = fbnd.khi[b];
     const int k0 = klo - 1, nbin = khi - klo + 1;
 #pragma unroll
     for (int kk = 0; kk < KB; ++kk) Sblk[kk * 64 + lane] = make_float2(0.f, 0.f);
     if (lane < ns * 2) carry[lane] = 0.0;
-    __syncthreads();
+    wave_lds_sync();
     const auto gain = O::g(bands[b]);
     for (int it = 0; it < n_iter; ++it) {
       typename O::Arr v;
@@ -657,13 +657,13 @@ __global__ __launch_bounds__(64) void fused_long_kernel(const FbSec* __restrict_
       for (int sct = 0; sct < ns; ++sct) {
         double c1[1] = {carry[sct * 2]}, c2[1] = {carry[sct * 2 + 1]};
         section<VT, 4>(v, secs[b * ns + sct], Qtab + (int64_t)(b * ns + sct) * 64, lane, c1, c2);
-        __syncthreads();                                // every lane has read the incoming carry
+        wave_lds_sync();                                // every lane has read the incoming carry
         if (lane == 0) {
           carry[sct * 2] = c1[0];
           carry[sct * 2 + 1] = c2[0];
         }
       }
-      __syncthreads();
+      wave_lds_sync();
       // the STFT sees y[0..T) then zeros, not the filter's ringing
       const int base = (it * 64 + lane) * kL;
       float vf[kL];
@@ -692,13 +692,13 @@ __global__ __launch_bounds__(64) void fused_long_kernel(const FbSec* __restrict_
         if (!(lane & 1)) Sblk[kk * 64 + m] = make_float2(sx, sy);
       }
     }
-    __syncthreads();
+    wave_lds_sync();
     float2 S[KB];
 #pragma unroll
     for (int kk = 0; kk < KB; ++kk) S[kk] = Sblk[kk * 64 + lane];
     blocksum_finish<KB>(S, tw, lane, k0, nbin, nblk, J, scale2, mode, eps,
                         feat + ((bt * nb_out + bmap[b]) * C + ch) * (int64_t)J);
-    __syncthreads();
+    wave_lds_sync();
   }
 }
 
