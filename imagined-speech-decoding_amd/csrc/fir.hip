@@ -18,8 +18,8 @@
 #include "common.h"
 
 struct isd_fir_plan {
-  int n_taps, n_blk;     // n_blk = 2 * ceil(n_taps / 16) blocks of 8 taps; device tables are zero-padded to 8 * n_blk
-  float* d_hf;
+  int n_taps, n_blk;     // n_blk = ceil(n_taps / 8) blocks of 8 taps; device tables are zero-padded to 8 * (n_blk + 3)
+  float* d_hf;           // fp32 taps, each stored twice
   double* d_hd;
 };
 
@@ -33,40 +33,46 @@ constexpr int kFirSkew = kFirR + 2;      // LDS elements per 8-sample block (8-b
 template <typename VT> struct FirOps;
 template <> struct FirOps<f2> {
   using S = float;
+  using Tap = f2;
   static constexpr int NR = 2;
   static __device__ __forceinline__ f2 make(float a, float b) { return (f2){a, b}; }
-  static __device__ __forceinline__ f2 fma_(float h, f2 w, f2 acc) { return __builtin_elementwise_fma((f2){h, h}, w, acc); }
+  // taps arrive as (h, h) pairs (the fp32 table stores every tap twice): an aligned SGPR pair is a v_pk_fma_f32
+  // operand as it stands
+  static __device__ __forceinline__ f2 fma_(f2 h, f2 w, f2 acc) { return __builtin_elementwise_fma(h, w, acc); }
   static __device__ __forceinline__ float get(f2 v, int r) { return r ? v.y : v.x; }
 };
 template <> struct FirOps<double> {
   using S = double;
+  using Tap = double;
   static constexpr int NR = 1;
   static __device__ __forceinline__ double make(double a, double) { return a; }
   static __device__ __forceinline__ double fma_(double h, double w, double acc) { return fma(h, w, acc); }
   static __device__ __forceinline__ double get(double v, int) { return v; }
 };
 
-// sample m of the row extended by limited odd reflection (mne.filter._smart_pad 'reflect_limited')
+// sample m of the row extended by limited odd reflection (mne.filter._smart_pad 'reflect_limited'), branch-free:
+// inside the row x[m]; outside 2 x[edge] - x[mirror] while the mirror lies within n_edge samples of the edge, else 0
 template <typename S>
 __device__ __forceinline__ S fir_ext(const S* __restrict__ row, int m, int T, int n_edge) {
-  if (m >= 0 && m < T) return row[m];
-  if (m < 0) {
-    const int d = -m;
-    return d <= n_edge ? (S)2 * row[0] - row[d] : (S)0;
-  }
-  const int d = m - (T - 1);
-  return d <= n_edge ? (S)2 * row[T - 1] - row[T - 1 - d] : (S)0;
+  const bool left = m < 0, right = m >= T;
+  const int d = left ? -m : m - (T - 1);                       // distance from the edge sample (outside the row)
+  const bool out = left || right, far = out && d > n_edge;
+  const int edge = left ? 0 : T - 1;
+  int idx = left ? d : (right ? T - 1 - d : m);
+  idx = far ? edge : idx;
+  const S v = row[idx], e = row[edge];
+  return far ? (S)0 : (out ? (S)2 * e - v : v);
 }
 
 template <typename VT>
 __global__ __launch_bounds__(64) void fir_kernel(const typename FirOps<VT>::S* __restrict__ x,
                                                  typename FirOps<VT>::S* __restrict__ y,
-                                                 const typename FirOps<VT>::S* __restrict__ taps, int64_t rows, int T,
+                                                 const typename FirOps<VT>::Tap* __restrict__ taps, int64_t rows, int T,
                                                  int half, int n_blk, int n_edge) {
   using O = FirOps<VT>;
   using S = typename O::S;
   extern __shared__ __attribute__((aligned(16))) unsigned char fir_smem[];
-  VT* xs = reinterpret_cast<VT*>(fir_smem);                    // [(64 + n_blk) blocks][kFirSkew]
+  VT* xs = reinterpret_cast<VT*>(fir_smem);                    // [(64 + n_blk + 2) blocks][kFirSkew], the last 2 only prefetched
   const int lane = threadIdx.x;
   const int tile0 = blockIdx.x * kFirTile;
   const int64_t r0 = (int64_t)blockIdx.y * O::NR;
@@ -83,29 +89,54 @@ __global__ __launch_bounds__(64) void fir_kernel(const typename FirOps<VT>::S* _
   }
   __syncthreads();
 
-  // 16-sample register window as two halves that swap roles every block (no register moves): n_blk is even
-  VT acc[kFirR], wa[kFirR], wb[kFirR];
+  // 24-sample register window as three 8-sample blocks that rotate roles (no register moves); the block needed
+  // next and its taps are requested one block of FMAs ahead of their use
+  VT acc[kFirR], w0[kFirR], w1[kFirR], w2[kFirR];
+  const VT* nx = xs + lane * kFirSkew;
+  auto fetch = [&](VT (&w)[kFirR], int blk) {
 #pragma unroll
-  for (int r = 0; r < kFirR; ++r) {
-    acc[r] = O::make((S)0, (S)0);
-    wa[r] = xs[lane * kFirSkew + r];
-  }
-  auto block = [&](const VT (&lo)[kFirR], const VT (&hi)[kFirR], const S* hk) {
+    for (int r = 0; r < kFirR; ++r) w[r] = nx[blk * kFirSkew + r];
+  };
+  using Tap = typename O::Tap;
+  auto fetch_taps = [&](Tap (&h)[kFirR], int blk) {
+#pragma unroll
+    for (int j = 0; j < kFirR; ++j) h[j] = taps[blk * kFirR + j];        // wave-uniform: scalar loads
+  };
+  auto block = [&](const VT (&lo)[kFirR], const VT (&hi)[kFirR], const Tap (&h)[kFirR]) {
 #pragma unroll
     for (int j = 0; j < kFirR; ++j) {
-      const S h = hk[j];                                       // wave-uniform: scalar loads
 #pragma unroll
-      for (int r = 0; r < kFirR; ++r) acc[r] = O::fma_(h, r + j < kFirR ? lo[r + j] : hi[r + j - kFirR], acc[r]);
+      for (int r = 0; r < kFirR; ++r) acc[r] = O::fma_(h[j], r + j < kFirR ? lo[r + j] : hi[r + j - kFirR], acc[r]);
     }
   };
-  for (int kb = 0; kb < n_blk; kb += 2) {
-    const VT* nx = xs + (lane + kb + 1) * kFirSkew;
 #pragma unroll
-    for (int r = 0; r < kFirR; ++r) wb[r] = nx[r];
-    block(wa, wb, taps + kb * kFirR);
-#pragma unroll
-    for (int r = 0; r < kFirR; ++r) wa[r] = nx[kFirSkew + r];
-    block(wb, wa, taps + (kb + 1) * kFirR);
+  for (int r = 0; r < kFirR; ++r) acc[r] = O::make((S)0, (S)0);
+  Tap ha[kFirR], hb[kFirR], hc[kFirR];
+  fetch(w0, 0);
+  fetch(w1, 1);
+  fetch_taps(ha, 0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): the loop starts with nothing in flight
+  int kb = 0;
+  for (; kb + 3 <= n_blk; kb += 3) {                           // taps table and LDS window are padded by 3 blocks
+    // Each prefetch (LDS window block + scalar tap loads) is issued in front of a block of FMAs that does not
+    // need it and awaited behind that block.  The wait is explicit: taps come through SMEM, whose results return
+    // out of order, so a wait placed at their first use would be lgkmcnt(0) right after the next prefetch was issued.
+#define ISD_FIR_PHASE(LO, HI, H, WN, BN, HN, TN)  \
+    fetch(WN, BN); fetch_taps(HN, TN);            \
+    __builtin_amdgcn_sched_barrier(0);            \
+    block(LO, HI, H);                             \
+    __builtin_amdgcn_sched_barrier(0);            \
+    __builtin_amdgcn_s_waitcnt(0xC07F);           /* lgkmcnt(0) */ \
+    __builtin_amdgcn_sched_barrier(0);
+    ISD_FIR_PHASE(w0, w1, ha, w2, kb + 2, hb, kb + 1)
+    ISD_FIR_PHASE(w1, w2, hb, w0, kb + 3, hc, kb + 2)
+    ISD_FIR_PHASE(w2, w0, hc, w1, kb + 4, ha, kb + 3)
+#undef ISD_FIR_PHASE
+  }
+  if (kb < n_blk) {                                            // one or two blocks left
+    fetch(w2, kb + 2); fetch_taps(hb, kb + 1);
+    block(w0, w1, ha);
+    if (kb + 1 < n_blk) block(w1, w2, hb);
   }
 
   const int n0 = tile0 + lane * kFirR;
@@ -146,15 +177,15 @@ extern "C" int isd_fir_plan_create(isd_fir_plan** out, int n_taps, const double*
   }
   isd_fir_plan* p = new isd_fir_plan();
   p->n_taps = n_taps;
-  p->n_blk = 2 * ((n_taps + 2 * kFirR - 1) / (2 * kFirR));
-  const int n = p->n_blk * kFirR;
+  p->n_blk = (n_taps + kFirR - 1) / kFirR;
+  const int n = (p->n_blk + 3) * kFirR;                         // the kernel prefetches up to 3 blocks past the end
   double* hd = new double[n]();
-  float* hf = new float[n]();
-  for (int k = 0; k < n_taps; ++k) { hd[k] = taps[k]; hf[k] = (float)taps[k]; }
+  float* hf = new float[2 * n]();                                 // every tap twice: (h, h)
+  for (int k = 0; k < n_taps; ++k) { hd[k] = taps[k]; hf[2 * k] = hf[2 * k + 1] = (float)taps[k]; }
   hipError_t e = hipMalloc(&p->d_hd, n * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&p->d_hf, n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&p->d_hf, 2 * n * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(p->d_hd, hd, n * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p->d_hf, hf, n * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->d_hf, hf, 2 * n * sizeof(float), hipMemcpyHostToDevice);
   delete[] hd;
   delete[] hf;
   if (e != hipSuccess) {
@@ -183,12 +214,13 @@ static int fir_launch(const isd_fir_plan* p, const void* x, void* y, int64_t row
   using S = typename FirOps<VT>::S;
   const int64_t groups = cdiv(rows, FirOps<VT>::NR);
   ISD_CHECK_ARG(groups <= 65535 * (int64_t)32768, "isd_fir_zero_phase: too many rows (%lld)", (long long)rows);
-  const size_t lds = (size_t)(64 + p->n_blk) * kFirSkew * sizeof(VT);
+  const size_t lds = (size_t)(64 + p->n_blk + 2) * kFirSkew * sizeof(VT);
   ISD_CHECK_ARG(lds <= 160 * 1024, "isd_fir_zero_phase: %d taps need %zu bytes of LDS", p->n_taps, lds);
   if (lds > 64 * 1024)
     ISD_HIP_TRY(hipFuncSetAttribute((const void*)fir_kernel<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int n_edge = (p->n_taps < T ? p->n_taps : T) - 1;
-  const S* taps = sizeof(S) == 4 ? (const S*)p->d_hf : (const S*)p->d_hd;
+  using Tap = typename FirOps<VT>::Tap;
+  const Tap* taps = sizeof(S) == 4 ? (const Tap*)p->d_hf : (const Tap*)p->d_hd;
   const unsigned tiles = (unsigned)cdiv(T, kFirTile);
   // grid.y is limited to 65535: walk the row groups in slabs
   for (int64_t g0 = 0; g0 < groups; g0 += 65535) {
