@@ -269,13 +269,14 @@ class Trainer:
         flat = model.flat_params()
         gflat = model.flat_grads()
         self.flat, self.flat_grad = flat, gflat
-        # The optimizer sees the flat block as ~64 equal views (AdamW is elementwise with uniform
-        # hyper-parameters, so this equals per-tensor AdamW); more views = more blocks in torch's
-        # fused multi-tensor kernel than one 100k-element tensor would get.  Measured inside the step (rocprofv3):
-        # 64 views = 2 launches x 18 us of GPU time; 8 views = one launch of 96 us (8 blocks).  The host side of
-        # opt.step() (~100 us with 64 views, tools/adamw_probe.py) runs under the previous kernels.
+        # The optimizer sees the flat block as 36 equal views (AdamW is elementwise with uniform hyper-parameters,
+        # so this equals per-tensor AdamW).  torch's fused multi-tensor kernel gives every tensor its own blocks and
+        # takes at most 36 tensors (4 lists deep) per launch; each launch is latency-bound at ~18 us for these sizes.
+        # Measured inside the step (rocprofv3 / bench.py): 8 views = one launch of 96 us (8 blocks), 64 views = two
+        # launches of 18 us, 36 views = one (CNN stage 0.458 -> 0.447 ms).  The host side of opt.step() runs under
+        # the previous kernels (tools/adamw_probe.py).
         n = flat.numel()
-        step = max(1024, -(-n // 64))
+        step = max(1024, -(-n // 36))
         self.chunks = []
         for lo in range(0, n, step):
             p = nn.Parameter(flat[lo:lo + step])

@@ -67,17 +67,54 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
 }
 
+// cnn3 / cnn4 weights [F][F][5] -> frag order, forward and transposed+flipped (dgrad) copies; `nbx` blocks of 256
+// threads share one (zone, layer), this is block `bx` of them.
+__device__ __forceinline__ void prep_conv_body(const float* __restrict__ params, const ZoneDesc& zd, int z,
+                                               float* __restrict__ wf, float* __restrict__ wt, int F, int layer,
+                                               int64_t zstride, int bf16, int bx, int nbx) {
+  const int GT = F / 16;
+  const int ncg = F / 4;
+  const float* W = params + zd.p_off + F * kTaps + F + (int64_t)F * F * zd.cin + (int64_t)layer * F * F * kTaps;
+  const int total = ncg * kTaps * GT * 64;
+  for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
+    const int lane = e & 63;
+    const int blk = e >> 6;
+    const int gt = blk % GT;
+    const int k = (blk / GT) % kTaps;
+    const int cg = blk / (GT * kTaps);
+    const int g = gt * 16 + (lane & 15);
+    const int c = cg * 4 + (lane >> 4);
+    const float a = W[(g * F + c) * kTaps + k];
+    const float b = W[(c * F + g) * kTaps + (kTaps - 1 - k)];        // dIn[g] <- dOut[c], flipped taps
+    wf[z * zstride + e] = bf16 ? bf16_round(a) : a;
+    wt[z * zstride + e] = bf16 ? bf16_round(b) : b;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Weight preparation.  "frag order": block (cg, k, gt) holds, for lane l,
 //   W[gt*16 + (l&15)][4*cg + (l>>4)][k]   (zero beyond Cin)   -> one coalesced A-fragment load.
 // ---------------------------------------------------------------------------------------
+// One launch prepares everything a step needs (short dependent launches cost ~4 us of hand-over each on top of
+// their run time): blocks [0, nbw) the fused cnn1 o cnn2 weights, [nbw, nbw + F) its bias, and -- with
+// n_layers == 4 -- 4 blocks per layer behind them the cnn3 / cnn4 fragment tables.
+struct PrepConvArgs {
+  float *w3, *w3t, *w4, *w4t;
+  int64_t zstride;
+  int n_layers;
+};
 __global__ __launch_bounds__(256) void prep_fused_kernel(const float* __restrict__ params,
                                                          const ZoneDesc* __restrict__ zones,
                                                          float* __restrict__ wfrag, float* __restrict__ beff, int F,
-                                                         int nbw, int bf16) {
+                                                         int nbw, int bf16, PrepConvArgs pc) {
   __shared__ float red[256];
   const int z = blockIdx.y;
   const ZoneDesc zd = zones[z];
+  if ((int)blockIdx.x >= nbw + F) {
+    const int r = blockIdx.x - (nbw + F), layer = r >> 2;
+    prep_conv_body(params, zd, z, layer ? pc.w4 : pc.w3, layer ? pc.w4t : pc.w3t, F, layer, pc.zstride, bf16, r & 3, 4);
+    return;
+  }
   const int GT = F / 16;
   const int ncg = (zd.cin + 3) / 4;
   const float* W1 = params + zd.p_off;                 // [F][5]
@@ -127,31 +164,6 @@ __global__ __launch_bounds__(256) void prep_fused_kernel(const float* __restrict
     __syncthreads();
   }
   if (threadIdx.x == 0) beff[z * F + g] = red[0];
-}
-
-// cnn3 / cnn4 weights [F][F][5] -> frag order, forward and transposed+flipped (dgrad) copies.
-__global__ void prep_conv_kernel(const float* __restrict__ params, const ZoneDesc* __restrict__ zones,
-                                 float* __restrict__ wf, float* __restrict__ wt, int F, int layer, int64_t zstride,
-                                 int bf16) {
-  const int z = blockIdx.y;
-  const ZoneDesc zd = zones[z];
-  const int GT = F / 16;
-  const int ncg = F / 4;
-  const float* W = params + zd.p_off + F * kTaps + F + (int64_t)F * F * zd.cin + (int64_t)layer * F * F * kTaps;
-  const int total = ncg * kTaps * GT * 64;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int lane = e & 63;
-    const int blk = e >> 6;
-    const int gt = blk % GT;
-    const int k = (blk / GT) % kTaps;
-    const int cg = blk / (GT * kTaps);
-    const int g = gt * 16 + (lane & 15);
-    const int c = cg * 4 + (lane >> 4);
-    const float a = W[(g * F + c) * kTaps + k];
-    const float b = W[(c * F + g) * kTaps + (kTaps - 1 - k)];        // dIn[g] <- dOut[c], flipped taps
-    wf[z * zstride + e] = bf16 ? bf16_round(a) : a;
-    wt[z * zstride + e] = bf16 ? bf16_round(b) : b;
-  }
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -1273,16 +1285,6 @@ __global__ __launch_bounds__(NW * 64) void featcnn_tail_kernel(TailArgs a) {
   for (int e = threadIdx.x; e < a.slab; e += NW * 64) slab[e] = comb[e];
 }
 
-// reduced slab -> cnn3 / cnn4 gradients (adjacent in the flat block), FC gradients, loss
-__global__ __launch_bounds__(256) void featcnn_tail_scatter_kernel(const float* __restrict__ red, float* __restrict__ dw34,
-                                                                   float* __restrict__ dfc, float* __restrict__ loss,
-                                                                   int n34, int nfc) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < n34) dw34[e] = red[e];
-  else if (e < n34 + nfc) dfc[e - n34] = red[e];
-  else if (e == n34 + nfc) loss[0] = red[e];
-}
-
 // ---------------------------------------------------------------------------------------
 // GELU + mean over time (fast.py:117-118) and its backward (in place on the activation).
 // one 16-lane row per (item, zone, filter) row of length T
@@ -1708,7 +1710,13 @@ __global__ __launch_bounds__(256) void conv5_wgrad_wide_kernel(WgradArgs a) {
 // (coalesced 256-B rows, 4 independent load streams per element, LDS combine).  blockIdx.y selects a run of
 // L slabs (slab index = k * stride); with gridDim.y > 1 the run's sum is written over its own first slab, and
 // a second launch (stride = L) adds the run sums -- a fixed order, so the result is deterministic.
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ part, float* __restrict__ out,
+// The final sums can land in up to three places (elements [0, n0) -> o0, [n0, n0 + n1) -> o1, the rest -> o2):
+// the classifier tail's slab holds the cnn3/cnn4 gradients, the FC gradients and the loss back to back.
+struct ReduceDst {
+  float *o0, *o1, *o2;
+  int64_t n0, n1;
+};
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ part, ReduceDst out,
                                                            int64_t n, int n_slabs, int L, int stride) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1727,12 +1735,15 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ p
   red[grp][lane] = s0 + s1;
   __syncthreads();
   if (grp == 0 && e < n) {
-    float* dst = gridDim.y > 1 ? part + (int64_t)k0 * stride * n : out;
-    dst[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (gridDim.y > 1) part[(int64_t)k0 * stride * n + e] = v;
+    else if (e < out.n0) out.o0[e] = v;
+    else if (e < out.n0 + out.n1) out.o1[e - out.n0] = v;
+    else out.o2[e - out.n0 - out.n1] = v;
   }
 }
 
-static inline void launch_reduce_slabs(float* part, float* out, int64_t n, int n_slabs, hipStream_t st) {
+static inline void launch_reduce_slabs(float* part, ReduceDst out, int64_t n, int n_slabs, hipStream_t st) {
   const unsigned bx = (unsigned)cdiv(n, 64);
   if (n_slabs >= 64 && bx < 1024) {            // few elements, many slabs: two levels so the whole chip takes part
     int L = 8;
@@ -1743,6 +1754,9 @@ static inline void launch_reduce_slabs(float* part, float* out, int64_t n, int n
   } else {
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(bx, 1), dim3(256), 0, st, part, out, n, n_slabs, n_slabs, 1);
   }
+}
+static inline void launch_reduce_slabs(float* part, float* out, int64_t n, int n_slabs, hipStream_t st) {
+  launch_reduce_slabs(part, ReduceDst{out, nullptr, nullptr, n, 0}, n, n_slabs, st);
 }
 
 // Chain dWeff / dbeff back to cnn1.weight, cnn1.bias, cnn2.weight.  grid = (blocks, zones):
@@ -2055,14 +2069,10 @@ static int launch_conv(int mode, int bf16, const ConvArgs& a, int n_zones, hipSt
 static int launch_prep(const isd_conv4_plan* p, const Geo& g, const float* params, float* ws, hipStream_t st) {
   const int F = p->F;
   const int nbw = (int)cdiv(((int64_t)(p->max_cz + 3) / 4) * 4 * F, 256);
-  hipLaunchKernelGGL(prep_fused_kernel, dim3(nbw + F, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_eff,
-                     ws + g.o_beff, F, nbw, p->act_bf16);
-  if (p->n_layers == 4) {
-    hipLaunchKernelGGL(prep_conv_kernel, dim3(4, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_w3,
-                       ws + g.o_w3t, F, 0, p->conv_zstride, p->act_bf16);
-    hipLaunchKernelGGL(prep_conv_kernel, dim3(4, p->Z), dim3(256), 0, st, params, p->d_zones, ws + g.o_w4,
-                       ws + g.o_w4t, F, 1, p->conv_zstride, p->act_bf16);
-  }
+  PrepConvArgs pc{ws + g.o_w3, ws + g.o_w3t, ws + g.o_w4, ws + g.o_w4t, p->conv_zstride, p->n_layers};
+  const int extra = p->n_layers == 4 ? 8 : 0;
+  hipLaunchKernelGGL(prep_fused_kernel, dim3(nbw + F + extra, p->Z), dim3(256), 0, st, params, p->d_zones,
+                     ws + g.o_eff, ws + g.o_beff, F, nbw, p->act_bf16, pc);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
@@ -2354,16 +2364,15 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
   hipLaunchKernelGGL(featcnn_tail_kernel<TNW>, dim3(blocks), dim3(TNW * 64), lds, st, t);
   ISD_LAUNCH_CHECK();
   if (!labels) return ISD_OK;
-  float* red = ws + g.o_s;                                        // free activation-sized scratch
-  launch_reduce_slabs(ws + g.o_part, red, t.slab, blocks, st);
   if (train) {
-    // cnn3 / cnn4 gradients sit back to back in the flat block
+    // the slab sums go straight to their places: cnn3 / cnn4 gradients (back to back in the flat block), the FC
+    // gradients, the loss
     float* dw34 = dparams + p->p_off[0] + F * kTaps + F + (int64_t)F * F * p->cz[0];
-    hipLaunchKernelGGL(featcnn_tail_scatter_kernel, dim3((unsigned)cdiv(t.slab, 256)), dim3(256), 0, st, red, dw34, dfc,
-                       loss, n34, nfc);
+    launch_reduce_slabs(ws + g.o_part, ReduceDst{dw34, dfc, loss, n34, nfc}, t.slab, blocks, st);
   } else {
-    // evaluation with labels: only the loss (last element of the reduced slab) is wanted
-    hipLaunchKernelGGL(featcnn_tail_scatter_kernel, dim3(1), dim3(1), 0, st, red + n34 + nfc, red, red, loss, 0, 0);
+    // evaluation with labels: only the loss (last element of the slab) is wanted; the rest goes to scratch
+    float* red = ws + g.o_s;                                      // free activation-sized scratch
+    launch_reduce_slabs(ws + g.o_part, ReduceDst{red, red + n34, loss, n34, nfc}, t.slab, blocks, st);
   }
   ISD_LAUNCH_CHECK();
   if (!train) return ISD_OK;
