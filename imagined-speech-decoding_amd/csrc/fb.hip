@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
 // power (stft.hip): every lane holds half of a 64-sample block, forms the half-block sums of the band's bins and
 // their two neighbours, lane pairs are joined by one DPP shift and the 64 block sums of the row wait in LDS for
 // blocksum_finish.  The filtered rows (86 MB per trial at the stress shape) are never written.
-// The x row is staged once in LDS in the padded chunk layout and re-read for every band.
+// The x row is re-read from global memory (L2 / MALL resident) for every band and pass.
 template <typename VT, int KB>
 __global__ __launch_bounds__(64) void fused_long_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                                                         const double* __restrict__ Qtab, const float2* __restrict__ blk,
@@ -608,8 +608,7 @@ __global__ __launch_bounds__(64) void fused_long_kernel(const FbSec* __restrict_
   const int lane = threadIdx.x;
   const int n_iter = (T + 4 * kSeg - 1) / (4 * kSeg);
   const int n_chunk = n_iter * 64;
-  float* xrow = reinterpret_cast<float*>(smem_raw);                         // [n_chunk][kPad]
-  float2* Sblk = reinterpret_cast<float2*>(xrow + n_chunk * kPad);         // [KB][64]
+  float2* Sblk = reinterpret_cast<float2*>(smem_raw);                      // [KB][64]
   float2* tw = Sblk + KB * 64;                                             // [64]  e^{-2 pi i u / nblk}
   double* carry = reinterpret_cast<double*>(tw + 64);                      // [ns][2]
   const int64_t row = blockIdx.x;
@@ -617,18 +616,7 @@ __global__ __launch_bounds__(64) void fused_long_kernel(const FbSec* __restrict_
   const int ch = (int)(row - bt * C);
   const int nblk = 1 << log2_nblk;
   const float* src = x + row * (int64_t)T;
-  for (int e = lane * 4; e < n_chunk * kL; e += 256) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (vec && e + 3 < T) {
-      v = *reinterpret_cast<const float4*>(src + e);
-    } else {
-      if (e + 0 < T) v.x = src[e];
-      if (e + 1 < T) v.y = src[e + 1];
-      if (e + 2 < T) v.z = src[e + 2];
-      if (e + 3 < T) v.w = src[e + 3];
-    }
-    *reinterpret_cast<float4*>(xrow + (e >> 5) * kPad + (e & 31)) = v;
-  }
+  (void)n_chunk;
   if (lane < nblk) {
     float sn, cs;
     sincospif(2.f * (float)lane / (float)nblk, &sn, &cs);
@@ -645,10 +633,21 @@ __global__ __launch_bounds__(64) void fused_long_kernel(const FbSec* __restrict_
     const auto gain = O::g(bands[b]);
     for (int it = 0; it < n_iter; ++it) {
       typename O::Arr v;
-      const float* cp = xrow + (it * 64 + lane) * kPad;
+      // the lane's 32 samples straight from global memory (128 contiguous bytes per lane, 8 KiB per wave; the row
+      // is re-read once per band and stays in L2 / MALL): a row staged in LDS would cost 18 KiB per wave and hold
+      // the CU at 7 waves
+      const int e0 = (it * 64 + lane) * kL;
 #pragma unroll
       for (int n = 0; n < kL; n += 4) {
-        const float4 f = *reinterpret_cast<const float4*>(cp + n);
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec && e0 + n + 3 < T) {
+          f = *reinterpret_cast<const float4*>(src + e0 + n);
+        } else {
+          if (e0 + n + 0 < T) f.x = src[e0 + n];
+          if (e0 + n + 1 < T) f.y = src[e0 + n + 1];
+          if (e0 + n + 2 < T) f.z = src[e0 + n + 2];
+          if (e0 + n + 3 < T) f.w = src[e0 + n + 3];
+        }
         O::put(v, n, (typename O::S)f.x * gain);
         O::put(v, n + 1, (typename O::S)f.y * gain);
         O::put(v, n + 2, (typename O::S)f.z * gain);
@@ -668,7 +667,11 @@ __global__ __launch_bounds__(64) void fused_long_kernel(const FbSec* __restrict_
       const int base = (it * 64 + lane) * kL;
       float vf[kL];
 #pragma unroll
-      for (int n = 0; n < kL; ++n) vf[n] = base + n < T ? (float)O::at(v, n) : 0.f;
+      for (int n = 0; n < kL; ++n) vf[n] = (float)O::at(v, n);
+      if ((it + 1) * 64 * kL > T) {                     // only the last pass of a ragged row (wave-uniform)
+#pragma unroll
+        for (int n = 0; n < kL; ++n) vf[n] = base + n < T ? vf[n] : 0.f;
+      }
       // half-block DFT sums with block-local phase (this lane's 32 samples start at offset 32*(lane&1) in the block)
       const float2 none = make_float2(0.f, 0.f);
       float2 P[KB];
@@ -942,8 +945,7 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
         fbnd.klo[i] = all.klo[fb->host_map[k][i]];
         fbnd.khi[i] = all.khi[fb->host_map[k][i]];
       }
-      const size_t lds = sizeof(float) * (size_t)n_iter * 64 * kPad + sizeof(float2) * ((size_t)KB * 64 + 64) +
-                         sizeof(double) * 2 * kMaxSec;
+      const size_t lds = sizeof(float2) * ((size_t)KB * 64 + 64) + sizeof(double) * 2 * kMaxSec;
 #define ISD_FL_LAUNCH(VT, K)                                                                                      \
   hipLaunchKernelGGL((fused_long_kernel<VT, K>), dim3((unsigned)rows), dim3(64), lds, s, fs.d_sec, fs.d_band, fs.d_Q, \
                      st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections, st->J, log2_nblk, st->n / 2,         \
