@@ -46,9 +46,9 @@ struct EegStats {
   double Ts[33];                // Ts[e] = sum_rows sum_{s>T-e} x[s]
   // raw accumulators of eeg_stats_kernel (eeg_stats_derive_kernel turns them into A, H, Tl, Hs, Ts above)
   double D[5][256];             // D[q][i][j] = sum_rows sum_k x[16k+i] x[16k+j+16q]   (matrix cores)
-  double Qh[32][kMaxK];         // Qh[s][d] = sum_rows x[s] x[s+d],      s < 31
-  double Qt[32][kMaxK];         // Qt[i][d] = sum_rows x[T-i] x[T-i+d],  1 <= i <= 31
-  double Sh[32], St[32];        // Sh[s] = sum_rows x[s];  St[i] = sum_rows x[T-i]
+  double Pe[2][32][96];         // Gram blocks of the head / tail windows (eeg_stats_edge_kernel):
+                                //   sum_rows x[s] x[s+d] = Pe[0][s][s+d],  sum_rows x[T-i] x[T-i+d] = Pe[1][31-i][31-i+d],
+                                //   sum_rows x[s] = Pe[0][31][s],          sum_rows x[T-i]        = Pe[1][31][31-i]
   double u1[kF2], u2[kF2];      // sum u, sum u^2 per g
   double a1[kF2], a2[kF2];      // sum a4, sum a4^2 per h
   double dy3s[kF2], dy3x[kF2];  // BN3 backward sums
@@ -114,64 +114,127 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 //  * edges: per row only the products x[s] x[s+d] for the first / last 31 samples are accumulated (lane = lag d);
 //    their prefix sums over s -- what the zero padding of the temporal convolution removes -- are formed once, in
 //    eeg_stats_derive_kernel, not per row.
-// fp32 accumulation stays within one wave's share of the rows (a few hundred), then fp64 atomics.
+// fp32 accumulation stays within one workgroup's share of the rows (eight waves, a few hundred rows each), then
+// fp64 atomics.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void eeg_stats_kernel(const float* __restrict__ x, EegStats* __restrict__ st,
-                                                       int64_t rows, int T) {
-  __shared__ float win[2][96];                         // head x[0..94), tail x[T-31 .. T+63), zero extended
-  const int lane = threadIdx.x;
+constexpr int kStatWaves = 4;                          // waves per workgroup
+// Two kernels, so that neither carries the other's accumulators: the bulk one (20 MFMA accumulators + 17 operands)
+// runs at 8 waves per SIMD, the edge one (62 lag products per lane) at 4 -- every row costs one memory latency, and
+// the short rows of the feature classifier ([B, 5120, 65]) are nothing but latency.
+//  bulk: D_q and the sum of all samples;  edge: Qh, Qt, Sh, St.
+// The waves of a workgroup meet in LDS (fp32) before ONE set of fp64 global atomics per workgroup: 2048 waves
+// sending 85 atomics per lane to the same ~5 k addresses took 0.15 ms on their own.
+__global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_kernel(const float* __restrict__ x,
+                                                                    EegStats* __restrict__ st, int64_t rows, int T) {
+  __shared__ float tot[21][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < 21 * 64; e += 64 * kStatWaves) (&tot[0][0])[e] = 0.f;
   f32x4 Dq[5];
 #pragma unroll
   for (int q = 0; q < 5; ++q) Dq[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float qh[31], qt[31];
+  float rs = 0.f;
+  // 256 samples per step: the 17 distinct operands x[s0 + lane + 16 j] are requested together (one load per MFMA
+  // operand, issued right before its use, left the loop waiting a full memory latency per 64 samples), then the
+  // 20 MFMAs run.  Two rows are in flight at once: short rows (the feature classifier's T = 65) are one step each.
+  const int64_t stride = (int64_t)gridDim.x * kStatWaves;
+  for (int64_t r = (int64_t)blockIdx.x * kStatWaves + wave; r < rows; r += 2 * stride) {
+    const float* srcA = x + r * (int64_t)T;
+    const bool two = r + stride < rows;                           // wave-uniform
+    const float* srcB = x + (two ? r + stride : r) * (int64_t)T;
+    for (int s0 = 0; s0 < T; s0 += 256) {
+      float vA[17], vB[17];
 #pragma unroll
-  for (int i = 0; i < 31; ++i) qh[i] = qt[i] = 0.f;
-  float sh = 0.f, stl = 0.f, rs = 0.f;
-  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-    const float* src = x + r * (int64_t)T;
-    for (int s0 = 0; s0 < T; s0 += 64) {
-      const int idx = s0 + lane;
-      const float a = idx < T ? src[idx] : 0.f;
-      rs += a;
-      Dq[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, Dq[0], 0, 0, 0);
+      for (int j = 0; j < 17; ++j) {
+        const int idx = s0 + lane + 16 * j;
+        vA[j] = idx < T ? srcA[idx] : 0.f;
+        vB[j] = (two && idx < T) ? srcB[idx] : 0.f;
+      }
 #pragma unroll
-      for (int q = 1; q < 5; ++q) {
-        const float b = idx + 16 * q < T ? src[idx + 16 * q] : 0.f;
-        Dq[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, Dq[q], 0, 0, 0);
+      for (int u = 0; u < 4; ++u) {
+        if (s0 + 64 * u >= T) break;                              // wave-uniform
+        const float a = vA[4 * u], b = vB[4 * u];
+        rs += a + b;
+        Dq[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, Dq[0], 0, 0, 0);
+#pragma unroll
+        for (int q = 1; q < 5; ++q) Dq[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vA[4 * u + q], Dq[q], 0, 0, 0);
+        Dq[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, b, Dq[0], 0, 0, 0);
+#pragma unroll
+        for (int q = 1; q < 5; ++q) Dq[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, vB[4 * u + q], Dq[q], 0, 0, 0);
       }
     }
-    __syncthreads();
-    for (int u = lane; u < 96; u += 64) {
-      win[0][u] = u < T ? src[u] : 0.f;
-      const int t = T - 31 + u;
-      win[1][u] = (t >= 0 && t < T) ? src[t] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 31; ++s) {
-      qh[s] = fmaf(win[0][s], win[0][s + lane], qh[s]);            // x[s] x[s+d]
-      qt[s] = fmaf(win[1][30 - s], win[1][30 - s + lane], qt[s]);  // i = s + 1:  x[T-i] x[T-i+d]
-    }
-    if (lane < 31) {
-      sh += win[0][lane];                                           // x[s],   s = lane
-      stl += win[1][30 - lane];                                     // x[T-i], i = lane + 1
-    }
   }
+  __syncthreads();                                              // tot[] is zero
 #pragma unroll
   for (int q = 0; q < 5; ++q)
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) atomicAdd(&st->D[q][(4 * (lane >> 4) + rr) * 16 + (lane & 15)], (double)Dq[q][rr]);
+    for (int rr = 0; rr < 4; ++rr) atomicAdd(&tot[q * 4 + rr][lane], Dq[q][rr]);
+  const float rtot = wave_sum(rs);
+  if (lane == 0) atomicAdd(&tot[20][0], rtot);
+  __syncthreads();
+  for (int e = threadIdx.x; e < 20 * 64; e += 64 * kStatWaves) {
+    const int slot = e >> 6, l = e & 63;
+    atomicAdd(&st->D[slot >> 2][(4 * (l >> 4) + (slot & 3)) * 16 + (l & 15)], (double)tot[slot][l]);
+  }
+  if (threadIdx.x == 0) atomicAdd(&st->S, (double)tot[20][0]);
+}
+
+// Edge sums on the matrix cores.  Per row let y[0..95) be its head window x[0..95) (blockIdx.y = 0) or its tail
+// window x[T-31 .. T+64) (blockIdx.y = 1), zero outside the row.  Everything the zero padding needs is inside the
+// Gram block  P[a][j] = sum_rows y[a] y[j],  a < 31, j < 96:   x[s] x[s+d] = P_head[s][s+d],
+// x[T-i] x[T-i+d] = P_tail[31-i][31-i+d];  a row of ones in slot a = 31 adds the column sums sum_rows y[j].
+// The contraction runs over ROWS: one MFMA step takes 4 rows (k = lane >> 4), A = y[16 mt + i] (2 tiles),
+// B = y[16 nt + i] (6 tiles), 6 loads and 12 MFMAs per 4 rows, 48 accumulator registers.  (The per-lane form --
+// 62 lag products per lane and row behind an LDS window -- held 200+ VGPRs and paid a memory latency per row.)
+__global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_edge_kernel(const float* __restrict__ x,
+                                                                         EegStats* __restrict__ st, int64_t rows,
+                                                                         int T) {
+  __shared__ float tot[32][96];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int which = blockIdx.y;
+  const int base = which ? T - 31 : 0;
+  for (int e = threadIdx.x; e < 32 * 96; e += 64 * kStatWaves) (&tot[0][0])[e] = 0.f;
+  f32x4 acc[2][6];
 #pragma unroll
-  for (int s = 0; s < 31; ++s) {
-    atomicAdd(&st->Qh[s][lane], (double)qh[s]);
-    atomicAdd(&st->Qt[s + 1][lane], (double)qt[s]);
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int64_t n_grp = (rows + 3) >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kStatWaves;
+  for (int64_t g = (int64_t)blockIdx.x * kStatWaves + wave; g < n_grp; g += 2 * stride) {   // two groups in flight
+    float b[2][6];
+    bool live[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t r = (g + h * stride) * 4 + q;
+      live[h] = g + h * stride < n_grp && r < rows;
+      const float* src = x + (live[h] ? r : 0) * (int64_t)T;
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt) {
+        const int t = base + 16 * nt + i;
+        b[h][nt] = (live[h] && t >= 0 && t < T) ? src[t] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float a0 = b[h][0];
+      const float a1 = i == 15 ? (live[h] ? 1.f : 0.f) : b[h][1];   // slot a = 31: the row of ones
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt) {
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[h][nt], acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[h][nt], acc[1][nt], 0, 0, 0);
+      }
+    }
   }
-  if (lane < 31) {
-    atomicAdd(&st->Sh[lane], (double)sh);
-    atomicAdd(&st->St[lane + 1], (double)stl);
-  }
-  const float tot = wave_sum(rs);
-  if (lane == 0) atomicAdd(&st->S, (double)tot);
+  __syncthreads();                                              // tot[] is zero
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) atomicAdd(&tot[16 * mt + 4 * q + rr][16 * nt + i], acc[mt][nt][rr]);
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * 96; e += 64 * kStatWaves)
+    atomicAdd(&st->Pe[which][e / 96][e % 96], (double)tot[e / 96][e % 96]);
 }
 
 // raw accumulators -> the quantities eeg_finalize1_kernel consumes.  One block of 64 threads (thread = lag d).
@@ -182,19 +245,19 @@ __global__ __launch_bounds__(64) void eeg_stats_derive_kernel(EegStats* __restri
   st->A[d] = a;
   double h = 0.0, t = 0.0;
   for (int k = 1; k < 32; ++k) {
-    h += st->Qh[k - 1][d];                               // H[k][d] = sum_{s<k} x[s] x[s+d]
+    h += st->Pe[0][k - 1][k - 1 + d];                    // H[k][d] = sum_{s<k} x[s] x[s+d]
     st->H[k][d] = h;
   }
   for (int e = 2; e < 33; ++e) {
-    t += st->Qt[e - 1][d];                               // Tl[e][d] = sum_{i<e} x[T-i] x[T-i+d]
+    t += st->Pe[1][32 - e][32 - e + d];                  // Tl[e][d] = sum_{i<e} x[T-i] x[T-i+d],  i = e - 1
     st->Tl[e][d] = t;
   }
   if (d == 0) {
     double hs = 0.0, ts = 0.0;
     st->Hs[0] = 0.0;
-    for (int k = 1; k < 32; ++k) { hs += st->Sh[k - 1]; st->Hs[k] = hs; }
+    for (int k = 1; k < 32; ++k) { hs += st->Pe[0][31][k - 1]; st->Hs[k] = hs; }
     st->Ts[0] = st->Ts[1] = 0.0;
-    for (int e = 2; e < 33; ++e) { ts += st->St[e - 1]; st->Ts[e] = ts; }
+    for (int e = 2; e < 33; ++e) { ts += st->Pe[1][31][32 - e]; st->Ts[e] = ts; }
   }
 }
 
@@ -1107,8 +1170,12 @@ extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, cons
   const int64_t rows = B * C;
   ISD_HIP_TRY(hipMemsetAsync(S, 0, sizeof(EegStats), st));
   if (training) {
-    const int grid = rows < 2048 ? (int)rows : 2048;
-    hipLaunchKernelGGL(eeg_stats_kernel, dim3(grid), dim3(64), 0, st, x, S, rows, T);
+    const int64_t want = cdiv(rows, kStatWaves);
+    const int grid = want < 2048 ? (int)want : 2048;             // bulk: 32 waves per CU
+    hipLaunchKernelGGL(eeg_stats_kernel, dim3(grid), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
+    const int64_t want_e = cdiv(cdiv(rows, 4), kStatWaves);
+    const int grid_e = want_e < 512 ? (int)want_e : 512;         // edge: 4 rows per MFMA step, head and tail blocks
+    hipLaunchKernelGGL(eeg_stats_edge_kernel, dim3(grid_e, 2), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
     hipLaunchKernelGGL(eeg_stats_derive_kernel, dim3(1), dim3(64), 0, st, S);
   }
   hipLaunchKernelGGL(eeg_finalize1_kernel, dim3(1), dim3(256), 0, st, params, buffers, S, Cf, p->off, C, K, T, rows,
