@@ -344,37 +344,55 @@ __global__ __launch_bounds__(256) void eeg_finalize1_kernel(const float* __restr
 }
 
 // z[b,g,t] = sum_c Ws[g,c] x[b,c,t] on the matrix cores: M = the 16 rows g, N = 16 time steps, K = 4 channels per
-// MFMA; one wave per (trial, time tile) walks all channels.  (The scalar version gave one thread per (b,t) a serial
-// loop over C: 2.3 ms at C = 5120, T = 65 with 65 live threads per workgroup.)
+// MFMA.  One workgroup per (trial, time tile); its four waves take a quarter of the channels each (16 channels =
+// 8 loads and 4 independent MFMA chains per step) and meet in LDS in a fixed order.  (One wave per tile walking
+// all channels left 640 waves on the chip at C = 5120, T = 65: 0.29 ms; the scalar version before it 2.3 ms.)
 __global__ __launch_bounds__(256) void eeg_spatial_kernel(const float* __restrict__ x, const float* __restrict__ Ws,
                                                           float* __restrict__ z, int C, int T, int n_tiles) {
+  __shared__ float red[3][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= n_tiles) return;
+  const int tile = blockIdx.x;
   const int b = blockIdx.y;
   const int t = tile * 16 + jl;
   const bool tv = t < T;
   const float* xb = x + (int64_t)b * C * T + (tv ? t : 0);
   const float* wr = Ws + jl * C;
-  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;       // two chains: consecutive MFMAs do not depend
-  int c0 = 0;
-  for (; c0 + 8 <= C; c0 += 8) {
-    const int ca = c0 + q, cb = c0 + 4 + q;
-    const float a0 = wr[ca], a1 = wr[cb];
-    const float b0 = tv ? xb[(int64_t)ca * T] : 0.f, b1 = tv ? xb[(int64_t)cb * T] : 0.f;
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+  const int cq = ((C + 15) / 16) * 4;                           // channels per wave, a multiple of 4
+  const int c_lo = wave * cq, c_hi = c_lo + cq < C ? c_lo + cq : C;
+  f32x4 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int c0 = c_lo;
+  for (; c0 + 16 <= c_hi; c0 += 16) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + 4 * k + q;
+      av[k] = wr[c];
+      bv[k] = tv ? xb[(int64_t)c * T] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bv[k], acc[k], 0, 0, 0);
   }
-  for (; c0 < C; c0 += 4) {
+  for (; c0 < c_hi; c0 += 4) {
     const int c = c0 + q;
-    const bool cv = c < C;
+    const bool cv = c < c_hi;
     const float a0 = cv ? wr[c] : 0.f;
     const float b0 = (cv && tv) ? xb[(int64_t)c * T] : 0.f;
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0], 0, 0, 0);
   }
-  if (tv) {
+  f32x4 sum;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) z[((int64_t)b * kF2 + 4 * q + r) * T + t] = acc0[r] + acc1[r];
+  for (int r = 0; r < 4; ++r) sum[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave - 1][r][lane] = sum[r];
+  }
+  __syncthreads();
+  if (wave == 0 && tv) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      z[((int64_t)b * kF2 + 4 * q + r) * T + t] = ((sum[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
   }
 }
 
@@ -1180,7 +1198,7 @@ extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, cons
   }
   hipLaunchKernelGGL(eeg_finalize1_kernel, dim3(1), dim3(256), 0, st, params, buffers, S, Cf, p->off, C, K, T, rows,
                      training, momentum, eps);
-  hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(cdiv(T, 16), 4), (unsigned)B), dim3(256), 0, st, x,
+  hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(T, 16), (unsigned)B), dim3(256), 0, st, x,
                      params + p->off.Ws, ws + w.z, C, T, (int)cdiv(T, 16));
   hipLaunchKernelGGL(eeg_tconv_kernel, dim3((unsigned)cdiv(Tp, 256), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.z,
                      params + p->off.Wt, ws + w.u, S, K, T, Tp, training);
