@@ -402,20 +402,24 @@ __global__ __launch_bounds__(256) void eeg_tconv_kernel(const float* __restrict_
                                                         int Tp, int want_stats) {
   __shared__ float red[4];
   const int bg = blockIdx.y, g = bg & (kF2 - 1), f = g >> 1, P = K / 2;
-  const int tp = blockIdx.x * 256 + threadIdx.x;
   const float* zr = z + (int64_t)bg * T;
   const float* w = Wt + f * K;
-  float acc = 0.f;
-  if (tp < Tp) {
+  // a workgroup strides over its row: the per-row sums reach the 16 fp64 accumulators through one atomic per
+  // workgroup, and 35 k workgroups queueing on 16 addresses were what the kernel spent its time on (0.37 ms)
+  float t1 = 0.f, t2 = 0.f;
+  for (int tp = blockIdx.x * 256 + threadIdx.x; tp < Tp; tp += gridDim.x * 256) {
+    float acc = 0.f;
     for (int k = 0; k < K; ++k) {
       const int t = tp + k - P;
       if (t >= 0 && t < T) acc = fmaf(w[k], zr[t], acc);
     }
     u[(int64_t)bg * Tp + tp] = acc;
+    t1 += acc;
+    t2 = fmaf(acc, acc, t2);
   }
   if (want_stats) {
-    const float s1 = block_sum(tp < Tp ? acc : 0.f, red);
-    const float s2 = block_sum(tp < Tp ? acc * acc : 0.f, red);
+    const float s1 = block_sum(t1, red);
+    const float s2 = block_sum(t2, red);
     if (threadIdx.x == 0) {
       atomicAdd(&st->u1[g], (double)s1);
       atomicAdd(&st->u2[g], (double)s2);
@@ -423,7 +427,6 @@ __global__ __launch_bounds__(256) void eeg_tconv_kernel(const float* __restrict_
   }
 }
 
-// BN2 coefficients: y2 = A2 u + B2
 __global__ void eeg_finalize2_kernel(const float* __restrict__ params, float* __restrict__ bufs,
                                      const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N2,
                                      int training, float momentum, float eps) {
@@ -675,9 +678,9 @@ __global__ __launch_bounds__(256) void eeg_bwd_pool2_kernel(const float* __restr
                                                             int T2, int T2p, int P1, float dpr, uint64_t seed) {
   __shared__ float red[4];
   const int bg = blockIdx.y, g = bg & (kF2 - 1);
-  const int tp = blockIdx.x * 256 + threadIdx.x;
-  float dy = 0.f, xh = 0.f;
-  if (tp < Tp) {
+  float t1 = 0.f, t2 = 0.f;
+  for (int tp = blockIdx.x * 256 + threadIdx.x; tp < Tp; tp += gridDim.x * 256) {   // one atomic pair per workgroup
+    float dy = 0.f, xh = 0.f;
     const int v = tp / P1;
     if (v < T2) {
       float dp = 0.f;                                   // dp2[v] = sum_k Wd[g,k] da3[v - k + 8]
@@ -698,9 +701,11 @@ __global__ __launch_bounds__(256) void eeg_bwd_pool2_kernel(const float* __restr
       xh = (co->s1[g >> 1] * uv + co->o1[g >> 1] * co->wsum[g] - co->mu2[g]) / co->sig2[g];
     }
     dy2[(int64_t)bg * Tp + tp] = dy;
+    t1 += dy;
+    t2 = fmaf(dy, xh, t2);
   }
-  const float s1 = block_sum(dy, red);
-  const float s2 = block_sum(dy * xh, red);
+  const float s1 = block_sum(t1, red);
+  const float s2 = block_sum(t2, red);
   if (threadIdx.x == 0) {
     atomicAdd(&st->dy2s[g], (double)s1);
     atomicAdd(&st->dy2x[g], (double)s2);
@@ -713,17 +718,17 @@ __global__ __launch_bounds__(256) void eeg_bwd_bn2_kernel(float* __restrict__ dy
                                                           int Tp) {
   __shared__ float red[4];
   const int bg = blockIdx.y, g = bg & (kF2 - 1);
-  const int tp = blockIdx.x * 256 + threadIdx.x;
-  float d = 0.f, du = 0.f;
-  if (tp < Tp) {
+  float t1 = 0.f, t2 = 0.f;
+  for (int tp = blockIdx.x * 256 + threadIdx.x; tp < Tp; tp += gridDim.x * 256) {   // one atomic pair per workgroup
     const float uv = u[(int64_t)bg * Tp + tp];
     const float xh = (co->s1[g >> 1] * uv + co->o1[g >> 1] * co->wsum[g] - co->mu2[g]) / co->sig2[g];
-    d = co->cA2[g] * (dy2[(int64_t)bg * Tp + tp] - co->cB2[g] - xh * co->cC2[g]);
+    const float d = co->cA2[g] * (dy2[(int64_t)bg * Tp + tp] - co->cB2[g] - xh * co->cC2[g]);
     dy2[(int64_t)bg * Tp + tp] = d;
-    du = d * uv;
+    t1 += d;
+    t2 = fmaf(d, uv, t2);
   }
-  const float s1 = block_sum(d, red);
-  const float s2 = block_sum(du, red);
+  const float s1 = block_sum(t1, red);
+  const float s2 = block_sum(t2, red);
   if (threadIdx.x == 0) {
     atomicAdd(&st->Sd[g], (double)s1);
     atomicAdd(&st->Su[g], (double)s2);
@@ -1170,6 +1175,15 @@ extern "C" int64_t isd_eegnet_workspace_bytes(const isd_eegnet_plan* p, int64_t 
   return eeg_layout(p, B).total * 4;
 }
 
+// workgroups per row for the kernels that end in one fp64 atomic per workgroup and statistic: enough of them to
+// fill the chip (~4 k workgroups), no more
+static unsigned row_blocks(int row_len, int64_t n_rows) {
+  const int64_t full = cdiv(row_len, 256);
+  int64_t want = cdiv(4096, n_rows > 0 ? n_rows : 1);
+  if (want < 1) want = 1;
+  return (unsigned)(want < full ? want : full);
+}
+
 extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, const float* params, float* buffers,
                                   float* out, void* workspace, int64_t B, int training, float momentum, float eps,
                                   float dropout_p, uint64_t seed, void* stream) {
@@ -1200,7 +1214,7 @@ extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, cons
                      training, momentum, eps);
   hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(T, 16), (unsigned)B), dim3(256), 0, st, x,
                      params + p->off.Ws, ws + w.z, C, T, (int)cdiv(T, 16));
-  hipLaunchKernelGGL(eeg_tconv_kernel, dim3((unsigned)cdiv(Tp, 256), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.z,
+  hipLaunchKernelGGL(eeg_tconv_kernel, dim3(row_blocks(Tp, B * kF2), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.z,
                      params + p->off.Wt, ws + w.u, S, K, T, Tp, training);
   hipLaunchKernelGGL(eeg_finalize2_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
                      (double)B * (double)Tp, training, momentum, eps);
@@ -1262,7 +1276,7 @@ extern "C" int isd_eegnet_backward(const isd_eegnet_plan* p, const float* x, con
                        dparams + p->off.Wd);
     hipLaunchKernelGGL(cv_bwd_dp2_kernel, dim3((unsigned)cdiv(B * T2, 256)), dim3(256), 0, st, ws + w.da4, ws + w.w3b,
                        ws + w.da3, B, T2, T2p);
-    hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3((unsigned)cdiv(Tp, 256), (unsigned)rows16), dim3(256), 0, st,
+    hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st,
                        ws + w.da3, (const float*)nullptr, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, p->P1, dropout_p,
                        seed);
   } else {
@@ -1274,12 +1288,12 @@ extern "C" int isd_eegnet_backward(const isd_eegnet_plan* p, const float* x, con
                      ws + w.dpooled, params + p->off.Wp, Cf, ws + w.da4, ws + w.da3, T2p, T3, dropout_p, seed);
   hipLaunchKernelGGL(eeg_bwd_sepw_kernel, dim3(kF2 * kF2 + kF2 * kK2), dim3(256), 0, st, ws + w.da4, ws + w.a3,
                      ws + w.da3, ws + w.p2, S, (int)B, T2, T2p);
-  hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3((unsigned)cdiv(Tp, 256), (unsigned)rows16), dim3(256), 0, st,
+  hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st,
                      ws + w.da3, params + p->off.Wd, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, p->P1, dropout_p, seed);
   }
   hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
                      (double)B * (double)Tp, 2);
-  hipLaunchKernelGGL(eeg_bwd_bn2_kernel, dim3((unsigned)cdiv(Tp, 256), (unsigned)rows16), dim3(256), 0, st, ws + w.dy2,
+  hipLaunchKernelGGL(eeg_bwd_bn2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st, ws + w.dy2,
                      ws + w.u, Cf, S, Tp);
   {
     const size_t lds = sizeof(float) * (size_t)((T + K + 64) + (Tp + 2 * K + 64));
