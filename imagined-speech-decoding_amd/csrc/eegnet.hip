@@ -275,9 +275,16 @@ __global__ __launch_bounds__(256) void eeg_finalize1_kernel(const float* __restr
   {
     // wsum[g] = sum_c Ws[g,c]: 16 threads per row, then a 16-term finish
     const int g = threadIdx.x >> 4, j = threadIdx.x & 15;
-    float s = 0.f;
-    for (int c = j; c < C; c += 16) s += Ws[g * C + c];
-    wpart[g][j] = s;
+    // eight independent partial sums: a single chain of C/16 dependent loads was 0.09 ms at C = 5120
+    const float* wr = Ws + g * C;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int c = j;
+    for (; c + 112 < C; c += 128) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += wr[c + 16 * i];
+    }
+    for (; c < C; c += 16) s[0] += wr[c];
+    wpart[g][j] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   }
   __syncthreads();
   if (threadIdx.x < kF2) {
@@ -791,20 +798,42 @@ __global__ __launch_bounds__(64) void eeg_bwd_dws_kernel(const float* __restrict
   for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int chunks_per_b = (T + 255) / 256;
   const int64_t n_chunks = (int64_t)B * chunks_per_b;
+  const bool vec = (T & 3) == 0 && ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
   for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
     const int64_t b = ch / chunks_per_b;
     const int t_lo = (int)(ch - b * chunks_per_b) * 256;
     const int t_hi = t_lo + 256 < T ? t_lo + 256 : T;
     const float* vr = v + (b * kF2 + jl) * (int64_t)T;
-    for (int t0 = t_lo; t0 < t_hi; t0 += 4) {
-      const int t = t0 + q;
-      const float af = t < t_hi ? vr[t] : 0.f;
+    // 16 time steps per pass: lane (q, jl) owns the 4 consecutive steps t0 + 4q .. 4q+3 of its row (one 16-byte
+    // load per operand row instead of four scalar ones); MFMA step s contracts element s of every lane, i.e. the
+    // K index q stands for time t0 + 4q + s in both operands
+    for (int t0 = t_lo; t0 < t_hi; t0 += 16) {
+      const int t = t0 + 4 * q;
+      float af[4] = {0.f, 0.f, 0.f, 0.f};
+      if (vec && t + 3 < t_hi) {
+        const float4 f = *reinterpret_cast<const float4*>(vr + t);
+        af[0] = f.x; af[1] = f.y; af[2] = f.z; af[3] = f.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) af[e] = t + e < t_hi ? vr[t + e] : 0.f;
+      }
 #pragma unroll
       for (int ct = 0; ct < 16; ++ct) {
         if (ct < n_ctile) {
           const int c = c_base + ct * 16 + jl;
-          const float bf = (c < C && t < t_hi) ? x[(b * C + c) * (int64_t)T + t] : 0.f;
-          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[ct], 0, 0, 0);
+          float bf[4] = {0.f, 0.f, 0.f, 0.f};
+          if (c < C) {
+            const float* xr = x + (b * C + c) * (int64_t)T;
+            if (vec && t + 3 < t_hi) {
+              const float4 f = *reinterpret_cast<const float4*>(xr + t);
+              bf[0] = f.x; bf[1] = f.y; bf[2] = f.z; bf[3] = f.w;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bf[e] = t + e < t_hi ? xr[t + e] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc[ct], 0, 0, 0);
         }
       }
     }
