@@ -46,6 +46,8 @@ struct EegStats {
   double Ts[33];                // Ts[e] = sum_rows sum_{s>T-e} x[s]
   // raw accumulators of eeg_stats_kernel (eeg_stats_derive_kernel turns them into A, H, Tl, Hs, Ts above)
   double D[5][256];             // D[q][i][j] = sum_rows sum_k x[16k+i] x[16k+j+16q]   (matrix cores)
+  double Gs[80][80];            // short rows (T <= 79): upper triangle of the full Gram matrix sum_rows y[a] y[j], with
+                                //   y = (x[0..T), 1, 0, ...) (eeg_stats_gram_kernel); everything below is derived from it
   double Pe[2][32][96];         // Gram blocks of the head / tail windows (eeg_stats_edge_kernel):
                                 //   sum_rows x[s] x[s+d] = Pe[0][s][s+d],  sum_rows x[T-i] x[T-i+d] = Pe[1][31-i][31-i+d],
                                 //   sum_rows x[s] = Pe[0][31][s],          sum_rows x[T-i]        = Pe[1][31][31-i]
@@ -235,6 +237,89 @@ __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_edge_kernel(const f
   __syncthreads();
   for (int e = threadIdx.x; e < 32 * 96; e += 64 * kStatWaves)
     atomicAdd(&st->Pe[which][e / 96][e % 96], (double)tot[e / 96][e % 96]);
+}
+
+// Short rows (T <= 79, e.g. the 65 frames of the stress features): the whole row fits one Gram matrix.  With
+// y = (x[0..T), 1, 0, ...) padded to 16 MT entries, G[a][j] = sum_rows y[a] y[j] holds every lag product
+// (x[s] x[s+d] = G[s][s+d]) and, in column T, the per-sample sums.  Contracted over rows like the edge blocks: MT
+// loads and MT (MT + 1) / 2 MFMAs (upper-triangular tiles) per 4 rows -- 15 at T = 65 against 64 for the bulk + edge
+// pair, one pass over x instead of two.
+template <int MT>
+__global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_gram_kernel(const float* __restrict__ x,
+                                                                         EegStats* __restrict__ st, int64_t rows,
+                                                                         int T) {
+  __shared__ float tot[16 * MT][16 * MT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  for (int e = threadIdx.x; e < 256 * MT * MT; e += 64 * kStatWaves) (&tot[0][0])[e] = 0.f;
+  f32x4 acc[MT][MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < MT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int64_t n_grp = (rows + 3) >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kStatWaves;
+  for (int64_t g = (int64_t)blockIdx.x * kStatWaves + wave; g < n_grp; g += 2 * stride) {   // two groups in flight
+    float y[2][MT];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t r = (g + h * stride) * 4 + q;
+      const bool live = g + h * stride < n_grp && r < rows;
+      const float* src = x + (live ? r : 0) * (int64_t)T;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int idx = 16 * t + i;
+        y[h][t] = !live ? 0.f : (idx < T ? src[idx] : (idx == T ? 1.f : 0.f));
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = mt; nt < MT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[h][mt], y[h][nt], acc[mt][nt], 0, 0, 0);
+  }
+  __syncthreads();                                              // tot[] is zero
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = mt; nt < MT; ++nt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) atomicAdd(&tot[16 * mt + 4 * q + rr][16 * nt + i], acc[mt][nt][rr]);
+  __syncthreads();
+  for (int e = threadIdx.x; e < 256 * MT * MT; e += 64 * kStatWaves) {
+    const int a = e / (16 * MT), j = e - a * (16 * MT);
+    if (j >= a && a <= T && j <= T) atomicAdd(&st->Gs[a][j], (double)tot[a][j]);
+  }
+}
+
+// Gs -> the quantities eeg_finalize1_kernel consumes (same definitions as eeg_stats_derive_kernel: samples outside
+// the row are zero).  One block of 64 threads (thread = lag d).
+__global__ __launch_bounds__(64) void eeg_stats_gram_derive_kernel(EegStats* __restrict__ st, int T) {
+  const int d = threadIdx.x;
+  double a = 0.0;
+  for (int s = 0; s + d < T; ++s) a += st->Gs[s][s + d];
+  st->A[d] = a;
+  double h = 0.0, t = 0.0;
+  for (int k = 1; k < 32; ++k) {
+    const int s = k - 1;
+    if (s + d < T) h += st->Gs[s][s + d];                // H[k][d] = sum_{s<k} x[s] x[s+d]
+    st->H[k][d] = h;
+  }
+  for (int e = 2; e < 33; ++e) {
+    const int s = T - (e - 1);
+    if (s >= 0 && s + d < T) t += st->Gs[s][s + d];      // Tl[e][d] = sum_{i<e} x[T-i] x[T-i+d]
+    st->Tl[e][d] = t;
+  }
+  if (d == 0) {
+    double tot = 0.0, hs = 0.0, ts = 0.0;
+    for (int j = 0; j < T; ++j) tot += st->Gs[j][T];
+    st->S = tot;
+    st->Hs[0] = 0.0;
+    for (int k = 1; k < 32; ++k) { if (k - 1 < T) hs += st->Gs[k - 1][T]; st->Hs[k] = hs; }
+    st->Ts[0] = st->Ts[1] = 0.0;
+    for (int e = 2; e < 33; ++e) { if (T - (e - 1) >= 0) ts += st->Gs[T - (e - 1)][T]; st->Ts[e] = ts; }
+  }
 }
 
 // raw accumulators -> the quantities eeg_finalize1_kernel consumes.  One block of 64 threads (thread = lag d).
@@ -1231,13 +1316,27 @@ extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, cons
   const int64_t rows = B * C;
   ISD_HIP_TRY(hipMemsetAsync(S, 0, sizeof(EegStats), st));
   if (training) {
-    const int64_t want = cdiv(rows, kStatWaves);
-    const int grid = want < 2048 ? (int)want : 2048;             // bulk: 32 waves per CU
-    hipLaunchKernelGGL(eeg_stats_kernel, dim3(grid), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
-    const int64_t want_e = cdiv(cdiv(rows, 4), kStatWaves);
-    const int grid_e = want_e < 512 ? (int)want_e : 512;         // edge: 4 rows per MFMA step, head and tail blocks
-    hipLaunchKernelGGL(eeg_stats_edge_kernel, dim3(grid_e, 2), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
-    hipLaunchKernelGGL(eeg_stats_derive_kernel, dim3(1), dim3(64), 0, st, S);
+    if (T <= 79) {
+      const int MT = (T + 16) / 16;                              // 16 MT >= T + 1: room for the column of ones
+      const int64_t want_g = cdiv(cdiv(rows, 4), kStatWaves);
+      const int grid_g = want_g < 1024 ? (int)want_g : 1024;
+      switch (MT) {
+        case 1: hipLaunchKernelGGL(eeg_stats_gram_kernel<1>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+        case 2: hipLaunchKernelGGL(eeg_stats_gram_kernel<2>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+        case 3: hipLaunchKernelGGL(eeg_stats_gram_kernel<3>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+        case 4: hipLaunchKernelGGL(eeg_stats_gram_kernel<4>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+        default: hipLaunchKernelGGL(eeg_stats_gram_kernel<5>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+      }
+      hipLaunchKernelGGL(eeg_stats_gram_derive_kernel, dim3(1), dim3(64), 0, st, S, T);
+    } else {
+      const int64_t want = cdiv(rows, kStatWaves);
+      const int grid = want < 2048 ? (int)want : 2048;             // bulk: 32 waves per CU
+      hipLaunchKernelGGL(eeg_stats_kernel, dim3(grid), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
+      const int64_t want_e = cdiv(cdiv(rows, 4), kStatWaves);
+      const int grid_e = want_e < 512 ? (int)want_e : 512;         // edge: 4 rows per MFMA step, head and tail blocks
+      hipLaunchKernelGGL(eeg_stats_edge_kernel, dim3(grid_e, 2), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
+      hipLaunchKernelGGL(eeg_stats_derive_kernel, dim3(1), dim3(64), 0, st, S);
+    }
   }
   hipLaunchKernelGGL(eeg_finalize1_kernel, dim3(1), dim3(256), 0, st, params, buffers, S, Cf, p->off, C, K, T, rows,
                      training, momentum, eps);
