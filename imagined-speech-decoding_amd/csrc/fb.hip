@@ -595,14 +595,19 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
 // power (stft.hip): every lane holds half of a 64-sample block, forms the half-block sums of the band's bins and
 // their two neighbours, lane pairs are joined by one DPP shift and the 64 block sums of the row wait in LDS for
 // blocksum_finish.  The filtered rows (86 MB per trial at the stress shape) are never written.
-// The x row is re-read from global memory (L2 / MALL resident) for every band and pass.
+// The x row is re-read from global memory for every band and pass, and kLongShare one-wave workgroups share a row
+// (each takes every kLongShare-th band).  Their ids are congruent mod 8 -- workgroups go to the 8 XCDs round-robin
+// by id, and each XCD has its own L2 -- and lie within 64 consecutive ids, so the sharers run on one XCD at about
+// the same time and the rows in flight there (~80 x 16 KiB) fit its 4 MiB L2.  With one workgroup per row walking
+// all bands the rows in flight were ~10x the L2: the PMC counters showed 6.1 GB through the fabric for a 268 MB input.
+constexpr int kLongShare = 8;
 template <typename VT, int KB>
-__global__ __launch_bounds__(64) void fused_long_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fused_long_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                                                         const double* __restrict__ Qtab, const float2* __restrict__ blk,
                                                         const float* __restrict__ x, float* __restrict__ feat, int C,
                                                         int T, int nb, int ns, int J, int log2_nblk, int n_bins_max,
                                                         float scale2, FusedBands fbnd, int mode, float eps, int vec,
-                                                        const int* __restrict__ bmap, int nb_out) {
+                                                        const int* __restrict__ bmap, int nb_out, int64_t n_rows) {
   using O = VOps<VT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x;
@@ -611,7 +616,11 @@ __global__ __launch_bounds__(64) void fused_long_kernel(const FbSec* __restrict_
   float2* Sblk = reinterpret_cast<float2*>(smem_raw);                      // [KB][64]
   float2* tw = Sblk + KB * 64;                                             // [64]  e^{-2 pi i u / nblk}
   double* carry = reinterpret_cast<double*>(tw + 64);                      // [ns][2]
-  const int64_t row = blockIdx.x;
+  // id = 64 q + 8 w + c  <->  row = 8 q + c, band subset w
+  const int64_t id = blockIdx.x;
+  const int64_t row = (id >> 6) * 8 + (id & 7);
+  const int share = (int)((id >> 3) & 7);
+  if (row >= n_rows) return;
   const int64_t bt = row / C;
   const int ch = (int)(row - bt * C);
   const int nblk = 1 << log2_nblk;
@@ -623,7 +632,7 @@ __global__ __launch_bounds__(64) void fused_long_kernel(const FbSec* __restrict_
     tw[lane] = make_float2(cs, -sn);
   }
   wave_lds_sync();
-  for (int b = 0; b < nb; ++b) {
+  for (int b = share; b < nb; b += kLongShare) {
     const int klo = fbnd.klo[b], khi = fbnd.khi[b];
     const int k0 = klo - 1, nbin = khi - klo + 1;
 #pragma unroll
@@ -931,7 +940,7 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
       if (nbin > nbmax) nbmax = nbin;
     }
     const int64_t rows = B * C;
-    ISD_CHECK_ARG(rows <= 0x7fffffffLL, "isd_features_fused: too many rows (%lld)", (long long)rows);
+    ISD_CHECK_ARG(rows <= 0x7fffffffLL / 16, "isd_features_fused: too many rows (%lld)", (long long)rows);
     int log2_nblk = 0;
     while ((64 << log2_nblk) < st->n) ++log2_nblk;
     const int KB = nbmax + 2 <= 4 ? 4 : nbmax + 2 <= 6 ? 6 : 8;
@@ -947,9 +956,9 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
       }
       const size_t lds = sizeof(float2) * ((size_t)KB * 64 + 64) + sizeof(double) * 2 * kMaxSec;
 #define ISD_FL_LAUNCH(VT, K)                                                                                      \
-  hipLaunchKernelGGL((fused_long_kernel<VT, K>), dim3((unsigned)rows), dim3(64), lds, s, fs.d_sec, fs.d_band, fs.d_Q, \
-                     st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections, st->J, log2_nblk, st->n / 2,         \
-                     st->scale * st->scale, fbnd, mode, eps, vec, fs.d_map, fb->n_bands)
+  hipLaunchKernelGGL((fused_long_kernel<VT, K>), dim3((unsigned)(cdiv(rows, 8) * 8 * kLongShare)), dim3(64), lds, s, \
+                     fs.d_sec, fs.d_band, fs.d_Q, st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections, st->J,  \
+                     log2_nblk, st->n / 2, st->scale * st->scale, fbnd, mode, eps, vec, fs.d_map, fb->n_bands, rows)
       if (k == 0) {
         if (KB == 4) ISD_FL_LAUNCH(float, 4); else if (KB == 6) ISD_FL_LAUNCH(float, 6); else ISD_FL_LAUNCH(float, 8);
       } else {
