@@ -600,7 +600,7 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
 // by id, and each XCD has its own L2 -- and lie within 64 consecutive ids, so the sharers run on one XCD at about
 // the same time and the rows in flight there (~80 x 16 KiB) fit its 4 MiB L2.  With one workgroup per row walking
 // all bands the rows in flight were ~10x the L2: the PMC counters showed 6.1 GB through the fabric for a 268 MB input.
-constexpr int kLongShare = 8;
+constexpr int kLongShare = 8;                    // measured: 4 -> 4.58 ms, 8 -> 4.47 ms per 128 stress trials
 template <typename VT, int KB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fused_long_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                                                         const double* __restrict__ Qtab, const float2* __restrict__ blk,
@@ -616,10 +616,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fu
   float2* Sblk = reinterpret_cast<float2*>(smem_raw);                      // [KB][64]
   float2* tw = Sblk + KB * 64;                                             // [64]  e^{-2 pi i u / nblk}
   double* carry = reinterpret_cast<double*>(tw + 64);                      // [ns][2]
-  // id = 64 q + 8 w + c  <->  row = 8 q + c, band subset w
+  // id = 8 kLongShare q + 8 w + c  <->  row = 8 q + c, band subset w
   const int64_t id = blockIdx.x;
-  const int64_t row = (id >> 6) * 8 + (id & 7);
-  const int share = (int)((id >> 3) & 7);
+  const int64_t row = (id / (8 * kLongShare)) * 8 + (id & 7);
+  const int share = (int)((id >> 3) % kLongShare);
   if (row >= n_rows) return;
   const int64_t bt = row / C;
   const int ch = (int)(row - bt * C);
