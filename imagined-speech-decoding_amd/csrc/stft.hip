@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ x, 
 //   R_k[j] = sum over the n/hop blocks m of frame j of S_k[m],   S_k[m] = sum_{t in block m} y[t] e^{-2 pi i k t/n},
 // so a row costs one 64-sample DFT sum per lane for the band's bins and their two neighbours, two sliding-window
 // sums over lanes (log2(n/hop) shuffles each) and a few complex multiplies per frame -- not a 1024-point FFT per
-// frame (513 bins computed, 3 used).  Reads each row once, coalesced; the block layout is transposed through LDS.
+// frame (513 bins computed, 3 used).  Reads each row once, coalesced; the block layout is transposed through LDS,
+// half a row at a time.
 // ---------------------------------------------------------------------------------------
 template <int H, int KB>
 __global__ __launch_bounds__(64) void bandpower_blocksum_kernel(const float2* __restrict__ tab,
@@ -118,52 +119,73 @@ __global__ __launch_bounds__(64) void bandpower_blocksum_kernel(const float2* __
                                                                 int64_t R, int C, int T, int nb, int J, int n,
                                                                 int log2_nblk, float scale2, BandArgs ba, int mode,
                                                                 float eps) {
-  constexpr int RS = H + 4;                                   // padded block stride: conflict-free ds_read_b128
+  // Two passes of 32 blocks: lane l owns HALF of block p*32 + (l >> 1) (H/2 samples), so the transposing LDS tile
+  // holds half a row (9 KiB instead of 18 KiB at H = 64: 12 instead of 8 waves per CU on a pure streaming kernel).
+  // Both halves use the first H/2 table columns; the odd lane rotates its sum by e^{-2 pi i k (H/2) / n}
+  // (column H/2) and a DPP shift joins the pair.
+  constexpr int HH = H / 2, RS = HH + 4;                      // padded half-block stride: conflict-free ds_read_b128
   __shared__ __attribute__((aligned(16))) float tile[64 * RS];
+  __shared__ float2 Sblk[KB][64];
   __shared__ float2 tw[64];                                   // e^{-2 pi i u / nblk}
   const int lane = threadIdx.x;
   const int64_t row = blockIdx.x;
   const int band = (int)((row / C) % nb);
   const int klo = ba.klo[band], khi = ba.khi[band];
   const int nbin = khi - klo + 1, k0 = klo - 1;
-  const int nblk = 1 << log2_nblk, half = nblk >> 1;
+  const int nblk = 1 << log2_nblk;
   const float* src = y + row * (int64_t)T;
   const bool vec = (T & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-#pragma unroll
-  for (int it = 0; it < H / 4; ++it) {
-    const int e = (it * 64 + lane) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (vec && e + 3 < T) {
-      v = *reinterpret_cast<const float4*>(src + e);
-    } else {
-      if (e + 0 < T) v.x = src[e];
-      if (e + 1 < T) v.y = src[e + 1];
-      if (e + 2 < T) v.z = src[e + 2];
-      if (e + 3 < T) v.w = src[e + 3];
-    }
-    *reinterpret_cast<float4*>(tile + (e / H) * RS + (e % H)) = v;
-  }
   if (lane < nblk) {
     float sn, cs;
     sincospif(2.f * (float)lane / (float)nblk, &sn, &cs);
     tw[lane] = make_float2(cs, -sn);
   }
-  __syncthreads();
-  float2 S[KB];
-#pragma unroll
-  for (int kk = 0; kk < KB; ++kk) S[kk] = make_float2(0.f, 0.f);
-  const float* sp = tile + lane * RS;
   const int kmax = n / 2;
-  for (int i0 = 0; i0 < H; i0 += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(sp + i0);
+  for (int p = 0; p < 2; ++p) {
+    wave_lds_sync();                                            // the previous pass has read its tile
+#pragma unroll
+    for (int it = 0; it < HH / 4; ++it) {
+      const int el = (it * 64 + lane) * 4;                      // position inside the half row
+      const int e = p * 32 * H + el;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec && e + 3 < T) {
+        v = *reinterpret_cast<const float4*>(src + e);
+      } else {
+        if (e + 0 < T) v.x = src[e];
+        if (e + 1 < T) v.y = src[e + 1];
+        if (e + 2 < T) v.z = src[e + 2];
+        if (e + 3 < T) v.w = src[e + 3];
+      }
+      *reinterpret_cast<float4*>(tile + (el / HH) * RS + (el % HH)) = v;
+    }
+    wave_lds_sync();
+    float2 P[KB];
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) P[kk] = make_float2(0.f, 0.f);
+    const float* sp = tile + lane * RS;
+    for (int i0 = 0; i0 < HH; i0 += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(sp + i0);
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        const int k = k0 + kk < kmax ? k0 + kk : kmax;            // unused slots repeat a valid table row
+        const float2* tb = tab + (int64_t)k * H + i0;             // wave-uniform -> scalar loads
+        P[kk].x = fmaf(v.x, tb[0].x, fmaf(v.y, tb[1].x, fmaf(v.z, tb[2].x, fmaf(v.w, tb[3].x, P[kk].x))));
+        P[kk].y = fmaf(v.x, tb[0].y, fmaf(v.y, tb[1].y, fmaf(v.z, tb[2].y, fmaf(v.w, tb[3].y, P[kk].y))));
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < KB; ++kk) {
-      const int k = k0 + kk < kmax ? k0 + kk : kmax;              // unused slots repeat a valid table row
-      const float2* tb = tab + (int64_t)k * H + i0;               // wave-uniform -> scalar loads
-      S[kk].x = fmaf(v.x, tb[0].x, fmaf(v.y, tb[1].x, fmaf(v.z, tb[2].x, fmaf(v.w, tb[3].x, S[kk].x))));
-      S[kk].y = fmaf(v.x, tb[0].y, fmaf(v.y, tb[1].y, fmaf(v.z, tb[2].y, fmaf(v.w, tb[3].y, S[kk].y))));
+      const int k = k0 + kk < kmax ? k0 + kk : kmax;
+      const float2 ph = tab[(int64_t)k * H + HH];               // the odd lane's offset inside the block
+      const float2 q = (lane & 1) ? make_float2(P[kk].x * ph.x - P[kk].y * ph.y, P[kk].x * ph.y + P[kk].y * ph.x) : P[kk];
+      const float sx = q.x + row_shl<1>(q.x), sy = q.y + row_shl<1>(q.y);
+      if (!(lane & 1)) Sblk[kk][p * 32 + (lane >> 1)] = make_float2(sx, sy);
     }
   }
+  wave_lds_sync();
+  float2 S[KB];
+#pragma unroll
+  for (int kk = 0; kk < KB; ++kk) S[kk] = Sblk[kk][lane];
   blocksum_finish<KB>(S, tw, lane, k0, nbin, nblk, J, scale2, mode, eps, feat + row * (int64_t)J);
 }
 
