@@ -829,32 +829,37 @@ __global__ __launch_bounds__(256) void eeg_bwd_bn2_kernel(float* __restrict__ dy
 
 // T1[g][k] = sum_{b,t'} da2[b,g,t'] zpad[b,g,t'+k]  (lane = t' inside a 64 block, K accumulators in registers)
 // and v[b,g,t] = sum_k Wt[f,k] da2[b,g,t-k+P].   grid (B*16), one wave per (b,g) row.
+// grid (B*16, segments): a workgroup takes kCorrSeg time steps of its row (with the whole row in LDS -- 33 KiB at
+// T = 4096 -- a CU held 4 of these one-wave workgroups and the kernel was the slowest of the raw stress head).
+constexpr int kCorrSeg = 1024;
 __global__ __launch_bounds__(64) void eeg_bwd_corr_kernel(const float* __restrict__ da2, const float* __restrict__ z,
                                                           const float* __restrict__ Wt, float* __restrict__ v,
                                                           EegStats* __restrict__ st, int K, int T, int Tp) {
-  extern __shared__ float sm[];                         // zpad [T + 2P + 64], da2 row padded [Tp + 2K + 64]
+  extern __shared__ float sm[];                         // z[s0 - P + j], j < L + K + 64;  da2[s0 - K + j], j < L + 2K + 64
   const int bg = blockIdx.x, g = bg & (kF2 - 1), f = g >> 1, P = K / 2, lane = threadIdx.x;
+  const int s0 = blockIdx.y * kCorrSeg, L = kCorrSeg;
   float* zp = sm;
-  float* dp = sm + T + 2 * P + 64;
+  float* dp = sm + L + K + 64;
   const float* zr = z + (int64_t)bg * T;
   const float* dr = da2 + (int64_t)bg * Tp;
-  for (int i = lane; i < T + 2 * P + 64; i += 64) {
-    const int t = i - P;
-    zp[i] = (t >= 0 && t < T) ? zr[t] : 0.f;
+  for (int j = lane; j < L + K + 64; j += 64) {
+    const int t = s0 - P + j;
+    zp[j] = (t >= 0 && t < T) ? zr[t] : 0.f;
   }
-  for (int i = lane; i < Tp + 2 * K + 64; i += 64) {
-    const int t = i - K;
-    dp[i] = (t >= 0 && t < Tp) ? dr[t] : 0.f;
+  for (int j = lane; j < L + 2 * K + 64; j += 64) {
+    const int t = s0 - K + j;
+    dp[j] = (t >= 0 && t < Tp) ? dr[t] : 0.f;
   }
-  __syncthreads();
+  wave_lds_sync();
   float acc[kMaxK];
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) acc[k] = 0.f;
-  for (int t0 = 0; t0 < Tp; t0 += 64) {
-    const float dv = dp[K + t0 + lane];                 // 0 beyond Tp
+  const int n1 = Tp - s0 < L ? Tp - s0 : L;             // t' = s0 + u, u < n1
+  for (int u0 = 0; u0 < n1; u0 += 64) {
+    const float dv = dp[K + u0 + lane];                 // da2[s0 + u0 + lane], 0 beyond Tp
 #pragma unroll
     for (int k = 0; k < kMaxK; ++k)
-      if (k < K) acc[k] = fmaf(dv, zp[t0 + lane + k], acc[k]);
+      if (k < K) acc[k] = fmaf(dv, zp[u0 + lane + k], acc[k]);    // z[t' + k - P]
   }
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) {
@@ -864,10 +869,11 @@ __global__ __launch_bounds__(64) void eeg_bwd_corr_kernel(const float* __restric
     }
   }
   const float* w = Wt + f * K;
-  for (int t = lane; t < T; t += 64) {
+  const int n2 = T - s0 < L ? T - s0 : L;               // t = s0 + u, u < n2
+  for (int u = lane; u < n2; u += 64) {
     float a = 0.f;
-    for (int k = 0; k < K; ++k) a = fmaf(w[k], dp[K + t - k + P], a);   // index t-k+P in [-K, Tp+K) is padded
-    v[(int64_t)bg * T + t] = a;
+    for (int k = 0; k < K; ++k) a = fmaf(w[k], dp[K + u - k + P], a);   // da2[t - k + P]
+    v[(int64_t)bg * T + s0 + u] = a;
   }
 }
 
@@ -1424,10 +1430,9 @@ extern "C" int isd_eegnet_backward(const isd_eegnet_plan* p, const float* x, con
   hipLaunchKernelGGL(eeg_bwd_bn2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st, ws + w.dy2,
                      ws + w.u, Cf, S, Tp);
   {
-    const size_t lds = sizeof(float) * (size_t)((T + K + 64) + (Tp + 2 * K + 64));
-    ISD_CHECK_ARG(lds <= 64 * 1024, "isd_eegnet_backward: T=%d too long for the correlation tile", T);
-    hipLaunchKernelGGL(eeg_bwd_corr_kernel, dim3((unsigned)rows16), dim3(64), lds, st, ws + w.dy2, ws + w.z,
-                       params + p->off.Wt, ws + w.v, S, K, T, Tp);
+    const size_t lds = sizeof(float) * (size_t)((kCorrSeg + K + 64) + (kCorrSeg + 2 * K + 64));
+    hipLaunchKernelGGL(eeg_bwd_corr_kernel, dim3((unsigned)rows16, (unsigned)cdiv(Tp, kCorrSeg)), dim3(64), lds, st,
+                       ws + w.dy2, ws + w.z, params + p->off.Wt, ws + w.v, S, K, T, Tp);
   }
   const int64_t n_chunks = B * ((T + 255) / 256);
   const int slabs = n_chunks < w.n_slabs ? (int)n_chunks : w.n_slabs;
