@@ -942,22 +942,35 @@ __global__ __launch_bounds__(64) void eeg_bwd_dws_kernel(const float* __restrict
   }
 }
 
-// dWs[g,c] = s1[f] * sum_slabs raw + o1[f] * Sd[g]
-__global__ __launch_bounds__(256) void eeg_bwd_dws_reduce_kernel(const float* __restrict__ part, int n_slabs,
-                                                                 const EegStats* __restrict__ st,
-                                                                 const EegCoef* __restrict__ co,
-                                                                 float* __restrict__ dWs, int C) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= kF2 * C) return;
-  const int g = e / C, f = g >> 1;
+// dWs[g,c] = s1[f] * sum_slabs raw + o1[f] * Sd[g].  Block = 64 elements x 16 slab groups (coalesced 256-B rows, two
+// independent chains per group, LDS combine in a fixed order): one thread per element walking up to 1024 slabs on
+// its own was a 0.15 ms chain of dependent loads.
+__global__ __launch_bounds__(1024) void eeg_bwd_dws_reduce_kernel(const float* __restrict__ part, int n_slabs,
+                                                                  const EegStats* __restrict__ st,
+                                                                  const EegCoef* __restrict__ co,
+                                                                  float* __restrict__ dWs, int C) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  const int n = kF2 * C;
   float s0 = 0.f, s1 = 0.f;
-  int k = 0;
-  for (; k + 1 < n_slabs; k += 2) {
-    s0 += part[(int64_t)k * kF2 * C + e];
-    s1 += part[(int64_t)(k + 1) * kF2 * C + e];
+  if (e < n) {
+    int k = grp;
+    for (; k + 16 < n_slabs; k += 32) {
+      s0 += part[(int64_t)k * n + e];
+      s1 += part[(int64_t)(k + 16) * n + e];
+    }
+    if (k < n_slabs) s0 += part[(int64_t)k * n + e];
   }
-  if (k < n_slabs) s0 += part[(int64_t)k * kF2 * C + e];
-  dWs[e] = co->s1[f] * (s0 + s1) + co->o1[f] * (float)st->Sd[g];
+  red[grp][lane] = s0 + s1;
+  __syncthreads();
+  if (grp == 0 && e < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][lane];
+    const int g = e / C, f = g >> 1;
+    dWs[e] = co->s1[f] * t + co->o1[f] * (float)st->Sd[g];
+  }
 }
 
 // Final assembly of the stage-1 gradients (dWt, dgamma1, dbeta1) and the separable weights.  One block.
@@ -1438,7 +1451,7 @@ extern "C" int isd_eegnet_backward(const isd_eegnet_plan* p, const float* x, con
   const int slabs = n_chunks < w.n_slabs ? (int)n_chunks : w.n_slabs;
   hipLaunchKernelGGL(eeg_bwd_dws_kernel, dim3(slabs, (unsigned)cdiv(C, 256)), dim3(64), 0, st, ws + w.v, x, ws + w.part,
                      (int)B, C, T);
-  hipLaunchKernelGGL(eeg_bwd_dws_reduce_kernel, dim3((unsigned)cdiv((int64_t)kF2 * C, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(eeg_bwd_dws_reduce_kernel, dim3((unsigned)cdiv((int64_t)kF2 * C, 64)), dim3(1024), 0, st,
                      ws + w.part, slabs, S, Cf, dparams + p->off.Ws, C);
   hipLaunchKernelGGL(eeg_bwd_final_kernel, dim3(1), dim3(256), 0, st, params, dparams, S, Cf, p->off, C, K,
                      (double)(B * C) * (double)Tp, !p->cv);
