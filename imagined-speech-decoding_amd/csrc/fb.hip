@@ -646,10 +646,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fu
       // is re-read once per band and stays in L2 / MALL): a row staged in LDS would cost 18 KiB per wave and hold
       // the CU at 7 waves
       const int e0 = (it * 64 + lane) * kL;
+      const bool whole = vec && (it + 1) * 64 * kL <= T;          // wave-uniform: the pass lies inside the row
 #pragma unroll
       for (int n = 0; n < kL; n += 4) {
         float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (vec && e0 + n + 3 < T) {
+        if (whole) {                                              // no per-element bounds arithmetic on the common path
+          f = *reinterpret_cast<const float4*>(src + e0 + n);
+        } else if (vec && e0 + n + 3 < T) {
           f = *reinterpret_cast<const float4*>(src + e0 + n);
         } else {
           if (e0 + n + 0 < T) f.x = src[e0 + n];
