@@ -946,7 +946,7 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
     ISD_CHECK_ARG(rows <= 0x7fffffffLL / 16, "isd_features_fused: too many rows (%lld)", (long long)rows);
     int log2_nblk = 0;
     while ((64 << log2_nblk) < st->n) ++log2_nblk;
-    const int KB = nbmax + 2 <= 4 ? 4 : nbmax + 2 <= 6 ? 6 : 8;
+    const int KB = nbmax + 2 <= 4 ? 4 : nbmax + 2 <= 5 ? 5 : nbmax + 2 <= 6 ? 6 : 8;   // band bins + two neighbours
     const int n_iter = (st->T + 4 * kSeg - 1) / (4 * kSeg);
     const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     for (int k = 0; k < 2; ++k) {
@@ -963,9 +963,11 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
                      fs.d_sec, fs.d_band, fs.d_Q, st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections, st->J,  \
                      log2_nblk, st->n / 2, st->scale * st->scale, fbnd, mode, eps, vec, fs.d_map, fb->n_bands, rows)
       if (k == 0) {
-        if (KB == 4) ISD_FL_LAUNCH(float, 4); else if (KB == 6) ISD_FL_LAUNCH(float, 6); else ISD_FL_LAUNCH(float, 8);
+        if (KB == 4) ISD_FL_LAUNCH(float, 4); else if (KB == 5) ISD_FL_LAUNCH(float, 5);
+        else if (KB == 6) ISD_FL_LAUNCH(float, 6); else ISD_FL_LAUNCH(float, 8);
       } else {
-        if (KB == 4) ISD_FL_LAUNCH(double, 4); else if (KB == 6) ISD_FL_LAUNCH(double, 6); else ISD_FL_LAUNCH(double, 8);
+        if (KB == 4) ISD_FL_LAUNCH(double, 4); else if (KB == 5) ISD_FL_LAUNCH(double, 5);
+        else if (KB == 6) ISD_FL_LAUNCH(double, 6); else ISD_FL_LAUNCH(double, 8);
       }
 #undef ISD_FL_LAUNCH
       ISD_LAUNCH_CHECK();

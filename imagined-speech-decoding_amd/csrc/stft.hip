@@ -345,15 +345,17 @@ extern "C" int isd_stft_bandpower(const isd_stft_plan* p, const float* y, float*
     if (ok && rows <= 0x7fffffffLL) {
       int log2_nblk = 0;
       while ((p->hop << log2_nblk) < p->n) ++log2_nblk;
-      const int KB = nbmax + 2 <= 4 ? 4 : nbmax + 2 <= 6 ? 6 : 8;
+      const int KB = nbmax + 2 <= 4 ? 4 : nbmax + 2 <= 5 ? 5 : nbmax + 2 <= 6 ? 6 : 8;
       hipStream_t st = (hipStream_t)stream;
 #define ISD_BS_LAUNCH(H, K)                                                                                        \
   hipLaunchKernelGGL((bandpower_blocksum_kernel<H, K>), dim3((unsigned)rows), dim3(64), 0, st, p->d_blk, y, feat, rows, \
                      (int)C, p->T, n_bands, p->J, p->n, log2_nblk, p->scale * p->scale, ba, mode, eps)
       if (p->hop == 64) {
-        if (KB == 4) ISD_BS_LAUNCH(64, 4); else if (KB == 6) ISD_BS_LAUNCH(64, 6); else ISD_BS_LAUNCH(64, 8);
+        if (KB == 4) ISD_BS_LAUNCH(64, 4); else if (KB == 5) ISD_BS_LAUNCH(64, 5);
+        else if (KB == 6) ISD_BS_LAUNCH(64, 6); else ISD_BS_LAUNCH(64, 8);
       } else {
-        if (KB == 4) ISD_BS_LAUNCH(32, 4); else if (KB == 6) ISD_BS_LAUNCH(32, 6); else ISD_BS_LAUNCH(32, 8);
+        if (KB == 4) ISD_BS_LAUNCH(32, 4); else if (KB == 5) ISD_BS_LAUNCH(32, 5);
+        else if (KB == 6) ISD_BS_LAUNCH(32, 6); else ISD_BS_LAUNCH(32, 8);
       }
 #undef ISD_BS_LAUNCH
       ISD_LAUNCH_CHECK();
