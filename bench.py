@@ -2,10 +2,15 @@
 """Headline benchmark: trials/sec end-to-end on synthetic EEG (BASELINE.json metric).
 
 One step = one pass of the hot path over one batch that is already resident in HBM:
-  extract_features (Butterworth filterbank -> STFT 64/32 -> log band power, HIP)
-  -> Conv4Layers(nb*C, 32) + Linear(32, 5) forward -> softmax-CE -> backward (HIP)
+  extract_features (Butterworth filterbank -> STFT -> log band power, HIP)
+  -> CNN classifier forward -> softmax-CE -> backward (HIP)
   -> [N > 1: one flat-bucket RCCL all-reduce] -> AdamW step (torch, fused).
-Workload = BASELINE config 2: 4096 trials per GPU, 64 ch, 2 s @ 256 Hz, 9 bands, fp32.
+
+Workloads (``--config``):
+  cfg2 (default; the configuration BASELINE.json's metric is quoted on): 4096 trials per GPU, 64 ch, 2 s @ 256 Hz,
+        9 bands, STFT 64/32, Conv4Layers(576, 32) + Linear(32, 5), fp32   (``--bf16``: BASELINE config 3)
+  cfg5 (high-resolution stress): 2048 trials per GPU, 128 ch, 4 s @ 1024 Hz, 40 bands, STFT 1024/960,
+        EEGNet_Encoder(5120, 32) + Linear(32, 5), fp32
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -26,11 +31,22 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
+FP32_PEAK_TFLOPS = 157.3     # fp32 vector peak (packed v_pk_fma_f32) == fp32-input MFMA peak
+
+CONFIGS = {
+    "cfg2": dict(C=64, T=512, fs=256.0, bands="BANDS_9", nperseg=64, noverlap=32, batch=4096, steps=20, warmup=5,
+                 workload="cfg2: 64ch x 2s@256Hz EEG, 9-band Butterworth(4) filterbank -> STFT(64/32) log band power "
+                          "-> Conv4Layers(576,32)+Linear(32,5) fwd+bwd, softmax-CE, AdamW"),
+    "cfg5": dict(C=128, T=4096, fs=1024.0, bands="BANDS_40", nperseg=1024, noverlap=960, batch=2048, steps=5, warmup=2,
+                 workload="cfg5 (stress): 128ch x 4s@1024Hz EEG, 40-band Butterworth(4) filterbank -> STFT(1024/960) "
+                          "log band power [B,5120,65] -> EEGNet_Encoder(5120,32)+Linear(32,5) fwd+bwd (train-mode "
+                          "BatchNorm, dropout 0.25), softmax-CE, AdamW"),
+}
 
 
 def synth_trials(B, C, T, fs, seed):
-    """SURVEY.md 8d synthetic EEG: unit white noise + 0.5 sin(2 pi f_y t + phi) on the channels of zone y."""
+    """SURVEY.md 8d synthetic EEG: unit white noise + 0.5 sin(2 pi f_y t + phi) on the channels of zone y
+    (channels 64..127 of the stress configuration are a second copy of the 64-electrode montage)."""
     import isd_amd
     rng = np.random.default_rng(seed)
     X = rng.standard_normal((B, C, T), dtype=np.float32)
@@ -40,51 +56,115 @@ def synth_trials(B, C, T, fs, seed):
     t = np.arange(T) / fs
     zones = isd_amd.zone_index_lists()
     for i in range(B):
-        ch = [c for c in zones[int(y[i])] if c < C]
+        ch = [c + o for o in range(0, C, 64) for c in zones[int(y[i])] if c + o < C]
         X[i, ch] += (0.5 * np.sin(2.0 * np.pi * tone[y[i]] * t + phase[i])).astype(np.float32)
     return X, y
 
 
-def cpu_baseline(C, T, fs, n_trials=128, steps=16):
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg_name, cfg):
     """The oracle (CPU restatement of the same pipeline) timed on this box's host cores, bounded sample."""
     from oracle import cnn as ocnn, dsp as odsp
     # the GPU box grants a 16-CPU share per GPU (cpu_count reports the whole host)
     threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(threads)
+    C, T, fs = cfg["C"], cfg["T"], cfg["fs"]
+    bands = getattr(odsp, cfg["bands"])
+    n_trials, steps = (128, 16) if cfg_name == "cfg2" else (3, 1)   # cfg5: ~8 s of scipy per trial
     X, y = synth_trials(n_trials, C, T, fs, seed=123)
-    p = ocnn.init_conv4_params(9 * C, 32, prefix="cnn.", seed=0)
-    p["fc.weight"] = torch.randn(5, 32) * 0.1
-    p["fc.bias"] = torch.zeros(5)
-    for v in p.values():
+    nb = len(bands)
+    torch.manual_seed(0)
+    if cfg_name == "cfg2":
+        p = ocnn.init_conv4_params(nb * C, 32, prefix="cnn.", seed=0)
+        p["fc.weight"] = torch.randn(5, 32) * 0.1
+        p["fc.bias"] = torch.zeros(5)
+        logits_of = lambda feats: ocnn.feature_cnn_logits(feats, p)                       # noqa: E731
+    else:
+        p = {"temporal_conv.0.weight": torch.randn(8, 1, 1, 64) * 0.1, "spatial_conv.0.weight": torch.randn(16, 1, nb * C, 1) * 0.01,
+             "separable_conv.0.weight": torch.randn(16, 1, 1, 16) * 0.2, "separable_conv.1.weight": torch.randn(16, 16, 1, 1) * 0.2,
+             "projector.2.weight": torch.randn(32, 16) * 0.2, "projector.2.bias": torch.zeros(32),
+             "fc.weight": torch.randn(5, 32) * 0.1, "fc.bias": torch.zeros(5)}
+        for name, n in (("temporal_conv.1", 8), ("spatial_conv.1", 16), ("separable_conv.2", 16)):
+            p[name + ".weight"], p[name + ".bias"] = torch.ones(n), torch.zeros(n)
+            p[name + ".running_mean"], p[name + ".running_var"] = torch.zeros(n), torch.ones(n)
+        logits_of = lambda feats: torch.nn.functional.linear(                            # noqa: E731
+            ocnn.eegnet_encoder(feats.reshape(feats.shape[0], nb * C, -1), p, training=True), p["fc.weight"], p["fc.bias"])
+    train = [v for k, v in p.items() if "running" not in k]
+    for v in train:
         v.requires_grad_()
-    opt = torch.optim.AdamW(list(p.values()), lr=5e-4)
+    opt = torch.optim.AdamW(train, lr=5e-4)
     yt = torch.from_numpy(y)
     t_feat = t_cnn = 0.0
     for _ in range(steps):
         t0 = time.perf_counter()
-        feats = torch.from_numpy(odsp.extract_features_scipy(X, fs=fs, bands=odsp.BANDS_9))
+        feats = torch.from_numpy(odsp.extract_features_scipy(X, fs=fs, bands=bands, nperseg=cfg["nperseg"],
+                                                             noverlap=cfg["noverlap"]))
         t1 = time.perf_counter()
         opt.zero_grad()
-        ocnn.cross_entropy(ocnn.feature_cnn_logits(feats, p), yt).backward()
+        ocnn.cross_entropy(logits_of(feats), yt).backward()
         opt.step()
         t2 = time.perf_counter()
         t_feat += t1 - t0
         t_cnn += t2 - t1
     total = t_feat + t_cnn
-    return {"value": round(n_trials * steps / total, 2), "unit": "trials/s", "cores": threads, "kind": "port",
+    return {"value": round(n_trials * steps / total, 2), "unit": "trials/s", "cores": threads, "cpu_model": cpu_model(),
+            "kind": "port",
             "sample": f"{steps} steps x {n_trials} trials of the same workload through oracle/ (scipy butter/sosfilt/"
-                      f"stft fp64 on 1 thread: {t_feat / steps:.2f} s/step; torch-CPU CNN fwd+bwd+AdamW on {threads} "
-                      f"threads: {t_cnn / steps:.2f} s/step)"}
+                      f"stft fp64 on 1 thread: {t_feat / steps:.2f} s/step; torch-CPU classifier fwd+bwd+AdamW on "
+                      f"{threads} threads: {t_cnn / steps:.2f} s/step)"}
+
+
+def hip_event_ms(fn, stream, n):
+    """Mean duration of ``fn`` over n launches, HIP events recorded on the launch stream."""
+    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    fn()
+    for a, b in zip(e0, e1):
+        a.record(stream)
+        fn()
+        b.record(stream)
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in zip(e0, e1)]))
+
+
+def filterbank_hbm_roofline(fx, x, nb, n=4):
+    """North-star evidence: achieved HBM rate of the MATERIALISING filterbank stage (read x once, write nb filtered
+    copies -- what the scipy path does), measured after the timed region on (a slice of) the resident batch."""
+    B, C, T = x.shape
+    per_trial = (1 + nb) * C * T * 4
+    Bs = int(min(B, max(1, (24 << 30) // per_trial)))                # keep the filtered tensor under 24 GiB
+    xs = x[:Bs].contiguous()
+    y = torch.empty((Bs, nb, C, T), dtype=torch.float32, device=x.device)
+    ms = hip_event_ms(lambda: fx.fb.forward(xs, out=y), torch.cuda.current_stream(), n)
+    by = per_trial * Bs
+    launches = {"f32": "fb_kernel<float,%d>", "f64": "fb_kernel<double,%d>",
+                "mixed": "fb_kernel<float,%d> + fb_kernel<double,%d> (per-band precision)"}[fx.fb.precision]
+    gpr = 1 if T <= 512 else 2 if T <= 1024 else 4
+    del y
+    return {"bound": "hbm", "kernel": launches.replace("%d", str(gpr)), "achieved": round(by / (ms * 1e-3) / 1e9, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": None, "ms_per_pass": round(ms, 4), "trials_per_pass": Bs, "algorithmic_bytes_per_pass": by}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096, help="trials per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="trials per GPU (default: the configuration's batch)")
     ap.add_argument("--two-kernel", action="store_true", help="materialise the filtered signals (fb + bandpower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-roofline", action="store_true", help="skip the filterbank-stage HBM measurement")
     ap.add_argument("--bf16", action="store_true", help="config 3: bf16 activations/grads in the CNN, fp32 accumulate")
     ap.add_argument("--overlap", action="store_true",
                     help="extract the features of the next batch on a second HIP stream while the CNN trains on the "
@@ -94,10 +174,16 @@ def main():
                     help="N > 1 only: wait for the gradient all-reduce before extracting the next batch's features "
                          "(default: the all-reduce of step k runs under the feature extraction of batch k+1)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    args.steps = cfg["steps"] if args.steps is None else args.steps
+    args.warmup = cfg["warmup"] if args.warmup is None else args.warmup
+    args.batch = cfg["batch"] if args.batch is None else args.batch
+    if args.config == "cfg5" and (args.bf16 or args.two_kernel):
+        raise SystemExit("--bf16 / --two-kernel apply to cfg2")
 
     import torch.distributed as dist
     import isd_amd
-    from isd_amd.classifier import _FeatureModel
+    from isd_amd.classifier import _EEGNetFeatureModel, _FeatureModel
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,16 +203,20 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    B, C, T, fs = args.batch, 64, 512, 256.0
-    nb = len(isd_amd.BANDS_9)
+    B, C, T, fs = args.batch, cfg["C"], cfg["T"], cfg["fs"]
+    bands = getattr(isd_amd, cfg["bands"])
+    nb = len(bands)
     Xh, yh = synth_trials(B, C, T, fs, seed=rank)               # rank r uses default_rng(r)
     x = torch.from_numpy(Xh).to(dev)
     y = torch.from_numpy(yh).to(dev)
     del Xh
 
     torch.manual_seed(42)                                        # reference default seed (train_fast.py:275)
-    fx = isd_amd.FeatureExtractor(T, fs, isd_amd.BANDS_9)
-    model = _FeatureModel(nb * C, 32, 5, 4, "bf16" if args.bf16 else "f32").to(dev)
+    fx = isd_amd.FeatureExtractor(T, fs, bands, nperseg=cfg["nperseg"], noverlap=cfg["noverlap"])
+    if args.config == "cfg2":
+        model = _FeatureModel(nb * C, 32, 5, 4, "bf16" if args.bf16 else "f32").to(dev)
+    else:
+        model = _EEGNetFeatureModel(nb * C, 32, 5, kernel_length=64, dropout=0.25).to(dev)
     trainer = isd_amd.Trainer(model, lr=5e-4, weight_decay=1e-2, schedule=None)
     feats = torch.empty((B, nb, C, fx.n_frames), dtype=torch.float32, device=dev)
     yfilt = torch.empty((B, nb, C, T), dtype=torch.float32, device=dev) if args.two_kernel else None
@@ -224,14 +314,26 @@ def main():
         ms = dt / args.steps * 1e3
         t_feat = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         t_train = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if not (overlap or pipelined) else float("nan")
-        if fused:
-            # dominant kernel: the fused filterbank+STFT extractor; VALU-bound on its algorithmic traffic, so the
-            # compute roofline is the honest one: flops = cascade (5 flop/sample/section incl. fix-up) + band DFT
-            # algorithmic flops: cascade 9 flop/sample/section (3-op recursion + 2-FMA fix-up) + 1 (gain),
-            # band DFT 2 complex partial sums x 64 samples per (frame, bin)
-            n_sec, bins = 4, sum(hi - lo + 1 for lo, hi in fx.bins)
-            flops = B * C * (nb * T * (n_sec * 9 + 1) + bins * fx.n_frames * 64 * 4)
-            roof = {"bound": "mfma", "kernel": "fused_kernel<float> (fp32 VALU; fp32 vector peak == fp32 MFMA peak)",
+        n_sec, bins = 4, [hi - lo + 1 for lo, hi in fx.bins]
+        roof_hbm = None
+        if fused and args.config == "cfg2":
+            # dominant kernel: the fused filterbank+STFT extractor, fp32-VALU-bound on its algorithmic traffic, so the
+            # compute roofline is the honest one.  Algorithmic flops per (trial, channel): cascade = nb bands x T
+            # samples x (4 sections x 9 flop [3-op recursion + two state fix-up FMAs] + 1 gain multiply); band DFT =
+            # 64 windowed samples per (frame, in-band bin), one complex MAC by a real sample each (4 flop).
+            flops = B * C * (nb * T * (n_sec * 9 + 1) + sum(bins) * fx.n_frames * 64 * 4)
+            roof = {"bound": "valu", "kernel": "fused_kernel<float> (fp32 vector ALU; no MFMA in this kernel)",
+                    "achieved": round(flops / (t_feat * 1e-3) / 1e12, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(flops / (t_feat * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                    "ms_per_launch": round(t_feat, 4),
+                    "algorithmic_bytes_per_launch": B * C * 4 * (T + nb * fx.n_frames)}
+        elif fused:
+            # cfg5: fused_long_kernel<float,5> (24 bands) + fused_long_kernel<double,5> (16 bands), one launch each per
+            # extraction; the pair is VALU-bound.  Algorithmic flops per (trial, channel, band): cascade T x (4 x 9 + 1)
+            # + half-block DFT sums of the band's bins and their two Hann neighbours: (bins + 2) x T complex MACs x 4.
+            flops = B * C * sum(T * (n_sec * 9 + 1) + (nbin + 2) * T * 4 for nbin in bins)
+            roof = {"bound": "valu", "kernel": "fused_long_kernel<float,5> + fused_long_kernel<double,5> (one launch "
+                                               "each per extraction; priced against the fp32 vector peak)",
                     "achieved": round(flops / (t_feat * 1e-3) / 1e12, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(flops / (t_feat * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": None,
                     "ms_per_launch": round(t_feat, 4),
@@ -242,11 +344,18 @@ def main():
             roof = {"bound": "hbm", "kernel": "fb_kernel<float,1>", "achieved": round(by / (t_fb * 1e-3) / 1e9, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (t_fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "traffic": None, "ms_per_launch": round(t_fb, 4), "algorithmic_bytes_per_launch": by}
+        if fused and world == 1 and not args.no_hbm_roofline:
+            roof_hbm = filterbank_hbm_roofline(fx, x, nb)
         tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tf):
             try:
-                ent = json.load(open(tf)).get(roof["kernel"].split(" ")[0])
-                roof["traffic"] = ent["bytes_per_launch"] if ent and B == 4096 else None
+                table = json.load(open(tf))
+                ent = table.get(roof["kernel"].split(" ")[0])
+                roof["traffic"] = ent["bytes_per_launch"] if ent and B == ent.get("trials_per_launch", 4096) else None
+                if roof_hbm:
+                    ent = table.get(roof_hbm["kernel"].split(" ")[0])
+                    if ent and ent.get("trials_per_launch", 4096) == roof_hbm["trials_per_pass"]:
+                        roof_hbm["traffic"] = ent["bytes_per_launch"]
             except Exception:
                 pass
         line = {
@@ -255,8 +364,7 @@ def main():
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 activations/grads in the CNN, f32 features + accumulate" if args.bf16 else "f32",
             "data": "synthetic",
-            "config": {"workload": "cfg2: 64ch x 2s@256Hz EEG, 9-band Butterworth(4) filterbank -> STFT(64/32) "
-                                   "log band power -> Conv4Layers(576,32)+Linear(32,5) fwd+bwd, softmax-CE, AdamW",
+            "config": {"workload": cfg["workload"],
                        "trials_per_gpu": B, "global_batch": global_batch, "parallelism": f"dp{world}",
                        "feature_path": "fused" if fused else "filterbank+bandpower kernels",
                        "streams": "features of batch k+1 overlap the CNN step of batch k" if overlap else
@@ -267,8 +375,10 @@ def main():
             "final_loss": round(loss, 5),
             "roofline": roof,
         }
+        if roof_hbm:
+            line["roofline_hbm"] = roof_hbm
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(C, T, fs)
+            line["cpu_baseline"] = cpu_baseline(args.config, cfg)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

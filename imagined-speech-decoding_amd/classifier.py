@@ -14,9 +14,10 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .constants import BANDS_9, CLASSES, ELECTRODES, ZONES
+from .constants import BANDS_9, BANDS_40, CLASSES, ELECTRODES, ZONES
 from .features import FeatureExtractor
-from .nn import FAST, FeatureCNN, _FlatParamMixin, _stream, fast_config, token_mean_predict
+from .nn import (FAST, EEGNet_Encoder, FeatureCNN, _FlatParamMixin, _dropout_seed, _stream, fast_config,
+                 token_mean_predict)
 
 
 def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0):
@@ -67,6 +68,9 @@ class _FeatureModel(_FlatModel):
     def conv_plan(self, x):
         return self.net.cnn._plan(x.shape[-1])
 
+    def _conv_channels(self):
+        return self.net.cnn.channels
+
     hidden_act = ()
 
 
@@ -84,6 +88,9 @@ class _FastModel(_FlatModel):
     def conv_plan(self, x):
         c = self.net.config
         return self.net.head._plan(c.window_len, c.slide_step)
+
+    def _conv_channels(self):
+        return len(self.net.config.electrodes)
 
     hidden_act = (True,)
 
@@ -117,6 +124,34 @@ class HotPath:
 
     def forward(self, x, labels=None, global_batch=None, want_grad=False):
         """x f32 CUDA [B, C, T] -> dict(loss, logits, pred); with labels and want_grad also fills the gradients."""
+        self._check_inputs(x, labels)
+        with torch.cuda.device(x.device):
+            return self._forward(x, labels, global_batch, want_grad)
+
+    def _check_inputs(self, x, labels):
+        """The kernels take raw pointers: everything they assume about the operands is checked here."""
+        if not isinstance(x, torch.Tensor):
+            raise TypeError("x must be a torch tensor")
+        if x.dtype != torch.float32:
+            raise TypeError(f"x must be float32, got {x.dtype}")
+        if x.dim() != 3:
+            raise ValueError("x must be [batch, channels, time]")
+        if not x.is_contiguous():
+            raise ValueError("x must be contiguous (pass x.contiguous())")
+        c_total = self.model._conv_channels()
+        if x.shape[1] != c_total:
+            raise ValueError(f"expected {c_total} channels, got {x.shape[1]}")
+        if labels is not None:
+            if not isinstance(labels, torch.Tensor) or labels.device != x.device:
+                raise TypeError("labels must be a tensor on the device of x")
+            if labels.dtype not in (torch.uint8, torch.int64):
+                raise TypeError(f"labels must be uint8 or int64, got {labels.dtype}")
+            if labels.dim() != 1 or labels.shape[0] != x.shape[0] or not labels.is_contiguous():
+                raise ValueError("labels must be a contiguous [batch] vector")
+        if not x.is_cuda:
+            raise TypeError("x must be a CUDA tensor (the product has no CPU path)")
+
+    def _forward(self, x, labels, global_batch, want_grad):
         m, L = self.model, _lib.lib()
         flat, n_conv, offs = self._layout()
         gflat = m.flat_grads() if want_grad else None
@@ -192,6 +227,105 @@ class HotPath:
         return out
 
 
+class _EEGNetFeatureNet(nn.Module):
+    """``EEGNet_Encoder(in_channels, F)`` through the unmodified head contract, then ``Linear(F, n_classes)``:
+    the "EEGNet-style depthwise CNN" classifier of BASELINE config 5."""
+
+    def __init__(self, in_channels, feature_dim, n_classes, kernel_length, dropout):
+        super().__init__()
+        self.enc = EEGNet_Encoder(in_channels, feature_dim, kernel_length, dropout)
+        self.fc = nn.Linear(feature_dim, n_classes)
+
+    def token_logits(self, feats):
+        from .nn import linear
+        B = feats.shape[0]
+        h = self.enc(feats.reshape(B, -1, feats.shape[-1]))
+        return linear(h, self.fc.weight, self.fc.bias).unsqueeze(1)      # [B, 1, n_classes]
+
+    def forward(self, feats):
+        return self.token_logits(feats).squeeze(1)
+
+
+class _EEGNetFeatureModel(_FlatModel):
+    """Flat block = [EEGNet_Encoder parameters in state_dict order | fc.weight | fc.bias]."""
+
+    def __init__(self, in_channels, feature_dim, n_classes, kernel_length=64, dropout=0.25):
+        super().__init__()
+        self.net = _EEGNetFeatureNet(in_channels, feature_dim, n_classes, kernel_length, dropout)
+
+    def _conv(self):
+        return self.net.enc
+
+    def _dense_layers(self):
+        return [self.net.fc]
+
+    def _conv_channels(self):
+        return self.net.enc.in_channels
+
+    def make_path(self):
+        return EEGNetPath(self)
+
+
+class EEGNetPath(HotPath):
+    """Autograd-free step of  EEGNet_Encoder -> Linear -> softmax-CE  (same contract as ``HotPath``).
+
+    With ``want_grad`` the encoder runs in training mode (batch statistics, running buffers and
+    ``num_batches_tracked`` updated, dropout with the module's own counter-based stream); otherwise in eval mode."""
+
+    def _forward(self, x, labels, global_batch, want_grad):
+        m, L = self.model, _lib.lib()
+        enc, fc = m.net.enc, m.net.fc
+        flat = m.flat_params()
+        gflat = m.flat_grads() if want_grad else None
+        bufs = enc.flat_buffers()
+        B, _, T = x.shape
+        plan = enc._plan_for(T)
+        dev, st = x.device, _stream()
+        n_enc = plan.n_params
+        F_, n_cls = fc.in_features, fc.out_features
+        fp, f4 = flat.data_ptr(), 4
+        wo, bo = n_enc, n_enc + fc.weight.numel()
+        training = bool(want_grad and labels is not None)
+        bn = enc._bns()[0]
+        p_drop = enc.p if training else 0.0
+        enc._calls += 1
+        seed = _dropout_seed(enc._stream_id, enc._calls)
+        if training:
+            for b in enc._bns():
+                b.num_batches_tracked += 1
+        ws = self._buf("eeg", int(L.isd_eegnet_workspace_bytes(plan._h, B)) // 4, dev)
+        h = self._buf("h", B * F_, dev)
+        _lib.check(L.isd_eegnet_forward(plan._h, x.data_ptr(), fp, bufs.data_ptr(), h.data_ptr(), ws.data_ptr(), B,
+                                        int(training), 0.1 if bn.momentum is None else float(bn.momentum),
+                                        float(bn.eps), float(p_drop), seed, st))
+        ytok = self._buf("ytok", B * n_cls, dev)
+        _lib.check(L.isd_linear_forward(h.data_ptr(), fp + wo * f4, fp + bo * f4, ytok.data_ptr(), 0, B, F_, n_cls, 0, st))
+        logits = torch.empty((B, n_cls), dtype=torch.float32, device=dev)
+        pred = torch.empty((B,), dtype=torch.int64, device=dev)
+        out = {"logits": logits, "pred": pred}
+        if labels is None:
+            _lib.check(L.isd_softmax_ce(ytok.data_ptr(), 0, 0, logits.data_ptr(), 0, 0, pred.data_ptr(), B, 1, n_cls,
+                                        1.0, 0, st))
+            return out
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dlt = self._buf("dlt", B * n_cls, dev)
+        cws = self._buf("cews", int(L.isd_softmax_ce_workspace_bytes(B)) // 4 + 1, dev)
+        _lib.check(L.isd_softmax_ce(ytok.data_ptr(), labels.data_ptr(), labels.element_size(), logits.data_ptr(),
+                                    loss.data_ptr(), dlt.data_ptr() if training else 0, pred.data_ptr(), B, 1, n_cls,
+                                    1.0 / float(global_batch or B), cws.data_ptr(), st))
+        out["loss"] = loss
+        if not training:
+            return out
+        gp = gflat.data_ptr()
+        dh = self._buf("dh", B * F_, dev)
+        lws = self._buf("lws", int(L.isd_linear_workspace_bytes(B, F_, n_cls)) // 4 + 64, dev)
+        _lib.check(L.isd_linear_backward(h.data_ptr(), fp + wo * f4, dlt.data_ptr(), 0, dh.data_ptr(), gp + wo * f4,
+                                         gp + bo * f4, lws.data_ptr(), B, F_, n_cls, 0, st))
+        _lib.check(L.isd_eegnet_backward(plan._h, x.data_ptr(), fp, dh.data_ptr(), gp, ws.data_ptr(), B, float(p_drop),
+                                         seed, st))
+        return out
+
+
 # ----------------------------------------------------------------------------- data parallel helper
 class GradientBucket:
     """One flat gradient all-reduce per step.  With ``torch.distributed`` initialised
@@ -264,7 +398,8 @@ class Trainer:
     """AdamW(lr 5e-4, wd 1e-2, torch defaults) on the flat parameter + the reference's per-step schedule."""
 
     def __init__(self, model, lr=5e-4, weight_decay=1e-2, schedule=None, bucket=None):
-        self.model, self.path = model, HotPath(model)
+        self.model = model
+        self.path = model.make_path() if hasattr(model, "make_path") else HotPath(model)
         self.bucket = bucket or GradientBucket()
         flat = model.flat_params()
         gflat = model.flat_grads()
@@ -327,18 +462,47 @@ def _to_device(X, device):
     return torch.as_tensor(np.ascontiguousarray(X, dtype=np.float32)).to(device)
 
 
+class NotFittedError(ValueError, AttributeError):
+    """Same base classes as ``sklearn.exceptions.NotFittedError`` (raised by predict before fit)."""
+
+
 class _Estimator:
+    """sklearn estimator protocol: constructor arguments are stored verbatim under their own names
+    (``get_params`` / ``set_params`` / ``sklearn.base.clone`` work), ``fit`` starts from scratch unless
+    ``warm_start=True``, fitted state lives in trailing-underscore attributes."""
     classes_ = np.arange(len(CLASSES))
     class_names_ = list(CLASSES)
+    _param_names = ("max_epochs", "batch_size", "lr", "weight_decay", "warmup_epochs", "seed", "device", "shuffle",
+                    "verbose", "warm_start")
 
     def __init__(self, max_epochs=200, batch_size=64, lr=5e-4, weight_decay=1e-2, warmup_epochs=10, seed=42,
-                 device=None, shuffle=True, verbose=False):
+                 device=None, shuffle=True, verbose=False, warm_start=False):
         self.max_epochs, self.batch_size, self.lr, self.weight_decay = max_epochs, batch_size, lr, weight_decay
         self.warmup_epochs, self.seed, self.shuffle, self.verbose = warmup_epochs, seed, shuffle, verbose
         self.device = device
+        self.warm_start = warm_start
+        self._reset()
+
+    def _reset(self):
         self.model_ = None
         self.trainer_ = None
         self.history_ = []
+
+    def get_params(self, deep=True):
+        return {k: getattr(self, k) for k in self._param_names}
+
+    def set_params(self, **params):
+        for k, v in params.items():
+            if k not in self._param_names:
+                raise ValueError(f"invalid parameter {k!r} for {type(self).__name__}")
+            setattr(self, k, v)
+        return self
+
+    def _fitted_model(self):
+        if self.model_ is None:
+            raise NotFittedError(f"this {type(self).__name__} instance is not fitted yet: call fit(X, y) (or load a "
+                                 "state dict) before predict / decision_function")
+        return self.model_
 
     def _device(self):
         if self.device is not None:
@@ -348,6 +512,9 @@ class _Estimator:
         return torch.device("cuda", torch.cuda.current_device())
 
     def _build(self, X):
+        raise NotImplementedError
+
+    def _n_classes(self):
         raise NotImplementedError
 
     def _inputs(self, xb):
@@ -365,14 +532,24 @@ class _Estimator:
 
     def fit(self, X, y):
         """X [n, C, T] (ndarray or CUDA tensor), y int [n] in label order CLASSES.  Returns self."""
+        yh = np.asarray(y.cpu() if isinstance(y, torch.Tensor) else y)
+        n = len(X)
+        if yh.ndim != 1 or n != yh.shape[0]:
+            raise ValueError("X and y disagree on the number of trials")
+        if yh.dtype.kind not in "iu":
+            raise TypeError(f"y must hold integer class indices, got dtype {yh.dtype}")
+        n_cls = self._n_classes()
+        if n and (int(yh.min()) < 0 or int(yh.max()) >= n_cls):
+            # torch's CE asserts here; the loss kernel indexes a register array with the label
+            raise ValueError(f"labels must lie in [0, {n_cls}) (order = CLASSES); got "
+                             f"[{int(yh.min())}, {int(yh.max())}]")
         dev = self._device()
         X = _to_device(X, dev)
-        y = torch.as_tensor(np.asarray(y.cpu() if isinstance(y, torch.Tensor) else y)).to(dev)
+        y = torch.as_tensor(yh).to(dev)
         if y.dtype not in (torch.uint8, torch.int64):
             y = y.long()
-        n = X.shape[0]
-        if n != y.shape[0]:
-            raise ValueError("X and y disagree on the number of trials")
+        if not self.warm_start:
+            self._reset()                     # sklearn semantics: a second fit() does not continue the first
         model = self._ensure_model(X)
         X, batch_inputs = self._prepare_fit(X)
         bs = min(self.batch_size, n)
@@ -399,9 +576,10 @@ class _Estimator:
 
     def decision_function(self, X, batch_size=4096):
         """Logits [n, n_classes] as a NumPy array."""
+        model = self._fitted_model()
         dev = self._device()
-        model = self._ensure_model(X if isinstance(X, torch.Tensor) else np.asarray(X))
-        path = self.trainer_.path if self.trainer_ is not None else HotPath(model)
+        path = self.trainer_.path if self.trainer_ is not None else (
+            model.make_path() if hasattr(model, "make_path") else HotPath(model))
         outs = []
         for i in range(0, len(X), batch_size):
             xb = self._inputs(_to_device(X[i:i + batch_size], dev))
@@ -410,9 +588,10 @@ class _Estimator:
 
     def predict(self, X, batch_size=4096):
         """Class indices int64 [n] (argmax, ties -> lowest index; order = CLASSES)."""
+        model = self._fitted_model()
         dev = self._device()
-        model = self._ensure_model(X if isinstance(X, torch.Tensor) else np.asarray(X))
-        path = self.trainer_.path if self.trainer_ is not None else HotPath(model)
+        path = self.trainer_.path if self.trainer_ is not None else (
+            model.make_path() if hasattr(model, "make_path") else HotPath(model))
         outs = []
         for i in range(0, len(X), batch_size):
             xb = self._inputs(_to_device(X[i:i + batch_size], dev))
@@ -430,6 +609,9 @@ class FilterbankCNNClassifier(_Estimator):
     ``n_layers=2`` with the 5-band set is config 1.
     """
 
+    _param_names = _Estimator._param_names + ("fs", "bands", "order", "nperseg", "noverlap", "eps", "feature_dim",
+                                              "n_classes", "n_layers", "fused", "precision", "cache_features")
+
     def __init__(self, fs=256.0, bands=BANDS_9, order=4, nperseg=64, noverlap=None, eps=1e-10, feature_dim=32,
                  n_classes=5, n_layers=4, fused=None, precision="fp32", cache_features=True, **kw):
         super().__init__(**kw)
@@ -440,6 +622,9 @@ class FilterbankCNNClassifier(_Estimator):
         self.fs, self.bands, self.order = fs, bands, order
         self.nperseg, self.noverlap, self.eps = nperseg, noverlap, eps
         self.feature_dim, self.n_classes, self.n_layers, self.fused = feature_dim, n_classes, n_layers, fused
+
+    def _reset(self):
+        super()._reset()
         self.extractor_ = None
 
     def _extractor(self, T):
@@ -451,6 +636,9 @@ class FilterbankCNNClassifier(_Estimator):
     def extract_features(self, trials):
         """trials f32 CUDA [B, C, T] -> [B, nb, C, J] (same as the module-level ``extract_features``)."""
         return self._extractor(trials.shape[-1])(trials, fused=self.fused)
+
+    def _n_classes(self):
+        return int(self.n_classes)
 
     def _build(self, X):
         fx = self._extractor(X.shape[-1])
@@ -476,20 +664,45 @@ class FilterbankCNNClassifier(_Estimator):
         return feats, (lambda fb: fb)
 
 
+class FilterbankEEGNetClassifier(FilterbankCNNClassifier):
+    """extract_features -> ``EEGNet_Encoder(nb*C, feature_dim)`` (fast.py:122-167, through the head contract
+    fast.py:203-210) -> ``Linear(feature_dim, n_classes)``: BASELINE config 5, the high-resolution stress
+    configuration (128 ch, 4 s @ 1024 Hz, 40 two-hertz bands, 1024-point STFT with hop 64 -> 65 frames)."""
+
+    _param_names = FilterbankCNNClassifier._param_names + ("kernel_length", "dropout")
+
+    def __init__(self, fs=1024.0, bands=BANDS_40, nperseg=1024, noverlap=960, kernel_length=64, dropout=0.25, **kw):
+        super().__init__(fs=fs, bands=bands, nperseg=nperseg, noverlap=noverlap, **kw)
+        if self.precision != "fp32":
+            raise ValueError("the EEGNet head computes in fp32")
+        self.kernel_length, self.dropout = kernel_length, dropout
+
+    def _build(self, X):
+        fx = self._extractor(X.shape[-1])
+        return _EEGNetFeatureModel(fx.n_bands * X.shape[1], self.feature_dim, self.n_classes, self.kernel_length,
+                                   self.dropout)
+
+
 class FASTHeadClassifier(_Estimator):
     """The reference's FAST in ``forward_mode='train_head'`` on raw EEG: zone-wise Conv4Layers over sliding
     windows -> Linear(256, 32) + GELU -> Linear(32, 5) -> mean over windows (fast.py:273-278)."""
 
+    _param_names = _Estimator._param_names + ("config",)
+
     def __init__(self, config=None, **kw):
         super().__init__(**kw)
         self.config = config
+
+    def _n_classes(self):
+        return int(self.config.n_classes) if self.config is not None else len(CLASSES)
 
     def _build(self, X):
         cfg = self.config or fast_config(ELECTRODES, ZONES, seq_len=int(X.shape[-1]))
         return _FastModel(cfg)
 
     def load_reference_state_dict(self, sd, X_like=None):
-        """Load a reference FAST state_dict (keys ``head.encoders...``, ``input_layer.0...``, ``last_layer...``)."""
+        """Load a reference FAST state_dict (keys ``head.encoders...``, ``input_layer.0...``, ``last_layer...``).
+        The estimator then counts as fitted; ``fit`` continues from these weights only with ``warm_start=True``."""
         if self.model_ is None:
             self.model_ = _FastModel(self.config or fast_config()).to(self._device())
         missing, unexpected = self.model_.net.load_state_dict(sd, strict=False)

@@ -542,6 +542,29 @@ class Conv4Layers(_Conv4Params, _FlatParamMixin):
         return _ConvStackFn.apply(x, theta, self._plan(x.shape[-1])).squeeze(1)
 
 
+_dropout_streams = [0]
+
+
+def _new_dropout_stream():
+    """Every module instance that draws dropout masks owns a stream id: the zone encoders of one Head are called in
+    lockstep on identically shaped tensors, so (global seed + call index) alone would hand them identical masks."""
+    _dropout_streams[0] += 1
+    return _dropout_streams[0]
+
+
+def _dropout_seed(stream_id, call):
+    """Counter-based seed = f(torch seed, data-parallel rank, module instance, call index): splitmix64-style mixing of
+    the four words so neighbouring streams / ranks / calls are unrelated."""
+    rank = 0
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        rank = torch.distributed.get_rank()
+    z = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (stream_id + 1) + 0xBF58476D1CE4E5B9 * (rank + 1)
+         + 0x94D049BB133111EB * call) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return (z ^ (z >> 31)) & 0x7FFFFFFFFFFFFFFF
+
+
 class _BNStackMixin(_FlatParamMixin):
     """Shared plumbing of the BatchNorm heads: packed running buffers, per-length plans, the autograd call."""
 
@@ -558,11 +581,14 @@ class _BNStackMixin(_FlatParamMixin):
                     off += n
         return flat
 
-    def _run(self, x):
-        T = x.shape[-1]
+    def _plan_for(self, T):
         plan = self._plans.get(T)
         if plan is None:
             plan = self._plans[T] = self._make_plan(T)
+        return plan
+
+    def _run(self, x):
+        plan = self._plan_for(x.shape[-1])
         flat = self.flat_params()
         theta = torch.cat([p.reshape(-1) for p in self._ordered_params()]) if torch.is_grad_enabled() else flat
         bn = self._bns()[0]
@@ -572,7 +598,7 @@ class _BNStackMixin(_FlatParamMixin):
                 b.num_batches_tracked += 1
         return _EEGNetFn.apply(x, theta, self.flat_buffers(), plan, self.training,
                                0.1 if bn.momentum is None else bn.momentum, bn.eps, self.p if self.training else 0.0,
-                               (torch.initial_seed() + self._calls) & 0x7FFFFFFFFFFFFFFF)
+                               _dropout_seed(self._stream_id, self._calls))
 
 
 class EEGNet_Encoder(nn.Module, _BNStackMixin):
@@ -595,6 +621,7 @@ class EEGNet_Encoder(nn.Module, _BNStackMixin):
         self.projector = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), nn.Linear(F2, feature_dim))
         self._plans = {}
         self._calls = 0
+        self._stream_id = _new_dropout_stream()
 
     def _bns(self):
         return [self.temporal_conv[1], self.spatial_conv[1], self.separable_conv[2]]
@@ -633,6 +660,7 @@ class CVBlock(nn.Module, _BNStackMixin):
         self.projector = nn.Linear(self.flat_dim, dim_token)
         self._plans = {}
         self._calls = 0
+        self._stream_id = _new_dropout_stream()
 
     def _bns(self):
         return [self.bn1, self.bn2, self.bn3]
@@ -792,11 +820,12 @@ class AttentionBlock(nn.Module):
         self.linear = nn.Sequential(nn.Linear(embed_dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
                                     nn.Linear(hidden_dim, embed_dim), nn.Dropout(dropout))
         self.num_heads, self.p = num_heads, dropout
+        self._stream_id = _new_dropout_stream()
 
     def forward(self, x):
         p = self.p if self.training else 0.0
         AttentionBlock._calls += 1
-        seed = (torch.initial_seed() + 7919 * AttentionBlock._calls) & 0x7FFFFFFFFFFFFFFF
+        seed = _dropout_seed(self._stream_id, AttentionBlock._calls)
         h = layer_norm(x, self.layer_norm_1.weight, self.layer_norm_1.bias, self.layer_norm_1.eps)
         qkv = linear(h, self.attn.in_proj_weight, self.attn.in_proj_bias)
         ctx = _AttentionFn.apply(qkv, self.num_heads, p, seed)

@@ -6,7 +6,8 @@
 Imports the *reference itself* (``/root/reference/src/fast/models/fast.py``,
 read-only) and scipy.signal, runs them on seeded inputs and stores inputs +
 outputs as small ``.npz`` files.  The reference never travels to the GPU box;
-these vectors do.  IDs follow SURVEY.md 8c (G1..G9).
+these vectors do.  IDs follow SURVEY.md 8c (G1..G9); G10..G14 were added by the build (BN heads, FIR,
+the stress configuration's shapes).
 """
 import os
 import sys
@@ -292,8 +293,78 @@ def g12():
     save("g12_fir.npz", **out)
 
 
+def _randomize_bn(m):
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.uniform_(-0.2, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.3, 0.3)
+
+
+# ---------------------------------------------------------------- G13: EEGNet_Encoder at the stress configuration's shapes
+def g13():
+    """BASELINE config 5 head shapes (src/fast/models/fast.py:122-167): EEGNet_Encoder(40 bands x 128 ch = 5120, 32) on
+    the [B, 5120, 65] feature map and EEGNet_Encoder(128, 32) on raw [B, 128, 4096] trials.  Inputs are regenerated by
+    the tests from the NumPy seed; the input gradient is stored for every `dx_stride`-th channel."""
+    out = {}
+    for tag, (C, T, B, stride) in {"f5120": (5120, 65, 2, 97), "r128": (128, 4096, 2, 16)}.items():
+        torch.manual_seed(13)
+        m = EEGNet_Encoder(C, 32, dropout=0.0)
+        _randomize_bn(m)
+        out.update(sd_np(m, f"{tag}.sd."))
+        x = torch.from_numpy(np.random.default_rng(13).standard_normal((B, C, T)).astype(np.float32)).requires_grad_()
+        m.eval()
+        with torch.no_grad():
+            out[f"{tag}.y_eval"] = m(x).numpy()
+        m.train()
+        y = m(x)
+        y.square().sum().backward()
+        out[f"{tag}.cfg"] = np.array([C, T, B, stride])
+        out[f"{tag}.y_train"], out[f"{tag}.dx_sub"] = y.detach().numpy(), x.grad.numpy()[:, ::stride].copy()
+        out.update(grads_np(m, f"{tag}.grad."))
+        out.update({k: v for k, v in sd_np(m, f"{tag}.sd_after.").items() if "running" in k or "num_batches" in k})
+    save("g13_eegnet_cfg5.npz", **out)
+
+
+# ---------------------------------------------------------------- G14: stress configuration composed end to end
+def g14():
+    """BASELINE config 5 composed: trials [2, 128, 4096] @ 1024 Hz -> spec S with the 40-band set, nperseg 1024 /
+    noverlap 960 (scipy butter / sosfilt / stft; J = 65) -> the reference EEGNet_Encoder(5120, 32) in train mode
+    (dropout 0) -> Linear(32, 5) -> CrossEntropyLoss -> every gradient."""
+    fs, T, C, B = 1024.0, 4096, 128, 2
+    x = np.random.default_rng(14).standard_normal((B, C, T)).astype(np.float32)
+    feats = []
+    for _, lo, hi in odsp.BANDS_40:
+        sos = ss.butter(4, (lo, hi), "bandpass", fs=fs, output="sos")
+        yb = ss.sosfilt(sos, x.astype(np.float64), axis=-1)
+        f, _, Z = ss.stft(yb, fs=fs, nperseg=1024, noverlap=960)
+        idx = np.where((f >= lo) & (f <= hi))[0]
+        feats.append(np.log((np.abs(Z[..., idx, :]) ** 2).mean(axis=-2) + 1e-10))
+    feat = np.stack(feats, axis=1).astype(np.float32)                 # [B, 40, C, 65]
+    torch.manual_seed(14)
+    enc = EEGNet_Encoder(40 * C, 32, dropout=0.0)
+    fc = torch.nn.Linear(32, 5)
+    _randomize_bn(enc)
+    enc.train()
+    labels = torch.tensor([3, 1])
+    logits = fc(enc(torch.from_numpy(feat).reshape(B, 40 * C, -1)))
+    loss = torch.nn.CrossEntropyLoss()(logits, labels)
+    loss.backward()
+    out = {"cfg": np.array([B, C, T, fs, 1024, 960, 40]), "labels": labels.numpy().astype(np.uint8),
+           "feat_sub": feat[:, ::3, ::16].copy(),                      # [2, 14, 8, 65] of the feature map
+           "feat_sum": feat.astype(np.float64).sum(axis=(2, 3)),       # per (trial, band) checksum of the rest
+           "logits": logits.detach().numpy(), "loss": loss.detach().numpy()}
+    out.update(sd_np(enc, "enc.sd."))
+    out.update(sd_np(fc, "fc.sd."))
+    out.update(grads_np(enc, "enc.grad."))
+    out.update(grads_np(fc, "fc.grad."))
+    save("g14_cfg5_composed.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5_g9, g6, g7, g8, g10, g11, g12):
+    for fn in (g1, g2, g3, g4, g5_g9, g6, g7, g8, g10, g11, g12, g13, g14):
         if not only or fn.__name__ in only:
             fn()

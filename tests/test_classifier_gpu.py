@@ -159,3 +159,35 @@ def test_fused_classifier_step_modes_match_layerwise_path(isd):
     ref_loss.backward()
     g_ref = torch.cat([p.grad.reshape(-1) for p in m._ordered_params()])
     assert abs(float(tr["loss"]) - float(ref_loss)) < 1e-6 and rel_err(g_fused.cpu(), g_ref.cpu()) < 1e-5
+
+
+def test_second_fit_starts_from_scratch_and_is_reproducible(isd):
+    """fit() is not a warm start -- two fits with one seed give identical parameters (the kernels of this
+    path are deterministic: partial slabs, no float atomics); warm_start=True continues instead."""
+    X, y = odsp.synth_trials(32, 64, 512, 256.0, seed=4)
+    clf = isd.FilterbankCNNClassifier(max_epochs=3, batch_size=16, warmup_epochs=1, seed=11)
+    clf.fit(X, y)
+    first = clf.model_.flat_params().clone()
+    n_hist = len(clf.history_)
+    clf.fit(X, y)
+    assert torch.equal(first, clf.model_.flat_params()) and len(clf.history_) == n_hist
+    clf.set_params(warm_start=True)
+    clf.fit(X, y)
+    assert not torch.equal(first, clf.model_.flat_params()) and len(clf.history_) == 2 * n_hist
+    from isd_amd.classifier import NotFittedError
+    with pytest.raises(NotFittedError):
+        isd.FilterbankCNNClassifier().predict(X)
+    with pytest.raises(ValueError, match="expected 576 channels"):
+        clf.trainer_.path.forward(torch.zeros(4, 64, 17, device="cuda"))             # raw trials instead of features
+
+
+def test_zone_encoders_of_one_head_draw_different_dropout_masks(isd):
+    """encoders called in lockstep on identically shaped inputs must not share masks."""
+    import isd_amd.nn as inn
+    torch.manual_seed(0)
+    a = inn.EEGNet_Encoder(6, 16, dropout=0.5).cuda().train()
+    b = inn.EEGNet_Encoder(6, 16, dropout=0.5).cuda().train()
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(8, 6, 250, device="cuda")
+    ya, yb = a(x).detach(), b(x).detach()
+    assert a._calls == b._calls == 1 and not torch.allclose(ya, yb)

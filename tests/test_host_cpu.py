@@ -132,3 +132,70 @@ def test_report_aggregation_matches_known_metrics(tmp_path):
     from sklearn.model_selection import KFold
     ref = [v for _, v in KFold(5, shuffle=True, random_state=42).split(np.arange(23))]
     assert all(sorted(a.tolist()) == sorted(b.tolist()) for (_, a), b in zip(folds, ref))
+
+
+def test_hot_path_rejects_operands_the_kernels_cannot_take():
+    """HotPath hands raw pointers to the kernels, so dtype / layout / channel count / label checks are host
+    side and raise before any launch (all reachable without a GPU)."""
+    import torch
+    from isd_amd.classifier import HotPath, _FeatureModel
+    hp = HotPath(_FeatureModel(9 * 8, 32, 5, 4))
+    good = torch.zeros(4, 72, 17)
+    with pytest.raises(TypeError, match="float32"):
+        hp.forward(good.double())
+    with pytest.raises(ValueError, match="contiguous"):
+        hp.forward(torch.zeros(4, 17, 72).transpose(1, 2))
+    with pytest.raises(ValueError, match="expected 72 channels"):
+        hp.forward(torch.zeros(4, 64, 17))
+    with pytest.raises(ValueError, match=r"\[batch, channels, time\]"):
+        hp.forward(torch.zeros(4, 72))
+    with pytest.raises(TypeError, match="uint8 or int64"):
+        hp.forward(good, torch.zeros(4, dtype=torch.int32))
+    with pytest.raises(ValueError, match="contiguous \\[batch\\] vector"):
+        hp.forward(good, torch.zeros(5, dtype=torch.int64))
+    with pytest.raises(TypeError, match="no CPU path"):
+        hp.forward(good, torch.zeros(4, dtype=torch.int64))
+
+
+def test_estimators_follow_the_sklearn_protocol_on_the_host_side():
+    """get_params / set_params / sklearn.clone, NotFittedError before fit, label range checked before any launch."""
+    import isd_amd
+    from isd_amd.classifier import NotFittedError
+    from sklearn.base import clone
+    clf = isd_amd.FilterbankCNNClassifier(max_epochs=3, batch_size=16, bands=isd_amd.BANDS_5, n_layers=2, seed=7)
+    params = clf.get_params()
+    assert params["max_epochs"] == 3 and params["bands"] is isd_amd.BANDS_5 and params["warm_start"] is False
+    twin = clone(clf)
+    assert twin is not clf and twin.get_params() == params and twin.model_ is None
+    assert clf.set_params(lr=1e-3) is clf and clf.lr == 1e-3
+    with pytest.raises(ValueError, match="invalid parameter"):
+        clf.set_params(nonsense=1)
+    X = np.zeros((6, 64, 512), np.float32)
+    for est in (clf, isd_amd.FASTHeadClassifier()):
+        with pytest.raises(NotFittedError):
+            est.predict(X)
+        with pytest.raises(NotFittedError):
+            est.decision_function(X)
+        with pytest.raises(ValueError, match=r"labels must lie in \[0, 5\)"):
+            est.fit(X, np.array([1, 2, 3, 4, 5, 1]))          # the answer sheet's 1-based labels
+        with pytest.raises(ValueError, match=r"labels must lie in"):
+            est.fit(X, np.array([0, 1, 2, -100, 0, 1]))
+        with pytest.raises(ValueError, match="disagree"):
+            est.fit(X, np.zeros(5, np.int64))
+        with pytest.raises(TypeError, match="integer class indices"):
+            est.fit(X, np.zeros(6, np.float32))
+    assert isinstance(NotFittedError("x"), (ValueError, AttributeError))
+
+
+def test_dropout_streams_differ_per_module_instance_and_call():
+    """the zone encoders of one Head run in lockstep; their masks must not coincide."""
+    import torch
+    import isd_amd.nn as inn
+    torch.manual_seed(0)
+    a, b = inn.EEGNet_Encoder(6, 32), inn.EEGNet_Encoder(6, 32)
+    assert a._stream_id != b._stream_id
+    seeds = {inn._dropout_seed(sid, call) for sid in (a._stream_id, b._stream_id) for call in (1, 2, 3)}
+    assert len(seeds) == 6 and all(0 <= s < 2 ** 63 for s in seeds)
+    head = inn.Head("EEGNet_Encoder", ["a", "b", "c", "d"], {"z0": ["a", "b"], "z1": ["c", "d"]}, 16)
+    ids = [enc._stream_id for enc in head.encoders.values()]
+    assert len(set(ids)) == len(ids)

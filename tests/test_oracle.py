@@ -215,3 +215,56 @@ def test_adamw_trajectory_matches_reference_golden():
     np.testing.assert_allclose(losses, g9["losses"], rtol=1e-5)
     for k in keys:
         assert rel_err(p[k].detach(), g9["final." + k]) < 1e-5, k
+
+
+# ---------------------------------------------------------------- BASELINE config 5 (stress) shapes
+@pytest.mark.parametrize("tag", ["f5120", "r128"])
+def test_eegnet_at_stress_shapes_matches_reference_golden(tag):
+    """G13: EEGNet_Encoder(5120, 32) on [2, 5120, 65] and EEGNet_Encoder(128, 32) on [2, 128, 4096]."""
+    g = load_golden("g13_eegnet_cfg5.npz")
+    C, T, B, stride = (int(v) for v in g[f"{tag}.cfg"])
+    p = _t(g, f"{tag}.sd.")
+    for k, v in p.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_()
+    x = torch.from_numpy(np.random.default_rng(13).standard_normal((B, C, T)).astype(np.float32)).requires_grad_()
+    with torch.no_grad():
+        assert rel_err(ocnn.eegnet_encoder(x, p, training=False), g[f"{tag}.y_eval"]) < 1e-5
+    y = ocnn.eegnet_encoder(x, p, training=True)
+    y.square().sum().backward()
+    assert rel_err(y.detach(), g[f"{tag}.y_train"]) < 1e-5
+    assert rel_err(x.grad[:, ::stride], g[f"{tag}.dx_sub"]) < 1e-4
+    for k in g.files:
+        if k.startswith(f"{tag}.grad."):
+            assert rel_err(p[k[len(tag) + 6:]].grad, g[k]) < 1e-4, k
+    for name in ("temporal_conv.1", "spatial_conv.1", "separable_conv.2"):
+        for buf in ("running_mean", "running_var"):
+            assert rel_err(p[f"{name}.{buf}"], g[f"{tag}.sd_after.{name}.{buf}"]) < 1e-6
+
+
+def test_stress_configuration_composed_matches_golden():
+    """G14: [2, 128, 4096] @ 1024 Hz -> 40-band spec S (1024 / 960) -> EEGNet_Encoder(5120, 32) -> Linear -> CE, the
+    oracle's restatement against scipy + the reference module."""
+    g = load_golden("g14_cfg5_composed.npz")
+    B, C, T, fs, nperseg, nov, nb = (int(v) for v in g["cfg"])
+    x = np.random.default_rng(14).standard_normal((B, C, T)).astype(np.float32)
+    feat = odsp.extract_features(x, fs=float(fs), bands=odsp.BANDS_40, nperseg=nperseg, noverlap=nov)
+    assert feat.shape == (B, nb, C, 65)
+    assert np.abs(feat[:, ::3, ::16] - g["feat_sub"]).max() < 1e-5            # log domain
+    np.testing.assert_allclose(feat.astype(np.float64).sum(axis=(2, 3)), g["feat_sum"], rtol=1e-6)
+    p = _t(g, "enc.sd.")
+    w, b = torch.from_numpy(g["fc.sd.weight"]).requires_grad_(), torch.from_numpy(g["fc.sd.bias"]).requires_grad_()
+    for k, v in p.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_()
+    h = ocnn.eegnet_encoder(torch.from_numpy(feat).reshape(B, nb * C, -1), p, training=True)
+    logits = torch.nn.functional.linear(h, w, b)
+    loss = ocnn.cross_entropy(logits, torch.from_numpy(g["labels"]))
+    loss.backward()
+    assert rel_err(logits.detach(), g["logits"]) < 1e-4 and abs(float(loss) - float(g["loss"])) < 1e-5
+    scale = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("enc.grad."))
+    for k in g.files:
+        if k.startswith("enc.grad."):
+            tol = 1e-3 * max(float(np.abs(g[k]).max()), 1e-3 * scale)        # fp32 features in, fp32 autograd
+            assert float((p[k[9:]].grad - torch.from_numpy(g[k])).abs().max()) < tol, k
+    assert rel_err(w.grad, g["fc.grad.weight"]) < 1e-3 and rel_err(b.grad, g["fc.grad.bias"]) < 1e-3
