@@ -27,16 +27,17 @@ constexpr int kL = 32;          // samples per lane
 constexpr int kSeg = 16 * kL;   // samples per 16-lane group
 constexpr int kPad = kL + 4;    // LDS chunk stride (floats)
 constexpr int kMaxSec = 8;
+constexpr int64_t kMaxRows = 0x7fffffffLL / (8 * 8);   // rows = trials x channels: 32-bit row / workgroup ids on the device
 
 struct FbSec {                  // constants of one (band, section); wave-uniform -> SMEM loads
   double Mp[4][4];              // M^(1,2,4,8), row-major 2x2, M = A^32
   double P[4];                  // M^16
+  double N16d[4];               // A^16: joins the two 16-sample halves a lane runs side by side
   double a1d, a2d;
-  double hd[kL][2];             // zero-input response seen at the output: row 0 of A^n
+  double hdq[2][kL / 2];        // zero-input response seen at the output (row 0 of A^n), n < 16, structure-of-arrays
   float a1f, a2f;
-  float hf[kL][2];
-  float hq[2][kL / 2];          // first half of the table, structure-of-arrays (the packed fp32 cascade, below)
-  float N16f[4];                // A^16: joins the two 16-sample halves a lane runs side by side in one register pair
+  float N16f[4];
+  float hq[2][kL / 2];
 };
 
 struct FbBand {
@@ -67,61 +68,63 @@ namespace isd {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// Value types: float (one row per lane group), double (fp64 FMA issues at the same rate as unpacked
-// fp32 on gfx950), and f2 = TWO rows packed in a register pair so the cascade runs on
-// v_pk_fma_f32 / v_pk_add_f32.  Measured at cfg2 (tools/ubench/valu_rate.hip: v_fma_f32 70 TF,
-// v_pk_fma_f32 119 TF, v_fma_f64 62 TF) the packed variant halves the cascade's instruction count
-// but its 64 extra VGPRs cost a wave per SIMD and it ran slower (2.10 vs 1.49 ms), so the dispatch
-// uses float / double; f2 is kept for the kernels that can afford the registers.
+// The lane's 32 input samples, always fp32: 16 register PAIRS {sample j, sample j + 16}.
+typedef f2 XArr[kL / 2];
+
+// Arithmetic types of the in-chunk recursion.  The two 16-sample halves of the chunk are independent recurrences
+// (zero state each) joined afterwards through A^16 (section<>, below):
+//  * float: the halves share one register pair, so the whole cascade runs on v_pk_add / v_pk_fma_f32
+//    (tools/ubench/valu_rate.hip: v_fma_f32 70 TF, v_pk_fma_f32 119 TF, v_fma_f64 62 TF);
+//  * double (bands with a pole too close to z = 1 for fp32): the halves are two interleaved dependency chains of
+//    v_fma_f64.  The chunk stays fp64 until the state fix-up has been added: the zero-state response of a chunk is
+//    ~30x larger than the signal for these bands (it cancels against the fix-up), so rounding it to fp32 first costs
+//    1.6e-6 of the peak where the fp64 sum is good to 6e-8.
 template <typename VT> struct VOps;
 template <> struct VOps<float> {
   using S = float;
-  static constexpr int NR = 1;
-  // chunk container: 16 register PAIRS {sample j, sample j + 16}.  The two 16-sample halves of the chunk are
-  // independent recurrences (zero state each), so the whole cascade runs on v_pk_add/v_pk_fma_f32; the halves
-  // are joined afterwards through A^16 (section<>, below).
   typedef f2 Arr[kL / 2];
   static __device__ __forceinline__ float at(const Arr& a, int n) { return (n & 16) ? a[n & 15].y : a[n & 15].x; }
-  static __device__ __forceinline__ void put(Arr& a, int n, float s) { if (n & 16) a[n & 15].y = s; else a[n & 15].x = s; }
-  static __device__ __forceinline__ float splat(float s) { return s; }
-  static __device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
-  static __device__ __forceinline__ float get(float v, int) { return v; }
-  static __device__ __forceinline__ void set(float& v, int, float s) { v = s; }
-  static __device__ __forceinline__ float a1(const FbSec& s) { return s.a1f; }
-  static __device__ __forceinline__ float a2(const FbSec& s) { return s.a2f; }
-  static __device__ __forceinline__ float h(const FbSec& s, int n, int j) { return s.hf[n][j]; }
   static __device__ __forceinline__ float g(const FbBand& b) { return b.gf; }
-};
-template <> struct VOps<f2> {
-  using S = float;
-  static constexpr int NR = 2;
-  typedef f2 Arr[kL];
-  static __device__ __forceinline__ f2 at(const Arr& a, int n) { return a[n]; }
-  static __device__ __forceinline__ void put(Arr& a, int n, f2 s) { a[n] = s; }
-  static __device__ __forceinline__ f2 splat(float s) { return (f2){s, s}; }
-  static __device__ __forceinline__ f2 fma_(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-  static __device__ __forceinline__ float get(f2 v, int r) { return r ? v.y : v.x; }
-  static __device__ __forceinline__ void set(f2& v, int r, float s) { if (r) v.y = s; else v.x = s; }
-  static __device__ __forceinline__ float a1(const FbSec& s) { return s.a1f; }
-  static __device__ __forceinline__ float a2(const FbSec& s) { return s.a2f; }
-  static __device__ __forceinline__ float h(const FbSec& s, int n, int j) { return s.hf[n][j]; }
-  static __device__ __forceinline__ float g(const FbBand& b) { return b.gf; }
+  static __device__ __forceinline__ void from_x(Arr& v, const XArr& xs, float gain) {
+#pragma unroll
+    for (int j = 0; j < kL / 2; ++j) v[j] = xs[j] * gain;
+  }
+  static __device__ __forceinline__ void to_f32(const Arr& v, XArr& o) {
+#pragma unroll
+    for (int j = 0; j < kL / 2; ++j) o[j] = v[j];
+  }
 };
 template <> struct VOps<double> {
   using S = double;
-  static constexpr int NR = 1;
-  typedef double Arr[kL];
+  typedef double Arr[kL];                          // natural order: n < 16 first half, n >= 16 second half
   static __device__ __forceinline__ double at(const Arr& a, int n) { return a[n]; }
-  static __device__ __forceinline__ void put(Arr& a, int n, double s) { a[n] = s; }
-  static __device__ __forceinline__ double splat(double s) { return s; }
-  static __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
-  static __device__ __forceinline__ double get(double v, int) { return v; }
-  static __device__ __forceinline__ void set(double& v, int, double s) { v = s; }
-  static __device__ __forceinline__ double a1(const FbSec& s) { return s.a1d; }
-  static __device__ __forceinline__ double a2(const FbSec& s) { return s.a2d; }
-  static __device__ __forceinline__ double h(const FbSec& s, int n, int j) { return s.hd[n][j]; }
   static __device__ __forceinline__ double g(const FbBand& b) { return b.gd; }
+  static __device__ __forceinline__ void from_x(Arr& v, const XArr& xs, double gain) {
+#pragma unroll
+    for (int j = 0; j < kL / 2; ++j) {
+      v[j] = (double)xs[j].x * gain;
+      v[j + 16] = (double)xs[j].y * gain;
+    }
+  }
+  static __device__ __forceinline__ void to_f32(const Arr& v, XArr& o) {
+#pragma unroll
+    for (int j = 0; j < kL / 2; ++j) o[j] = (f2){(float)v[j], (float)v[j + 16]};
+  }
 };
+
+// The same pointer, opaque to the compiler from here on: loads through the result cannot be hoisted above this point
+// or merged with earlier loads of the structure.  The scalar tables of a section (116 dwords in the fp64 instance) do
+// not fit the SGPR file at once; left alone, the scheduler clusters their s_loads at the top of the section and the
+// register allocator spills the surplus into VGPR lanes (v_writelane / v_readlane: 42 % of the VALU instructions of
+// the first fp64 long-row kernel).
+// (The opaque part is a zero OFFSET, not the pointer: the result is still based on the __restrict__ kernel argument,
+// so the loads stay scalar -- a laundered pointer may alias the kernel's stores and its loads turn into vector loads.)
+template <typename P>
+__device__ __forceinline__ const P* later(const P* p) {
+  int zero = 0;
+  asm volatile("" : "+s"(zero));
+  return reinterpret_cast<const P*>(reinterpret_cast<const char*>(p) + zero);
+}
 
 template <int D>
 __device__ __forceinline__ void scan_step(double& e1, double& e2, const double* M) {
@@ -130,17 +133,18 @@ __device__ __forceinline__ void scan_step(double& e1, double& e2, const double* 
   e2 = fma(M[2], p1, fma(M[3], p2, e2));
 }
 
-// One biquad section over the lane's chunk(s), including the cross-chunk state fix-up.
-// c1/c2[r]: incoming state of the wave's first group for row-set r (GPR == 4 loop carry), updated.
+// One biquad section over the lane's chunk, including the cross-chunk state fix-up.
+// c1/c2: incoming state of the wave's first group (GPR == 4 loop carry), updated.
 template <typename VT, int GPR>
 __device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& sc, const double* __restrict__ Qsec,
-                                        int lane, double (&c1)[VOps<VT>::NR], double (&c2)[VOps<VT>::NR]) {
-  using O = VOps<VT>;
-  constexpr int NR = O::NR;
-  const VT na1 = O::splat(-O::a1(sc)), na2 = O::splat(-O::a2(sc));
-  VT s1 = O::splat(0), s2 = O::splat(0);
-  [[maybe_unused]] float sA1 = 0.f, sA2 = 0.f;            // fp32 path: final state of the first half (zero start)
+                                        int lane, double& c1, double& c2) {
+  // in-chunk recursion from zero state, both halves side by side; sA = final state of the first half,
+  // (e1, e2) = state after the whole chunk = A^16 sA + sB
+  double e1, e2;
+  [[maybe_unused]] float sA1f = 0.f, sA2f = 0.f;
+  [[maybe_unused]] double sA1d = 0.0, sA2d = 0.0;
   if constexpr (std::is_same<VT, float>::value) {
+    const float na1 = -sc.a1f, na2 = -sc.a2f;
     const f2 NA1 = {na1, na1}, NA2 = {na2, na2};
     f2 S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
 #pragma unroll
@@ -151,85 +155,93 @@ __device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& 
       S2 = __builtin_elementwise_fma(NA2, y, -x);
       v[j] = y;
     }
-    sA1 = S1.x; sA2 = S2.x;
-    // state after the whole chunk from a zero start: A^16 sA + sB
-    s1 = fmaf(sc.N16f[0], S1.x, fmaf(sc.N16f[1], S2.x, S1.y));
-    s2 = fmaf(sc.N16f[2], S1.x, fmaf(sc.N16f[3], S2.x, S2.y));
+    sA1f = S1.x; sA2f = S2.x;
+    e1 = (double)fmaf(sc.N16f[0], S1.x, fmaf(sc.N16f[1], S2.x, S1.y));
+    e2 = (double)fmaf(sc.N16f[2], S1.x, fmaf(sc.N16f[3], S2.x, S2.y));
   } else {
+    const double na1 = -sc.a1d, na2 = -sc.a2d;
+    double s1a = 0.0, s2a = 0.0, s1b = 0.0, s2b = 0.0;
 #pragma unroll
-    for (int n = 0; n < kL; ++n) {
-      const VT x = O::at(v, n);
-      const VT y = x + s1;
-      s1 = O::fma_(na1, y, s2);
-      s2 = O::fma_(na2, y, -x);
-      O::put(v, n, y);
+    for (int j = 0; j < kL / 2; ++j) {
+      const double xa = v[j], xb = v[j + 16];
+      const double ya = xa + s1a, yb = xb + s1b;
+      s1a = fma(na1, ya, s2a);
+      s1b = fma(na1, yb, s2b);
+      s2a = fma(na2, ya, -xa);
+      s2b = fma(na2, yb, -xb);
+      v[j] = ya;
+      v[j + 16] = yb;
     }
+    sA1d = s1a; sA2d = s2a;
+    e1 = fma(sc.N16d[0], s1a, fma(sc.N16d[1], s2a, s1b));
+    e2 = fma(sc.N16d[2], s1a, fma(sc.N16d[3], s2a, s2b));
   }
-  double i1[NR], i2[NR];
+  // inclusive scan of the chunk-end states over the 16 lanes of a DPP row (always fp64)
+  const FbSec& sm = *later(&sc);
+  scan_step<1>(e1, e2, sm.Mp[0]);
+  scan_step<2>(e1, e2, sm.Mp[1]);
+  scan_step<4>(e1, e2, sm.Mp[2]);
+  scan_step<8>(e1, e2, sm.Mp[3]);
+  double i1 = row_shr<1>(e1);                          // exclusive; lane 0 of each 16-lane row -> 0
+  double i2 = row_shr<1>(e2);
+  if (GPR > 1) {
+    // group totals (wave-uniform) and the serial chain over the 4 groups of the wave
+    double E1[4], E2[4];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    double e1 = (double)O::get(s1, r), e2 = (double)O::get(s2, r);
-    scan_step<1>(e1, e2, sc.Mp[0]);
-    scan_step<2>(e1, e2, sc.Mp[1]);
-    scan_step<4>(e1, e2, sc.Mp[2]);
-    scan_step<8>(e1, e2, sc.Mp[3]);
-    i1[r] = row_shr<1>(e1);                            // exclusive; lane 0 of each 16-lane row -> 0
-    i2[r] = row_shr<1>(e2);
-    if (GPR > 1) {
-      // group totals (wave-uniform) and the serial chain over the 4 groups of the wave
-      double E1[4], E2[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        E1[g] = read_lane(e1, 16 * g + 15);
-        E2[g] = read_lane(e2, 16 * g + 15);
-      }
-      double C1[4], C2[4];
-      C1[0] = (GPR == 4) ? c1[r] : 0.0;
-      C2[0] = (GPR == 4) ? c2[r] : 0.0;
-#pragma unroll
-      for (int g = 1; g < 4; ++g) {
-        if (g % GPR == 0) {
-          C1[g] = 0.0;
-          C2[g] = 0.0;
-        } else {
-          C1[g] = fma(sc.P[0], C1[g - 1], fma(sc.P[1], C2[g - 1], E1[g - 1]));
-          C2[g] = fma(sc.P[2], C1[g - 1], fma(sc.P[3], C2[g - 1], E2[g - 1]));
-        }
-      }
-      if (GPR == 4) {
-        c1[r] = fma(sc.P[0], C1[3], fma(sc.P[1], C2[3], E1[3]));
-        c2[r] = fma(sc.P[2], C1[3], fma(sc.P[3], C2[3], E2[3]));
-      }
-      const int q = lane >> 4;
-      const double m1 = q == 0 ? C1[0] : q == 1 ? C1[1] : q == 2 ? C1[2] : C1[3];
-      const double m2 = q == 0 ? C2[0] : q == 1 ? C2[1] : q == 2 ? C2[2] : C2[3];
-      const double* Q = Qsec + (lane & 15) * 4;        // M^i of this lane
-      i1[r] = fma(Q[0], m1, fma(Q[1], m2, i1[r]));
-      i2[r] = fma(Q[2], m1, fma(Q[3], m2, i2[r]));
+    for (int g = 0; g < 4; ++g) {
+      E1[g] = read_lane(e1, 16 * g + 15);
+      E2[g] = read_lane(e2, 16 * g + 15);
     }
-  }
-  VT t1, t2;
+    double C1[4], C2[4];
+    C1[0] = (GPR == 4) ? c1 : 0.0;
+    C2[0] = (GPR == 4) ? c2 : 0.0;
+    const FbSec& sp = *later(&sc);
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    O::set(t1, r, (typename O::S)i1[r]);
-    O::set(t2, r, (typename O::S)i2[r]);
+    for (int g = 1; g < 4; ++g) {
+      if (g % GPR == 0) {
+        C1[g] = 0.0;
+        C2[g] = 0.0;
+      } else {
+        C1[g] = fma(sp.P[0], C1[g - 1], fma(sp.P[1], C2[g - 1], E1[g - 1]));
+        C2[g] = fma(sp.P[2], C1[g - 1], fma(sp.P[3], C2[g - 1], E2[g - 1]));
+      }
+    }
+    if (GPR == 4) {
+      c1 = fma(sp.P[0], C1[3], fma(sp.P[1], C2[3], E1[3]));
+      c2 = fma(sp.P[2], C1[3], fma(sp.P[3], C2[3], E2[3]));
+    }
+    const int q = lane >> 4;
+    const double m1 = q == 0 ? C1[0] : q == 1 ? C1[1] : q == 2 ? C1[2] : C1[3];
+    const double m2 = q == 0 ? C2[0] : q == 1 ? C2[1] : q == 2 ? C2[2] : C2[3];
+    const double* Q = Qsec + (lane & 15) * 4;          // M^i of this lane
+    i1 = fma(Q[0], m1, fma(Q[1], m2, i1));
+    i2 = fma(Q[2], m1, fma(Q[3], m2, i2));
   }
+  // zero-input correction; the table scalars are fetched here, after the scan released its matrix SGPRs
+  const FbSec& sh = *later(&sc);
   if constexpr (std::is_same<VT, float>::value) {
-    // incoming state of the second half: A^16 t + sA; both halves then take the same 16-entry table.
-    // The table scalars are fetched here, after the scan released its matrix SGPRs: hoisted to the top of the
-    // section they do not fit beside them and the compiler spills SGPRs into VGPR lanes.
-    __builtin_amdgcn_sched_barrier(0);
-    const float u1 = fmaf(sc.N16f[0], t1, fmaf(sc.N16f[1], t2, sA1));
-    const float u2 = fmaf(sc.N16f[2], t1, fmaf(sc.N16f[3], t2, sA2));
+    const float t1 = (float)i1, t2 = (float)i2;
+    // incoming state of the second half: A^16 t + sA; both halves then take the same 16-entry table
+    const float u1 = fmaf(sh.N16f[0], t1, fmaf(sh.N16f[1], t2, sA1f));
+    const float u2 = fmaf(sh.N16f[2], t1, fmaf(sh.N16f[3], t2, sA2f));
     const f2 T1 = {t1, u1}, T2 = {t2, u2};
 #pragma unroll
     for (int j = 0; j < kL / 2; ++j)
-      v[j] = __builtin_elementwise_fma((f2){sc.hq[0][j], sc.hq[0][j]}, T1,
-                                       __builtin_elementwise_fma((f2){sc.hq[1][j], sc.hq[1][j]}, T2, v[j]));
+      v[j] = __builtin_elementwise_fma((f2){sh.hq[0][j], sh.hq[0][j]}, T1,
+                                       __builtin_elementwise_fma((f2){sh.hq[1][j], sh.hq[1][j]}, T2, v[j]));
   } else {
+    const double u1 = fma(sh.N16d[0], i1, fma(sh.N16d[1], i2, sA1d));
+    const double u2 = fma(sh.N16d[2], i1, fma(sh.N16d[3], i2, sA2d));
 #pragma unroll
-    for (int n = 0; n < kL; ++n)
-      v[n] = O::fma_(O::splat(O::h(sc, n, 0)), t1, O::fma_(O::splat(O::h(sc, n, 1)), t2, v[n]));
+    for (int q = 0; q < kL / 2; q += 4) {
+      const FbSec& sq = *later(&sc);                         // 8 table doubles (16 SGPRs) per batch
+#pragma unroll
+      for (int j = q; j < q + 4; ++j) {
+        const double h1 = sq.hdq[0][j], h2 = sq.hdq[1][j];
+        v[j] = fma(h1, i1, fma(h2, i2, v[j]));
+        v[j + 16] = fma(h1, u1, fma(h2, u2, v[j + 16]));
+      }
+    }
   }
 }
 
@@ -283,153 +295,230 @@ __device__ __forceinline__ void tile_store(const float* tile, float* __restrict_
   }
 }
 
-// Load the lane's chunk of every row-set through the LDS tile (coalesced global reads, chunk-major
-// registers) and scale it by `gain`.
-template <typename VT>
-__device__ __forceinline__ void load_chunks(typename VOps<VT>::Arr& v, float* tile, const float* __restrict__ x,
-                                            int lane, const int64_t (&xbase)[VOps<VT>::NR][4], const int (&gt0)[4],
-                                            int T, bool vec) {
-  using O = VOps<VT>;
+// Load the lane's chunk through the LDS tile (coalesced global reads, chunk-major registers).
+__device__ __forceinline__ void load_chunks(XArr& xs, float* tile, const float* __restrict__ x, int lane,
+                                            const int64_t (&xbase)[4], const int (&gt0)[4], int T, bool vec) {
+  wave_lds_sync();
+  tile_load(tile, x, lane, xbase, gt0, T, vec);
+  wave_lds_sync();
+  const float* src = tile + lane * kPad;              // (q*16 + i) == lane
 #pragma unroll
-  for (int r = 0; r < O::NR; ++r) {
-    wave_lds_sync();
-    tile_load(tile, x, lane, xbase[r], gt0, T, vec);
-    wave_lds_sync();
-    const float* src = tile + lane * kPad;            // (q*16 + i) == lane
-#pragma unroll
-    for (int n = 0; n < kL; n += 4) {
-      const float4 f = *reinterpret_cast<const float4*>(src + n);
-      if constexpr (O::NR == 1) {
-        O::put(v, n, (typename O::S)f.x);
-        O::put(v, n + 1, (typename O::S)f.y);
-        O::put(v, n + 2, (typename O::S)f.z);
-        O::put(v, n + 3, (typename O::S)f.w);
-      } else {
-        O::set(v[n], r, f.x);
-        O::set(v[n + 1], r, f.y);
-        O::set(v[n + 2], r, f.z);
-        O::set(v[n + 3], r, f.w);
-      }
-    }
+  for (int n = 0; n < kL / 2; n += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(src + n);
+    const float4 b = *reinterpret_cast<const float4*>(src + n + 16);
+    xs[n] = (f2){a.x, b.x};
+    xs[n + 1] = (f2){a.y, b.y};
+    xs[n + 2] = (f2){a.z, b.z};
+    xs[n + 3] = (f2){a.w, b.w};
   }
 }
 
-// One wave per workgroup.  GPR = 16-lane groups per row (1: T<=512, 2: T<=1024, 4: any T);
-// the wave serves NR * 4/GPR rows.
+// The lane's chunk written back as 32 consecutive floats of its LDS tile row.
+template <typename VT>
+__device__ __forceinline__ void chunk_to_tile(float* dst, const typename VOps<VT>::Arr& v) {
+  using O = VOps<VT>;
+#pragma unroll
+  for (int n = 0; n < kL; n += 4)
+    *reinterpret_cast<float4*>(dst + n) = make_float4((float)O::at(v, n), (float)O::at(v, n + 1),
+                                                      (float)O::at(v, n + 2), (float)O::at(v, n + 3));
+}
+
+// Rows of at most 1024 samples.  One wave per workgroup; GPR = 16-lane groups per row (1: T<=512, 2: T<=1024);
+// the wave serves 4/GPR rows.  The input chunk stays in registers (fp32) for all bands.
 template <typename VT, int GPR>
 __global__ __launch_bounds__(64) void fb_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                                                 const double* __restrict__ Qtab, const float* __restrict__ x,
-                                                float* __restrict__ y, int64_t R, int C, int T, int nb, int ns,
+                                                float* __restrict__ y, int R, int C, int T, int nb, int ns,
                                                 int vec, const int* __restrict__ bmap, int nb_out) {
   using O = VOps<VT>;
-  constexpr int NR = O::NR;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* tile = reinterpret_cast<float*>(smem_raw);                        // [4][16][kPad]
-  double* carry = reinterpret_cast<double*>(smem_raw + 4 * 16 * kPad * 4);  // [NR][nb][ns][2]  (GPR == 4)
+  static_assert(GPR == 1 || GPR == 2, "long rows take fb_long_kernel");
+  __shared__ __attribute__((aligned(16))) float tile[4 * 16 * kPad];
   const int lane = threadIdx.x;
-  constexpr int RPS = 4 / GPR;                                             // rows per row-set
-  const int64_t row0 = (int64_t)blockIdx.x * (RPS * NR);
-  const int n_iter = (GPR == 4) ? (T + 4 * kSeg - 1) / (4 * kSeg) : 1;
-
-  if (GPR == 4) {
-    for (int j = lane; j < NR * nb * ns * 2; j += 64) carry[j] = 0.0;
+  constexpr int RPS = 4 / GPR;                                             // rows per wave
+  const int row0 = blockIdx.x * RPS;
+  int64_t xbase[4], yrow[4];
+  int gt0[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    gt0[g] = (g % GPR) * kSeg;
+    const int row = row0 + g / GPR;
+    const bool ok = row < R && gt0[g] < T;
+    xbase[g] = ok ? row * (int64_t)T : -1;
+    const int bt = row / C, ch = row - bt * C;
+    yrow[g] = ok ? ((int64_t)bt * nb_out * C + ch) * (int64_t)T : -1;     // band 0 of the row's trial
   }
-
-  for (int it = 0; it < n_iter; ++it) {
-    int64_t xbase[NR][4];
-    int64_t rowg[NR][4];
-    int gt0[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      gt0[g] = (it * GPR + g % GPR) * kSeg;
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const int64_t row = row0 + r * RPS + g / GPR;
-        rowg[r][g] = row;
-        xbase[r][g] = (row < R && gt0[g] < T) ? row * (int64_t)T : -1;
-      }
+  const int64_t bstride = (int64_t)C * T;
+  XArr xs;
+  load_chunks(xs, tile, x, lane, xbase, gt0, T, vec != 0);
+  for (int b = 0; b < nb; ++b) {
+    typename O::Arr v;
+    O::from_x(v, xs, O::g(bands[b]));
+    for (int s = 0; s < ns; ++s) {
+      double c1 = 0.0, c2 = 0.0;
+      section<VT, GPR>(v, secs[b * ns + s], Qtab + (int64_t)(b * ns + s) * 64, lane, c1, c2);
     }
-    typename O::Arr xs;
-    load_chunks<VT>(xs, tile, x, lane, xbase, gt0, T, vec != 0);
-    constexpr int NA = sizeof(typename O::Arr) / sizeof(xs[0]);
-    for (int b = 0; b < nb; ++b) {
+    wave_lds_sync();                              // earlier readers of the tile are done
+    chunk_to_tile<VT>(tile + lane * kPad, v);
+    wave_lds_sync();
+    int64_t ybase[4];
+    const int64_t boff = (int64_t)bmap[b] * bstride;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ybase[g] = yrow[g] < 0 ? -1 : yrow[g] + boff;
+    tile_store(tile, y, lane, ybase, gt0, T, vec != 0);
+  }
+}
+
+// The lane's 32 samples of pass `it` straight from global memory (128 contiguous bytes per lane, 8 KiB per wave).
+__device__ __forceinline__ void load_chunk_direct(XArr& xs, const float* __restrict__ src, int it, int lane, int T,
+                                                  bool vec) {
+  const int e0 = (it * 64 + lane) * kL;
+  const bool whole = vec && (it + 1) * 64 * kL <= T;            // wave-uniform: the pass lies inside the row
+  float4 f[kL / 4];
+#pragma unroll
+  for (int n = 0; n < kL; n += 4) {
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (whole) {                                                // no per-element bounds arithmetic on the common path
+      q = *reinterpret_cast<const float4*>(src + e0 + n);
+    } else if (vec && e0 + n + 3 < T) {
+      q = *reinterpret_cast<const float4*>(src + e0 + n);
+    } else {
+      if (e0 + n + 0 < T) q.x = src[e0 + n];
+      if (e0 + n + 1 < T) q.y = src[e0 + n + 1];
+      if (e0 + n + 2 < T) q.z = src[e0 + n + 2];
+      if (e0 + n + 3 < T) q.w = src[e0 + n + 3];
+    }
+    f[n / 4] = q;
+  }
+#pragma unroll
+  for (int n = 0; n < kL / 2; n += 4) {
+    const float4 a = f[n / 4], b = f[n / 4 + 4];
+    xs[n] = (f2){a.x, b.x};
+    xs[n + 1] = (f2){a.y, b.y};
+    xs[n + 2] = (f2){a.z, b.z};
+    xs[n + 3] = (f2){a.w, b.w};
+  }
+}
+
+constexpr int kLongShare = 8;                    // one-wave workgroups sharing a long row (fused_long_kernel: 4 -> 4.58 ms, 8 -> 4.47 ms per 128 stress trials)
+
+// Rows longer than 1024 samples (the stress configuration: 4096).  One row per wave, 2048 samples per pass, the
+// section states carried from pass to pass in LDS.  The band loop is outermost and the x pass is re-read from global
+// memory for every band (it stays in the XCD's L2): nothing of x lives in registers across bands, which is what
+// lets the fp64 instance run at 4 waves per SIMD (the first version kept x and the chunk as doubles: 201 VGPRs, 2
+// waves per SIMD, 18.6 % of the HBM peak).  kLongShare one-wave workgroups share a row, each taking every
+// kLongShare-th band; their ids are congruent mod 8 (workgroups go to the 8 XCDs round-robin by id, each XCD has its
+// own L2) inside 64 consecutive ids, so the re-reads of a row hit one L2.  The filtered pass leaves through half of
+// the chunk-major LDS tile at a time (coalesced float4 stores, 4.6 KiB of LDS per wave).
+template <typename VT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fb_long_kernel(
+    const FbSec* __restrict__ secs, const FbBand* __restrict__ bands, const double* __restrict__ Qtab,
+    const float* __restrict__ x, float* __restrict__ y, int C, int T, int nb, int ns, int vec,
+    const int* __restrict__ bmap, int nb_out, int n_rows) {
+  using O = VOps<VT>;
+  __shared__ __attribute__((aligned(16))) float tile[2 * 16 * kPad];        // 32 chunks: half a pass
+  __shared__ double carry[kMaxSec * 2];
+  const int lane = threadIdx.x;
+  const int n_iter = (T + 4 * kSeg - 1) / (4 * kSeg);
+  // id = 8 kLongShare q + 8 w + c  <->  row = 8 q + c, band subset w
+  const int id = blockIdx.x;
+  const int row = (id / (8 * kLongShare)) * 8 + (id & 7);
+  const int share = (id >> 3) % kLongShare;
+  if (row >= n_rows) return;
+  const int bt = row / C, ch = row - bt * C;
+  const float* src = x + row * (int64_t)T;
+  float* dst0 = y + ((int64_t)bt * nb_out * C + ch) * (int64_t)T;
+  const int64_t bstride = (int64_t)C * T;
+  for (int b = share; b < nb; b += kLongShare) {
+    if (lane < ns * 2) carry[lane] = 0.0;
+    wave_lds_sync();
+    float* dst = dst0 + (int64_t)bmap[b] * bstride;
+    const auto gain = O::g(bands[b]);
+    for (int it = 0; it < n_iter; ++it) {
+      XArr xs;
+      load_chunk_direct(xs, src, it, lane, T, vec != 0);
       typename O::Arr v;
-      const auto gain = O::g(bands[b]);
-#pragma unroll
-      for (int n = 0; n < NA; ++n) v[n] = xs[n] * gain;
-      for (int s = 0; s < ns; ++s) {
-        const int bs = b * ns + s;
-        double c1[NR], c2[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          c1[r] = (GPR == 4) ? carry[(r * nb * ns + bs) * 2] : 0.0;
-          c2[r] = (GPR == 4) ? carry[(r * nb * ns + bs) * 2 + 1] : 0.0;
+      O::from_x(v, xs, gain);
+      for (int sct = 0; sct < ns; ++sct) {
+        double c1 = carry[sct * 2], c2 = carry[sct * 2 + 1];
+        section<VT, 4>(v, secs[b * ns + sct], Qtab + (int64_t)(b * ns + sct) * 64, lane, c1, c2);
+        wave_lds_sync();                                // every lane has read the incoming carry
+        if (lane == 0) {
+          carry[sct * 2] = c1;
+          carry[sct * 2 + 1] = c2;
         }
-        section<VT, GPR>(v, secs[bs], Qtab + (int64_t)bs * 64, lane, c1, c2);
-        if (GPR == 4 && n_iter > 1 && lane == 0) {
+      }
+      // transposition to coalesced stores, half a pass (1024 samples = 32 chunks) at a time
 #pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            carry[(r * nb * ns + bs) * 2] = c1[r];
-            carry[(r * nb * ns + bs) * 2 + 1] = c2[r];
+      for (int h = 0; h < 2; ++h) {
+        wave_lds_sync();                                // the previous half's readers are done
+        if ((lane >> 5) == h) chunk_to_tile<VT>(tile + (lane & 31) * kPad, v);
+        wave_lds_sync();
+        const int t_half = (it * 2 + h) * 2 * kSeg;     // first sample of this half pass
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = (k * 64 + lane) * 4;            // element inside the half pass
+          const int t = t_half + e;
+          if (t >= T) continue;
+          const float4 val = *reinterpret_cast<const float4*>(tile + (e >> 5) * kPad + (e & 31));
+          float* p = dst + t;
+          if (vec && t + 3 < T) {
+            *reinterpret_cast<float4*>(p) = val;
+          } else {
+            p[0] = val.x;
+            if (t + 1 < T) p[1] = val.y;
+            if (t + 2 < T) p[2] = val.z;
+            if (t + 3 < T) p[3] = val.w;
           }
         }
       }
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        wave_lds_sync();                              // earlier readers of the tile are done
-        float* dst = tile + lane * kPad;
-#pragma unroll
-        for (int n = 0; n < kL; n += 4)
-          *reinterpret_cast<float4*>(dst + n) =
-              make_float4((float)O::get(O::at(v, n), r), (float)O::get(O::at(v, n + 1), r),
-                          (float)O::get(O::at(v, n + 2), r), (float)O::get(O::at(v, n + 3), r));
-        wave_lds_sync();
-        int64_t ybase[4];
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          if (xbase[r][gq] < 0) { ybase[gq] = -1; continue; }
-          const int64_t row = rowg[r][gq];
-          const int64_t bt = row / C, ch = row - bt * C;
-          ybase[gq] = ((bt * nb_out + bmap[b]) * C + ch) * (int64_t)T;
-        }
-        tile_store(tile, y, lane, ybase, gt0, T, vec != 0);
-      }
     }
+    wave_lds_sync();
   }
 }
 
 struct FusedBands {
   int klo[kMaxBands];
   int khi[kMaxBands];
+  float inv[kMaxBands];          // 1 / (number of bins), 0 for an empty band
 };
+
+// log(P + eps) on the hardware log2 (v_log_f32, 1 ulp): |error| <= 2e-6 in the log domain for P + eps >= 1e-10,
+// against the 1e-4 feature gate; the libm logf costs ~20 instructions per value and every band needs two.
+__device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.69314718055994531f; }
 
 // Windowed DFT of the band's own bins over the lane's chunk (register pairs) and the reduction to
 // band magnitude / power.  Frame j of the row is chunk j-1 (first window half, table entries 0..31)
 // followed by chunk j (second half, 32..63): every lane forms both partial sums, `row_shr:1` joins
 // neighbours.  o0 = frame (lane & 15), o16 = frame 16 (meaningful on lane 15).
+// MAG: mean magnitude (a square root per bin and frame) instead of mean power -- a template parameter because the
+// compiler turns the run-time test into selects and evaluates both square roots (a third of the loop) either way.
+template <bool MAG>
 __device__ __forceinline__ void band_reduce_pairs(const f2 (&vf)[kL / 2], const float2* __restrict__ dft, int klo,
                                                   int khi, bool mine_lo_hi_valid, int my_klo, int my_khi, float scale2,
-                                                  int mode, float& o0, float& o16) {
+                                                  float& o0, float& o16) {
   float acc = 0.f, acc16 = 0.f;
   for (int k = klo; k <= khi; ++k) {
-    const float2* __restrict__ tb = dft + k * 64;
-    f2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+    const f2* __restrict__ tb = reinterpret_cast<const f2*>(dft + k * 64);   // [4][16] sample-pair entries (stft.hip)
+    // four real dot products over the lane's 32 samples: first / second window half x real / imaginary part; each
+    // accumulates the j-part and the (j + 16)-part in the two lanes of a packed register
+    f2 a1r = {0.f, 0.f}, a1i = {0.f, 0.f}, a2r = {0.f, 0.f}, a2i = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < kL / 2; ++j) {
-      // the 128 table scalars of a bin do not fit the SGPR file at once: fetch them in two batches of 64
-      if (j == kL / 4) __builtin_amdgcn_sched_barrier(0);
-      const f2 pr = vf[j];                                              // samples j, j + 16
-      const f2 x0 = __builtin_shufflevector(pr, pr, 0, 0), x1 = __builtin_shufflevector(pr, pr, 1, 1);
-      const float2 ca0 = tb[j], cb0 = tb[kL + j], ca1 = tb[j + 16], cb1 = tb[kL + j + 16];
-      p1 = __builtin_elementwise_fma(x0, (f2){ca0.x, ca0.y}, p1);
-      p2 = __builtin_elementwise_fma(x0, (f2){cb0.x, cb0.y}, p2);
-      p1 = __builtin_elementwise_fma(x1, (f2){ca1.x, ca1.y}, p1);
-      p2 = __builtin_elementwise_fma(x1, (f2){cb1.x, cb1.y}, p2);
+    for (int q = 0; q < kL / 2; q += 8) {
+      const f2* __restrict__ tq = later(tb);          // 64 table scalars per batch in the SGPR file
+#pragma unroll
+      for (int j = q; j < q + 8; ++j) {
+        const f2 pr = vf[j];                          // samples j, j + 16
+        a1r = __builtin_elementwise_fma(pr, tq[j], a1r);
+        a1i = __builtin_elementwise_fma(pr, tq[16 + j], a1i);
+        a2r = __builtin_elementwise_fma(pr, tq[32 + j], a2r);
+        a2i = __builtin_elementwise_fma(pr, tq[48 + j], a2i);
+      }
     }
+    const f2 p1 = {a1r.x + a1r.y, a1i.x + a1i.y}, p2 = {a2r.x + a2r.y, a2i.x + a2i.y};
     const float zr = p2.x + row_shr<1>(p1.x), zi = p2.y + row_shr<1>(p1.y);
     float pw = (zr * zr + zi * zi) * scale2;
     float pw16 = (p1.x * p1.x + p1.y * p1.y) * scale2;
-    if (mode == ISD_BP_MAGNITUDE) { pw = sqrtf(pw); pw16 = sqrtf(pw16); }
+    if (MAG) { pw = sqrtf(pw); pw16 = sqrtf(pw16); }
     const bool in = !mine_lo_hi_valid || (k >= my_klo && k <= my_khi);
     acc += in ? pw : 0.f;
     acc16 += in ? pw16 : 0.f;
@@ -438,50 +527,55 @@ __device__ __forceinline__ void band_reduce_pairs(const f2 (&vf)[kL / 2], const 
   o16 = acc16;
 }
 
+// the STFT sees y[0..T) then zeros, not the filter's ringing
+__device__ __forceinline__ void zero_past_end(XArr& vf, int i, int T) {
+#pragma unroll
+  for (int j = 0; j < kL / 2; ++j) {
+    if (i * kL + j >= T) vf[j].x = 0.f;
+    if (i * kL + j + 16 >= T) vf[j].y = 0.f;
+  }
+}
+
 // Band aggregation of materialised filtered signals y[B][nb][C][T] (nperseg 64 / hop 32, T <= 512):
 // same chunk layout as the filterbank (coalesced float4 loads through the LDS tile), direct DFT of
 // each row's own band bins.  HBM-bound: reads nb*C*T*4 bytes per trial, writes nb*C*J*4.
+template <bool MAG>
 __global__ __launch_bounds__(64) void bandpower_direct_kernel(const float2* __restrict__ dft,
                                                               const float* __restrict__ y, float* __restrict__ feat,
-                                                              int64_t R, int C, int T, int nb, int J, float scale2,
+                                                              int R, int C, int T, int nb, int J, float scale2,
                                                               FusedBands fbnd, int mode, float eps, int vec) {
-  using O = VOps<float>;
   __shared__ __attribute__((aligned(16))) float tile[4 * 16 * kPad];
   const int lane = threadIdx.x;
   const int i = lane & 15;
-  const int64_t row0 = (int64_t)blockIdx.x * 4;
-  int64_t xbase[1][4];
+  const int row0 = blockIdx.x * 4;
+  int64_t xbase[4];
   int gt0[4];
   int wlo = 1 << 30, whi = -1;                                  // wave-uniform union of the 4 rows' bin ranges
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     gt0[g] = 0;
-    const int64_t r = row0 + g;
-    xbase[0][g] = (r < R) ? r * (int64_t)T : -1;
+    const int r = row0 + g;
+    xbase[g] = (r < R) ? r * (int64_t)T : -1;
     if (r < R) {
-      const int band = (int)((r / C) % nb);
+      const int band = (r / C) % nb;
       if (fbnd.khi[band] >= fbnd.klo[band]) {
         wlo = fbnd.klo[band] < wlo ? fbnd.klo[band] : wlo;
         whi = fbnd.khi[band] > whi ? fbnd.khi[band] : whi;
       }
     }
   }
-  typename O::Arr vf;
-  load_chunks<float>(vf, tile, y, lane, xbase, gt0, T, vec != 0);
-  if (T < kSeg) {
-#pragma unroll
-    for (int n = 0; n < kL; ++n)
-      if (i * kL + n >= T) O::put(vf, n, 0.f);
-  }
-  const int64_t row = row0 + (lane >> 4);
-  const int band = (int)((row / C) % nb);
+  XArr vf;
+  load_chunks(vf, tile, y, lane, xbase, gt0, T, vec != 0);
+  if (T < kSeg) zero_past_end(vf, i, T);
+  const int row = row0 + (lane >> 4);
+  const int band = (row / C) % nb;
   const int klo = fbnd.klo[band], khi = fbnd.khi[band];
   float o0, o16;
-  band_reduce_pairs(vf, dft, wlo, whi, true, klo, khi, scale2, mode, o0, o16);
-  const float inv = khi >= klo ? 1.f / (float)(khi - klo + 1) : 0.f;
+  band_reduce_pairs<MAG>(vf, dft, wlo, whi, true, klo, khi, scale2, o0, o16);
+  const float inv = fbnd.inv[band];
   o0 *= inv;
   o16 *= inv;
-  if (mode == ISD_BP_LOGPOWER) { o0 = logf(o0 + eps); o16 = logf(o16 + eps); }
+  if (mode == ISD_BP_LOGPOWER) { o0 = fast_log(o0 + eps); o16 = fast_log(o16 + eps); }
   if (row < R) {
     float* o = feat + row * (int64_t)J;                         // feat has the same [B][nb][C] row order as y
     if (i < J) o[i] = o0;
@@ -490,107 +584,62 @@ __global__ __launch_bounds__(64) void bandpower_direct_kernel(const float2* __re
 }
 
 // Fused spec-S extractor for T <= 512, nperseg 64 / hop 32: after the cascade each lane
-// holds chunk i of its row(s); STFT frame j is chunk j-1 (window first half) followed by
+// holds chunk i of its row; STFT frame j is chunk j-1 (window first half) followed by
 // chunk j (second half), so every lane forms two partial windowed DFT sums per bin and
 // one DPP row_shr joins neighbours.  Only the band's own bins are evaluated.
-template <typename VT>
+// Everything that does not depend on the band (the row's trial / channel split -- an integer division -- and its
+// output address) is computed once in front of the band loop: inside it the compiler does not hoist them out of the
+// `row < R` branch, and they were a tenth of the loop's instructions.
+template <typename VT, bool MAG>
 __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                                                    const float2* __restrict__ dft, const float* __restrict__ x,
-                                                   float* __restrict__ feat, int64_t R, int C, int T, int nb, int ns,
+                                                   float* __restrict__ feat, int R, int C, int T, int nb, int ns,
                                                    int J, float scale2, FusedBands fbnd, int mode, float eps,
                                                    int vec, const int* __restrict__ bmap, int nb_out) {
   using O = VOps<VT>;
-  constexpr int NR = O::NR;
-  using FT = typename std::conditional<NR == 2, f2, float>::type;      // DFT arithmetic is fp32
-  using FO = VOps<FT>;
   __shared__ __attribute__((aligned(16))) float tile[4 * 16 * kPad];
   const int lane = threadIdx.x;
   const int i = lane & 15;
-  const int64_t row0 = (int64_t)blockIdx.x * (4 * NR);
-  int64_t xbase[NR][4];
+  const int row0 = blockIdx.x * 4;
+  int64_t xbase[4];
   int gt0[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     gt0[g] = 0;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) xbase[r][g] = (row0 + r * 4 + g < R) ? (row0 + r * 4 + g) * (int64_t)T : -1;
+    xbase[g] = (row0 + g < R) ? (row0 + g) * (int64_t)T : -1;
   }
-  typename O::Arr xs;
-  load_chunks<VT>(xs, tile, x, lane, xbase, gt0, T, vec != 0);
-  constexpr int NA = sizeof(typename O::Arr) / sizeof(xs[0]);
+  const int row = row0 + (lane >> 4);
+  const bool row_ok = row < R;
+  const int bt = row / C, ch = row - bt * C;
+  float* const orow = feat + ((int64_t)bt * nb_out * C + ch) * (int64_t)J + i;   // band 0, frame i of this lane's row
+  const int64_t bstride = (int64_t)C * J;
+  const bool st0 = row_ok && i < J, st16 = row_ok && i == 15 && J == 17;
+  XArr xs;
+  load_chunks(xs, tile, x, lane, xbase, gt0, T, vec != 0);
   for (int b = 0; b < nb; ++b) {
     typename O::Arr v;
-    const auto gain = O::g(bands[b]);
-#pragma unroll
-    for (int n = 0; n < NA; ++n) v[n] = xs[n] * gain;
+    O::from_x(v, xs, O::g(bands[b]));
     for (int s = 0; s < ns; ++s) {
-      double c1[NR], c2[NR];
-#pragma unroll
-      for (int r = 0; r < NR; ++r) c1[r] = c2[r] = 0.0;
+      double c1 = 0.0, c2 = 0.0;
       section<VT, 1>(v, secs[b * ns + s], nullptr, lane, c1, c2);
     }
-    typename FO::Arr vf;                              // fp32 copy for the DFT (aliases v when VT is fp32)
-#pragma unroll
-    for (int n = 0; n < kL; ++n) {
-      if constexpr (NR == 1) {
-        FO::put(vf, n, (float)O::at(v, n));
-      } else {
-        vf[n] = v[n];
-      }
-    }
-    if (T < kSeg) {                                   // the STFT sees y[0..T) then zeros, not the filter's ringing
-#pragma unroll
-      for (int n = 0; n < kL; ++n)
-        if (i * kL + n >= T) FO::put(vf, n, FO::splat(0.f));
-    }
-    const int klo = fbnd.klo[b], khi = fbnd.khi[b];
-    float acc[NR], acc16[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) acc[r] = acc16[r] = 0.f;
-    if constexpr (NR == 1) {
-      band_reduce_pairs(vf, dft, klo, khi, false, 0, 0, scale2, mode, acc[0], acc16[0]);
-    } else {
-      for (int k = klo; k <= khi; ++k) {
-        const float2* __restrict__ tb = dft + k * 64;
-        FT p1r = FO::splat(0.f), p1i = FO::splat(0.f), p2r = FO::splat(0.f), p2i = FO::splat(0.f);
-#pragma unroll
-        for (int n = 0; n < kL; ++n) {
-          const float2 ca = tb[n], cb = tb[kL + n];
-          p1r = FO::fma_(vf[n], FO::splat(ca.x), p1r);
-          p1i = FO::fma_(vf[n], FO::splat(ca.y), p1i);
-          p2r = FO::fma_(vf[n], FO::splat(cb.x), p2r);
-          p2i = FO::fma_(vf[n], FO::splat(cb.y), p2i);
-        }
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const float a1r = FO::get(p1r, r), a1i = FO::get(p1i, r);
-          const float zr = FO::get(p2r, r) + row_shr<1>(a1r), zi = FO::get(p2i, r) + row_shr<1>(a1i);
-          const float pw = (zr * zr + zi * zi) * scale2;
-          const float pw16 = (a1r * a1r + a1i * a1i) * scale2;
-          acc[r] += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw) : pw;
-          acc16[r] += (mode == ISD_BP_MAGNITUDE) ? sqrtf(pw16) : pw16;
-        }
-      }
-    }
-    const float inv = khi >= klo ? 1.f / (float)(khi - klo + 1) : 0.f;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      float o0 = acc[r] * inv, o16 = acc16[r] * inv;
-      if (mode == ISD_BP_LOGPOWER) { o0 = logf(o0 + eps); o16 = logf(o16 + eps); }
-      const int64_t row = row0 + r * 4 + (lane >> 4);
-      if (row < R) {
-        const int64_t bt = row / C;
-        const int ch = (int)(row - bt * C);
-        float* o = feat + ((bt * nb_out + bmap[b]) * C + ch) * (int64_t)J;
-        if (i < J) o[i] = o0;
-        if (i == 15 && J == 17) o[16] = o16;
-      }
-    }
+    XArr vf;                                          // fp32 copy for the DFT (the chunk itself when VT is fp32)
+    O::to_f32(v, vf);
+    if (T < kSeg) zero_past_end(vf, i, T);
+    float o0, o16;
+    band_reduce_pairs<MAG>(vf, dft, fbnd.klo[b], fbnd.khi[b], false, 0, 0, scale2, o0, o16);
+    const float inv = fbnd.inv[b];
+    o0 *= inv;
+    o16 *= inv;
+    if (mode == ISD_BP_LOGPOWER) { o0 = fast_log(o0 + eps); o16 = fast_log(o16 + eps); }
+    float* o = orow + (int64_t)bmap[b] * bstride;
+    if (st0) o[0] = o0;
+    if (st16) o[1] = o16;
   }
 }
 
 // Fused spec-S extractor for long rows with heavily overlapped frames (stress configuration: 4096 samples,
-// nperseg 1024, hop 64): the filterbank cascade of fb_kernel<VT, 4> (one row per wave, 2048 samples per pass, the
+// nperseg 1024, hop 64): the filterbank cascade of fb_long_kernel (one row per wave, 2048 samples per pass, the
 // section states carried across passes) followed, in registers, by the per-block DFT sums of the block-sum band
 // power (stft.hip): every lane holds half of a 64-sample block, forms the half-block sums of the band's bins and
 // their two neighbours, lane pairs are joined by one DPP shift and the 64 block sums of the row wait in LDS for
@@ -600,32 +649,29 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
 // by id, and each XCD has its own L2 -- and lie within 64 consecutive ids, so the sharers run on one XCD at about
 // the same time and the rows in flight there (~80 x 16 KiB) fit its 4 MiB L2.  With one workgroup per row walking
 // all bands the rows in flight were ~10x the L2: the PMC counters showed 6.1 GB through the fabric for a 268 MB input.
-constexpr int kLongShare = 8;                    // measured: 4 -> 4.58 ms, 8 -> 4.47 ms per 128 stress trials
 template <typename VT, int KB>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fused_long_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                                                         const double* __restrict__ Qtab, const float2* __restrict__ blk,
                                                         const float* __restrict__ x, float* __restrict__ feat, int C,
                                                         int T, int nb, int ns, int J, int log2_nblk, int n_bins_max,
                                                         float scale2, FusedBands fbnd, int mode, float eps, int vec,
-                                                        const int* __restrict__ bmap, int nb_out, int64_t n_rows) {
+                                                        const int* __restrict__ bmap, int nb_out, int n_rows) {
   using O = VOps<VT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x;
   const int n_iter = (T + 4 * kSeg - 1) / (4 * kSeg);
-  const int n_chunk = n_iter * 64;
   float2* Sblk = reinterpret_cast<float2*>(smem_raw);                      // [KB][64]
   float2* tw = Sblk + KB * 64;                                             // [64]  e^{-2 pi i u / nblk}
   double* carry = reinterpret_cast<double*>(tw + 64);                      // [ns][2]
   // id = 8 kLongShare q + 8 w + c  <->  row = 8 q + c, band subset w
-  const int64_t id = blockIdx.x;
-  const int64_t row = (id / (8 * kLongShare)) * 8 + (id & 7);
-  const int share = (int)((id >> 3) % kLongShare);
+  const int id = blockIdx.x;
+  const int row = (id / (8 * kLongShare)) * 8 + (id & 7);
+  const int share = (id >> 3) % kLongShare;
   if (row >= n_rows) return;
-  const int64_t bt = row / C;
-  const int ch = (int)(row - bt * C);
+  const int bt = row / C;
+  const int ch = row - bt * C;
   const int nblk = 1 << log2_nblk;
   const float* src = x + row * (int64_t)T;
-  (void)n_chunk;
   if (lane < nblk) {
     float sn, cs;
     sincospif(2.f * (float)lane / (float)nblk, &sn, &cs);
@@ -641,37 +687,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fu
     wave_lds_sync();
     const auto gain = O::g(bands[b]);
     for (int it = 0; it < n_iter; ++it) {
+      // the lane's 32 samples straight from global memory (the row is re-read once per band and stays in L2 / MALL):
+      // a row staged in LDS would cost 18 KiB per wave and hold the CU at 7 waves
+      XArr xs;
+      load_chunk_direct(xs, src, it, lane, T, vec != 0);
       typename O::Arr v;
-      // the lane's 32 samples straight from global memory (128 contiguous bytes per lane, 8 KiB per wave; the row
-      // is re-read once per band and stays in L2 / MALL): a row staged in LDS would cost 18 KiB per wave and hold
-      // the CU at 7 waves
-      const int e0 = (it * 64 + lane) * kL;
-      const bool whole = vec && (it + 1) * 64 * kL <= T;          // wave-uniform: the pass lies inside the row
-#pragma unroll
-      for (int n = 0; n < kL; n += 4) {
-        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (whole) {                                              // no per-element bounds arithmetic on the common path
-          f = *reinterpret_cast<const float4*>(src + e0 + n);
-        } else if (vec && e0 + n + 3 < T) {
-          f = *reinterpret_cast<const float4*>(src + e0 + n);
-        } else {
-          if (e0 + n + 0 < T) f.x = src[e0 + n];
-          if (e0 + n + 1 < T) f.y = src[e0 + n + 1];
-          if (e0 + n + 2 < T) f.z = src[e0 + n + 2];
-          if (e0 + n + 3 < T) f.w = src[e0 + n + 3];
-        }
-        O::put(v, n, (typename O::S)f.x * gain);
-        O::put(v, n + 1, (typename O::S)f.y * gain);
-        O::put(v, n + 2, (typename O::S)f.z * gain);
-        O::put(v, n + 3, (typename O::S)f.w * gain);
-      }
+      O::from_x(v, xs, gain);
       for (int sct = 0; sct < ns; ++sct) {
-        double c1[1] = {carry[sct * 2]}, c2[1] = {carry[sct * 2 + 1]};
+        double c1 = carry[sct * 2], c2 = carry[sct * 2 + 1];
         section<VT, 4>(v, secs[b * ns + sct], Qtab + (int64_t)(b * ns + sct) * 64, lane, c1, c2);
         wave_lds_sync();                                // every lane has read the incoming carry
         if (lane == 0) {
-          carry[sct * 2] = c1[0];
-          carry[sct * 2 + 1] = c2[0];
+          carry[sct * 2] = c1;
+          carry[sct * 2 + 1] = c2;
         }
       }
       wave_lds_sync();
@@ -685,7 +713,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fu
         for (int n = 0; n < kL; ++n) vf[n] = base + n < T ? vf[n] : 0.f;
       }
       // half-block DFT sums with block-local phase (this lane's 32 samples start at offset 32*(lane&1) in the block)
-      const float2 none = make_float2(0.f, 0.f);
       float2 P[KB];
 #pragma unroll
       for (int kk = 0; kk < KB; ++kk) {
@@ -698,7 +725,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fu
         const float2 ph = tb[kL];                       // e^{-2 pi i k 32 / n}: the odd lane's offset in the block
         P[kk] = (lane & 1) ? make_float2(acc.x * ph.x - acc.y * ph.y, acc.x * ph.y + acc.y * ph.x)
                            : make_float2(acc.x, acc.y);
-        (void)none;
       }
       const int m = it * 32 + (lane >> 1);
 #pragma unroll
@@ -712,7 +738,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fu
 #pragma unroll
     for (int kk = 0; kk < KB; ++kk) S[kk] = Sblk[kk * 64 + lane];
     blocksum_finish<KB>(S, tw, lane, k0, nbin, nblk, J, scale2, mode, eps,
-                        feat + ((bt * nb_out + bmap[b]) * C + ch) * (int64_t)J);
+                        feat + (((int64_t)bt * nb_out + bmap[b]) * C + ch) * (int64_t)J);
     wave_lds_sync();
   }
 }
@@ -756,16 +782,17 @@ extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections
       const double A[4] = {-a1, 1.0, -a2, 0.0};
       double An[4] = {1, 0, 0, 1};
       for (int k = 0; k < kL; ++k) {              // h[n] = row 0 of A^n ; afterwards An = A^32
-        sc.hd[k][0] = An[0];
-        sc.hd[k][1] = An[1];
-        sc.hf[k][0] = (float)An[0];
-        sc.hf[k][1] = (float)An[1];
         if (k < kL / 2) {
+          sc.hdq[0][k] = An[0];
+          sc.hdq[1][k] = An[1];
           sc.hq[0][k] = (float)An[0];
           sc.hq[1][k] = (float)An[1];
         }
         if (k == kL / 2)
-          for (int e = 0; e < 4; ++e) sc.N16f[e] = (float)An[e];
+          for (int e = 0; e < 4; ++e) {
+            sc.N16d[e] = An[e];
+            sc.N16f[e] = (float)An[e];
+          }
         mat2_mul(A, An, An);
       }
       double Mk[4];
@@ -861,15 +888,11 @@ extern "C" int isd_fb_plan_precision(const isd_fb_plan* p) { return p ? p->preci
 template <typename VT, int GPR>
 static int fb_launch(const isd_fb_plan* p, const FbSet& fs, const float* x, float* y, int64_t R, int C, int T,
                      hipStream_t st) {
-  constexpr int NR = VOps<VT>::NR;
-  const int64_t items = cdiv(R, (int64_t)NR * (4 / GPR));
-  ISD_CHECK_ARG(items <= 0x7fffffffLL, "isd_fb_forward: too many rows (%lld)", (long long)R);
-  const size_t lds = 4 * 16 * kPad * 4 + (GPR == 4 ? (size_t)NR * fs.nb * p->n_sections * 2 * 8 : 0);
-  ISD_CHECK_ARG(lds <= 64 * 1024, "isd_fb_forward: n_bands*n_sections too large for the carry tile");
+  const int64_t items = cdiv(R, (int64_t)(4 / GPR));
   const int vec = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  hipLaunchKernelGGL((fb_kernel<VT, GPR>), dim3((unsigned)items), dim3(64), lds, st, fs.d_sec, fs.d_band, fs.d_Q, x, y,
-                     R, C, T, fs.nb, p->n_sections, vec, fs.d_map, p->n_bands);
+  hipLaunchKernelGGL((fb_kernel<VT, GPR>), dim3((unsigned)items), dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y,
+                     (int)R, C, T, fs.nb, p->n_sections, vec, fs.d_map, p->n_bands);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
@@ -879,7 +902,12 @@ static int fb_launch_t(const isd_fb_plan* p, const FbSet& fs, const float* x, fl
                        hipStream_t st) {
   if (T <= kSeg) return fb_launch<VT, 1>(p, fs, x, y, R, C, T, st);
   if (T <= 2 * kSeg) return fb_launch<VT, 2>(p, fs, x, y, R, C, T, st);
-  return fb_launch<VT, 4>(p, fs, x, y, R, C, T, st);
+  const int vec = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  hipLaunchKernelGGL((fb_long_kernel<VT>), dim3((unsigned)(cdiv(R, 8) * 8 * kLongShare)), dim3(64), 0, st, fs.d_sec,
+                     fs.d_band, fs.d_Q, x, y, C, T, fs.nb, p->n_sections, vec, fs.d_map, p->n_bands, (int)R);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
 }
 
 extern "C" int isd_fb_forward(const isd_fb_plan* p, const float* x, float* y, int64_t B, int64_t C, int64_t T,
@@ -891,21 +919,33 @@ extern "C" int isd_fb_forward(const isd_fb_plan* p, const float* x, float* y, in
   ISD_CHECK_ARG(x && y, "isd_fb_forward: null argument");
   hipStream_t st = (hipStream_t)stream;
   const int64_t R = B * C;
+  ISD_CHECK_ARG(R <= kMaxRows, "isd_fb_forward: too many rows (%lld)", (long long)R);
   int rc = ISD_OK;
   if (p->set[0].nb) rc = fb_launch_t<float>(p, p->set[0], x, y, R, (int)C, (int)T, st);
   if (rc == ISD_OK && p->set[1].nb) rc = fb_launch_t<double>(p, p->set[1], x, y, R, (int)C, (int)T, st);
   return rc;
 }
 
+// host side of FusedBands: bin ranges plus 1 / (number of bins)
+static void set_band(FusedBands& f, int i, int klo, int khi) {
+  f.klo[i] = klo;
+  f.khi[i] = khi;
+  f.inv[i] = khi >= klo ? 1.f / (float)(khi - klo + 1) : 0.f;
+}
+
 template <typename VT>
 static int fused_launch(const isd_fb_plan* fb, const FbSet& fs, const isd_stft_plan* st, const float* x, float* feat,
                         int64_t R, int C, const FusedBands& fbnd, int mode, float eps, hipStream_t stream) {
-  const int64_t items = cdiv(R, 4 * VOps<VT>::NR);
-  ISD_CHECK_ARG(items <= 0x7fffffffLL, "isd_features_fused: too many rows (%lld)", (long long)R);
+  const int64_t items = cdiv(R, 4);
   const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  hipLaunchKernelGGL((fused_kernel<VT>), dim3((unsigned)items), dim3(64), 0, stream, fs.d_sec, fs.d_band, st->d_dft, x,
-                     feat, R, C, st->T, fs.nb, fb->n_sections, st->J, st->scale * st->scale, fbnd, mode, eps, vec,
-                     fs.d_map, fb->n_bands);
+  if (mode == ISD_BP_MAGNITUDE)
+    hipLaunchKernelGGL((fused_kernel<VT, true>), dim3((unsigned)items), dim3(64), 0, stream, fs.d_sec, fs.d_band,
+                       st->d_dft, x, feat, (int)R, C, st->T, fs.nb, fb->n_sections, st->J, st->scale * st->scale, fbnd,
+                       mode, eps, vec, fs.d_map, fb->n_bands);
+  else
+    hipLaunchKernelGGL((fused_kernel<VT, false>), dim3((unsigned)items), dim3(64), 0, stream, fs.d_sec, fs.d_band,
+                       st->d_dft, x, feat, (int)R, C, st->T, fs.nb, fb->n_sections, st->J, st->scale * st->scale, fbnd,
+                       mode, eps, vec, fs.d_map, fb->n_bands);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
@@ -929,6 +969,7 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
   int rc = fill_band_args(st, fb->n_bands, klo, khi, all.klo, all.khi, "isd_features_fused");
   if (rc) return rc;
   if (B == 0) return ISD_OK;
+  ISD_CHECK_ARG(B * C <= kMaxRows, "isd_features_fused: too many rows (%lld)", (long long)(B * C));
   hipStream_t s = (hipStream_t)stream;
   if (!short_rows) {
     // long rows, heavily overlapped frames: filterbank + block sums in one kernel per band set
@@ -943,7 +984,6 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
       if (nbin > nbmax) nbmax = nbin;
     }
     const int64_t rows = B * C;
-    ISD_CHECK_ARG(rows <= 0x7fffffffLL / 16, "isd_features_fused: too many rows (%lld)", (long long)rows);
     int log2_nblk = 0;
     while ((64 << log2_nblk) < st->n) ++log2_nblk;
     const int KB = nbmax + 2 <= 4 ? 4 : nbmax + 2 <= 5 ? 5 : nbmax + 2 <= 6 ? 6 : 8;   // band bins + two neighbours
@@ -953,15 +993,12 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
       const FbSet& fs = fb->set[k];
       if (!fs.nb) continue;
       FusedBands fbnd = {};
-      for (int i = 0; i < fs.nb; ++i) {
-        fbnd.klo[i] = all.klo[fb->host_map[k][i]];
-        fbnd.khi[i] = all.khi[fb->host_map[k][i]];
-      }
+      for (int i = 0; i < fs.nb; ++i) set_band(fbnd, i, all.klo[fb->host_map[k][i]], all.khi[fb->host_map[k][i]]);
       const size_t lds = sizeof(float2) * ((size_t)KB * 64 + 64) + sizeof(double) * 2 * kMaxSec;
 #define ISD_FL_LAUNCH(VT, K)                                                                                      \
   hipLaunchKernelGGL((fused_long_kernel<VT, K>), dim3((unsigned)(cdiv(rows, 8) * 8 * kLongShare)), dim3(64), lds, s, \
                      fs.d_sec, fs.d_band, fs.d_Q, st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections, st->J,  \
-                     log2_nblk, st->n / 2, st->scale * st->scale, fbnd, mode, eps, vec, fs.d_map, fb->n_bands, rows)
+                     log2_nblk, st->n / 2, st->scale * st->scale, fbnd, mode, eps, vec, fs.d_map, fb->n_bands, (int)rows)
       if (k == 0) {
         if (KB == 4) ISD_FL_LAUNCH(float, 4); else if (KB == 5) ISD_FL_LAUNCH(float, 5);
         else if (KB == 6) ISD_FL_LAUNCH(float, 6); else ISD_FL_LAUNCH(float, 8);
@@ -978,10 +1015,7 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
     const FbSet& fs = fb->set[k];
     if (!fs.nb) continue;
     FusedBands fbnd = {};                                  // the set's bands, in the set's order
-    for (int i = 0; i < fs.nb; ++i) {
-      fbnd.klo[i] = all.klo[fb->host_map[k][i]];
-      fbnd.khi[i] = all.khi[fb->host_map[k][i]];
-    }
+    for (int i = 0; i < fs.nb; ++i) set_band(fbnd, i, all.klo[fb->host_map[k][i]], all.khi[fb->host_map[k][i]]);
     rc = k ? fused_launch<double>(fb, fs, st, x, feat, B * C, (int)C, fbnd, mode, eps, s)
            : fused_launch<float>(fb, fs, st, x, feat, B * C, (int)C, fbnd, mode, eps, s);
     if (rc) return rc;
@@ -992,12 +1026,16 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
 int isd::bandpower_direct(const isd_stft_plan* st, const float* y, float* feat, int64_t R, int C, int nb,
                           const int* klo, const int* khi, int mode, float eps, hipStream_t stream) {
   FusedBands fbnd = {};
-  for (int b = 0; b < nb; ++b) { fbnd.klo[b] = klo[b]; fbnd.khi[b] = khi[b]; }
+  for (int b = 0; b < nb; ++b) set_band(fbnd, b, klo[b], khi[b]);
   const int64_t items = cdiv(R, 4);
-  ISD_CHECK_ARG(items <= 0x7fffffffLL, "isd_stft_bandpower: too many rows (%lld)", (long long)R);
+  ISD_CHECK_ARG(R <= kMaxRows, "isd_stft_bandpower: too many rows (%lld)", (long long)R);
   const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  hipLaunchKernelGGL(bandpower_direct_kernel, dim3((unsigned)items), dim3(64), 0, stream, st->d_dft, y, feat, R, C,
-                     st->T, nb, st->J, st->scale * st->scale, fbnd, mode, eps, vec);
+  if (mode == ISD_BP_MAGNITUDE)
+    hipLaunchKernelGGL(bandpower_direct_kernel<true>, dim3((unsigned)items), dim3(64), 0, stream, st->d_dft, y, feat,
+                       (int)R, C, st->T, nb, st->J, st->scale * st->scale, fbnd, mode, eps, vec);
+  else
+    hipLaunchKernelGGL(bandpower_direct_kernel<false>, dim3((unsigned)items), dim3(64), 0, stream, st->d_dft, y, feat,
+                       (int)R, C, st->T, nb, st->J, st->scale * st->scale, fbnd, mode, eps, vec);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }

@@ -219,15 +219,24 @@ extern "C" int isd_stft_plan_create(isd_stft_plan** out, int T, int nperseg, int
   p->scale = (float)(1.0 / wsum);
   for (int i = 0; i < nperseg / 2; ++i)
     tw[i] = make_float2((float)cos(2.0 * M_PI * i / nperseg), (float)(-sin(2.0 * M_PI * i / nperseg)));
-  // direct-DFT table for the fused 64/32 kernel: tab[k][n] = w[n] * exp(-2 pi i k n / 64)
+  // direct-DFT table for the fused 64/32 kernel: w[n] * exp(-2 pi i k n / 64), laid out for a lane that holds its 32
+  // samples as register pairs {j, j + 16}: tab[k][c][j] = (t_c[j], t_c[j + 16]), c = 0/1: real/imaginary part over
+  // the first window half (n = 0..31), c = 2/3: over the second half (n = 32..63).  A packed FMA of a sample pair
+  // with one table entry then needs no broadcast of either operand; the two lanes of the sum are added at the end.
   std::vector<float2> dft;
   if (nperseg == 64) {
     dft.resize(33 * 64);
     for (int k = 0; k <= 32; ++k)
-      for (int i = 0; i < 64; ++i) {
-        const double ph = 2.0 * M_PI * ((k * i) % 64) / 64.0;
-        dft[k * 64 + i] = make_float2((float)((double)win[i] * cos(ph)), (float)(-(double)win[i] * sin(ph)));
-      }
+      for (int c = 0; c < 4; ++c)
+        for (int j = 0; j < 16; ++j) {
+          float t[2];
+          for (int h = 0; h < 2; ++h) {
+            const int i = (c >> 1) * 32 + j + 16 * h;
+            const double ph = 2.0 * M_PI * ((k * i) % 64) / 64.0;
+            t[h] = (c & 1) ? (float)(-(double)win[i] * sin(ph)) : (float)((double)win[i] * cos(ph));
+          }
+          dft[k * 64 + c * 16 + j] = make_float2(t[0], t[1]);
+        }
   }
   // block-sum table for heavily overlapped frames
   std::vector<float2> blk;

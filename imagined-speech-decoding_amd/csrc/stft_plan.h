@@ -7,7 +7,7 @@ struct isd_stft_plan {
   float scale;          // 1 / sum(window)  (scipy scaling='spectrum')
   float* d_win;         // [n] periodic Hann
   float2* d_tw;         // [n/2] exp(-2 pi i k / n)
-  float2* d_dft;        // n == 64 only: [33][64] w[n] * exp(-2 pi i k n / 64)
+  float2* d_dft;        // n == 64 only: [33][4][16] w[n] * exp(-2 pi i k n / 64) as sample pairs (stft.hip plan create)
   float2* d_blk;        // heavily overlapped frames (n = 2^a * hop, hop 32 or 64, T <= 64 * hop): [n/2+1][hop]
                         // exp(-2 pi i k i / n), the per-block DFT table of the block-sum band-power kernel
 };
