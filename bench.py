@@ -146,11 +146,15 @@ def filterbank_hbm_roofline(fx, x, nb, n=4):
     y = torch.empty((Bs, nb, C, T), dtype=torch.float32, device=x.device)
     ms = hip_event_ms(lambda: fx.fb.forward(xs, out=y), torch.cuda.current_stream(), n)
     by = per_trial * Bs
-    launches = {"f32": "fb_kernel<float,%d>", "f64": "fb_kernel<double,%d>",
-                "mixed": "fb_kernel<float,%d> + fb_kernel<double,%d> (per-band precision)"}[fx.fb.precision]
-    gpr = 1 if T <= 512 else 2 if T <= 1024 else 4
+    if T <= 1024:
+        launches = {"f32": "fb_kernel<float,%d>", "f64": "fb_kernel<double,%d>",
+                    "mixed": "fb_kernel<float,%d> + fb_kernel<double,%d> (per-band precision)"}[fx.fb.precision]
+        launches = launches.replace("%d", "1" if T <= 512 else "2")
+    else:
+        launches = {"f32": "fb_long_kernel_f32", "f64": "fb_long_kernel_f64",
+                    "mixed": "fb_long_kernel_f32 + fb_long_kernel_f64 (per-band precision)"}[fx.fb.precision]
     del y
-    return {"bound": "hbm", "kernel": launches.replace("%d", str(gpr)), "achieved": round(by / (ms * 1e-3) / 1e9, 1),
+    return {"bound": "hbm", "kernel": launches, "achieved": round(by / (ms * 1e-3) / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": None, "ms_per_pass": round(ms, 4), "trials_per_pass": Bs, "algorithmic_bytes_per_pass": by}
 

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "stft_plan.h"
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 #include <string.h>
 #include <type_traits>
@@ -135,8 +136,12 @@ __device__ __forceinline__ void scan_step(double& e1, double& e2, const double* 
 
 // One biquad section over the lane's chunk, including the cross-chunk state fix-up.
 // c1/c2: incoming state of the wave's first group (GPR == 4 loop carry), updated.
+// Qsec (GPR > 1): the 16 per-lane matrices M^i of this section, [16][4] doubles.  The long-row kernels stage them in
+// LDS once per band: as a per-lane global load inside the section they were waited for ~100 instructions after issue,
+// at L2 latency under a saturated write stream (PMC: the fp32 long-row kernel sat in s_waitcnt for half of its wave
+// cycles).
 template <typename VT, int GPR>
-__device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& sc, const double* __restrict__ Qsec,
+__device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& sc, const double* Qsec,
                                         int lane, double& c1, double& c2) {
   // in-chunk recursion from zero state, both halves side by side; sA = final state of the first half,
   // (e1, e2) = state after the whole chunk = A^16 sA + sB
@@ -195,7 +200,7 @@ __device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& 
     double C1[4], C2[4];
     C1[0] = (GPR == 4) ? c1 : 0.0;
     C2[0] = (GPR == 4) ? c2 : 0.0;
-    const FbSec& sp = *later(&sc);
+    const FbSec& sp = sm;
 #pragma unroll
     for (int g = 1; g < 4; ++g) {
       if (g % GPR == 0) {
@@ -213,7 +218,9 @@ __device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& 
     const int q = lane >> 4;
     const double m1 = q == 0 ? C1[0] : q == 1 ? C1[1] : q == 2 ? C1[2] : C1[3];
     const double m2 = q == 0 ? C2[0] : q == 1 ? C2[1] : q == 2 ? C2[2] : C2[3];
-    const double* Q = Qsec + (lane & 15) * 4;          // M^i of this lane
+    const double2* Q2 = reinterpret_cast<const double2*>(Qsec + (lane & 15) * 4);      // M^i of this lane
+    const double2 Qa = Q2[0], Qb = Q2[1];
+    const double Q[4] = {Qa.x, Qa.y, Qb.x, Qb.y};
     i1 = fma(Q[0], m1, fma(Q[1], m2, i1));
     i2 = fma(Q[2], m1, fma(Q[3], m2, i2));
   }
@@ -233,15 +240,25 @@ __device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& 
     const double u1 = fma(sh.N16d[0], i1, fma(sh.N16d[1], i2, sA1d));
     const double u2 = fma(sh.N16d[2], i1, fma(sh.N16d[3], i2, sA2d));
 #pragma unroll
-    for (int q = 0; q < kL / 2; q += 4) {
-      const FbSec& sq = *later(&sc);                         // 8 table doubles (16 SGPRs) per batch
+    for (int q = 0; q < kL / 2; q += 8) {
+      const FbSec& sq = *later(&sc);                         // 16 table doubles (32 SGPRs) per batch
 #pragma unroll
-      for (int j = q; j < q + 4; ++j) {
+      for (int j = q; j < q + 8; ++j) {
         const double h1 = sq.hdq[0][j], h2 = sq.hdq[1][j];
         v[j] = fma(h1, i1, fma(h2, i2, v[j]));
         v[j + 16] = fma(h1, u1, fma(h2, u2, v[j + 16]));
       }
     }
+  }
+}
+
+// The band's per-lane matrices (Qtab: [band * ns + section][16 lanes][4 doubles]) into LDS, 32 bytes per lane.
+__device__ __forceinline__ void stage_q(double* Qlds, const double* __restrict__ Qtab, int b, int ns, int lane) {
+  for (int e = lane; e < ns * 16; e += 64) {
+    const double2* q = reinterpret_cast<const double2*>(Qtab + (int64_t)b * ns * 64 + e * 4);
+    const double2 a = q[0], c = q[1];
+    reinterpret_cast<double2*>(Qlds + e * 4)[0] = a;
+    reinterpret_cast<double2*>(Qlds + e * 4)[1] = c;
   }
 }
 
@@ -313,14 +330,24 @@ __device__ __forceinline__ void load_chunks(XArr& xs, float* tile, const float* 
   }
 }
 
-// The lane's chunk written back as 32 consecutive floats of its LDS tile row.
+// The lane's chunk written back as 32 consecutive floats of its LDS tile row.  fp32: register pair j holds samples
+// j and j + 16, which is exactly one ds_write2_b32 (two dword slots 16 apart) -- assembling float4s first costs 32
+// register moves and their temporaries, which the 96-register fp32 long-row kernel does not have.
 template <typename VT>
 __device__ __forceinline__ void chunk_to_tile(float* dst, const typename VOps<VT>::Arr& v) {
-  using O = VOps<VT>;
+  if constexpr (std::is_same<VT, float>::value) {
+    // (inline asm: written as scalar stores, the SLP vectoriser re-assembles the float4s.  A DS write reads its
+    // operands at issue and wave_lds_sync() waits for lgkmcnt(0) before any lane reads the tile.)
+    const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)dst;
 #pragma unroll
-  for (int n = 0; n < kL; n += 4)
-    *reinterpret_cast<float4*>(dst + n) = make_float4((float)O::at(v, n), (float)O::at(v, n + 1),
-                                                      (float)O::at(v, n + 2), (float)O::at(v, n + 3));
+    for (int j = 0; j < kL / 2; ++j)
+      asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(a), "v"(v[j].x), "v"(v[j].y), "i"(j), "i"(j + 16)
+                   : "memory");
+  } else {
+#pragma unroll
+    for (int n = 0; n < kL; n += 4)
+      *reinterpret_cast<float4*>(dst + n) = make_float4((float)v[n], (float)v[n + 1], (float)v[n + 2], (float)v[n + 3]);
+  }
 }
 
 // Rows of at most 1024 samples.  One wave per workgroup; GPR = 16-lane groups per row (1: T<=512, 2: T<=1024);
@@ -368,34 +395,44 @@ __global__ __launch_bounds__(64) void fb_kernel(const FbSec* __restrict__ secs, 
   }
 }
 
-// The lane's 32 samples of pass `it` straight from global memory (128 contiguous bytes per lane, 8 KiB per wave).
-__device__ __forceinline__ void load_chunk_direct(XArr& xs, const float* __restrict__ src, int it, int lane, int T,
-                                                  bool vec) {
+// The lane's 32 samples of pass `it` straight from global memory (128 contiguous bytes per lane, 8 KiB per wave), in
+// two steps so that the loads can be requested long before they are needed:
+//   chunk_issue  -- eight float4 loads, unconditionally and back to back (addresses clamped into the row);
+//   chunk_finish -- zeroes what lies past the end of the row (ragged last pass only) and forms the sample pairs.
+// With the bounds tests around the individual loads the compiler merged the variants per load and put an
+// s_waitcnt vmcnt(0) behind every one of them: eight serial L2 round trips per pass (PMC: the fp32 long-row kernel
+// sat in s_waitcnt for half of its wave cycles).  VEC: rows are 16-byte aligned and T % 4 == 0.
+template <bool VEC>
+__device__ __forceinline__ void chunk_issue(float4 (&f)[kL / 4], const float* __restrict__ src, int it, int lane,
+                                            int T) {
   const int e0 = (it * 64 + lane) * kL;
-  const bool whole = vec && (it + 1) * 64 * kL <= T;            // wave-uniform: the pass lies inside the row
-  float4 f[kL / 4];
+  if (VEC) {
+    const int emax = T - 4;                                     // last valid float4 of the row
 #pragma unroll
-  for (int n = 0; n < kL; n += 4) {
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (whole) {                                                // no per-element bounds arithmetic on the common path
-      q = *reinterpret_cast<const float4*>(src + e0 + n);
-    } else if (vec && e0 + n + 3 < T) {
-      q = *reinterpret_cast<const float4*>(src + e0 + n);
-    } else {
-      if (e0 + n + 0 < T) q.x = src[e0 + n];
-      if (e0 + n + 1 < T) q.y = src[e0 + n + 1];
-      if (e0 + n + 2 < T) q.z = src[e0 + n + 2];
-      if (e0 + n + 3 < T) q.w = src[e0 + n + 3];
+    for (int n = 0; n < kL / 4; ++n) {
+      const int e = e0 + 4 * n;
+      f[n] = *reinterpret_cast<const float4*>(src + (e < emax ? e : emax));
     }
-    f[n / 4] = q;
-  }
+  } else {
+    const int last = T - 1;
 #pragma unroll
-  for (int n = 0; n < kL / 2; n += 4) {
-    const float4 a = f[n / 4], b = f[n / 4 + 4];
-    xs[n] = (f2){a.x, b.x};
-    xs[n + 1] = (f2){a.y, b.y};
-    xs[n + 2] = (f2){a.z, b.z};
-    xs[n + 3] = (f2){a.w, b.w};
+    for (int n = 0; n < kL / 4; ++n) {
+      const int e = e0 + 4 * n;
+      f[n] = make_float4(src[e < last ? e : last], src[e + 1 < last ? e + 1 : last], src[e + 2 < last ? e + 2 : last],
+                         src[e + 3 < last ? e + 3 : last]);
+    }
+  }
+}
+__device__ __forceinline__ float f4_get(const float4& q, int c) { return c == 0 ? q.x : c == 1 ? q.y : c == 2 ? q.z : q.w; }
+__device__ __forceinline__ void chunk_finish(XArr& xs, const float4 (&f)[kL / 4], int it, int lane, int T) {
+  if ((it + 1) * 64 * kL > T) {                                 // wave-uniform: the ragged last pass
+    const int e0 = (it * 64 + lane) * kL;
+#pragma unroll
+    for (int j = 0; j < kL / 2; ++j)
+      xs[j] = (f2){e0 + j < T ? f4_get(f[j >> 2], j & 3) : 0.f, e0 + j + 16 < T ? f4_get(f[(j >> 2) + 4], j & 3) : 0.f};
+  } else {
+#pragma unroll
+    for (int j = 0; j < kL / 2; ++j) xs[j] = (f2){f4_get(f[j >> 2], j & 3), f4_get(f[(j >> 2) + 4], j & 3)};
   }
 }
 
@@ -409,13 +446,19 @@ constexpr int kLongShare = 8;                    // one-wave workgroups sharing 
 // kLongShare-th band; their ids are congruent mod 8 (workgroups go to the 8 XCDs round-robin by id, each XCD has its
 // own L2) inside 64 consecutive ids, so the re-reads of a row hit one L2.  The filtered pass leaves through half of
 // the chunk-major LDS tile at a time (coalesced float4 stores, 4.6 KiB of LDS per wave).
-template <typename VT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fb_long_kernel(
+template <typename VT, bool VEC, bool EARLYX>
+__device__ __forceinline__ void fb_long_body(
     const FbSec* __restrict__ secs, const FbBand* __restrict__ bands, const double* __restrict__ Qtab,
-    const float* __restrict__ x, float* __restrict__ y, int C, int T, int nb, int ns, int vec,
+    const float* __restrict__ x, float* __restrict__ y, int C, int T, int nb, int ns,
     const int* __restrict__ bmap, int nb_out, int n_rows) {
   using O = VOps<VT>;
+  // EARLYX: the x pass of the NEXT (band, pass) is requested in front of this pass's stores (vmcnt retires in issue
+  // order, so a load issued behind the eight stores waits for their acknowledgement).  Measured on the fp32 instance:
+  // 1.96 ms per 128 stress trials at the 4 waves per SIMD its 32 extra live registers leave, against 1.70 ms without
+  // it at 5 waves -- not dispatched.
+  constexpr bool kEarlyX = EARLYX;
   __shared__ __attribute__((aligned(16))) float tile[2 * 16 * kPad];        // 32 chunks: half a pass
+  __shared__ __attribute__((aligned(16))) double Qlds[kMaxSec * 64];        // the band's per-lane M^i
   __shared__ double carry[kMaxSec * 2];
   const int lane = threadIdx.x;
   const int n_iter = (T + 4 * kSeg - 1) / (4 * kSeg);
@@ -428,25 +471,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fb
   const float* src = x + row * (int64_t)T;
   float* dst0 = y + ((int64_t)bt * nb_out * C + ch) * (int64_t)T;
   const int64_t bstride = (int64_t)C * T;
+  float4 xf[kL / 4];
+  if (kEarlyX) chunk_issue<VEC>(xf, src, 0, lane, T);
   for (int b = share; b < nb; b += kLongShare) {
     if (lane < ns * 2) carry[lane] = 0.0;
+    stage_q(Qlds, Qtab, b, ns, lane);
     wave_lds_sync();
     float* dst = dst0 + (int64_t)bmap[b] * bstride;
     const auto gain = O::g(bands[b]);
     for (int it = 0; it < n_iter; ++it) {
-      XArr xs;
-      load_chunk_direct(xs, src, it, lane, T, vec != 0);
+      if (!kEarlyX) chunk_issue<VEC>(xf, src, it, lane, T);
       typename O::Arr v;
-      O::from_x(v, xs, gain);
+      {
+        XArr xs;
+        chunk_finish(xs, xf, it, lane, T);
+        O::from_x(v, xs, gain);
+      }
       for (int sct = 0; sct < ns; ++sct) {
         double c1 = carry[sct * 2], c2 = carry[sct * 2 + 1];
-        section<VT, 4>(v, secs[b * ns + sct], Qtab + (int64_t)(b * ns + sct) * 64, lane, c1, c2);
+        section<VT, 4>(v, secs[b * ns + sct], Qlds + sct * 64, lane, c1, c2);
         wave_lds_sync();                                // every lane has read the incoming carry
         if (lane == 0) {
           carry[sct * 2] = c1;
           carry[sct * 2 + 1] = c2;
         }
       }
+      if (kEarlyX) chunk_issue<VEC>(xf, src, it + 1 < n_iter ? it + 1 : 0, lane, T);
       // transposition to coalesced stores, half a pass (1024 samples = 32 chunks) at a time
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -461,7 +511,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fb
           if (t >= T) continue;
           const float4 val = *reinterpret_cast<const float4*>(tile + (e >> 5) * kPad + (e & 31));
           float* p = dst + t;
-          if (vec && t + 3 < T) {
+          if (VEC) {                                    // T % 4 == 0: t < T implies t + 3 < T
             *reinterpret_cast<float4*>(p) = val;
           } else {
             p[0] = val.x;
@@ -475,6 +525,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fb
     wave_lds_sync();
   }
 }
+
+#define ISD_FB_LONG_ARGS                                                                                          \
+  const FbSec *__restrict__ secs, const FbBand *__restrict__ bands, const double *__restrict__ Qtab,            \
+      const float *__restrict__ x, float *__restrict__ y, int C, int T, int nb, int ns,                         \
+      const int *__restrict__ bmap, int nb_out, int n_rows
+// the register cap is per instance: 96 VGPRs (5 waves per SIMD) for fp32, 128 (4 waves) for fp64
+template <bool VEC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void fb_long_kernel_f32(ISD_FB_LONG_ARGS) {
+  fb_long_body<float, VEC, false>(secs, bands, Qtab, x, y, C, T, nb, ns, bmap, nb_out, n_rows);
+}
+template <bool VEC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fb_long_kernel_f64(ISD_FB_LONG_ARGS) {
+  fb_long_body<double, VEC, false>(secs, bands, Qtab, x, y, C, T, nb, ns, bmap, nb_out, n_rows);
+}
+#undef ISD_FB_LONG_ARGS
 
 struct FusedBands {
   int klo[kMaxBands];
@@ -649,12 +714,13 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
 // by id, and each XCD has its own L2 -- and lie within 64 consecutive ids, so the sharers run on one XCD at about
 // the same time and the rows in flight there (~80 x 16 KiB) fit its 4 MiB L2.  With one workgroup per row walking
 // all bands the rows in flight were ~10x the L2: the PMC counters showed 6.1 GB through the fabric for a 268 MB input.
-template <typename VT, int KB>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fused_long_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
+template <typename VT, int KB, bool VEC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(std::is_same<VT, float>::value && KB <= 5 ? 5 : 4)))
+void fused_long_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                                                         const double* __restrict__ Qtab, const float2* __restrict__ blk,
                                                         const float* __restrict__ x, float* __restrict__ feat, int C,
                                                         int T, int nb, int ns, int J, int log2_nblk, int n_bins_max,
-                                                        float scale2, FusedBands fbnd, int mode, float eps, int vec,
+                                                        float scale2, FusedBands fbnd, int mode, float eps,
                                                         const int* __restrict__ bmap, int nb_out, int n_rows) {
   using O = VOps<VT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -662,7 +728,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fu
   const int n_iter = (T + 4 * kSeg - 1) / (4 * kSeg);
   float2* Sblk = reinterpret_cast<float2*>(smem_raw);                      // [KB][64]
   float2* tw = Sblk + KB * 64;                                             // [64]  e^{-2 pi i u / nblk}
-  double* carry = reinterpret_cast<double*>(tw + 64);                      // [ns][2]
+  double* carry = reinterpret_cast<double*>(tw + 64);                      // [kMaxSec][2]
+  double* Qlds = carry + kMaxSec * 2;                                      // [kMaxSec][16][4] the band's per-lane M^i
   // id = 8 kLongShare q + 8 w + c  <->  row = 8 q + c, band subset w
   const int id = blockIdx.x;
   const int row = (id / (8 * kLongShare)) * 8 + (id & 7);
@@ -678,24 +745,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fu
     tw[lane] = make_float2(cs, -sn);
   }
   wave_lds_sync();
+  const int lane0 = lane;
   for (int b = share; b < nb; b += kLongShare) {
+    // lane-derived addresses are recomputed per band instead of staying live across the whole kernel: hoisted, they
+    // were what the fp64 instance spilled to scratch at its 128-register cap (13 dwords per lane, written once per
+    // wave: 436 MB of scratch writes per 128 trials for 68 MB of features)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
     const int klo = fbnd.klo[b], khi = fbnd.khi[b];
     const int k0 = klo - 1, nbin = khi - klo + 1;
 #pragma unroll
     for (int kk = 0; kk < KB; ++kk) Sblk[kk * 64 + lane] = make_float2(0.f, 0.f);
     if (lane < ns * 2) carry[lane] = 0.0;
+    stage_q(Qlds, Qtab, b, ns, lane);
     wave_lds_sync();
     const auto gain = O::g(bands[b]);
     for (int it = 0; it < n_iter; ++it) {
       // the lane's 32 samples straight from global memory (the row is re-read once per band and stays in L2 / MALL):
       // a row staged in LDS would cost 18 KiB per wave and hold the CU at 7 waves
-      XArr xs;
-      load_chunk_direct(xs, src, it, lane, T, vec != 0);
       typename O::Arr v;
-      O::from_x(v, xs, gain);
+      {
+        float4 xf[kL / 4];
+        chunk_issue<VEC>(xf, src, it, lane, T);
+        XArr xs;
+        chunk_finish(xs, xf, it, lane, T);
+        O::from_x(v, xs, gain);
+      }
       for (int sct = 0; sct < ns; ++sct) {
         double c1 = carry[sct * 2], c2 = carry[sct * 2 + 1];
-        section<VT, 4>(v, secs[b * ns + sct], Qtab + (int64_t)(b * ns + sct) * 64, lane, c1, c2);
+        section<VT, 4>(v, secs[b * ns + sct], Qlds + sct * 64, lane, c1, c2);
         wave_lds_sync();                                // every lane has read the incoming carry
         if (lane == 0) {
           carry[sct * 2] = c1;
@@ -904,8 +982,12 @@ static int fb_launch_t(const isd_fb_plan* p, const FbSet& fs, const float* x, fl
   if (T <= 2 * kSeg) return fb_launch<VT, 2>(p, fs, x, y, R, C, T, st);
   const int vec = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  hipLaunchKernelGGL((fb_long_kernel<VT>), dim3((unsigned)(cdiv(R, 8) * 8 * kLongShare)), dim3(64), 0, st, fs.d_sec,
-                     fs.d_band, fs.d_Q, x, y, C, T, fs.nb, p->n_sections, vec, fs.d_map, p->n_bands, (int)R);
+  const dim3 grid((unsigned)(cdiv(R, 8) * 8 * kLongShare));
+#define ISD_FBL(K) hipLaunchKernelGGL(K, grid, dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y, C, T, fs.nb, \
+                                      p->n_sections, fs.d_map, p->n_bands, (int)R)
+  if (std::is_same<VT, float>::value) { if (vec) ISD_FBL(fb_long_kernel_f32<true>); else ISD_FBL(fb_long_kernel_f32<false>); }
+  else { if (vec) ISD_FBL(fb_long_kernel_f64<true>); else ISD_FBL(fb_long_kernel_f64<false>); }
+#undef ISD_FBL
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
@@ -994,11 +1076,12 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
       if (!fs.nb) continue;
       FusedBands fbnd = {};
       for (int i = 0; i < fs.nb; ++i) set_band(fbnd, i, all.klo[fb->host_map[k][i]], all.khi[fb->host_map[k][i]]);
-      const size_t lds = sizeof(float2) * ((size_t)KB * 64 + 64) + sizeof(double) * 2 * kMaxSec;
-#define ISD_FL_LAUNCH(VT, K)                                                                                      \
-  hipLaunchKernelGGL((fused_long_kernel<VT, K>), dim3((unsigned)(cdiv(rows, 8) * 8 * kLongShare)), dim3(64), lds, s, \
-                     fs.d_sec, fs.d_band, fs.d_Q, st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections, st->J,  \
-                     log2_nblk, st->n / 2, st->scale * st->scale, fbnd, mode, eps, vec, fs.d_map, fb->n_bands, (int)rows)
+      const size_t lds = sizeof(float2) * ((size_t)KB * 64 + 64) + sizeof(double) * (2 * kMaxSec + 64 * kMaxSec);
+#define ISD_FL_LAUNCH2(VT, K, V)                                                                                      \
+  hipLaunchKernelGGL((fused_long_kernel<VT, K, V>), dim3((unsigned)(cdiv(rows, 8) * 8 * kLongShare)), dim3(64), lds, s, \
+                     fs.d_sec, fs.d_band, fs.d_Q, st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections, st->J,      \
+                     log2_nblk, st->n / 2, st->scale * st->scale, fbnd, mode, eps, fs.d_map, fb->n_bands, (int)rows)
+#define ISD_FL_LAUNCH(VT, K) do { if (vec) ISD_FL_LAUNCH2(VT, K, true); else ISD_FL_LAUNCH2(VT, K, false); } while (0)
       if (k == 0) {
         if (KB == 4) ISD_FL_LAUNCH(float, 4); else if (KB == 5) ISD_FL_LAUNCH(float, 5);
         else if (KB == 6) ISD_FL_LAUNCH(float, 6); else ISD_FL_LAUNCH(float, 8);
@@ -1006,6 +1089,7 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
         if (KB == 4) ISD_FL_LAUNCH(double, 4); else if (KB == 5) ISD_FL_LAUNCH(double, 5);
         else if (KB == 6) ISD_FL_LAUNCH(double, 6); else ISD_FL_LAUNCH(double, 8);
       }
+#undef ISD_FL_LAUNCH2
 #undef ISD_FL_LAUNCH
       ISD_LAUNCH_CHECK();
     }
