@@ -44,6 +44,16 @@ __device__ __forceinline__ float bf16_round(float x) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return __uint_as_float(u & 0xffff0000u);
 }
+// two floats -> packed bf16 pair (RNE; v_cvt_pk_bf16_f32), low half = a
+__device__ __forceinline__ unsigned int bf16_pack(float a, float b) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef float fl2 __attribute__((ext_vector_type(2)));
+  const bf2 r = __builtin_convertvector((fl2){a, b}, bf2);
+  return __builtin_bit_cast(unsigned int, r);
+}
+__device__ __forceinline__ float bf16_lo(unsigned int u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int u) { return __uint_as_float(u & 0xffff0000u); }
+typedef short bf16x8 __attribute__((ext_vector_type(8)));   // MFMA operand: 8 bf16 in 4 VGPRs
 template <typename AT> struct Act;
 template <> struct Act<float> {
   static constexpr bool kBf16 = false;
@@ -103,10 +113,14 @@ struct PrepConvArgs {
   int64_t zstride;
   int n_layers;
 };
+// `wfrag16` (nullable): the same fused first-layer weights as bf16 MFMA A fragments in "tap-window" order (the
+// bf16 first-layer kernels below): block (cg, gt) holds, for lane l, the 8 bf16
+//   W[gt*16 + (l&15)][4*cg + (l>>4)][tap j],  j = 0..4, then three zeros            (16 bytes per lane).
 __global__ __launch_bounds__(256) void prep_fused_kernel(const float* __restrict__ params,
                                                          const ZoneDesc* __restrict__ zones,
                                                          float* __restrict__ wfrag, float* __restrict__ beff, int F,
-                                                         int nbw, int bf16, PrepConvArgs pc) {
+                                                         int nbw, int bf16, PrepConvArgs pc,
+                                                         uint4* __restrict__ wfrag16) {
   __shared__ float red[256];
   const int z = blockIdx.y;
   const ZoneDesc zd = zones[z];
@@ -144,6 +158,14 @@ __global__ __launch_bounds__(256) void prep_fused_kernel(const float* __restrict
     for (int k = 0; k < kTaps; ++k) {
       const float v = acc[k];
       wfrag[zd.eff_off + ((int64_t)(cg * kTaps + k) * GT + gt) * 64 + lane] = bf16 ? bf16_round(v) : v;
+    }
+    if (wfrag16) {
+      uint4 w;
+      w.x = bf16_pack(acc[0], acc[1]);
+      w.y = bf16_pack(acc[2], acc[3]);
+      w.z = bf16_pack(acc[4], 0.f);
+      w.w = 0u;
+      wfrag16[zd.eff_off / kTaps + ((int64_t)cg * GT + gt) * 64 + lane] = w;
     }
     return;
   }
@@ -497,6 +519,123 @@ __global__ __launch_bounds__(256) void conv5_fwd_glds_kernel(ConvArgs a) {
         if (a.bias) v += a.bias[z * a.F + g];
         ((float*)a.out)[((item * a.Z + z) * a.F + g) * (int64_t)a.Tout + t] = v;
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// BASELINE config 3 (bf16-mixed, scripts/train_fast.py:277): first-layer forward on the bf16 matrix cores.
+//   v_mfma_f32_16x16x32_bf16, M = 16 filters, N = 16 time steps, K = 32 = 4 input channels x an 8-sample window.
+// The K index of a channel runs over time: lane (t = l & 15, q = l >> 4) supplies the B operand
+//   x[c = 4 cg + q][t + j],  j = 0..7
+// and the A operand holds the 5 taps of that channel followed by three zeros (prep_fused_kernel, `wfrag16`), so one
+// MFMA applies all five taps of four channels (5/8 of its K is used; at 16x the fp32 rate the matrix pipe is idle
+// either way -- the kernel is bound by streaming x).  The window of a lane is built from ONE LDS dword per lane and
+// DPP row shifts (lane t holds x[c][t]; x[c][t + j] is the value of lane t + j of its 16-lane row): no transposed
+// staging, no per-lane gather.  Inputs stay fp32 in LDS (LDS-DMA, double-buffered as in conv5_fwd_glds_kernel) and are
+// rounded to bf16 (RNE) as the fragment is packed; accumulation is fp32; the output is written as bf16 in
+// [item][t][filter] order (8-byte stores of the lane's four consecutive filters), which is the layout the bf16 tail
+// and the bf16 weight-gradient kernel read.
+// Preconditions (host): one column tile (Tout <= 13 so that only sample 16 lies beyond the DPP row), Tin <= 17,
+// contiguous zone channels, whole-row windows, cin % 4 == 0, 16-byte aligned row blocks.
+// ---------------------------------------------------------------------------------------
+template <int GT, int NT>
+__global__ __launch_bounds__(256) void conv5_fwd_bf16_kernel(ConvArgs a, const uint4* __restrict__ wfrag16) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int z = blockIdx.y;
+  const ZoneDesc zd = a.zones[z];
+  const int cin = zd.cin;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t item0 = (int64_t)blockIdx.x * a.IPW;
+  const int n_items = (int)((a.items - item0) < a.IPW ? (a.items - item0) : a.IPW);
+  const int in_len = (a.IPW * kCK * a.RS + 3) & ~3;
+  constexpr int w_len = (kCK / 4) * GT * 64 * 4;            // floats: 16 bytes per lane and fragment
+  const int buf_len = in_len + w_len + 32;                  // 32 floats of slack: dead lanes read past the last row
+  const uint4* wbase = wfrag16 + zd.eff_off / kTaps;
+  const int n_chunks = (cin + kCK - 1) / kCK;
+  const int q = lane >> 4, jl = lane & 15;
+  const int chan0 = a.chan_idx[zd.idx_off];
+
+  auto stage = [&](int ch, int s) {
+    float* in_tile = smem + 4 + s * buf_len;
+    float* w_tile = in_tile + in_len;
+    const int c_lo = ch * kCK;
+    const int ckc = (cin - c_lo) < kCK ? (cin - c_lo) : kCK;
+    const int cnt4 = (ckc * a.Tin) >> 2;
+    for (int ii = wave; ii < n_items; ii += 4) {
+      const int64_t soff = ((item0 + ii) * a.Ctot + chan0 + c_lo) * (int64_t)a.Tx;
+      glds_copy16((const float*)a.in + soff, in_tile + ii * kCK * a.RS, cnt4, lane);
+    }
+    const int wlen4 = (ckc / 4) * GT * 64;                  // 16-byte pieces of the weight chunk
+    glds_copy16_strided(reinterpret_cast<const float*>(wbase + (int64_t)ch * (kCK / 4) * GT * 64), w_tile, wlen4,
+                        wave * 64, 256, lane);
+  };
+
+  f32x4 acc[NT][GT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int g = 0; g < GT; ++g) acc[j][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int t_ii[NT], boff[NT];
+  bool t_ok[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ct = j * 4 + wave;                            // one column tile per item (TT == 1)
+    t_ok[j] = ct < n_items;
+    t_ii[j] = t_ok[j] ? ct : 0;
+    boff[j] = t_ii[j] * kCK * a.RS + q * a.RS;
+  }
+  const bool has16 = a.Tin > 16;
+  const int j0 = jl < a.Tin ? jl : 0;                       // lane's own sample (rows shorter than 16: clamp, then zero)
+  const bool own_ok = jl < a.Tin;
+  stage(0, 0);
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    __syncthreads();                                        // drains this wave's DMA of chunk ch; all waves left chunk ch-1
+    if (ch + 1 < n_chunks) stage(ch + 1, (ch + 1) & 1);
+    const float* in_tile = smem + 4 + (ch & 1) * buf_len;
+    const uint4* w_tile = reinterpret_cast<const uint4*>(in_tile + in_len) + lane;
+    const int c_lo = ch * kCK;
+    const int ncg = ((cin - c_lo) < kCK ? (cin - c_lo) : kCK) / 4;
+    for (int cg = 0; cg < ncg; ++cg) {
+      bf16x8 af[GT];
+#pragma unroll
+      for (int g = 0; g < GT; ++g) af[g] = __builtin_bit_cast(bf16x8, w_tile[(cg * GT + g) * 64]);
+      const float* rowp = in_tile + cg * 4 * a.RS;
+#pragma unroll
+      for (int jj = 0; jj < NT; ++jj) {
+        const float* r = rowp + boff[jj];
+        float e0 = r[j0];
+        e0 = own_ok ? e0 : 0.f;
+        float s16 = has16 ? r[16] : 0.f;                    // the one sample beyond the DPP row that a stored output needs
+        s16 = jl == 12 ? s16 : 0.f;
+        const float e1 = row_shl<1>(e0), e2 = row_shl<2>(e0), e3 = row_shl<3>(e0), e4 = row_shl<4>(e0) + s16;
+        uint4 bw;
+        bw.x = bf16_pack(e0, e1);
+        bw.y = bf16_pack(e2, e3);
+        bw.z = bf16_pack(e4, 0.f);
+        bw.w = 0u;
+        const bf16x8 bfr = __builtin_bit_cast(bf16x8, bw);
+#pragma unroll
+        for (int g = 0; g < GT; ++g)
+          acc[jj][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g], bfr, acc[jj][g], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: D[row g = 4 q + r][col t = jl] -> out[item][t][g], four consecutive filters per lane
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    if (!t_ok[j] || jl >= a.Tout) continue;
+    const int64_t item = item0 + t_ii[j];
+#pragma unroll
+    for (int gt = 0; gt < GT; ++gt) {
+      const int g = gt * 16 + 4 * q;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[j][gt][r] + (a.bias ? a.bias[z * a.F + g + r] : 0.f);
+      uint2 o;
+      o.x = bf16_pack(v[0], v[1]);
+      o.y = bf16_pack(v[2], v[3]);
+      *reinterpret_cast<uint2*>((unsigned short*)a.out + ((item * a.Z + z) * a.Tout + jl) * (int64_t)a.F + g) = o;
     }
   }
 }
@@ -956,8 +1095,8 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a
 // the 4 waves through LDS in wave order and leave as one slab per workgroup: [dW3 | dW4 | dW_fc | db_fc | loss].
 // ---------------------------------------------------------------------------------------
 struct TailArgs {
-  const float* a2;           // [items][F][T1]
-  float* g2;                 // [items][F][T1] gradient w.r.t. A2 (training)
+  const void* a2;            // fp32 [items][F][T1], or (BF) bf16 [items][T1][F]
+  void* g2;                  // same layout: gradient w.r.t. A2 (training)
   const float* w3;           // frag-ordered cnn3 / cnn4 weights and their transposed + flipped copies (zone 0)
   const float* w4;
   const float* w3t;
@@ -1062,19 +1201,23 @@ __device__ __forceinline__ void tail_wgrad(const float* const (&G)[NI], const fl
   }
 }
 
+template <bool BF = false>
 __device__ __forceinline__ void tail_store_tile(const f32x4 (&acc)[2], float* __restrict__ tile, int T1, int q, int jl) {
   if (jl < T1) {
 #pragma unroll
     for (int gt = 0; gt < 2; ++gt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tile[(gt * 16 + 4 * q + r) * T1 + jl] = acc[gt][r];
+      for (int r = 0; r < 4; ++r) tile[(gt * 16 + 4 * q + r) * T1 + jl] = BF ? bf16_round(acc[gt][r]) : acc[gt][r];
   }
 }
 
 constexpr int kTailMaxCls = 16;
 constexpr int kTailNI = 1;        // items a wave carries side by side (measured at cfg 2: 1 -> 107 us, 2 -> 116 us: 512 VGPRs + spills)
 
-template <int NW>
+// BF (BASELINE config 3): A2 arrives and G2 leaves as bf16 in [item][t][filter] order (the bf16 first-layer kernels),
+// and every activation / activation gradient the tail hands from one layer to the next is rounded to bf16 (the
+// cnn3 / cnn4 fragment copies already are); the products are those of a bf16 MFMA, the accumulation is fp32.
+template <int NW, bool BF>
 __global__ __launch_bounds__(NW * 64) void featcnn_tail_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int F = 32, NI = kTailNI, WF = 8 * kTaps * 2 * 64;              // 5120 floats per fragment set
@@ -1133,10 +1276,21 @@ __global__ __launch_bounds__(NW * 64) void featcnn_tail_kernel(TailArgs a) {
     for (int i = 0; i < NI; ++i) {
       live[i] = first + i < a.items;
       item[i] = live[i] ? first + i : first;
-      const float4* src = reinterpret_cast<const float4*>(a.a2 + item[i] * tile);
-      float4* dst = reinterpret_cast<float4*>(tA2[i]);
-      if (lane < n4) dst[lane] = src[lane];
-      if (lane + 64 < n4) dst[lane + 64] = src[lane + 64];
+      if constexpr (BF) {
+        // [t][32] bf16: piece p = 8 consecutive filters of one step -> the fp32 [filter][t] tile
+        if (lane < 4 * T1) {
+          const uint4 w = reinterpret_cast<const uint4*>((const unsigned short*)a.a2 + item[i] * tile)[lane];
+          const int t = lane >> 2, g0 = (lane & 3) * 8;
+          float* d = tA2[i] + g0 * T1 + t;
+          d[0] = bf16_lo(w.x); d[T1] = bf16_hi(w.x); d[2 * T1] = bf16_lo(w.y); d[3 * T1] = bf16_hi(w.y);
+          d[4 * T1] = bf16_lo(w.z); d[5 * T1] = bf16_hi(w.z); d[6 * T1] = bf16_lo(w.w); d[7 * T1] = bf16_hi(w.w);
+        }
+      } else {
+        const float4* src = reinterpret_cast<const float4*>((const float*)a.a2 + item[i] * tile);
+        float4* dst = reinterpret_cast<float4*>(tA2[i]);
+        if (lane < n4) dst[lane] = src[lane];
+        if (lane + 64 < n4) dst[lane + 64] = src[lane + 64];
+      }
     }
     wave_lds_sync();
     f32x4 acc[NI][2];
@@ -1150,10 +1304,18 @@ __global__ __launch_bounds__(NW * 64) void featcnn_tail_kernel(TailArgs a) {
     clear();
     tail_conv<NI>(w3s + lane, tA2, T1, q, jl, acc);           // A3
 #pragma unroll
-    for (int i = 0; i < NI; ++i) tail_store_tile(acc[i], tA3[i], T1, q, jl);
+    for (int i = 0; i < NI; ++i) tail_store_tile<BF>(acc[i], tA3[i], T1, q, jl);
     wave_lds_sync();
     clear();
     tail_conv<NI>(w4s + lane, tA3, T1, q, jl, acc);           // A4 stays in registers
+    if constexpr (BF) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][gt][r] = bf16_round(acc[i][gt][r]);
+    }
     // GELU + mean over time: row sums inside each 16-lane row
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -1219,7 +1381,7 @@ __global__ __launch_bounds__(NW * 64) void featcnn_tail_kernel(TailArgs a) {
           for (int c = 0; c < n_cls; ++c) d = fmaf(fcs[c * F + g], logL[i][16 + c], d);
           acc[i][gt][r] = d * inv_t * gelu_grad_f(acc[i][gt][r]);
         }
-      tail_store_tile(acc[i], tG[i], T1, q, jl);
+      tail_store_tile<BF>(acc[i], tG[i], T1, q, jl);
       // FC gradients: flat element e = lane + 64 j of [n_cls][F]
 #pragma unroll
       for (int j = 0; j < kTailMaxCls * F / 64; ++j) {
@@ -1233,7 +1395,7 @@ __global__ __launch_bounds__(NW * 64) void featcnn_tail_kernel(TailArgs a) {
     clear();
     tail_conv<NI>(w4ts + lane, tG, T1, q, jl, acc);           // G3
 #pragma unroll
-    for (int i = 0; i < NI; ++i) tail_store_tile(acc[i], tH[i], T1, q, jl);
+    for (int i = 0; i < NI; ++i) tail_store_tile<BF>(acc[i], tH[i], T1, q, jl);
     wave_lds_sync();
     tail_wgrad<NI>(tH, tA2, T1, q, jl, accW3);
     clear();
@@ -1245,10 +1407,21 @@ __global__ __launch_bounds__(NW * 64) void featcnn_tail_kernel(TailArgs a) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
       if (live[i]) {
-        float4* dst = reinterpret_cast<float4*>(a.g2 + item[i] * tile);
-        const float4* src = reinterpret_cast<const float4*>(tG[i]);
-        if (lane < n4) dst[lane] = src[lane];
-        if (lane + 64 < n4) dst[lane + 64] = src[lane + 64];
+        if constexpr (BF) {
+          if (lane < 4 * T1) {
+            const int t = lane >> 2, g0 = (lane & 3) * 8;
+            const float* sp = tG[i] + g0 * T1 + t;
+            uint4 w;
+            w.x = bf16_pack(sp[0], sp[T1]); w.y = bf16_pack(sp[2 * T1], sp[3 * T1]);
+            w.z = bf16_pack(sp[4 * T1], sp[5 * T1]); w.w = bf16_pack(sp[6 * T1], sp[7 * T1]);
+            reinterpret_cast<uint4*>((unsigned short*)a.g2 + item[i] * tile)[lane] = w;
+          }
+        } else {
+          float4* dst = reinterpret_cast<float4*>((float*)a.g2 + item[i] * tile);
+          const float4* src = reinterpret_cast<const float4*>(tG[i]);
+          if (lane < n4) dst[lane] = src[lane];
+          if (lane + 64 < n4) dst[lane + 64] = src[lane + 64];
+        }
       }
     wave_lds_sync();                                          // tiles are reused by the next items
   }
@@ -1706,6 +1879,138 @@ __global__ __launch_bounds__(256) void conv5_wgrad_wide_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// BASELINE config 3: first-layer weight gradient on the bf16 matrix cores (companion of conv5_fwd_bf16_kernel).
+//   dW[g][c][k] = sum_items sum_t G[item][t][g] x[item][c][t + k],   v_mfma_f32_16x16x32_bf16 with
+//   M = 16 filters, N = 16 input channels, K = 32 = 2 items x 16 output steps (rows t >= Tout are zero).
+// A operand: the gradient arrives as bf16 [item][t][filter] (the bf16 tail writes it so); its LDS image keeps that
+//   layout, padded to 16 zero-filled rows per item, and ds_read_b64_tr_b16 delivers the transposed 8-step fragment
+//   (lane g <- column g of rows t0..t0+7: two 4-row blocks).
+// B operand: lane (channel c, q) reads the 12 consecutive fp32 samples x[c][8 (q & 1) .. + 11] of item q >> 1 once
+//   and packs them to bf16 twice (even and odd pairs): the five tap windows are register subsets, no shuffles.
+//   Samples past the end of a row belong to the next row (finite) and meet zero rows of the A operand.
+// Same workgroup roles, LDS-DMA double buffering, slab layout and dbias column as conv5_wgrad_wide_kernel.
+// Preconditions (host): F = 32 (64-byte gradient rows), Tout <= 13, Tin <= 17, IPS even.
+// ---------------------------------------------------------------------------------------
+template <int GT>
+__global__ __launch_bounds__(256) void conv5_wgrad_wide_bf16_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int z = blockIdx.y;
+  const ZoneDesc zd = a.zones[z];
+  const int cin = zd.cin, cin1 = zd.cin + 1;
+  const int c_base = blockIdx.z * 64;
+  if (c_base >= cin) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, jl = lane & 15;
+  const int cw = (cin - c_base) < 64 ? (cin - c_base) : 64;         // real rows of this channel group (multiple of 4)
+  const int c_mine = c_base + wave * 16 + jl;
+  const bool wave_live = c_base + wave * 16 < cin;
+  const bool with_bias = blockIdx.z == 0 && wave == 0;
+  const int do_len = 16 * a.F / 2;                                  // floats: 16 rows x F bf16 (rows >= Tout stay zero)
+  const int do_real4 = (a.Tout * a.F * 2) >> 4;                     // 16-byte pieces actually copied
+  const int in_len = 64 * a.Tin;                                    // per item (stride; cw * Tin are filled)
+  const int item_len = (do_len + in_len + 3) & ~3;
+  const int buf_len = a.IPS * item_len + 32;
+  const int64_t i_lo = (int64_t)blockIdx.x * a.items_per_wg;
+  const int64_t i_hi = (i_lo + a.items_per_wg) < a.items ? (i_lo + a.items_per_wg) : a.items;
+  const int chan0 = a.chan_idx[zd.idx_off];
+  // zero everything once: the pad rows of the gradient images are never written by the DMA, and the tail of both
+  // buffers is read by the last rows' junk columns
+  for (int e = threadIdx.x; e < 2 * buf_len + 8; e += 256) smem[e] = 0.f;
+  __syncthreads();
+
+  auto stage = [&](int64_t is, int s) {
+    float* buf = smem + s * buf_len;
+    const int n_it = (int)((i_hi - is) < a.IPS ? (i_hi - is) : a.IPS);
+    for (int ii = wave; ii < a.IPS; ii += 4) {
+      float* dst = buf + ii * item_len;
+      if (ii < n_it) {
+        glds_copy16(reinterpret_cast<const float*>((const unsigned short*)a.dout +
+                                                   ((is + ii) * a.Z + z) * (int64_t)a.Tout * a.F),
+                    dst, do_real4, lane);
+        glds_copy16((const float*)a.in + ((is + ii) * a.Ctot + chan0 + c_base) * (int64_t)a.Tx, dst + do_len,
+                    (cw * a.Tin) >> 2, lane);
+      } else {
+        // a missing second item of the last pair: its gradient image must read as zero (the x rows may be stale)
+        for (int e = lane; e < do_len; e += 64) dst[e] = 0.f;
+      }
+    }
+  };
+
+  f32x4 acc[GT][kTaps], accb[GT];
+#pragma unroll
+  for (int g = 0; g < GT; ++g) {
+    accb[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) acc[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int ih = q >> 1, t0 = 8 * (q & 1);                            // this lane group's item of the pair, first step
+  // transposed read: lane 4 r + p of a 16-lane group supplies row r, columns 4 p .. 4 p + 3 of a 4 x 16 block
+  const unsigned a_byte = (unsigned)((t0 + (jl >> 2)) * a.F + 4 * (jl & 3)) * 2u;
+  const int b_off = do_len + (wave * 16 + jl) * a.Tin + t0;          // x[c][t0 ...]
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem;
+  const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  int s = 0;
+  if (i_lo < i_hi) stage(i_lo, 0);
+  for (int64_t is = i_lo; is < i_hi; is += a.IPS, s ^= 1) {
+    __syncthreads();                                                   // DMA of this stage retired; previous stage consumed
+    if (is + a.IPS < i_hi) stage(is + a.IPS, s ^ 1);
+    if (!wave_live) continue;
+    const int n_it = (int)((i_hi - is) < a.IPS ? (i_hi - is) : a.IPS);
+    for (int ip = 0; ip < n_it; ip += 2) {
+      const int item_off = (s * buf_len + (ip + ih) * item_len);       // floats from smem
+      // A: G^T fragments of both filter tiles (rows t0 .. t0 + 7 of this lane group's item)
+      bf16x8 af[GT];
+#pragma unroll
+      for (int g = 0; g < GT; ++g) {
+        const unsigned addr = smem_base + (unsigned)item_off * 4u + a_byte + (unsigned)(g * 16 * 2);
+        uint2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(lo), "=&v"(hi)
+                     : "v"(addr), "i"(4 * 32 * 2)
+                     : "memory");
+        af[g] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+      }
+      // B: 12 samples of this lane's channel, packed as even pairs (e0e1, e2e3, ...) and odd pairs (e1e2, e3e4, ...)
+      const float* xr = smem + item_off + b_off;
+      float e[12];
+#pragma unroll
+      for (int n = 0; n < 12; ++n) e[n] = xr[n];
+      unsigned int pe[6], po[5];
+#pragma unroll
+      for (int n = 0; n < 6; ++n) pe[n] = bf16_pack(e[2 * n], e[2 * n + 1]);
+#pragma unroll
+      for (int n = 0; n < 5; ++n) po[n] = bf16_pack(e[2 * n + 1], e[2 * n + 2]);
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k) {
+        const int h = k >> 1;
+        const uint4 bw = (k & 1) ? make_uint4(po[h], po[h + 1], po[h + 2], po[h + 3])
+                                 : make_uint4(pe[h], pe[h + 1], pe[h + 2], pe[h + 3]);
+        const bf16x8 bfr = __builtin_bit_cast(bf16x8, bw);
+#pragma unroll
+        for (int g = 0; g < GT; ++g) acc[g][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g], bfr, acc[g][k], 0, 0, 0);
+      }
+      if (with_bias) {
+#pragma unroll
+        for (int g = 0; g < GT; ++g) accb[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g], ones, accb[g], 0, 0, 0);
+      }
+    }
+  }
+  if (!wave_live) return;
+  float* slab = a.part + (int64_t)blockIdx.x * a.slab_size + zd.wg_off;
+#pragma unroll
+  for (int g = 0; g < GT; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gg = g * 16 + 4 * q + r;
+      if (c_mine < cin) {
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) slab[((int64_t)gg * cin1 + c_mine) * kTaps + k] = acc[g][k][r];
+      }
+      if (with_bias && jl < kTaps) slab[((int64_t)gg * cin1 + cin) * kTaps + jl] = jl == 0 ? accb[g][r] : 0.f;
+    }
+}
+
 // sum the per-workgroup slabs: out[e] = sum_s part[s][e].  Block = 64 elements x 4 slab groups
 // (coalesced 256-B rows, 4 independent load streams per element, LDS combine).  blockIdx.y selects a run of
 // L slabs (slab index = k * stride); with gridDim.y > 1 the run's sum is written over its own first slab, and
@@ -1938,7 +2243,7 @@ struct Geo {           // derived sizes for one call
   int N, T1, TT, IPW, RS_a, RS_b, lin0, CK;
   int64_t items, act;  // act = floats of one activation tensor
   // workspace layout (floats)
-  int64_t o_eff, o_beff, o_w3, o_w3t, o_w4, o_w4t, o_a2, o_a3, o_a4, o_s, o_wg, o_wg34, o_part, total;
+  int64_t o_eff, o_eff16, o_beff, o_w3, o_w3t, o_w4, o_w4t, o_a2, o_a3, o_a4, o_s, o_wg, o_wg34, o_part, total;
   int ipw0, ipw1, ns0, ns1, cw0, cw1, grp0, grp1;   // wgrad: items per wg, slabs (incl. wave groups), channels per wg
   int64_t slab0, slab1;
 };
@@ -1984,6 +2289,7 @@ int make_geo(const isd_conv4_plan* p, int64_t B, int64_t T, Geo& g) {
   }
   int64_t o = 0;
   g.o_eff = o;  o += align_up(p->eff_size, 64);
+  g.o_eff16 = o; o += align_up(p->eff_size / kTaps * 4, 64);      // bf16 tap-window fragments: 16 bytes per (cg, gt, lane)
   g.o_beff = o; o += align_up((int64_t)p->Z * p->F, 64);
   const int64_t cw = align_up(p->conv_zstride * p->Z, 64);
   g.o_w3 = o; o += cw; g.o_w3t = o; o += cw; g.o_w4 = o; o += cw; g.o_w4t = o; o += cw;
@@ -2066,20 +2372,30 @@ static int launch_conv(int mode, int bf16, const ConvArgs& a, int n_zones, hipSt
   return ISD_OK;
 }
 
-static int launch_prep(const isd_conv4_plan* p, const Geo& g, const float* params, float* ws, hipStream_t st) {
+static int launch_prep(const isd_conv4_plan* p, const Geo& g, const float* params, float* ws, hipStream_t st,
+                       bool tap16 = false) {
   const int F = p->F;
   const int nbw = (int)cdiv(((int64_t)(p->max_cz + 3) / 4) * 4 * F, 256);
   PrepConvArgs pc{ws + g.o_w3, ws + g.o_w3t, ws + g.o_w4, ws + g.o_w4t, p->conv_zstride, p->n_layers};
   const int extra = p->n_layers == 4 ? 8 : 0;
   hipLaunchKernelGGL(prep_fused_kernel, dim3(nbw + F + extra, p->Z), dim3(256), 0, st, params, p->d_zones,
-                     ws + g.o_eff, ws + g.o_beff, F, nbw, p->act_bf16, pc);
+                     ws + g.o_eff, ws + g.o_beff, F, nbw, p->act_bf16, pc,
+                     tap16 ? reinterpret_cast<uint4*>(ws + g.o_eff16) : (uint4*)nullptr);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
 
+// BASELINE config 3 on the bf16 matrix cores: the classifier step (isd_featcnn_step) qualifies when the first layer is
+// one column tile of at most 13 output steps over whole, contiguous, 16-byte aligned rows (the spec-S feature map:
+// 17 frames) with 32 filters
+static bool bf16_mfma_ok(const isd_conv4_plan* p, const Geo& g, const void* x) {
+  return p->act_bf16 && p->F == 32 && g.lin0 && p->dma_ok && g.TT == 1 && g.T1 <= 13 && p->W <= 17 &&
+         ((uintptr_t)x & 15) == 0;
+}
+
 // cnn1 o cnn2 forward into the A2 buffer; `a` comes back filled with the shared fields for the later layers
 static int first_layer_forward(const isd_conv4_plan* p, const Geo& g, const float* x, int64_t T, float* ws,
-                               hipStream_t st, ConvArgs& a) {
+                               hipStream_t st, ConvArgs& a, bool tap16 = false) {
   const int F = p->F;
   int rc;
   a = ConvArgs{};
@@ -2089,6 +2405,32 @@ static int first_layer_forward(const isd_conv4_plan* p, const Geo& g, const floa
   // cnn1 o cnn2
   a.in = x; a.out = ws + g.o_a2; a.wfrag = ws + g.o_eff; a.bias = ws + g.o_beff; a.Tin = p->W; a.pad = 0; a.RS = g.RS_a;
   a.lin = g.lin0;
+  if (tap16) {
+    // bf16 matrix cores: 4 items per wave (NT), 16 per workgroup; fewer when the batch is small
+    int NT = 4;
+    int ipw = 16;
+    const int64_t per_cu = cdiv(g.items * p->Z, 512);
+    if (per_cu < ipw) { ipw = per_cu < 4 ? 4 : (int)per_cu; }
+    NT = (ipw + 3) / 4;
+    if (NT == 3) { NT = 4; }
+    ipw = NT * 4;
+    const size_t buf = (size_t)(((ipw * kCK * p->W + 3) & ~3) + (kCK / 4) * 2 * 64 * 4 + 32);
+    const size_t lds = sizeof(float) * (4 + 2 * buf);
+    a.IPW = ipw; a.RS = p->W;
+    const dim3 grid((unsigned)cdiv(g.items, ipw), p->Z);
+    const uint4* w16 = reinterpret_cast<const uint4*>(ws + g.o_eff16);
+#define ISD_BF_LAUNCH(N)                                                                                        \
+  do {                                                                                                          \
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_fwd_bf16_kernel<2, N>,                                   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+    hipLaunchKernelGGL((conv5_fwd_bf16_kernel<2, N>), grid, dim3(256), lds, st, a, w16);                        \
+  } while (0)
+    if (NT == 4) ISD_BF_LAUNCH(4); else if (NT == 2) ISD_BF_LAUNCH(2); else ISD_BF_LAUNCH(1);
+#undef ISD_BF_LAUNCH
+    ISD_LAUNCH_CHECK();
+    a.IPW = g.IPW;
+    return ISD_OK;
+  }
   {
     // wide inputs (>= 2 channel chunks): double-buffered LDS-DMA variant.  Two workgroups of 8 column tiles per CU
     // when there is enough work (the barrier / DMA wait of one runs under the MFMAs of the other), else one of 16.
@@ -2255,7 +2597,7 @@ __global__ void scatter_conv_grad_kernel(const float* __restrict__ wg, const isd
 
 // cnn1 o cnn2 backward: dWeff (+ dbeff in the ones channel) from g2 = dL/dA2, then the chain to W1, b1, W2
 static int first_layer_backward(const isd_conv4_plan* p, const Geo& g, const float* x, int64_t T, const float* params,
-                                const float* g2, float* dparams, float* ws, hipStream_t st) {
+                                const float* g2, float* dparams, float* ws, hipStream_t st, bool tap16 = false) {
   const int F = p->F;
   int rc;
   WgradArgs w = {};
@@ -2279,7 +2621,18 @@ static int first_layer_backward(const isd_conv4_plan* p, const Geo& g, const flo
     int ips = 4;
     while (ips > 1 && (size_t)(2 * (ips * item_len + 32) + 8) * 4 > 48 * 1024) --ips;
     const size_t lds = sizeof(float) * (size_t)(2 * (ips * item_len + 32) + 8);
-    if (g.lin0 && p->dma_ok && !p->act_bf16 && p->max_cz >= 64 && (F * g.T1) % 4 == 0 && lds <= 64 * 1024 &&
+    if (tap16) {
+      // bf16 matrix cores: gradient images of 16 x 32 bf16 (1 KiB) + 64 input rows per item, item pairs per K step
+      const int item16 = (16 * F / 2 + 64 * p->W + 3) & ~3;
+      const int ips16 = 4;
+      const size_t lds16 = sizeof(float) * (size_t)(2 * (ips16 * item16 + 32) + 8);
+      w.items_per_wg = ipw; w.IPS = ips16;
+      const dim3 grid((unsigned)R, p->Z, zg);
+      hipLaunchKernelGGL(conv5_wgrad_wide_bf16_kernel<2>, grid, dim3(256), lds16, st, w);
+      ISD_LAUNCH_CHECK();
+      n_slabs0 = R;
+      rc = ISD_OK;
+    } else if (g.lin0 && p->dma_ok && !p->act_bf16 && p->max_cz >= 64 && (F * g.T1) % 4 == 0 && lds <= 64 * 1024 &&
         ((uintptr_t)x & 15) == 0 && ((uintptr_t)g2 & 15) == 0) {
       w.items_per_wg = ipw; w.IPS = ips;
       const dim3 grid((unsigned)R, p->Z, zg);
@@ -2307,16 +2660,16 @@ static int first_layer_backward(const isd_conv4_plan* p, const Geo& g, const flo
 // One call for the whole classifier step on spec-S features: conv stack -> Linear -> softmax-CE forward and
 // backward (featcnn_tail_kernel between the two first-layer kernels).
 // ---------------------------------------------------------------------------------------
-static bool featcnn_ok(const isd_conv4_plan* p, const Geo& g, int n_cls) {
-  return p->Z == 1 && p->n_layers == 4 && p->F == 32 && !p->act_bf16 && g.TT == 1 && g.N == 1 && n_cls >= 1 &&
-         n_cls <= kTailMaxCls;
+static bool featcnn_ok(const isd_conv4_plan* p, const Geo& g, int n_cls, const void* x = nullptr) {
+  return p->Z == 1 && p->n_layers == 4 && p->F == 32 && (!p->act_bf16 || bf16_mfma_ok(p, g, x)) && g.TT == 1 &&
+         g.N == 1 && n_cls >= 1 && n_cls <= kTailMaxCls;
 }
 
 extern "C" int isd_featcnn_supported(const isd_conv4_plan* p, int64_t B, int64_t T, int n_cls) {
   if (!p || B < 1) return 0;
   Geo g;
   if (make_geo(p, B, T, g)) return 0;
-  return featcnn_ok(p, g, n_cls) ? 1 : 0;
+  return featcnn_ok(p, g, n_cls) ? 1 : 0;       // (bf16: additionally x must be 16-byte aligned; isd_featcnn_step checks)
 }
 
 extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const float* params, const float* fc_w,
@@ -2328,11 +2681,12 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
   Geo g;
   int rc = make_geo(p, B, T, g);
   if (rc) return rc;
-  if (!featcnn_ok(p, g, n_cls)) {
-    set_error("isd_featcnn_step: needs one zone, 4 layers, 32 filters, fp32 activations, <= 16 output steps, <= %d classes",
-              kTailMaxCls);
+  if (!featcnn_ok(p, g, n_cls, x)) {
+    set_error("isd_featcnn_step: needs one zone, 4 layers, 32 filters, <= 16 output steps (bf16 activations: <= 13, over "
+              "whole 16-byte aligned rows of at most 17 samples), <= %d classes", kTailMaxCls);
     return ISD_ERR_UNSUPPORTED;
   }
+  const bool tap16 = p->act_bf16 != 0;
   ISD_CHECK_ARG(x && params && fc_w && fc_b && logits && pred && workspace, "isd_featcnn_step: null argument");
   ISD_CHECK_ARG(!labels || label_bytes == 1 || label_bytes == 8, "isd_featcnn_step: labels must be uint8 or int64");
   const bool train = labels && dparams && dfc;
@@ -2340,10 +2694,10 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const int F = p->F;
-  rc = launch_prep(p, g, params, ws, st);
+  rc = launch_prep(p, g, params, ws, st, tap16);
   if (rc) return rc;
   ConvArgs a = {};
-  rc = first_layer_forward(p, g, x, T, ws, st, a);
+  rc = first_layer_forward(p, g, x, T, ws, st, a, tap16);
   if (rc) return rc;
   TailArgs t = {};
   t.a2 = ws + g.o_a2; t.g2 = ws + g.o_a4;
@@ -2360,8 +2714,13 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
   const int tile = (F * g.T1 + 3) & ~3;
   const size_t lds = sizeof(float) * (size_t)(4 * 8 * kTaps * 2 * 64 + kTailMaxCls * (F + 1) + TNW * kTailNI * (4 * tile + 64) + 16);
   ISD_CHECK_ARG(lds <= 160 * 1024 && (int64_t)blocks * t.slab <= g.total - g.o_part, "isd_featcnn_step: workspace");
-  ISD_HIP_TRY(hipFuncSetAttribute((const void*)featcnn_tail_kernel<TNW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(featcnn_tail_kernel<TNW>, dim3(blocks), dim3(TNW * 64), lds, st, t);
+  if (tap16) {
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)featcnn_tail_kernel<TNW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((featcnn_tail_kernel<TNW, true>), dim3(blocks), dim3(TNW * 64), lds, st, t);
+  } else {
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)featcnn_tail_kernel<TNW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((featcnn_tail_kernel<TNW, false>), dim3(blocks), dim3(TNW * 64), lds, st, t);
+  }
   ISD_LAUNCH_CHECK();
   if (!labels) return ISD_OK;
   if (train) {
@@ -2376,7 +2735,7 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
   }
   ISD_LAUNCH_CHECK();
   if (!train) return ISD_OK;
-  return first_layer_backward(p, g, x, T, params, ws + g.o_a4, dparams, ws, st);
+  return first_layer_backward(p, g, x, T, params, ws + g.o_a4, dparams, ws, st, tap16);
 }
 
 static int conv4_backward_impl(const isd_conv4_plan* p, const float* x, const float* params, const float* dfeat,

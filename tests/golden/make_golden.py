@@ -363,8 +363,43 @@ def g14():
     save("g14_cfg5_composed.npz", **out)
 
 
+# ---------------------------------------------------------------- G15: bf16-mixed (autocast) classifier at 576 channels
+def g15_inputs(m, fc):
+    """Parameters and inputs of G15 from NumPy's seeded generator (the tests rebuild them the same way, so the 2.4 MB
+    cnn2.weight is not stored): U(-1/sqrt(fan_in), 1/sqrt(fan_in)) like the torch default initialisation."""
+    rng = np.random.default_rng(15)
+    with torch.no_grad():
+        for mod, fan in ((m.cnn1, 5), (m.cnn2, 32 * 576), (m.cnn3, 160), (m.cnn4, 160), (fc, 32)):
+            for prm in mod.parameters():
+                prm.copy_(torch.from_numpy(rng.uniform(-1, 1, tuple(prm.shape)).astype(np.float32) / np.sqrt(fan)))
+    x = torch.from_numpy((rng.standard_normal((8, 576, 17)) * 2 - 5).astype(np.float32))      # log-power-like values
+    y = torch.from_numpy(rng.integers(0, 5, 8))
+    return x, y
+
+
+def g15():
+    """BASELINE config 3: the reference trains with precision='bf16-mixed' (scripts/train_fast.py:277), i.e.
+    torch.autocast(bfloat16) around the module.  The reference's Conv4Layers(576, 32) (fast.py:103-119) + Linear(32, 5)
+    on a spec-S shaped feature map [8, 576, 17], fp32 master weights: logits, loss and every gradient under CPU
+    autocast, and the same in fp32 (what the tolerance of the bf16 path is stated against)."""
+    m = Conv4Layers(576, 32)
+    fc = torch.nn.Linear(32, 5)
+    x, y = g15_inputs(m, fc)
+    out = {"labels": y.numpy().astype(np.uint8)}
+    for tag, ctx in (("fp32", torch.autocast("cpu", enabled=False)), ("bf16", torch.autocast("cpu", dtype=torch.bfloat16))):
+        m.zero_grad(); fc.zero_grad()
+        with ctx:
+            logits = fc(m(x))
+            loss = torch.nn.CrossEntropyLoss()(logits.float(), y)
+        loss.backward()
+        out[f"{tag}.logits"], out[f"{tag}.loss"] = logits.detach().float().numpy(), loss.detach().numpy()
+        for k, v in {**grads_np(m, f"{tag}.cnn.grad."), **grads_np(fc, f"{tag}.fc.grad.")}.items():
+            out[k] = v[:, :, ::9].copy() if k.endswith("cnn2.weight") else v      # every 9th of the 576 channels
+    save("g15_bf16_autocast.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5_g9, g6, g7, g8, g10, g11, g12, g13, g14):
+    for fn in (g1, g2, g3, g4, g5_g9, g6, g7, g8, g10, g11, g12, g13, g14, g15):
         if not only or fn.__name__ in only:
             fn()

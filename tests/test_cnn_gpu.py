@@ -299,3 +299,62 @@ def test_bf16_activation_mode_tolerance_vs_fp32(inn):
     x = torch.randn(4, 64, 250, device="cuda")
     a, b = h32(x).detach(), h16(x).detach()
     assert 0 < rel_err(b.cpu(), a.cpu()) < 2e-2
+
+
+def test_bf16_matrix_core_step_vs_reference_autocast_at_576_channels(inn):
+    """BASELINE config 3 at the cfg2 width: the classifier step on the bf16 matrix cores (conv5_fwd_bf16_kernel,
+    featcnn_tail_kernel<.., true>, conv5_wgrad_wide_bf16_kernel behind isd_featcnn_step) against G15 = the reference's
+    Conv4Layers(576, 32) + Linear under torch.autocast(bfloat16) on CPU (scripts/train_fast.py:277), and against its
+    fp32 run.  Stated tolerance: logits 2e-2 and parameter gradients 5e-2 of the tensor's largest magnitude, against
+    either -- the reference's own autocast run deviates from its fp32 run by 4e-3 / 8e-3 here."""
+    from test_oracle import g15_params
+    import isd_amd
+    from isd_amd.classifier import _FeatureModel
+    import isd_amd._lib as L
+    g = load_golden("g15_bf16_autocast.npz")
+    p, x, y = g15_params()
+    outs = {}
+    for mode in ("f32", "bf16"):
+        m = _FeatureModel(576, 32, 5, 4, mode).cuda()
+        m.net.cnn.load_state_dict({k: v for k, v in p.items() if k.startswith("cnn")})
+        m.net.fc.load_state_dict({k[3:]: v for k, v in p.items() if k.startswith("fc.")})
+        xd = x.cuda().contiguous()
+        assert L.lib().isd_featcnn_supported(m.conv_plan(xd)._h, 8, 17, 5) == 1
+        out = isd_amd.HotPath(m).forward(xd, y.cuda(), want_grad=True)
+        grads = {k: q.grad.detach().cpu().numpy().copy() for k, q in m.net.named_parameters()}
+        outs[mode] = (out["logits"].cpu().numpy(), float(out["loss"]), grads)
+    lg32, loss32, g32 = outs["f32"]
+    lg16, loss16, g16 = outs["bf16"]
+    assert rel_err(lg32, g["fp32.logits"]) < 1e-4 and abs(loss32 - float(g["fp32.loss"])) < 1e-5
+    for ref in ("bf16", "fp32"):
+        assert 0 < rel_err(lg16, g[f"{ref}.logits"]) < 2e-2, ref
+        assert abs(loss16 - float(g[f"{ref}.loss"])) < 5e-3, ref
+        for k, got in g16.items():
+            want = g[f"{ref}." + ("fc.grad." + k[3:] if k.startswith("fc.") else "cnn.grad." + k[4:])]
+            got = got[:, :, ::9] if k == "cnn.cnn2.weight" else got
+            assert rel_err(got, want) < 5e-2, (ref, k)
+    assert np.array_equal(lg16.argmax(1), g["bf16.logits"].argmax(1))
+
+
+@pytest.mark.parametrize("B,C,T", [(64, 72, 17), (37, 576, 17), (5, 64, 9), (130, 128, 16)])
+def test_bf16_matrix_core_step_shapes_vs_fp32_path(inn, B, C, T):
+    """Ragged batches (not a multiple of the items per workgroup / the item pairs of the weight gradient), a partial
+    last channel chunk, rows shorter than a DPP row: the bf16 step stays within its stated tolerance of the fp32 step;
+    inference, loss-only and training calls agree with each other."""
+    import isd_amd
+    from isd_amd.classifier import _FeatureModel
+    torch.manual_seed(B + C)
+    m32 = _FeatureModel(C, 32, 5, 4, "f32").cuda()
+    m16 = _FeatureModel(C, 32, 5, 4, "bf16").cuda()
+    m16.load_state_dict(m32.state_dict())
+    x = (torch.randn(B, C, T, device="cuda") * 2 - 5).contiguous()
+    y = torch.randint(0, 5, (B,), device="cuda")
+    o32 = isd_amd.HotPath(m32).forward(x, y, want_grad=True)
+    hp16 = isd_amd.HotPath(m16)
+    o16 = hp16.forward(x, y, want_grad=True)
+    assert 0 < rel_err(o16["logits"].cpu(), o32["logits"].cpu()) < 2e-2
+    assert rel_err(m16.flat_grads().cpu(), m32.flat_grads().cpu()) < 5e-2
+    inf = hp16.forward(x)
+    ev = hp16.forward(x, y)
+    assert torch.equal(inf["logits"], o16["logits"]) and torch.equal(inf["pred"], o16["pred"])
+    assert abs(float(ev["loss"]) - float(o16["loss"])) < 1e-6

@@ -268,3 +268,36 @@ def test_stress_configuration_composed_matches_golden():
             tol = 1e-3 * max(float(np.abs(g[k]).max()), 1e-3 * scale)        # fp32 features in, fp32 autograd
             assert float((p[k[9:]].grad - torch.from_numpy(g[k])).abs().max()) < tol, k
     assert rel_err(w.grad, g["fc.grad.weight"]) < 1e-3 and rel_err(b.grad, g["fc.grad.bias"]) < 1e-3
+
+
+def g15_params():
+    """G15's parameters and inputs, rebuilt exactly as tests/golden/make_golden.py::g15_inputs does."""
+    rng = np.random.default_rng(15)
+    shapes = (("cnn1.weight", (32, 1, 1, 5), 5), ("cnn1.bias", (32,), 5), ("cnn2.weight", (32, 32, 576, 1), 32 * 576),
+              ("cnn3.weight", (32, 32, 1, 5), 160), ("cnn4.weight", (32, 32, 1, 5), 160), ("fc.weight", (5, 32), 32),
+              ("fc.bias", (5,), 32))
+    p = {k: torch.from_numpy((rng.uniform(-1, 1, shp).astype(np.float32) / np.sqrt(fan)).astype(np.float32))
+         for k, shp, fan in shapes}
+    x = torch.from_numpy((rng.standard_normal((8, 576, 17)) * 2 - 5).astype(np.float32))
+    y = torch.from_numpy(rng.integers(0, 5, 8))
+    return p, x, y
+
+
+def test_feature_classifier_at_576_channels_matches_reference_golden():
+    """G15 (fp32 half): the reference's Conv4Layers(576, 32) + Linear(32, 5) on a [8, 576, 17] feature map; the bf16
+    half of the fixture (the reference under torch.autocast) is what the bf16 GPU path is compared with."""
+    g = load_golden("g15_bf16_autocast.npz")
+    p, x, y = g15_params()
+    assert np.array_equal(y.numpy().astype(np.uint8), g["labels"])
+    for v in p.values():
+        v.requires_grad_()
+    cnn = {k: v for k, v in p.items() if k.startswith("cnn")}
+    logits = torch.nn.functional.linear(ocnn.conv4layers(x, cnn), p["fc.weight"], p["fc.bias"])
+    loss = ocnn.cross_entropy(logits, y)
+    loss.backward()
+    assert rel_err(logits.detach(), g["fp32.logits"]) < 1e-5 and abs(float(loss) - float(g["fp32.loss"])) < 1e-6
+    for k, v in p.items():
+        want = g["fp32." + ("fc.grad." + k[3:] if k.startswith("fc.") else "cnn.grad." + k)]
+        got = v.grad.numpy()
+        got = got[:, :, ::9] if k == "cnn2.weight" else got
+        assert rel_err(got, want) < 1e-4, k
