@@ -87,6 +87,9 @@ SIGNATURES = {
     "isd_eegnet_workspace_bytes": (_i64, [_p, _i64]),
     "isd_eegnet_forward": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _f, C.c_uint64, _p]),
     "isd_eegnet_backward": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, C.c_uint64, _p]),
+    "isd_eegnet_forward_stage": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _f, C.c_uint64, _i, _p]),
+    "isd_eegnet_backward_stage": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _f, C.c_uint64, _i, _p]),
+    "isd_eegnet_sync_block": (_i, [_p, _i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "isd_softmax_ce_workspace_bytes": (_i64, [_i64]),
     "isd_softmax_ce": (_i, [_p, _p, _i, _p, _p, _p, _p, _i64, _i, _i, _f, _p, _p]),
 }

@@ -16,8 +16,8 @@ import torch.nn as nn
 from . import _lib
 from .constants import BANDS_9, BANDS_40, CLASSES, ELECTRODES, ZONES
 from .features import FeatureExtractor
-from .nn import (FAST, EEGNet_Encoder, FeatureCNN, _FlatParamMixin, _dropout_seed, _stream, fast_config,
-                 token_mean_predict)
+from .nn import (FAST, EEGNet_Encoder, FeatureCNN, _FlatParamMixin, _dropout_seed, _stream, eegnet_backward,
+                 eegnet_forward, fast_config, token_mean_predict)
 
 
 def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0):
@@ -295,9 +295,9 @@ class EEGNetPath(HotPath):
                 b.num_batches_tracked += 1
         ws = self._buf("eeg", int(L.isd_eegnet_workspace_bytes(plan._h, B)) // 4, dev)
         h = self._buf("h", B * F_, dev)
-        _lib.check(L.isd_eegnet_forward(plan._h, x.data_ptr(), fp, bufs.data_ptr(), h.data_ptr(), ws.data_ptr(), B,
-                                        int(training), 0.1 if bn.momentum is None else float(bn.momentum),
-                                        float(bn.eps), float(p_drop), seed, st))
+        # data parallel: BatchNorm over the global batch (the sum blocks are all-reduced between the stages)
+        world = eegnet_forward(plan, x, flat, bufs, h, ws, training, 0.1 if bn.momentum is None else float(bn.momentum),
+                               float(bn.eps), float(p_drop), seed, getattr(enc, "sync_bn", True))
         ytok = self._buf("ytok", B * n_cls, dev)
         _lib.check(L.isd_linear_forward(h.data_ptr(), fp + wo * f4, fp + bo * f4, ytok.data_ptr(), 0, B, F_, n_cls, 0, st))
         logits = torch.empty((B, n_cls), dtype=torch.float32, device=dev)
@@ -321,8 +321,7 @@ class EEGNetPath(HotPath):
         lws = self._buf("lws", int(L.isd_linear_workspace_bytes(B, F_, n_cls)) // 4 + 64, dev)
         _lib.check(L.isd_linear_backward(h.data_ptr(), fp + wo * f4, dlt.data_ptr(), 0, dh.data_ptr(), gp + wo * f4,
                                          gp + bo * f4, lws.data_ptr(), B, F_, n_cls, 0, st))
-        _lib.check(L.isd_eegnet_backward(plan._h, x.data_ptr(), fp, dh.data_ptr(), gp, ws.data_ptr(), B, float(p_drop),
-                                         seed, st))
+        eegnet_backward(plan, x, flat, dh, gflat, ws, float(p_drop), seed, world)
         return out
 
 
@@ -332,10 +331,12 @@ class GradientBucket:
     (backend 'nccl' == RCCL on ROCm, 'gloo' on CPU) the bucket is summed over ranks; the loss kernel
     already divided by the GLOBAL batch, so the sum is the global-mean gradient."""
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, always_collective=False):
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.group = process_group
+        # issue the collectives even in a group of one rank (the RCCL start / stream-wait path on a single GPU)
+        self.always_collective = bool(always_collective)
 
     @property
     def world_size(self):
@@ -354,8 +355,11 @@ class GradientBucket:
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
+    def _skip(self):
+        return self.dist is None or (self.world_size == 1 and not self.always_collective)
+
     def all_reduce_(self, flat_grad, extra=None):
-        if self.dist is None or self.world_size == 1:
+        if self._skip():
             return
         self._sum(flat_grad)
         if extra is not None:
@@ -365,7 +369,7 @@ class GradientBucket:
         """Start the bucket's all-reduce and return a handle for ``all_reduce_wait`` (None: nothing pending).
         RCCL runs it on its own stream behind the kernels already queued on the current one, so work launched
         between start and wait that does not touch the bucket (the next batch's feature extraction) overlaps it."""
-        if self.dist is None or self.world_size == 1:
+        if self._skip():
             return None
         if flat_grad.is_cuda and self.dist.get_backend(self.group) == "gloo":
             self._sum(flat_grad)
@@ -378,7 +382,7 @@ class GradientBucket:
             work.wait()                                   # the current stream waits for the collective; the host does not
 
     def broadcast_(self, flat_params, src=0):
-        if self.dist is not None and self.world_size > 1:
+        if not self._skip():
             if flat_params.is_cuda and self.dist.get_backend(self.group) == "gloo":
                 h = flat_params.detach().cpu()
                 self.dist.broadcast(h, src=src, group=self.group)

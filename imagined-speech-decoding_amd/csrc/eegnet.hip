@@ -689,20 +689,22 @@ __global__ __launch_bounds__(256) void eeg_bwd3_sums_kernel(const float* __restr
 }
 
 // BN backward coefficients for stage `which` (3 or 2) and the gamma/beta gradients
+// gs: 1 / world size under synchronised BatchNorm -- the sums are then global on every rank and the gradient
+// all-reduce that follows adds the ranks' copies
 __global__ void eeg_bwd_bn_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
                                        const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N,
-                                       int which) {
+                                       int which, double gs) {
   const int h = threadIdx.x;
   if (h >= kF2) return;
   if (which == 3) {
-    dparams[off.g3 + h] = (float)st->dy3x[h];
-    dparams[off.b3 + h] = (float)st->dy3s[h];
+    dparams[off.g3 + h] = (float)(st->dy3x[h] * gs);
+    dparams[off.b3 + h] = (float)(st->dy3s[h] * gs);
     co->cA3[h] = params[off.g3 + h] / co->sig3[h];
     co->cB3[h] = (float)(st->dy3s[h] / N);
     co->cC3[h] = (float)(st->dy3x[h] / N);
   } else {
-    dparams[off.g2 + h] = (float)st->dy2x[h];
-    dparams[off.b2 + h] = (float)st->dy2s[h];
+    dparams[off.g2 + h] = (float)(st->dy2x[h] * gs);
+    dparams[off.b2 + h] = (float)(st->dy2s[h] * gs);
     co->cA2[h] = params[off.g2 + h] / co->sig2[h];
     co->cB2[h] = (float)(st->dy2s[h] / N);
     co->cC2[h] = (float)(st->dy2x[h] / N);
@@ -987,7 +989,7 @@ __global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restr
                                                             float* __restrict__ dparams,
                                                             const EegStats* __restrict__ st,
                                                             const EegCoef* __restrict__ co, EegOff off, int C, int K,
-                                                            double N1, int separable) {
+                                                            double N1, int separable, double gs) {
   const float* Wt = params + off.Wt;
   if (separable) {
     for (int e = threadIdx.x; e < kF2 * kF2; e += 256) dparams[off.Wp + e] = (float)st->dWp[e / kF2][e % kF2];
@@ -1000,8 +1002,8 @@ __global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restr
     const double su = st->Su[2 * f] + st->Su[2 * f + 1];
     SD[f] = sd;
     SU[f] = su;
-    dparams[off.b1 + f] = (float)sd;
-    dparams[off.g1 + f] = (float)((su - co->mu1[f] * sd) / co->sig1[f]);
+    dparams[off.b1 + f] = (float)(sd * gs);
+    dparams[off.g1 + f] = (float)((su - co->mu1[f] * sd) / co->sig1[f] * gs);
   }
   __syncthreads();
   // dWt[f,k] = (g1/sig1) [ T1 - meanD N1 m[k] - (meanDa/sig1) (N1 (Wt G)[k] - mu1 N1 m[k]) ]
@@ -1015,7 +1017,7 @@ __global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restr
     for (int k2 = 0; k2 < K; ++k2) wg += (double)Wt[f * K + k2] * co->G[k2][k];
     const double val = ((double)params[off.g1 + f] / sig) *
                        (t1 - meanD * N1 * co->m[k] - (meanDa / sig) * (N1 * wg - mu * N1 * co->m[k]));
-    dparams[off.Wt + e] = (float)val;
+    dparams[off.Wt + e] = (float)(val * gs);
   }
 }
 
@@ -1326,63 +1328,89 @@ static unsigned row_blocks(int row_len, int64_t n_rows) {
   return (unsigned)(want < full ? want : full);
 }
 
-extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, const float* params, float* buffers,
-                                  float* out, void* workspace, int64_t B, int training, float momentum, float eps,
-                                  float dropout_p, uint64_t seed, void* stream) {
-  ISD_CHECK_ARG(p, "isd_eegnet_forward: null plan");
-  ISD_CHECK_ARG(B >= 0 && B <= 0x7fffffff / kF2, "isd_eegnet_forward: B=%lld", (long long)B);
-  if (B == 0) return ISD_OK;
-  ISD_CHECK_ARG(x && params && buffers && out && workspace, "isd_eegnet_forward: null argument");
-  ISD_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "isd_eegnet_forward: dropout_p=%g not in [0,1)", dropout_p);
-  const float dp = training ? dropout_p : 0.f;
-  hipStream_t st = (hipStream_t)stream;
-  float* ws = (float*)workspace;
+// ---------------------------------------------------------------------------------------
+// Forward / backward in stages.  Between two stages a block of fp64 batch sums sits complete in the workspace
+// (isd_eegnet_sync_block): under data parallelism the caller all-reduces it (SUM) there -- synchronised BatchNorm,
+// SURVEY.md 8(e) -- and passes the world size so that counts are global and the gradients that are assembled from
+// global sums are pre-divided (the gradient all-reduce that follows adds the ranks' copies).  world = 1 and the stages
+// run back to back are the single-device call.
+//   forward  0: x statistics            -> sync block F0 (autocorrelation sums of x: BN1)
+//            1: BN1 fold, projection, temporal conv -> F1 (sum u, sum u^2: BN2)
+//            2: BN2, ELU, pool, stage-2 conv        -> F2 (sum a4, sum a4^2: BN3)
+//            3: BN3, ELU, pool, projector
+//   backward 0: projector, BN3 sums      -> B0 (sum dy3, sum dy3 xhat3)
+//            1: BN3 backward, stage-2 conv gradients, pool -> B1 (sum dy2, sum dy2 xhat2)
+//            2: BN2 backward, correlations, dWs            -> B2 (sum da2, sum da2 u, sum da2 zpad)
+//            3: stage-1 gradients (dWt, BN1 affine), separable weights
+// ---------------------------------------------------------------------------------------
+static int eeg_forward_stage(const isd_eegnet_plan* p, int stage, const float* x, const float* params, float* buffers,
+                             float* out, float* ws, int64_t B, int training, float momentum, float eps, float dp,
+                             uint64_t seed, int world, hipStream_t st, void* stream) {
   const EegWs w = eeg_layout(p, B);
   EegStats* S = (EegStats*)(ws + w.stats);
   EegCoef* Cf = (EegCoef*)(ws + w.coef);
   const int C = p->C, K = p->K, T = p->T, Tp = p->Tp, T2 = p->T2, T2p = p->T2p, T3 = p->T3;
   const int64_t rows = B * C;
-  ISD_HIP_TRY(hipMemsetAsync(S, 0, sizeof(EegStats), st));
-  if (training) {
-    if (T <= 79) {
-      const int MT = (T + 16) / 16;                              // 16 MT >= T + 1: room for the column of ones
-      const int64_t want_g = cdiv(cdiv(rows, 4), kStatWaves);
-      const int grid_g = want_g < 1024 ? (int)want_g : 1024;
-      switch (MT) {
-        case 1: hipLaunchKernelGGL(eeg_stats_gram_kernel<1>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
-        case 2: hipLaunchKernelGGL(eeg_stats_gram_kernel<2>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
-        case 3: hipLaunchKernelGGL(eeg_stats_gram_kernel<3>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
-        case 4: hipLaunchKernelGGL(eeg_stats_gram_kernel<4>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
-        default: hipLaunchKernelGGL(eeg_stats_gram_kernel<5>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+  const double wd = (double)world;
+  if (stage == 0) {
+    ISD_HIP_TRY(hipMemsetAsync(S, 0, sizeof(EegStats), st));
+    if (training) {
+      if (T <= 79) {
+        const int MT = (T + 16) / 16;                              // 16 MT >= T + 1: room for the column of ones
+        const int64_t want_g = cdiv(cdiv(rows, 4), kStatWaves);
+        const int grid_g = want_g < 1024 ? (int)want_g : 1024;
+        switch (MT) {
+          case 1: hipLaunchKernelGGL(eeg_stats_gram_kernel<1>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+          case 2: hipLaunchKernelGGL(eeg_stats_gram_kernel<2>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+          case 3: hipLaunchKernelGGL(eeg_stats_gram_kernel<3>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+          case 4: hipLaunchKernelGGL(eeg_stats_gram_kernel<4>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+          default: hipLaunchKernelGGL(eeg_stats_gram_kernel<5>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+        }
+        hipLaunchKernelGGL(eeg_stats_gram_derive_kernel, dim3(1), dim3(64), 0, st, S, T);
+      } else {
+        const int64_t want = cdiv(rows, kStatWaves);
+        const int grid = want < 2048 ? (int)want : 2048;             // bulk: 32 waves per CU
+        hipLaunchKernelGGL(eeg_stats_kernel, dim3(grid), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
+        const int64_t want_e = cdiv(cdiv(rows, 4), kStatWaves);
+        const int grid_e = want_e < 512 ? (int)want_e : 512;         // edge: 4 rows per MFMA step, head and tail blocks
+        hipLaunchKernelGGL(eeg_stats_edge_kernel, dim3(grid_e, 2), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
+        hipLaunchKernelGGL(eeg_stats_derive_kernel, dim3(1), dim3(64), 0, st, S);
       }
-      hipLaunchKernelGGL(eeg_stats_gram_derive_kernel, dim3(1), dim3(64), 0, st, S, T);
-    } else {
-      const int64_t want = cdiv(rows, kStatWaves);
-      const int grid = want < 2048 ? (int)want : 2048;             // bulk: 32 waves per CU
-      hipLaunchKernelGGL(eeg_stats_kernel, dim3(grid), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
-      const int64_t want_e = cdiv(cdiv(rows, 4), kStatWaves);
-      const int grid_e = want_e < 512 ? (int)want_e : 512;         // edge: 4 rows per MFMA step, head and tail blocks
-      hipLaunchKernelGGL(eeg_stats_edge_kernel, dim3(grid_e, 2), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
-      hipLaunchKernelGGL(eeg_stats_derive_kernel, dim3(1), dim3(64), 0, st, S);
     }
+    ISD_LAUNCH_CHECK();
+    return ISD_OK;
   }
-  hipLaunchKernelGGL(eeg_finalize1_kernel, dim3(1), dim3(256), 0, st, params, buffers, S, Cf, p->off, C, K, T, rows,
-                     training, momentum, eps);
-  hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(T, 16), (unsigned)B), dim3(256), 0, st, x,
-                     params + p->off.Ws, ws + w.z, C, T, (int)cdiv(T, 16));
-  hipLaunchKernelGGL(eeg_tconv_kernel, dim3(row_blocks(Tp, B * kF2), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.z,
-                     params + p->off.Wt, ws + w.u, S, K, T, Tp, training);
-  hipLaunchKernelGGL(eeg_finalize2_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
-                     (double)B * (double)Tp, training, momentum, eps);
-  hipLaunchKernelGGL(eeg_pool2_kernel, dim3((unsigned)cdiv(T2, 256), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.u,
-                     Cf, ws + w.p2, Tp, T2, p->P1, dp, seed);
+  if (stage == 1) {
+    hipLaunchKernelGGL(eeg_finalize1_kernel, dim3(1), dim3(256), 0, st, params, buffers, S, Cf, p->off, C, K, T,
+                       rows * world, training, momentum, eps);
+    hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(T, 16), (unsigned)B), dim3(256), 0, st, x,
+                       params + p->off.Ws, ws + w.z, C, T, (int)cdiv(T, 16));
+    hipLaunchKernelGGL(eeg_tconv_kernel, dim3(row_blocks(Tp, B * kF2), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.z,
+                       params + p->off.Wt, ws + w.u, S, K, T, Tp, training);
+    ISD_LAUNCH_CHECK();
+    return ISD_OK;
+  }
+  if (stage == 2) {
+    hipLaunchKernelGGL(eeg_finalize2_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
+                       (double)B * (double)Tp * wd, training, momentum, eps);
+    hipLaunchKernelGGL(eeg_pool2_kernel, dim3((unsigned)cdiv(T2, 256), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.u,
+                       Cf, ws + w.p2, Tp, T2, p->P1, dp, seed);
+    if (p->cv) {
+      hipLaunchKernelGGL(cv_prep_kernel, dim3(kF2 * kF2 * kK2 / 256), dim3(256), 0, st, params + p->off.Wd, ws + w.w3f,
+                         ws + w.w3b);
+      hipLaunchKernelGGL(cv_conv3_kernel, dim3((unsigned)cdiv(B * T2p, 256)), dim3(256), 0, st, ws + w.p2, ws + w.w3f,
+                         ws + w.a4, S, B, T2, T2p, training);
+    } else {
+      hipLaunchKernelGGL(eeg_sep_kernel, dim3((unsigned)cdiv(T2p, 256), (unsigned)B), dim3(256), 0, st, ws + w.p2,
+                         params + p->off.Wd, params + p->off.Wp, training ? ws + w.a3 : nullptr, ws + w.a4, S, T2, T2p,
+                         training);
+    }
+    ISD_LAUNCH_CHECK();
+    return ISD_OK;
+  }
+  hipLaunchKernelGGL(eeg_finalize3_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
+                     (double)B * (double)T2p * wd, training, momentum, eps);
   if (p->cv) {
-    hipLaunchKernelGGL(cv_prep_kernel, dim3(kF2 * kF2 * kK2 / 256), dim3(256), 0, st, params + p->off.Wd, ws + w.w3f,
-                       ws + w.w3b);
-    hipLaunchKernelGGL(cv_conv3_kernel, dim3((unsigned)cdiv(B * T2p, 256)), dim3(256), 0, st, ws + w.p2, ws + w.w3f,
-                       ws + w.a4, S, B, T2, T2p, training);
-    hipLaunchKernelGGL(eeg_finalize3_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
-                       (double)B * (double)T2p, training, momentum, eps);
     const int64_t n3 = B * kF2 * T3;
     hipLaunchKernelGGL(cv_pool3_kernel, dim3((unsigned)cdiv(n3, 256)), dim3(256), 0, st, ws + w.a4, Cf, ws + w.pooled, n3,
                        T2p, T3, p->P2, dp, seed);
@@ -1390,11 +1418,6 @@ extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, cons
     return isd_linear_forward(ws + w.pooled, params + p->off.Wl, params + p->off.bl, out, nullptr, B, kF2 * T3, p->F, 0,
                               stream);
   }
-  hipLaunchKernelGGL(eeg_sep_kernel, dim3((unsigned)cdiv(T2p, 256), (unsigned)B), dim3(256), 0, st, ws + w.p2,
-                     params + p->off.Wd, params + p->off.Wp, training ? ws + w.a3 : nullptr, ws + w.a4, S, T2, T2p,
-                     training);
-  hipLaunchKernelGGL(eeg_finalize3_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
-                     (double)B * (double)T2p, training, momentum, eps);
   hipLaunchKernelGGL(eeg_pool3_kernel, dim3((unsigned)cdiv(B * kF2, 4)), dim3(256), 0, st, ws + w.a4, Cf,
                      ws + w.pooled, B * kF2, T2p, T3, dp, seed);
   ISD_LAUNCH_CHECK();
@@ -1402,68 +1425,163 @@ extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, cons
                             stream);
 }
 
-extern "C" int isd_eegnet_backward(const isd_eegnet_plan* p, const float* x, const float* params, const float* dout,
-                                   float* dparams, void* workspace, int64_t B, float dropout_p, uint64_t seed,
-                                   void* stream) {
-  ISD_CHECK_ARG(p, "isd_eegnet_backward: null plan");
-  ISD_CHECK_ARG(B >= 1, "isd_eegnet_backward: B=%lld", (long long)B);
-  ISD_CHECK_ARG(x && params && dout && dparams && workspace, "isd_eegnet_backward: null argument");
-  hipStream_t st = (hipStream_t)stream;
-  float* ws = (float*)workspace;
+static int eeg_forward_check(const isd_eegnet_plan* p, const float* x, const float* params, float* buffers, float* out,
+                             void* workspace, int64_t B, float dropout_p, int world) {
+  ISD_CHECK_ARG(p, "isd_eegnet_forward: null plan");
+  ISD_CHECK_ARG(B >= 0 && B <= 0x7fffffff / kF2, "isd_eegnet_forward: B=%lld", (long long)B);
+  ISD_CHECK_ARG(B == 0 || (x && params && buffers && out && workspace), "isd_eegnet_forward: null argument");
+  ISD_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "isd_eegnet_forward: dropout_p=%g not in [0,1)", dropout_p);
+  ISD_CHECK_ARG(world >= 1 && world <= 65536, "isd_eegnet_forward: world=%d", world);
+  return ISD_OK;
+}
+
+extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, const float* params, float* buffers,
+                                  float* out, void* workspace, int64_t B, int training, float momentum, float eps,
+                                  float dropout_p, uint64_t seed, void* stream) {
+  int rc = eeg_forward_check(p, x, params, buffers, out, workspace, B, dropout_p, 1);
+  if (rc || B == 0) return rc;
+  for (int stage = 0; stage < 4 && rc == ISD_OK; ++stage)
+    rc = eeg_forward_stage(p, stage, x, params, buffers, out, (float*)workspace, B, training, momentum, eps,
+                           training ? dropout_p : 0.f, seed, 1, (hipStream_t)stream, stream);
+  return rc;
+}
+
+extern "C" int isd_eegnet_forward_stage(const isd_eegnet_plan* p, int stage, const float* x, const float* params,
+                                        float* buffers, float* out, void* workspace, int64_t B, int training,
+                                        float momentum, float eps, float dropout_p, uint64_t seed, int world,
+                                        void* stream) {
+  int rc = eeg_forward_check(p, x, params, buffers, out, workspace, B, dropout_p, world);
+  if (rc || B == 0) return rc;
+  ISD_CHECK_ARG(stage >= 0 && stage < 4, "isd_eegnet_forward_stage: stage=%d not in [0,4)", stage);
+  return eeg_forward_stage(p, stage, x, params, buffers, out, (float*)workspace, B, training, momentum, eps,
+                           training ? dropout_p : 0.f, seed, world, (hipStream_t)stream, stream);
+}
+
+static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* x, const float* params,
+                              const float* dout, float* dparams, float* ws, int64_t B, float dropout_p, uint64_t seed,
+                              int world, hipStream_t st, void* stream) {
   const EegWs w = eeg_layout(p, B);
   EegStats* S = (EegStats*)(ws + w.stats);
   EegCoef* Cf = (EegCoef*)(ws + w.coef);
   const int C = p->C, K = p->K, T = p->T, Tp = p->Tp, T2 = p->T2, T2p = p->T2p, T3 = p->T3;
   const int64_t rows16 = B * kF2;
-  ISD_HIP_TRY(hipMemsetAsync((char*)S + offsetof(EegStats, dy3s), 0, sizeof(EegStats) - offsetof(EegStats, dy3s), st));
-  int rc = isd_linear_backward(ws + w.pooled, params + p->off.Wl, dout, nullptr, ws + w.dpooled, dparams + p->off.Wl,
-                               dparams + p->off.bl, ws + w.lin, B, kF2 * (p->cv ? T3 : 1), p->F, 0, stream);
-  if (rc) return rc;
-  if (p->cv) {
-    hipLaunchKernelGGL(cv_bwd3_sums_kernel, dim3((unsigned)cdiv(rows16, 4)), dim3(256), 0, st, ws + w.a4, ws + w.dpooled,
-                       Cf, S, rows16, T2p, T3, p->P2, dropout_p, seed);
+  const double wd = (double)world, gs = 1.0 / wd;
+  if (stage == 0) {
+    ISD_HIP_TRY(hipMemsetAsync((char*)S + offsetof(EegStats, dy3s), 0, sizeof(EegStats) - offsetof(EegStats, dy3s), st));
+    int rc = isd_linear_backward(ws + w.pooled, params + p->off.Wl, dout, nullptr, ws + w.dpooled, dparams + p->off.Wl,
+                                 dparams + p->off.bl, ws + w.lin, B, kF2 * (p->cv ? T3 : 1), p->F, 0, stream);
+    if (rc) return rc;
+    if (p->cv)
+      hipLaunchKernelGGL(cv_bwd3_sums_kernel, dim3((unsigned)cdiv(rows16, 4)), dim3(256), 0, st, ws + w.a4, ws + w.dpooled,
+                         Cf, S, rows16, T2p, T3, p->P2, dropout_p, seed);
+    else
+      hipLaunchKernelGGL(eeg_bwd3_sums_kernel, dim3((unsigned)cdiv(rows16, 4)), dim3(256), 0, st, ws + w.a4, ws + w.dpooled,
+                         Cf, S, rows16, T2p, T3, dropout_p, seed);
+    ISD_LAUNCH_CHECK();
+    return ISD_OK;
+  }
+  if (stage == 1) {
     hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
-                       (double)B * (double)T2p, 3);
-    hipLaunchKernelGGL(cv_bwd_da4_kernel, dim3((unsigned)cdiv(rows16 * T2p, 256)), dim3(256), 0, st, ws + w.a4,
-                       ws + w.dpooled, Cf, ws + w.da4, rows16 * T2p, T2p, T3, p->P2, dropout_p, seed);
-    const int slabs3 = B < w.n_slabs ? (int)B : w.n_slabs;
-    hipLaunchKernelGGL(cv_bwd_w3_kernel, dim3(slabs3), dim3(64), 0, st, ws + w.da4, ws + w.p2, ws + w.part, B, T2, T2p);
-    hipLaunchKernelGGL(cv_w3_reduce_kernel, dim3(kF2 * kF2 * kK2 / 256), dim3(256), 0, st, ws + w.part, slabs3,
-                       dparams + p->off.Wd);
-    hipLaunchKernelGGL(cv_bwd_dp2_kernel, dim3((unsigned)cdiv(B * T2, 256)), dim3(256), 0, st, ws + w.da4, ws + w.w3b,
-                       ws + w.da3, B, T2, T2p);
-    hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st,
-                       ws + w.da3, (const float*)nullptr, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, p->P1, dropout_p,
-                       seed);
-  } else {
-  hipLaunchKernelGGL(eeg_bwd3_sums_kernel, dim3((unsigned)cdiv(rows16, 4)), dim3(256), 0, st, ws + w.a4, ws + w.dpooled,
-                     Cf, S, rows16, T2p, T3, dropout_p, seed);
-  hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
-                     (double)B * (double)T2p, 3);
-  hipLaunchKernelGGL(eeg_bwd_sep_kernel, dim3((unsigned)cdiv(T2p, 256), (unsigned)B), dim3(256), 0, st, ws + w.a4,
-                     ws + w.dpooled, params + p->off.Wp, Cf, ws + w.da4, ws + w.da3, T2p, T3, dropout_p, seed);
-  hipLaunchKernelGGL(eeg_bwd_sepw_kernel, dim3(kF2 * kF2 + kF2 * kK2), dim3(256), 0, st, ws + w.da4, ws + w.a3,
-                     ws + w.da3, ws + w.p2, S, (int)B, T2, T2p);
-  hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st,
-                     ws + w.da3, params + p->off.Wd, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, p->P1, dropout_p, seed);
+                       (double)B * (double)T2p * wd, 3, gs);
+    if (p->cv) {
+      hipLaunchKernelGGL(cv_bwd_da4_kernel, dim3((unsigned)cdiv(rows16 * T2p, 256)), dim3(256), 0, st, ws + w.a4,
+                         ws + w.dpooled, Cf, ws + w.da4, rows16 * T2p, T2p, T3, p->P2, dropout_p, seed);
+      const int slabs3 = B < w.n_slabs ? (int)B : w.n_slabs;
+      hipLaunchKernelGGL(cv_bwd_w3_kernel, dim3(slabs3), dim3(64), 0, st, ws + w.da4, ws + w.p2, ws + w.part, B, T2, T2p);
+      hipLaunchKernelGGL(cv_w3_reduce_kernel, dim3(kF2 * kF2 * kK2 / 256), dim3(256), 0, st, ws + w.part, slabs3,
+                         dparams + p->off.Wd);
+      hipLaunchKernelGGL(cv_bwd_dp2_kernel, dim3((unsigned)cdiv(B * T2, 256)), dim3(256), 0, st, ws + w.da4, ws + w.w3b,
+                         ws + w.da3, B, T2, T2p);
+      hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st,
+                         ws + w.da3, (const float*)nullptr, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, p->P1, dropout_p,
+                         seed);
+    } else {
+      hipLaunchKernelGGL(eeg_bwd_sep_kernel, dim3((unsigned)cdiv(T2p, 256), (unsigned)B), dim3(256), 0, st, ws + w.a4,
+                         ws + w.dpooled, params + p->off.Wp, Cf, ws + w.da4, ws + w.da3, T2p, T3, dropout_p, seed);
+      hipLaunchKernelGGL(eeg_bwd_sepw_kernel, dim3(kF2 * kF2 + kF2 * kK2), dim3(256), 0, st, ws + w.da4, ws + w.a3,
+                         ws + w.da3, ws + w.p2, S, (int)B, T2, T2p);
+      hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st,
+                         ws + w.da3, params + p->off.Wd, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, p->P1, dropout_p, seed);
+    }
+    ISD_LAUNCH_CHECK();
+    return ISD_OK;
   }
-  hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
-                     (double)B * (double)Tp, 2);
-  hipLaunchKernelGGL(eeg_bwd_bn2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st, ws + w.dy2,
-                     ws + w.u, Cf, S, Tp);
-  {
-    const size_t lds = sizeof(float) * (size_t)((kCorrSeg + K + 64) + (kCorrSeg + 2 * K + 64));
-    hipLaunchKernelGGL(eeg_bwd_corr_kernel, dim3((unsigned)rows16, (unsigned)cdiv(Tp, kCorrSeg)), dim3(64), lds, st,
-                       ws + w.dy2, ws + w.z, params + p->off.Wt, ws + w.v, S, K, T, Tp);
+  if (stage == 2) {
+    hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
+                       (double)B * (double)Tp * wd, 2, gs);
+    hipLaunchKernelGGL(eeg_bwd_bn2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st, ws + w.dy2,
+                       ws + w.u, Cf, S, Tp);
+    {
+      const size_t lds = sizeof(float) * (size_t)((kCorrSeg + K + 64) + (kCorrSeg + 2 * K + 64));
+      hipLaunchKernelGGL(eeg_bwd_corr_kernel, dim3((unsigned)rows16, (unsigned)cdiv(Tp, kCorrSeg)), dim3(64), lds, st,
+                         ws + w.dy2, ws + w.z, params + p->off.Wt, ws + w.v, S, K, T, Tp);
+    }
+    const int64_t n_chunks = B * ((T + 255) / 256);
+    const int slabs = n_chunks < w.n_slabs ? (int)n_chunks : w.n_slabs;
+    hipLaunchKernelGGL(eeg_bwd_dws_kernel, dim3(slabs, (unsigned)cdiv(C, 256)), dim3(64), 0, st, ws + w.v, x, ws + w.part,
+                       (int)B, C, T);
+    // dWs takes the LOCAL sum of da2 (it is linear in the local batch): it runs in front of the all-reduce of B2
+    hipLaunchKernelGGL(eeg_bwd_dws_reduce_kernel, dim3((unsigned)cdiv((int64_t)kF2 * C, 64)), dim3(1024), 0, st,
+                       ws + w.part, slabs, S, Cf, dparams + p->off.Ws, C);
+    ISD_LAUNCH_CHECK();
+    return ISD_OK;
   }
-  const int64_t n_chunks = B * ((T + 255) / 256);
-  const int slabs = n_chunks < w.n_slabs ? (int)n_chunks : w.n_slabs;
-  hipLaunchKernelGGL(eeg_bwd_dws_kernel, dim3(slabs, (unsigned)cdiv(C, 256)), dim3(64), 0, st, ws + w.v, x, ws + w.part,
-                     (int)B, C, T);
-  hipLaunchKernelGGL(eeg_bwd_dws_reduce_kernel, dim3((unsigned)cdiv((int64_t)kF2 * C, 64)), dim3(1024), 0, st,
-                     ws + w.part, slabs, S, Cf, dparams + p->off.Ws, C);
+  // the stage-1 gradients are assembled from GLOBAL sums (BatchNorm's backward couples the whole batch): every rank
+  // computes the same global gradient, pre-divided by the world size; the separable weights are local sums
   hipLaunchKernelGGL(eeg_bwd_final_kernel, dim3(1), dim3(256), 0, st, params, dparams, S, Cf, p->off, C, K,
-                     (double)(B * C) * (double)Tp, !p->cv);
+                     (double)(B * C) * (double)Tp * wd, !p->cv, gs);
   ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
+static int eeg_backward_check(const isd_eegnet_plan* p, const float* x, const float* params, const float* dout,
+                              float* dparams, void* workspace, int64_t B, int world) {
+  ISD_CHECK_ARG(p, "isd_eegnet_backward: null plan");
+  ISD_CHECK_ARG(B >= 1, "isd_eegnet_backward: B=%lld", (long long)B);
+  ISD_CHECK_ARG(x && params && dout && dparams && workspace, "isd_eegnet_backward: null argument");
+  ISD_CHECK_ARG(world >= 1 && world <= 65536, "isd_eegnet_backward: world=%d", world);
+  return ISD_OK;
+}
+
+extern "C" int isd_eegnet_backward(const isd_eegnet_plan* p, const float* x, const float* params, const float* dout,
+                                   float* dparams, void* workspace, int64_t B, float dropout_p, uint64_t seed,
+                                   void* stream) {
+  int rc = eeg_backward_check(p, x, params, dout, dparams, workspace, B, 1);
+  for (int stage = 0; stage < 4 && rc == ISD_OK; ++stage)
+    rc = eeg_backward_stage(p, stage, x, params, dout, dparams, (float*)workspace, B, dropout_p, seed, 1,
+                            (hipStream_t)stream, stream);
+  return rc;
+}
+
+extern "C" int isd_eegnet_backward_stage(const isd_eegnet_plan* p, int stage, const float* x, const float* params,
+                                         const float* dout, float* dparams, void* workspace, int64_t B,
+                                         float dropout_p, uint64_t seed, int world, void* stream) {
+  int rc = eeg_backward_check(p, x, params, dout, dparams, workspace, B, world);
+  if (rc) return rc;
+  ISD_CHECK_ARG(stage >= 0 && stage < 4, "isd_eegnet_backward_stage: stage=%d not in [0,4)", stage);
+  return eeg_backward_stage(p, stage, x, params, dout, dparams, (float*)workspace, B, dropout_p, seed, world,
+                            (hipStream_t)stream, stream);
+}
+
+// The fp64 sums that are complete after `stage` (0..2) of the forward (backward = 0) or backward (backward = 1) pass:
+// byte offset from the workspace base and number of doubles.  Summed over the ranks between stage and stage + 1 they
+// make the BatchNorm statistics those of the global batch.
+extern "C" int isd_eegnet_sync_block(const isd_eegnet_plan* p, int64_t B, int backward, int stage, int64_t* byte_offset,
+                                     int64_t* n_doubles) {
+  ISD_CHECK_ARG(p && byte_offset && n_doubles, "isd_eegnet_sync_block: null argument");
+  ISD_CHECK_ARG(stage >= 0 && stage < 3 && B >= 0, "isd_eegnet_sync_block: stage=%d not in [0,3)", stage);
+  const EegWs w = eeg_layout(p, B);
+  size_t lo, hi;
+  if (!backward) {
+    if (stage == 0) { lo = offsetof(EegStats, A); hi = offsetof(EegStats, D); }                 // A, H, Tl, S, Hs, Ts
+    else if (stage == 1) { lo = offsetof(EegStats, u1); hi = offsetof(EegStats, a1); }
+    else { lo = offsetof(EegStats, a1); hi = offsetof(EegStats, dy3s); }
+  } else {
+    if (stage == 0) { lo = offsetof(EegStats, dy3s); hi = offsetof(EegStats, dy2s); }
+    else if (stage == 1) { lo = offsetof(EegStats, dy2s); hi = offsetof(EegStats, Sd); }
+    else { lo = offsetof(EegStats, Sd); hi = offsetof(EegStats, dWp); }                         // Sd, Su, T1
+  }
+  *byte_offset = w.stats * 4 + (int64_t)lo;
+  *n_doubles = (int64_t)((hi - lo) / sizeof(double));
   return ISD_OK;
 }

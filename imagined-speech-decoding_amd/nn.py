@@ -203,9 +203,69 @@ class EEGNetPlan:
                 pass
 
 
+def _bn_sync_world(sync, training):
+    """(torch.distributed, world size) when BatchNorm statistics are to be synchronised, else (None, 1)."""
+    import torch.distributed as dist
+    if sync and training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist, dist.get_world_size()
+    return None, 1
+
+
+def _all_reduce_block(dist, ws, byte_off, n_doubles):
+    """SUM over ranks of a block of fp64 batch sums inside the workspace (RCCL on the current stream; gloo, used by
+    rehearsals with ranks sharing a card, stages through the host)."""
+    blk = ws.view(torch.uint8)[byte_off:byte_off + 8 * n_doubles].view(torch.float64)
+    if blk.is_cuda and dist.get_backend() == "gloo":
+        h = blk.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        blk.copy_(h)
+    else:
+        dist.all_reduce(blk, op=dist.ReduceOp.SUM)
+
+
+def eegnet_forward(plan, x, flat, bufs, out, ws, training, momentum, eps, dropout_p, seed, sync=True):
+    """EEGNet_Encoder / CVBlock forward through the C ABI.  With torch.distributed initialised (world > 1) and
+    ``sync`` the three BatchNorm layers use the statistics of the GLOBAL batch: the pass runs in four
+    stages and the fp64 sum block of each stage is all-reduced in between.  Returns the world size that was used
+    (pass it to ``eegnet_backward``)."""
+    L, B, st = _lib.lib(), x.shape[0], _stream()
+    dist, world = _bn_sync_world(sync, training)
+    args = (x.data_ptr(), flat.data_ptr(), bufs.data_ptr(), out.data_ptr(), ws.data_ptr(), B, int(training),
+            float(momentum), float(eps), float(dropout_p), int(seed))
+    if world == 1:
+        _lib.check(L.isd_eegnet_forward(plan._h, *args, st))
+        return 1
+    off, n = C.c_int64(), C.c_int64()
+    for stage in range(4):
+        _lib.check(L.isd_eegnet_forward_stage(plan._h, stage, *args, world, st))
+        if stage < 3:
+            _lib.check(L.isd_eegnet_sync_block(plan._h, B, 0, stage, C.byref(off), C.byref(n)))
+            _all_reduce_block(dist, ws, off.value, n.value)
+    return world
+
+
+def eegnet_backward(plan, x, flat, dout, dflat, ws, dropout_p, seed, world=1):
+    """Parameter gradients of the forward above; ``world`` > 1: the BatchNorm backward sums are all-reduced between the
+    stages and the gradients assembled from global sums arrive pre-divided, so that the gradient all-reduce (SUM) of
+    data-parallel training yields the single-device gradient."""
+    L, B, st = _lib.lib(), x.shape[0], _stream()
+    args = (x.data_ptr(), flat.data_ptr(), dout.data_ptr(), dflat.data_ptr(), ws.data_ptr(), B, float(dropout_p),
+            int(seed))
+    if world == 1:
+        _lib.check(L.isd_eegnet_backward(plan._h, *args, st))
+        return
+    import torch.distributed as dist
+    off, n = C.c_int64(), C.c_int64()
+    for stage in range(4):
+        _lib.check(L.isd_eegnet_backward_stage(plan._h, stage, *args, world, st))
+        if stage < 3:
+            _lib.check(L.isd_eegnet_sync_block(plan._h, B, 1, stage, C.byref(off), C.byref(n)))
+            _all_reduce_block(dist, ws, off.value, n.value)
+
+
 class _EEGNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, flat, bufs, plan, training, momentum, eps, dropout_p, seed):
+    def forward(ctx, x, flat, bufs, plan, training, momentum, eps, dropout_p, seed, sync):
         x, flat = _f32c(x, "x"), _f32c(flat, "params")
         if ctx.needs_input_grad[0]:
             raise NotImplementedError("gradient w.r.t. the EEG input is not provided by the HIP EEGNet head")
@@ -214,10 +274,8 @@ class _EEGNetFn(torch.autograd.Function):
         ws = torch.empty(max(int(_lib.lib().isd_eegnet_workspace_bytes(plan._h, B)) // 4, 1), dtype=torch.float32,
                          device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().isd_eegnet_forward(plan._h, x.data_ptr(), flat.data_ptr(), bufs.data_ptr(),
-                                                     out.data_ptr(), ws.data_ptr(), B, int(training), float(momentum),
-                                                     float(eps), float(dropout_p), int(seed), _stream()))
-        ctx.plan, ctx.ws, ctx.dp, ctx.seed, ctx.training = plan, ws, float(dropout_p), int(seed), training
+            world = eegnet_forward(plan, x, flat, bufs, out, ws, training, momentum, eps, dropout_p, seed, sync)
+        ctx.plan, ctx.ws, ctx.dp, ctx.seed, ctx.training, ctx.world = plan, ws, float(dropout_p), int(seed), training, world
         ctx.save_for_backward(x, flat)
         return out
 
@@ -229,11 +287,9 @@ class _EEGNetFn(torch.autograd.Function):
         dflat = torch.empty_like(flat)
         dout = _f32c(dout, "dout")
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().isd_eegnet_backward(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dout.data_ptr(),
-                                                      dflat.data_ptr(), ctx.ws.data_ptr(), x.shape[0], ctx.dp,
-                                                      ctx.seed, _stream()))
+            eegnet_backward(ctx.plan, x, flat, dout, dflat, ctx.ws, ctx.dp, ctx.seed, ctx.world)
         ctx.ws = None
-        return None, dflat, None, None, None, None, None, None, None
+        return None, dflat, None, None, None, None, None, None, None, None
 
 
 class PaperHeadPlan:
@@ -598,7 +654,7 @@ class _BNStackMixin(_FlatParamMixin):
                 b.num_batches_tracked += 1
         return _EEGNetFn.apply(x, theta, self.flat_buffers(), plan, self.training,
                                0.1 if bn.momentum is None else bn.momentum, bn.eps, self.p if self.training else 0.0,
-                               _dropout_seed(self._stream_id, self._calls))
+                               _dropout_seed(self._stream_id, self._calls), getattr(self, "sync_bn", True))
 
 
 class EEGNet_Encoder(nn.Module, _BNStackMixin):
@@ -687,6 +743,7 @@ class CVBlock(nn.Module, _BNStackMixin):
 class HeadConv_Paper_Version(nn.Module, _BNStackMixin):
     """Drop-in for the reference's ``HeadConv_Paper_Version(in_channels, feature_dim=32)`` (fast.py:170-196); same
     parameter / buffer names, ``forward(x[B', C, T]) -> [B', feature_dim]``."""
+    _warned = False
 
     def __init__(self, in_channels, feature_dim=32):
         super().__init__()
@@ -720,6 +777,11 @@ class HeadConv_Paper_Version(nn.Module, _BNStackMixin):
             plan = self._plans[T] = PaperHeadPlan(self.in_channels, self.feature_dim, T)
         flat = self.flat_params()
         theta = torch.cat([p.reshape(-1) for p in self._ordered_params()]) if torch.is_grad_enabled() else flat
+        if self.training and _bn_sync_world(True, True)[1] > 1 and not HeadConv_Paper_Version._warned:
+            import warnings
+            HeadConv_Paper_Version._warned = True
+            warnings.warn("HeadConv_Paper_Version normalises with per-replica batch statistics under data parallelism "
+                          "(EEGNet_Encoder and CVBlock synchronise theirs): results differ from single-device training")
         if self.training:
             for b in self._bns():
                 b.num_batches_tracked += 1

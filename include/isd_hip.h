@@ -240,6 +240,22 @@ int isd_eegnet_forward(const isd_eegnet_plan* plan, const float* x, const float*
 int isd_eegnet_backward(const isd_eegnet_plan* plan, const float* x, const float* params, const float* dout,
                         float* dparams, void* workspace, int64_t B, float dropout_p, uint64_t seed,
                         void* stream);
+/* Synchronised BatchNorm under data parallelism (the reference's heads use plain nn.BatchNorm2d on one
+ * device, fast.py:46-63,133-159, so the single-device batch statistics are what a sharded batch must reproduce).
+ * The forward and backward passes above are four stages each (0..3); after stages 0, 1 and 2 a block of fp64 batch
+ * sums is complete in the workspace (isd_eegnet_sync_block gives its byte offset and length).  The caller runs the
+ * stages one by one with the same arguments on every rank, all-reduces (SUM) that block between two stages, and
+ * passes the number of ranks (equal shards): the statistics are then those of the global batch, and the parameter
+ * gradients sum to the single-device gradient under the usual gradient all-reduce.  world = 1 without all-reduces is
+ * isd_eegnet_forward / isd_eegnet_backward.  Evaluation (training == 0) needs no exchange. */
+int isd_eegnet_forward_stage(const isd_eegnet_plan* plan, int stage, const float* x, const float* params,
+                             float* buffers, float* out, void* workspace, int64_t B, int training, float momentum,
+                             float eps, float dropout_p, uint64_t seed, int world, void* stream);
+int isd_eegnet_backward_stage(const isd_eegnet_plan* plan, int stage, const float* x, const float* params,
+                              const float* dout, float* dparams, void* workspace, int64_t B, float dropout_p,
+                              uint64_t seed, int world, void* stream);
+int isd_eegnet_sync_block(const isd_eegnet_plan* plan, int64_t B, int backward, int stage, int64_t* byte_offset,
+                          int64_t* n_doubles);
 
 /* ------------------------------------------------------------------------
  * Transformer tail of FAST (src/fast/models/fast.py:10-29 AttentionBlock, :260-268 forward_transformer).
