@@ -557,10 +557,12 @@ __device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_log
 // neighbours.  o0 = frame (lane & 15), o16 = frame 16 (meaningful on lane 15).
 // MAG: mean magnitude (a square root per bin and frame) instead of mean power -- a template parameter because the
 // compiler turns the run-time test into selects and evaluates both square roots (a third of the loop) either way.
-template <bool MAG>
+// GPR: 16-lane groups per row (1: rows of <= 512 samples, frame 16 on lane 15; 2: <= 1024 samples, the neighbour join
+// crosses the DPP row boundary and frame 32 sits on lane 31 of the row's 32 lanes).
+template <bool MAG, int GPR = 1>
 __device__ __forceinline__ void band_reduce_pairs(const f2 (&vf)[kL / 2], const float2* __restrict__ dft, int klo,
                                                   int khi, bool mine_lo_hi_valid, int my_klo, int my_khi, float scale2,
-                                                  float& o0, float& o16) {
+                                                  float& o0, float& o16, bool row_start = false) {
   float acc = 0.f, acc16 = 0.f;
   for (int k = klo; k <= khi; ++k) {
     const f2* __restrict__ tb = reinterpret_cast<const f2*>(dft + k * 64);   // [4][16] sample-pair entries (stft.hip)
@@ -580,7 +582,14 @@ __device__ __forceinline__ void band_reduce_pairs(const f2 (&vf)[kL / 2], const 
       }
     }
     const f2 p1 = {a1r.x + a1r.y, a1i.x + a1i.y}, p2 = {a2r.x + a2r.y, a2i.x + a2i.y};
-    const float zr = p2.x + row_shr<1>(p1.x), zi = p2.y + row_shr<1>(p1.y);
+    float nr, ni;                                         // first-half sums of the previous chunk of the row
+    if (GPR == 1) {
+      nr = row_shr<1>(p1.x); ni = row_shr<1>(p1.y);
+    } else {
+      nr = wave_shr1(p1.x); ni = wave_shr1(p1.y);
+      nr = row_start ? 0.f : nr; ni = row_start ? 0.f : ni;
+    }
+    const float zr = p2.x + nr, zi = p2.y + ni;
     float pw = (zr * zr + zi * zi) * scale2;
     float pw16 = (p1.x * p1.x + p1.y * p1.y) * scale2;
     if (MAG) { pw = sqrtf(pw); pw16 = sqrtf(pw16); }
@@ -648,37 +657,42 @@ __global__ __launch_bounds__(64) void bandpower_direct_kernel(const float2* __re
   }
 }
 
-// Fused spec-S extractor for T <= 512, nperseg 64 / hop 32: after the cascade each lane
+// Fused spec-S extractor for T <= 1024 (GPR = 1: T <= 512; GPR = 2: the reference-native 800-sample trial,
+// src/fast/data/preprocess.py:62), nperseg 64 / hop 32: after the cascade each lane
 // holds chunk i of its row; STFT frame j is chunk j-1 (window first half) followed by
 // chunk j (second half), so every lane forms two partial windowed DFT sums per bin and
 // one DPP row_shr joins neighbours.  Only the band's own bins are evaluated.
 // Everything that does not depend on the band (the row's trial / channel split -- an integer division -- and its
 // output address) is computed once in front of the band loop: inside it the compiler does not hoist them out of the
 // `row < R` branch, and they were a tenth of the loop's instructions.
-template <typename VT, bool MAG>
+template <typename VT, bool MAG, int GPR>
 __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
+                                                   const double* __restrict__ Qtab,
                                                    const float2* __restrict__ dft, const float* __restrict__ x,
                                                    float* __restrict__ feat, int R, int C, int T, int nb, int ns,
                                                    int J, float scale2, FusedBands fbnd, int mode, float eps,
                                                    int vec, const int* __restrict__ bmap, int nb_out) {
   using O = VOps<VT>;
+  static_assert(GPR == 1 || GPR == 2, "rows of at most 1024 samples");
   __shared__ __attribute__((aligned(16))) float tile[4 * 16 * kPad];
   const int lane = threadIdx.x;
-  const int i = lane & 15;
-  const int row0 = blockIdx.x * 4;
+  constexpr int LPR = 16 * GPR;                             // lanes (= 32-sample chunks) per row
+  const int i = lane & (LPR - 1);
+  const int row0 = blockIdx.x * (4 / GPR);
   int64_t xbase[4];
   int gt0[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    gt0[g] = 0;
-    xbase[g] = (row0 + g < R) ? (row0 + g) * (int64_t)T : -1;
+    gt0[g] = (g % GPR) * kSeg;
+    const int r = row0 + g / GPR;
+    xbase[g] = (r < R && gt0[g] < T) ? r * (int64_t)T : -1;
   }
-  const int row = row0 + (lane >> 4);
+  const int row = row0 + lane / LPR;
   const bool row_ok = row < R;
   const int bt = row / C, ch = row - bt * C;
   float* const orow = feat + ((int64_t)bt * nb_out * C + ch) * (int64_t)J + i;   // band 0, frame i of this lane's row
   const int64_t bstride = (int64_t)C * J;
-  const bool st0 = row_ok && i < J, st16 = row_ok && i == 15 && J == 17;
+  const bool st0 = row_ok && i < J, st16 = row_ok && i == LPR - 1 && J == LPR + 1;
   XArr xs;
   load_chunks(xs, tile, x, lane, xbase, gt0, T, vec != 0);
   for (int b = 0; b < nb; ++b) {
@@ -686,13 +700,13 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
     O::from_x(v, xs, O::g(bands[b]));
     for (int s = 0; s < ns; ++s) {
       double c1 = 0.0, c2 = 0.0;
-      section<VT, 1>(v, secs[b * ns + s], nullptr, lane, c1, c2);
+      section<VT, GPR>(v, secs[b * ns + s], GPR > 1 ? Qtab + (int64_t)(b * ns + s) * 64 : nullptr, lane, c1, c2);
     }
     XArr vf;                                          // fp32 copy for the DFT (the chunk itself when VT is fp32)
     O::to_f32(v, vf);
-    if (T < kSeg) zero_past_end(vf, i, T);
+    if (T < LPR * kL) zero_past_end(vf, i, T);
     float o0, o16;
-    band_reduce_pairs<MAG>(vf, dft, fbnd.klo[b], fbnd.khi[b], false, 0, 0, scale2, o0, o16);
+    band_reduce_pairs<MAG, GPR>(vf, dft, fbnd.klo[b], fbnd.khi[b], false, 0, 0, scale2, o0, o16, i == 0);
     const float inv = fbnd.inv[b];
     o0 *= inv;
     o16 *= inv;
@@ -1018,16 +1032,16 @@ static void set_band(FusedBands& f, int i, int klo, int khi) {
 template <typename VT>
 static int fused_launch(const isd_fb_plan* fb, const FbSet& fs, const isd_stft_plan* st, const float* x, float* feat,
                         int64_t R, int C, const FusedBands& fbnd, int mode, float eps, hipStream_t stream) {
-  const int64_t items = cdiv(R, 4);
+  const bool two = st->T > kSeg;                          // rows of 513..1024 samples: two 16-lane groups per row
+  const int64_t items = cdiv(R, two ? 2 : 4);
   const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  if (mode == ISD_BP_MAGNITUDE)
-    hipLaunchKernelGGL((fused_kernel<VT, true>), dim3((unsigned)items), dim3(64), 0, stream, fs.d_sec, fs.d_band,
-                       st->d_dft, x, feat, (int)R, C, st->T, fs.nb, fb->n_sections, st->J, st->scale * st->scale, fbnd,
-                       mode, eps, vec, fs.d_map, fb->n_bands);
-  else
-    hipLaunchKernelGGL((fused_kernel<VT, false>), dim3((unsigned)items), dim3(64), 0, stream, fs.d_sec, fs.d_band,
-                       st->d_dft, x, feat, (int)R, C, st->T, fs.nb, fb->n_sections, st->J, st->scale * st->scale, fbnd,
-                       mode, eps, vec, fs.d_map, fb->n_bands);
+#define ISD_FUSED(M, G)                                                                                              \
+  hipLaunchKernelGGL((fused_kernel<VT, M, G>), dim3((unsigned)items), dim3(64), 0, stream, fs.d_sec, fs.d_band, fs.d_Q, \
+                     st->d_dft, x, feat, (int)R, C, st->T, fs.nb, fb->n_sections, st->J, st->scale * st->scale, fbnd,  \
+                     mode, eps, vec, fs.d_map, fb->n_bands)
+  if (mode == ISD_BP_MAGNITUDE) { if (two) ISD_FUSED(true, 2); else ISD_FUSED(true, 1); }
+  else { if (two) ISD_FUSED(false, 2); else ISD_FUSED(false, 1); }
+#undef ISD_FUSED
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
@@ -1040,10 +1054,10 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
   ISD_CHECK_ARG(B >= 0 && C >= 1 && C <= (1 << 20), "isd_features_fused: bad shape B=%lld C=%lld", (long long)B,
                 (long long)C);
   ISD_CHECK_ARG(mode >= ISD_BP_MAGNITUDE && mode <= ISD_BP_LOGPOWER, "isd_features_fused: bad mode %d", mode);
-  const bool short_rows = st->n == 64 && st->hop == 32 && st->T <= kSeg && st->d_dft;
+  const bool short_rows = st->n == 64 && st->hop == 32 && st->T <= 2 * kSeg && st->d_dft;
   const bool long_rows = st->d_blk && st->hop == 64 && st->T <= 64 * 64;
   if (!short_rows && !long_rows) {
-    set_error("isd_features_fused: needs nperseg=64/noverlap=32/T<=512, or hop 64 with nperseg = 2^a*64 and T<=4096 "
+    set_error("isd_features_fused: needs nperseg=64/noverlap=32/T<=1024, or hop 64 with nperseg = 2^a*64 and T<=4096 "
               "(got nperseg=%d hop=%d T=%d)", st->n, st->hop, st->T);
     return ISD_ERR_UNSUPPORTED;
   }

@@ -137,9 +137,10 @@ class FeatureExtractor:
         self._khi = _lib.int_array([b[1] for b in self.bins])
         n, hop = self.stft.nperseg, self.stft.nperseg - self.stft.noverlap
         nblk = n // hop if hop and n % hop == 0 else 0
-        # one kernel for filterbank + STFT + band power: short rows (64/32 frames, T <= 512), or long rows with
-        # heavily overlapped frames (hop 64, nperseg = 2^a * 64, T <= 4096, 1..6 interior bins per band)
-        short = n == 64 and self.stft.noverlap == 32 and T <= 512
+        # one kernel for filterbank + STFT + band power: short rows (64/32 frames, T <= 1024: the 512-sample trial of
+        # the headline configuration and the reference-native 800-sample trial), or long rows with heavily overlapped
+        # frames (hop 64, nperseg = 2^a * 64, T <= 4096, 1..6 interior bins per band)
+        short = n == 64 and self.stft.noverlap == 32 and T <= 1024
         long_ = (hop == 64 and nblk in (4, 8, 16, 32, 64) and T <= 4096 and
                  all(1 <= lo and hi <= n // 2 - 1 and 1 <= hi - lo + 1 <= 6 for lo, hi in self.bins))
         self.can_fuse = short or long_

@@ -81,7 +81,9 @@ def g3():
     out = {}
     for tag, bands, fs, T, C, nperseg, nov in (("c1", odsp.BANDS_5, 256.0, 512, 64, 64, 32),
                                                 ("c2", odsp.BANDS_9, 256.0, 512, 64, 64, 32),
-                                                ("c5", odsp.BANDS_40[:6], 1024.0, 4096, 4, 1024, 960)):
+                                                ("c5", odsp.BANDS_40[:6], 1024.0, 4096, 4, 1024, 960),
+                                                # the reference-native trial: 800 samples @ 250 Hz (preprocess.py:62)
+                                                ("c800", odsp.BANDS_9, 250.0, 800, 8, 64, 32)):
         B = 4 if C == 64 else 2
         x = np.random.default_rng(3).standard_normal((B, C, T)).astype(np.float32)
         feats = []

@@ -42,7 +42,8 @@ def test_sosfilt_matches_scipy_golden(tag):
         assert rel_err(y, g[f"{tag}_y"][:, j]) < 1e-11
 
 
-@pytest.mark.parametrize("tag,bands", [("c1", odsp.BANDS_5), ("c2", odsp.BANDS_9), ("c5", odsp.BANDS_40[:6])])
+@pytest.mark.parametrize("tag,bands", [("c1", odsp.BANDS_5), ("c2", odsp.BANDS_9), ("c5", odsp.BANDS_40[:6]),
+                                       ("c800", odsp.BANDS_9)])
 def test_spec_s_features_match_scipy_golden(tag, bands):
     g = load_golden("g3_features.npz")
     B, C, T, fs, nperseg, nov, nb = g[f"{tag}_cfg"]

@@ -19,11 +19,14 @@ def timeit(fn, n=20, warm=3):
 
 
 def main():
-    B, C, T = 4096, 64, 512
-    x = torch.randn(B, C, T, device="cuda")
-    for name, bands, prec in (("9band/f32", isd_amd.BANDS_9, "f32"), ("9band/f64", isd_amd.BANDS_9, "f64"),
-                              ("5band/auto", isd_amd.BANDS_5, "auto")):
-        fx = isd_amd.FeatureExtractor(T, 256.0, bands, precision=prec)
+    B, C = 4096, 64
+    for name, bands, prec, T, fs in (("9band/f32 T=512", isd_amd.BANDS_9, "f32", 512, 256.0),
+                                     ("9band/f64 T=512", isd_amd.BANDS_9, "f64", 512, 256.0),
+                                     ("5band/auto T=512", isd_amd.BANDS_5, "auto", 512, 256.0),
+                                     # the reference-native trial (src/fast/data/preprocess.py:62)
+                                     ("9band/f32 T=800 @250 Hz", isd_amd.BANDS_9, "f32", 800, 250.0)):
+        x = torch.randn(B, C, T, device="cuda")
+        fx = isd_amd.FeatureExtractor(T, fs, bands, precision=prec)
         nb = fx.n_bands
         y = torch.empty(B, nb, C, T, device="cuda")
         out = torch.empty(B, nb, C, fx.n_frames, device="cuda")
