@@ -199,3 +199,57 @@ class BasicDataset:
 
     def __getitem__(self, idx):
         return self.data[idx], self.labels[idx]
+
+
+class DeviceStager:
+    """Asynchronous host -> device staging (the ``pin_memory=True`` DataLoader + Lightning batch transfer of
+    scripts/train_fast.py:104-111,127-140): arrays are copied into pinned host buffers and uploaded with
+    ``non_blocking`` copies on a dedicated HIP stream, so the upload of the NEXT fold / subject / batch runs under the
+    kernels of the current one.  ``put`` returns at once; ``get`` makes the CURRENT stream wait (stream-side, no host
+    sync) for the copy that was started ``depth`` puts ago.
+
+        st = DeviceStager()
+        st.put(X0, y0)
+        for k in range(n):
+            if k + 1 < n: st.put(X[k + 1], y[k + 1])      # upload k+1 ...
+            xd, yd = st.get()                             # ... while batch k computes
+    """
+
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        self._queue = []
+        self._pinned = {}                                  # (slot, shape, dtype) -> reusable pinned buffer
+
+    def _pin(self, slot, arr):
+        torch = self.torch
+        t = torch.as_tensor(np.ascontiguousarray(arr))
+        key = (slot, tuple(t.shape), t.dtype)
+        buf = self._pinned.get(key)
+        if buf is None:
+            buf = self._pinned[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        buf.copy_(t)
+        return buf
+
+    def put(self, *arrays):
+        """Start the upload of one item (any number of arrays: trials, labels)."""
+        torch = self.torch
+        slot = len(self._queue) % 2                        # two pinned buffers per array position: double buffering
+        outs = []
+        with torch.cuda.stream(self.stream):
+            for i, a in enumerate(arrays):
+                host = self._pin((slot, i), a)
+                outs.append(host.to(self.device, non_blocking=True))
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self._queue.append((outs, done))
+
+    def get(self):
+        """Device tensors of the oldest pending item; the current stream is made to wait for its copy."""
+        outs, done = self._queue.pop(0)
+        self.torch.cuda.current_stream(self.device).wait_event(done)
+        for t in outs:
+            t.record_stream(self.torch.cuda.current_stream(self.device))
+        return outs if len(outs) > 1 else outs[0]

@@ -19,7 +19,8 @@ import numpy as np
 import torch
 
 from .classifier import cosine_scheduler, lr_multiplier
-from .nn import FAST, fast_config, token_mean_cross_entropy
+from .data import DeviceStager
+from .nn import FAST, fast_config, reset_dropout_streams, token_mean_cross_entropy
 
 
 def accuracy(y_true, y_pred):
@@ -58,28 +59,43 @@ def kfold_indices(n, n_folds, seed):
 
 
 def predict(model, X, batch_size=256, forward_mode="default"):
-    """``inference_on_loader`` (trainer.py:82-93): argmax class indices, int64."""
+    """``inference_on_loader`` (trainer.py:82-93): argmax class indices, int64.  ``X`` may already be on the device;
+    host arrays are uploaded batch by batch through pinned buffers, the copy of batch k+1 under the kernels of batch k."""
     model.eval()
     outs = []
+    n = len(X)
+    on_dev = isinstance(X, torch.Tensor) and X.is_cuda
     with torch.no_grad():
-        for i in range(0, len(X), batch_size):
-            xb = torch.as_tensor(X[i:i + batch_size], dtype=torch.float32).cuda()
-            outs.append(model(xb, forward_mode=forward_mode).argmax(dim=1).cpu())
-    return torch.cat(outs).numpy() if outs else np.zeros((0,), np.int64)
+        if on_dev:
+            for i in range(0, n, batch_size):
+                outs.append(model(X[i:i + batch_size].contiguous(), forward_mode=forward_mode).argmax(dim=1))
+        elif n:
+            st = DeviceStager()
+            st.put(np.asarray(X[:batch_size], dtype=np.float32))
+            for i in range(0, n, batch_size):
+                if i + batch_size < n:
+                    st.put(np.asarray(X[i + batch_size:i + 2 * batch_size], dtype=np.float32))
+                outs.append(model(st.get(), forward_mode=forward_mode).argmax(dim=1))
+    return torch.cat(outs).cpu().numpy() if outs else np.zeros((0,), np.int64)
 
 
 def train_one_fold(config, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, forward_mode="default", lr=5e-4,
                    warmup_epochs=10):
-    """One fine-tuning run; returns (best_val_acc, best_state_dict, history)."""
+    """One fine-tuning run; returns (best_val_acc, best_state_dict, history).  The fold's trials go to the device
+    once, asynchronously from pinned memory (the validation split uploads under the first training steps)."""
     torch.manual_seed(seed)
+    reset_dropout_streams()                              # the fold's masks do not depend on what ran before it
     model = FAST(config).cuda()
     opt = torch.optim.AdamW(model.parameters(), lr=lr)
     n = len(Xtr)
     bs = min(batch_size, n)
     iters = (n + bs - 1) // bs
     table = cosine_scheduler(1, 0.1, max_epochs, iters, warmup_epochs=min(warmup_epochs, max(max_epochs - 1, 0)))
-    Xd = torch.as_tensor(Xtr, dtype=torch.float32).cuda()
-    yd = torch.as_tensor(np.asarray(ytr)).cuda()
+    st = DeviceStager()
+    st.put(np.asarray(Xtr, dtype=np.float32), np.asarray(ytr))
+    st.put(np.asarray(Xva, dtype=np.float32))
+    Xd, yd = st.get()
+    Xva = st.get()
     gen = torch.Generator().manual_seed(seed)
     best, best_sd, hist, step = -1.0, None, [], 0
     for ep in range(max_epochs):
@@ -109,19 +125,69 @@ def _save_predictions(path, y_pred, y_true):
     np.savetxt(path, np.array([y_pred, y_true]).T, delimiter=",", fmt="%d", header="Predicted,True")
 
 
+def _fold_worker(device, tasks, results):
+    """Worker process of the fold packing: bound to one GPU, trains (subject, fold) tasks until the sentinel."""
+    torch.cuda.set_device(device)
+    while True:
+        task = tasks.get()
+        if task is None:
+            return
+        key, cfg, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, mode = task
+        acc, sd, _ = train_one_fold(cfg, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, mode)
+        results.put((key, acc, {k: v.cpu().numpy() for k, v in sd.items()}))
+
+
+def run_folds(fold_tasks, workers=0, devices=None):
+    """Train independent (subject, fold) fine-tunings.  ``fold_tasks``: {key: (cfg, Xtr, ytr, Xva, yva, max_epochs,
+    batch_size, seed, mode)}.  ``workers == 0``: one after another in this process.  Otherwise the trainings -- 75 of
+    them in the reference's protocol (scripts/train_fast.py:86-111), each launch-bound at batch 64 -- are packed over
+    ``workers`` processes bound round-robin to ``devices`` (default: every visible GPU): several small trainings share
+    a GPU, and the GPUs of a node work on different folds.  Returns {key: (best_val_acc, state_dict)}."""
+    if workers <= 0:
+        return {k: train_one_fold(*t)[:2] for k, t in fold_tasks.items()}
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    devices = list(range(torch.cuda.device_count())) if devices is None else list(devices)
+    tasks, results = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_fold_worker, args=(devices[w % len(devices)], tasks, results)) for w in range(workers)]
+    for p in procs:
+        p.start()
+    for k, t in fold_tasks.items():
+        tasks.put((k,) + tuple(t))
+    for _ in procs:
+        tasks.put(None)
+    out = {}
+    for _ in fold_tasks:
+        k, acc, sd = results.get()
+        out[k] = (acc, {n: torch.from_numpy(v) for n, v in sd.items()})
+    for p in procs:
+        p.join()
+        if p.exitcode != 0:
+            raise RuntimeError(f"fold worker exited with code {p.exitcode}")
+    return out
+
+
 def finetune_per_subject_cv(train_val, test, out_dir, config=None, n_folds=5, max_epochs=200, batch_size=64, seed=42,
-                            forward_mode="default"):
-    """``train_val`` / ``test``: {SID: (X [n,C,T], y)}.  Mirrors scripts/train_fast.py:68-265; returns the summary rows."""
+                            forward_mode="default", workers=0, devices=None):
+    """``train_val`` / ``test``: {SID: (X [n,C,T], y)}.  Mirrors scripts/train_fast.py:68-265; returns the summary rows.
+    ``workers`` > 0 packs the subject x fold trainings over that many processes / the GPUs in ``devices``
+    (``run_folds``); results do not depend on the packing."""
     save_dir = os.path.join(out_dir, "FAST")
     os.makedirs(save_dir, exist_ok=True)
     rows, gp, gt = [], [], []
+    fold_tasks = {}
+    for sid, (X, y) in train_val.items():
+        cfg = config or fast_config(seq_len=int(X.shape[-1]))
+        for fi, (tr, va) in enumerate(kfold_indices(len(X), n_folds, seed)):
+            fold_tasks[(sid, fi)] = (cfg, X[tr], y[tr], X[va], y[va], max_epochs, batch_size, seed, forward_mode)
+    done = run_folds(fold_tasks, workers, devices)
     for sid, (X, y) in train_val.items():
         cfg = config or fast_config(seq_len=int(X.shape[-1]))
         sub_dir = os.path.join(save_dir, f"sub-{sid}")
         os.makedirs(sub_dir, exist_ok=True)
         fold_rows, best_acc, best_sd = [], -1.0, None
-        for fi, (tr, va) in enumerate(kfold_indices(len(X), n_folds, seed)):
-            acc, sd, _ = train_one_fold(cfg, X[tr], y[tr], X[va], y[va], max_epochs, batch_size, seed, forward_mode)
+        for fi in range(n_folds):
+            acc, sd = done[(sid, fi)]
             fold_rows.append([fi, acc])
             if acc > best_acc:
                 best_acc, best_sd = acc, sd
@@ -197,13 +263,15 @@ def main(argv=None):
     ap.add_argument("--n_folds", type=int, default=5)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--forward_mode", default="default", choices=["default", "train_head"])
+    ap.add_argument("--workers", type=int, default=0, help="pack the subject x fold trainings over this many processes")
+    ap.add_argument("--devices", type=int, nargs="*", default=None, help="GPUs the workers are bound to (default: all)")
     args = ap.parse_args(argv)
     from .data import load_standardized
     torch.cuda.set_device(args.gpu)
     tv = load_standardized(args.data)
     te = load_standardized(args.test) if args.test else {}
     rows = finetune_per_subject_cv(tv, te, args.output_dir, None, args.n_folds, args.epochs, args.batch_size, args.seed,
-                                   args.forward_mode)
+                                   args.forward_mode, args.workers, args.devices)
     per, summary = process_results(args.output_dir)
     print(summary if summary else rows)
 

@@ -608,6 +608,14 @@ def _new_dropout_stream():
     return _dropout_streams[0]
 
 
+def reset_dropout_streams():
+    """Restart the per-module dropout stream numbering (and the attention call counter): a training run that builds its
+    model after this call draws the same masks wherever and in whatever order it is scheduled (the experiment driver
+    calls it per fold, so packing folds over worker processes does not change any result)."""
+    _dropout_streams[0] = 0
+    AttentionBlock._calls = 0
+
+
 def _dropout_seed(stream_id, call):
     """Counter-based seed = f(torch seed, data-parallel rank, module instance, call index): splitmix64-style mixing of
     the four words so neighbouring streams / ranks / calls are unrelated."""

@@ -191,3 +191,49 @@ def test_zone_encoders_of_one_head_draw_different_dropout_masks(isd):
     x = torch.randn(8, 6, 250, device="cuda")
     ya, yb = a(x).detach(), b(x).detach()
     assert a._calls == b._calls == 1 and not torch.allclose(ya, yb)
+
+
+def test_device_stager_uploads_asynchronously_and_in_order(isd):
+    """Pinned double-buffered H2D staging: items come back in order, on the device, equal to the host arrays -- also
+    when a pinned buffer is reused while an earlier item is still being consumed."""
+    from isd_amd.data import DeviceStager
+    rng = np.random.default_rng(0)
+    items = [(rng.standard_normal((17, 8, 500)).astype(np.float32), rng.integers(0, 5, 17).astype(np.uint8))
+             for _ in range(5)]
+    st = DeviceStager()
+    st.put(*items[0])
+    got = []
+    for k in range(5):
+        if k + 1 < 5:
+            st.put(*items[k + 1])
+        xd, yd = st.get()
+        assert xd.is_cuda and yd.is_cuda and yd.dtype == torch.uint8
+        got.append((xd.square().sum(), xd, yd))                 # work queued on the current stream behind the copy
+    torch.cuda.synchronize()
+    for (s, xd, yd), (xh, yh) in zip(got, items):
+        assert np.array_equal(xd.cpu().numpy(), xh) and np.array_equal(yd.cpu().numpy(), yh)
+        assert abs(float(s) - float((xh.astype(np.float64) ** 2).sum())) < 1e-2 * float((xh ** 2).sum())
+
+
+def test_fold_packing_over_worker_processes_equals_serial_run(isd, tmp_path):
+    """The subject x fold trainings packed over two worker processes (scripts/train_fast.py:86-111 runs them one after
+    another) give the results of the serial run: same fold accuracies, same best checkpoints."""
+    from isd_amd import experiment as E
+    import isd_amd.nn as inn
+    rng = np.random.default_rng(1)
+    electrodes = ["Fp1", "Fp2", "F3", "F4", "C3", "C4", "O1", "O2"]
+    zones = {"Frontal": ["Fp1", "Fp2", "F3", "F4"], "Central": ["C3", "C4"], "Occipital": ["O1", "O2"]}
+    cfg = inn.fast_config(electrodes, zones, dim_cnn=16, dim_token=16, seq_len=500, n_classes=3, num_layers=1,
+                          num_heads=4, dropout=0.1)
+    tv = {sid: (rng.standard_normal((12, 8, 500)).astype(np.float32), rng.integers(0, 3, 12).astype(np.uint8))
+          for sid in ("01", "02")}
+    a = E.finetune_per_subject_cv(tv, {}, str(tmp_path / "serial"), cfg, n_folds=2, max_epochs=2, batch_size=4, seed=1)
+    b = E.finetune_per_subject_cv(tv, {}, str(tmp_path / "packed"), cfg, n_folds=2, max_epochs=2, batch_size=4, seed=1,
+                                  workers=2)
+    assert [r[:2] for r in a] == [r[:2] for r in b]
+    for sid in ("01", "02"):
+        sa = torch.load(tmp_path / "serial" / "FAST" / f"sub-{sid}" / "best_subject.pth")
+        sb = torch.load(tmp_path / "packed" / "FAST" / f"sub-{sid}" / "best_subject.pth")
+        assert sa.keys() == sb.keys()
+        for k in sa:
+            assert rel_err(sb[k].float(), sa[k].float()) < 1e-5, k

@@ -1,29 +1,58 @@
-"""Throughput of the reference-native path: FAST 'train_head' on raw EEG (fwd+bwd+AdamW), device-resident."""
+"""Throughput of the reference-native paths on raw EEG (fwd+bwd+AdamW, device-resident trials):
+FAST 'train_head' through the autograd-free Trainer, and FAST 'default' -- the mode the reference trains
+(src/fast/train/trainer.py:58: zone CNN -> Linear+GELU -> cls/pos embedding -> 4 pre-LN transformer blocks ->
+classifier) -- through the autograd modules of isd_amd.nn with torch's fused AdamW."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import isd_amd
+import isd_amd.nn as inn
 from isd_amd.classifier import _FastModel
 from isd_amd.nn import fast_config
 
+
+def timed(step, n):
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, out
+
+
 def main():
-    for B, T in ((1024, 512), (4096, 512), (1024, 800)):
+    for B, T in ((64, 800), (1024, 512), (4096, 512), (1024, 800)):
         torch.manual_seed(0)
         m = _FastModel(fast_config(seq_len=T)).cuda()
         tr = isd_amd.Trainer(m)
         x = torch.randn(B, 64, T, device="cuda")
         y = torch.randint(0, 5, (B,), device="cuda")
-        for _ in range(2):
-            tr.step(x, y)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 5
-        for _ in range(n):
-            out = tr.step(x, y)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
-        print(f"FAST train_head B={B} T={T}: {dt*1e3:.2f} ms/step, {B/dt:.0f} trials/s, loss {float(out['loss']):.4f}, "
+        dt, out = timed(lambda: tr.step(x, y), 20 if B <= 1024 else 5)
+        print(f"FAST train_head B={B} T={T}: {dt*1e3:.3f} ms/step, {B/dt:.0f} trials/s, loss {float(out['loss']):.4f}, "
               f"mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+    for B, T in ((64, 800), (4096, 800), (4096, 512)):
+        torch.manual_seed(0)
+        net = inn.FAST(fast_config(seq_len=T)).cuda().train()
+        opt = torch.optim.AdamW(net.parameters(), lr=5e-4, fused=True)
+        x = torch.randn(B, 64, T, device="cuda")
+        y = torch.randint(0, 5, (B,), device="cuda")
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            logits = net(x, forward_mode="default")
+            loss = inn.token_mean_cross_entropy(logits.unsqueeze(1), y)
+            loss.backward()
+            opt.step()
+            return loss
+        dt, loss = timed(step, 20 if B <= 1024 else 5)
+        net.eval()
+        with torch.no_grad():
+            di, _ = timed(lambda: net(x, forward_mode="default"), 20 if B <= 1024 else 5)
+        print(f"FAST default    B={B} T={T}: {dt*1e3:.3f} ms/step, {B/dt:.0f} trials/s, loss {float(loss):.4f} | "
+              f"inference {di*1e3:.3f} ms, {B/di:.0f} trials/s")
+
 
 if __name__ == "__main__":
     main()
