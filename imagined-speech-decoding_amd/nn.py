@@ -142,6 +142,8 @@ class _LinearFn(torch.autograd.Function):
         K, N = x.shape[-1], w.shape[0]
         M = x.numel() // K
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        if M == 0:                                   # no rows: nothing reaches the weights
+            return dx, torch.zeros_like(w), torch.zeros(N, device=x.device) if ctx.has_bias else None, None
         dw = torch.empty_like(w)
         db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
         ws = torch.empty(max(int(_lib.lib().isd_linear_workspace_bytes(M, K, N)) // 4, 1), dtype=torch.float32,
@@ -453,6 +455,58 @@ class _EmbedFn(torch.autograd.Function):
             _lib.check(_lib.lib().isd_embed_backward(dtok.data_ptr(), dx.data_ptr(), dcls.data_ptr(), dpos.data_ptr(), B,
                                                      N, D, _stream()))
         return dx, dcls.view(cshape), dpos
+
+
+class _TailFusedFn(torch.autograd.Function):
+    """cls/pos embedding -> every AttentionBlock -> cls dropout -> last_layer in one launch per direction
+    (csrc/tailfused.hip).  The parameters are read from ``flat`` (the module's packed tail block); ``params`` are the
+    same tensors as autograd inputs, so that their gradients -- views of one flat gradient block -- reach them."""
+
+    @staticmethod
+    def forward(ctx, tokin, flat, cfg, *params):
+        tokin = _f32c(tokin, "tokens")
+        B, N, D = tokin.shape
+        n_pos, H, L, hidden, n_cls, p_attn, p_mlp, p_cls, seed, train = cfg
+        L_ = _lib.lib()
+        logits = torch.empty((B, n_cls), dtype=torch.float32, device=tokin.device)
+        save = xfinal = None
+        if train:
+            save = torch.empty(int(L_.isd_tail_fused_save_floats(B, N + 1, D, L)), dtype=torch.float32,
+                               device=tokin.device)
+            xfinal = torch.empty((B, D), dtype=torch.float32, device=tokin.device)
+        with torch.cuda.device(tokin.device):
+            _lib.check(L_.isd_tail_fused_forward(flat.data_ptr(), tokin.data_ptr(), logits.data_ptr(),
+                                                 save.data_ptr() if train else 0, xfinal.data_ptr() if train else 0,
+                                                 B, N, n_pos, D, H, L, hidden, n_cls, p_attn, p_mlp, p_cls, seed,
+                                                 _stream()))
+        ctx.cfg, ctx.dims = cfg, (B, N, D)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        if train:
+            ctx.save_for_backward(flat, save, xfinal)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        flat, save, xfinal = ctx.saved_tensors
+        n_pos, H, L, hidden, n_cls, p_attn, p_mlp, p_cls, seed, _ = ctx.cfg
+        B, N, D = ctx.dims
+        dlogits = _f32c(dlogits, "dlogits")
+        L_ = _lib.lib()
+        dtok = torch.empty((B, N, D), dtype=torch.float32, device=flat.device)
+        dflat = torch.empty_like(flat)
+        ws = torch.empty(int(L_.isd_tail_fused_workspace_floats(B, N, n_pos, D, L, n_cls)), dtype=torch.float32,
+                         device=flat.device)
+        with torch.cuda.device(flat.device):
+            _lib.check(L_.isd_tail_fused_backward(flat.data_ptr(), save.data_ptr(), xfinal.data_ptr(),
+                                                  dlogits.data_ptr(), dtok.data_ptr(), dflat.data_ptr(), ws.data_ptr(),
+                                                  B, N, n_pos, D, H, L, hidden, n_cls, p_attn, p_mlp, p_cls, seed,
+                                                  _stream()))
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = math.prod(shp)
+            grads.append(dflat[off:off + n].view(shp))
+            off += n
+        return (dtok, None, None, *grads)
 
 
 def linear(x, weight, bias=None, act=False):
@@ -931,6 +985,36 @@ class FAST(nn.Module):
         self.cls_token = nn.Parameter(torch.randn(1, 1, config.dim_token))
         self.last_layer = nn.Linear(config.dim_token, config.n_classes)
         self.dropout = nn.Dropout(config.dropout)
+        self.fuse_tail = True               # one launch per direction for the transformer tail where it applies
+        self._tail_stream, self._tail_calls = _new_dropout_stream(), 0
+
+    def _tail_params(self):
+        """The tail's parameters in the order of the fused kernels' flat block (include/isd_hip.h)."""
+        ps = [self.pos_embedding, self.cls_token]
+        for blk in self.transformer:
+            ps += [blk.layer_norm_1.weight, blk.layer_norm_1.bias, blk.attn.in_proj_weight, blk.attn.in_proj_bias,
+                   blk.attn.out_proj.weight, blk.attn.out_proj.bias, blk.layer_norm_2.weight, blk.layer_norm_2.bias,
+                   blk.linear[0].weight, blk.linear[0].bias, blk.linear[3].weight, blk.linear[3].bias]
+        return ps + [self.last_layer.weight, self.last_layer.bias]
+
+    def _tail_flat(self, ps):
+        """The tail's parameters as one contiguous block (re-packed in place if something moved them)."""
+        flat = _FlatParamMixin._as_flat([p.data for p in ps])
+        if flat is None:
+            flat = torch.cat([p.detach().reshape(-1).float() for p in ps]).contiguous()
+            off = 0
+            for p in ps:
+                p.data = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+        return flat
+
+    def _tail_fusable(self, tok):
+        c = self.config
+        blk = self.transformer[0] if len(self.transformer) else None
+        return (self.fuse_tail and blk is not None and tok.is_cuda and tok.dtype == torch.float32
+                and blk.layer_norm_1.eps == 1e-5 and blk.layer_norm_2.eps == 1e-5
+                and bool(_lib.lib().isd_tail_fused_supported(tok.shape[1], c.dim_token, c.num_heads, len(self.transformer),
+                                                             blk.linear[0].out_features, c.n_classes)))
 
     def forward_head(self, x, step_override=None):
         step = self.config.slide_step if step_override is None else step_override
@@ -951,6 +1035,16 @@ class FAST(nn.Module):
         """feature [B, N, Z, F] -> logits [B, n_classes]  (fast.py:260-268)."""
         B, N, Z, Fd = feature.shape
         tok = linear(feature.reshape(B, N, Z * Fd), self.input_layer[0].weight, self.input_layer[0].bias, act=True)
+        if self._tail_fusable(tok):
+            c = self.config
+            ps = self._tail_params()
+            train = torch.is_grad_enabled() and (tok.requires_grad or any(p.requires_grad for p in ps))
+            self._tail_calls += 1
+            p_blk = float(self.transformer[0].p) if self.training else 0.0
+            cfg = (self.pos_embedding.shape[1], c.num_heads, len(self.transformer), self.transformer[0].linear[0].out_features,
+                   c.n_classes, p_blk, p_blk, float(self.dropout.p) if self.training else 0.0,
+                   _dropout_seed(self._tail_stream, self._tail_calls), train)
+            return _TailFusedFn.apply(tok, self._tail_flat(ps), cfg, *ps)
         tok = _EmbedFn.apply(tok, self.cls_token, self.pos_embedding[:, :N + 1].contiguous())
         tok = self.transformer(tok)
         cls = self.dropout(tok[:, 0].contiguous())

@@ -279,6 +279,36 @@ int isd_attention_backward(const float* qkv, const float* probs, const float* dc
                            int H, int head_dim, float dropout_p, uint64_t seed, void* stream);
 
 /* ----------------------------------------------------------------------
+ * The whole transformer tail in ONE launch per direction (replaces the per-operator sequence above for
+ * FAST.forward_transformer, src/fast/models/fast.py:260-268 with AttentionBlock :10-29 -- the mode the reference
+ * trains, src/fast/train/trainer.py:58):
+ *   tokens = cat(cls, tokin) + pos[:N+1] -> L x [x += MHA(LN1 x); x += drop(W2 drop(gelu(W1 LN2 x)))] ->
+ *   logits = last_layer(drop(x[:, 0])).
+ * params: ONE flat f32 block,  pos_embedding [n_pos][D] | cls_token [D] | per block: layer_norm_1.{weight,bias} |
+ *   attn.in_proj_{weight [3D][D], bias} | attn.out_proj.{weight,bias} | layer_norm_2.{weight,bias} |
+ *   linear.0.{weight [2D][D], bias} | linear.3.{weight [D][2D], bias} | last_layer.{weight [n_cls][D], bias}
+ *   (isd_tail_fused_param_count floats).  tokin [B][N][D] = input_layer's output; logits [B][n_cls].
+ * Training: `save` (isd_tail_fused_save_floats(B, N+1, D, L) floats) and xfinal [B][D] receive what the backward
+ *   needs; both null for inference.  Dropout masks are counter-based (seed); pass the same seed to the backward.
+ * Backward: dlogits [B][n_cls] -> dtokin [B][N][D] and dparams (the block's layout, overwritten; positional rows past
+ *   N+1 get zeros); workspace = isd_tail_fused_workspace_floats floats (one partial block per wave, summed in a
+ *   fixed order: deterministic).
+ * Needs dim_token 16 or 32, hidden = 2 dim_token, N + 1 <= 8 tokens, head_dim <= 8, L <= 8, n_cls <= 16
+ * (isd_tail_fused_supported; the per-operator entry points cover everything else).
+ * ---------------------------------------------------------------------- */
+int isd_tail_fused_supported(int N, int D, int H, int L, int hidden, int n_cls);
+int64_t isd_tail_fused_param_count(int n_pos, int D, int L, int n_cls);
+int64_t isd_tail_fused_save_floats(int64_t B, int S, int D, int L);
+int64_t isd_tail_fused_workspace_floats(int64_t B, int N, int n_pos, int D, int L, int n_cls);
+int isd_tail_fused_forward(const float* params, const float* tokin, float* logits, float* save, float* xfinal,
+                           int64_t B, int N, int n_pos, int D, int H, int L, int hidden, int n_cls, float p_attn,
+                           float p_mlp, float p_cls, uint64_t seed, void* stream);
+int isd_tail_fused_backward(const float* params, const float* save, const float* xfinal, const float* dlogits,
+                            float* dtokin, float* dparams, float* workspace, int64_t B, int N, int n_pos, int D, int H,
+                            int L, int hidden, int n_cls, float p_attn, float p_mlp, float p_cls, uint64_t seed,
+                            void* stream);
+
+/* ----------------------------------------------------------------------
  * Whole classifier step on spec-S features in one call (the build-defined classifier of SURVEY 8d:
  * Conv4Layers(nb*C, 32) -> Linear(32, n_cls) -> softmax cross-entropy; replaces the call sequence
  * isd_conv4_forward / isd_linear_forward / isd_softmax_ce / isd_linear_backward / isd_conv4_backward).
