@@ -1,49 +1,60 @@
 // Transformer tail of FAST in ONE launch per direction (reference: src/fast/models/fast.py:10-29 `AttentionBlock`,
-// :260-268 `forward_transformer`; the mode the reference trains, src/fast/train/trainer.py:58):
+// :260-268 `forward_transformer`; the mode the reference trains, src/fast/train/trainer.py:58, at batch 64,
+// scripts/train_fast.py:274):
 //   cls token + positional embedding -> L x [ x += MHA(LN1(x));  x += MLP(LN2(x)) ] -> last_layer(dropout(x[:, 0])).
 // The sequence is <= 8 tokens of 32 features: per trial the whole tail is ~50 k multiply-adds per layer, and as
 // separate launches (tail.hip + fc.hip: ~45 forward, ~60 backward launches) it is pure launch latency.
 //
-// Mapping: ONE LANE PER TOKEN.  A wave holds the tokens of floor(64 / S) trials; a token's 32-feature residual stream
-// lives in the lane's registers for the whole kernel, every dense layer is a per-lane matrix-vector product whose
-// weights arrive through the scalar cache (all lanes use the same weights: one SGPR operand per FMA), LayerNorm and
-// GELU are lane-local, and the only cross-lane step -- a query reading the keys / values of the other tokens of its
-// trial -- goes through a [feature][lane] LDS tile (a row of 64 consecutive dwords: conflict-free, and the lanes of one
-// trial read one another's column by address).  Vector registers cannot be indexed at run time, so a dense layer
-// keeps its INPUT vector in registers (static indices) and streams its OUTPUTS, eight at a time, into such LDS columns;
-// the next layer loads them back into registers.  Dropout (attention probabilities, both MLP dropouts, the cls token)
-// is counter-based: element e of site s of layer l draws from hash(seed, l, s, e), regenerated in the backward pass.
+// Mapping: a wave holds the tokens of floor(64 / S) trials, ONE LANE PER TOKEN, and every activation tensor of the
+// wave lives in LDS as [feature][token] columns (stride 68 dwords).  That one layout serves three access patterns
+// without conflicts: the token's own lane walks its column (LayerNorm, GELU, softmax, the residual stream in
+// registers), the lanes of a trial read one another's columns by address (attention), and the matrix cores take the
+// columns directly as operands: a dense layer is  Y[64 tokens][N] = X[64][K] W[K][N]  on v_mfma_f32_16x16x4_f32 with
+// lane l supplying feature 4 s + (l >> 4) of token 16 mt + (l & 15) in k-step s, and a weight gradient is the same
+// product with the token index as K (lane l supplies feature l & 15 of token 4 s + (l >> 4)).  fp32 in, fp32
+// accumulate: the sums equal the fmaf chain of the per-operator kernels.  The block's weights are staged in LDS once
+// per layer ([K][N] images: transposed for the forward, as stored for the backward's W^T products).
+// (Earlier versions of this file multiplied per lane with the weights in the scalar file, then as LDS broadcasts:
+// 470 / 360 us per forward at any batch size -- one wave per SIMD waiting on every operand.  See DESIGN.md.)
+// Dropout (attention probabilities, both MLP dropouts, the cls token) is counter-based: element e of site s of
+// layer l draws from hash(seed, l, s, e), regenerated in the backward pass.
 //
-// The forward keeps what the backward needs (one record per layer and token, [layer][token][field]): LN statistics, qkv, attention
-// probabilities, the MLP pre-activation and the two residual-stream snapshots.  The backward is one launch per layer:
-// lane-local data gradients the same way (transposed weights are just the other loop order), and the weight
-// gradients -- sums over tokens of outer products -- on the matrix cores: the wave's 64 token rows of each
-// (gradient, input) pair meet in LDS and v_mfma_f32_16x16x4_f32 contracts over the tokens; persistent waves keep
-// the layer's accumulators in registers and leave one partial slab each.
+// The forward keeps what the backward needs, one record block per (layer, wave) laid out [field][lane] so that every
+// store is one 256-byte row: LN statistics, qkv, attention probabilities, the MLP pre-activation, the two
+// residual-stream snapshots.  The backward leaves each wave's partial parameter gradients in its own slab (the
+// parameter block's layout) and tail_fused_reduce_kernel adds the slabs in a fixed order: deterministic.
 #include "common.h"
 #include <math.h>
 
 namespace isd {
 
+#ifdef TF_TIMING                      // tools/ubench/tail_phases.hip: shader-clock stamps of wave 0, first layer visited
+__device__ long long tf_times[32];
+#define TF_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && tf_first) tf_times[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TF_MARK(k) do { } while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* tf_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* tf_gbl_ptr_t;
 
 // D = dim_token (template parameter: 32 in production, 16 in the reference's small test configuration); the MLP hidden
 // width is 2 D (fast.py:236)
 constexpr int kTMaxS = 8;          // tokens per trial, cls included
 constexpr int kTMaxL = 8;          // transformer blocks
 constexpr int kTMaxCls = 16;
+constexpr int kCS = 68;            // column stride in dwords: own-column, MFMA-operand and 16-byte tile stores all spread
 
-// saved per (layer, token): field offsets in floats
+// saved per (layer, token): field offsets (each field row is 64 lanes wide)
 template <int D> struct Sv {
   static constexpr int xin = 0, ln1 = D, qkv = D + 2, prob = 4 * D + 2, ctx = prob + 8 * kTMaxS, xmid = ctx + D,
                        ln2 = xmid + D, hpre = ln2 + 2, total = hpre + 2 * D;
 };
 
 // The tail's parameters live in ONE flat block (the host packs them once; nn.FAST keeps them packed) and the kernels
-// take it as a __restrict__ argument with integer offsets: pointers fetched from an argument structure carry no alias
-// information, and the compiler then loads every weight with per-lane vector loads instead of through the scalar cache.
-// Order inside the block = the reference's state_dict order of the tail:
-//   pos_embedding [1, n_tokens + 1, D] | cls_token [1, 1, D] | per block: layer_norm_1.{weight,bias} |
+// take it as a __restrict__ argument with integer offsets.  Order inside the block:
+//   pos_embedding [n_pos][D] | cls_token [D] | per block: layer_norm_1.{weight,bias} |
 //   attn.in_proj_{weight [3D, D], bias} | attn.out_proj.{weight, bias} | layer_norm_2.{weight,bias} |
 //   linear.0.{weight [2D, D], bias} | linear.3.{weight [D, 2D], bias} | ... | last_layer.{weight [n_cls, D], bias}
 struct TailLayerOff {
@@ -57,59 +68,126 @@ struct TailMeta {
   float p_attn, p_mlp, p_cls;
   unsigned long long seed;
 };
-struct TailLayerW {
-  const float *ln1w, *ln1b, *inw, *inb, *ow, *ob, *ln2w, *ln2b, *w1, *b1, *w2, *b2;
-};
 
-__device__ __forceinline__ float tf_keep(unsigned long long seed, int layer, int site, unsigned long long e, float p) {
-  if (p <= 0.f) return 1.f;
-  unsigned long long v = (e + 0x9E3779B97F4A7C15ull * (unsigned long long)(layer * 8 + site + 1)) ^ seed;
+// Counter-based dropout: element e of (layer, site) is kept when hash32(e, key(seed, layer, site)) / 2^24 >= p and then
+// scaled by 1 / (1 - p); p = 0 keeps everything with scale 1 through the same arithmetic (no branch).  The key is
+// wave-uniform (scalar ALU), the per-element part is murmur3's 32-bit finaliser.
+struct TfDrop {
+  unsigned key;
+  float p, inv;
+};
+__device__ __forceinline__ TfDrop tf_drop(unsigned long long seed, int layer, int site, float p) {
+  unsigned long long v = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(layer * 8 + site + 1);
   v ^= v >> 30; v *= 0xBF58476D1CE4E5B9ull;
   v ^= v >> 27; v *= 0x94D049BB133111EBull;
   v ^= v >> 31;
-  const float uu = (float)(v >> 40) * (1.f / 16777216.f);
-  return uu >= p ? 1.f / (1.f - p) : 0.f;
+  return {(unsigned)v ^ (unsigned)(v >> 32), p, 1.f / (1.f - p)};
+}
+__device__ __forceinline__ float tf_keep(const TfDrop& d, unsigned long long e) {
+  unsigned h = ((unsigned)e ^ ((unsigned)(e >> 32) * 0x27D4EB2Fu)) * 0x9E3779B1u ^ d.key;
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return (float)(h >> 8) * (1.f / 16777216.f) >= d.p ? d.inv : 0.f;
 }
 
-__device__ __forceinline__ float tf_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// GELU (erf form, nn.GELU's default) and its derivative.  erfc(|z|) = t (a1 + t (a2 + ...)) exp(-z^2), t = 1 / (1 + p |z|)
+// (Abramowitz & Stegun 7.1.26, absolute error 1.5e-7 -- the fp32 rounding level of the activation); libm's erff is
+// ~100 instructions per element and was half of the kernel's vector work.
+__device__ __forceinline__ void tf_gelu_parts(float x, float& cdf, float& ez) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+  ez = __expf(-z * z);                                   // exp(-x^2 / 2)
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f),
+                              0.254829592f);
+  const float c = 0.5f * poly * ez;                      // 0.5 erfc(|z|)
+  cdf = x < 0.f ? c : 1.f - c;                           // 0.5 (1 + erf(x / sqrt 2))
+}
+__device__ __forceinline__ float tf_gelu(float x) {
+  float cdf, ez;
+  tf_gelu_parts(x, cdf, ez);
+  return x * cdf;
+}
 __device__ __forceinline__ float tf_gelu_grad(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+  float cdf, ez;
+  tf_gelu_parts(x, cdf, ez);
+  return fmaf(x * 0.39894228040143267794f, ez, cdf);
 }
 
-// y[o] = b[o] + sum_i W[o][i] in[i] for o in [0, NO): outputs to the LDS column  out[o * 64]  (this lane's slot)
-template <int NI, int NO>
-__device__ __forceinline__ void matvec_to_lds(const float (&in)[NI], const float* __restrict__ W,
-                                              const float* __restrict__ b, float* out) {
-#pragma unroll 1
-  for (int oc = 0; oc < NO; oc += 2) {                    // rolled: the loop body is 2 x NI FMAs of code
-    // two weight rows (2 NI scalars) in the SGPR file at a time, two independent FMA chains
-    const float* w0 = W + oc * NI;
-    const float* w1 = w0 + NI;
-    float a0 = b[oc], a1 = b[oc + 1];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      a0 = fmaf(w0[i], in[i], a0);
-      a1 = fmaf(w1[i], in[i], a1);
-    }
-    out[oc * 64] = a0;
-    out[(oc + 1) * 64] = a1;
-    __builtin_amdgcn_sched_barrier(0);
+// ------------------------------------------------------------------------------------------- staging the weights
+// dst[i * STRIDE + o] = W[o][i]
+template <int NO, int NI, int STRIDE>
+__device__ __forceinline__ void stage_transposed(const float* __restrict__ W, float* dst, int lane) {
+  constexpr int kQ = NI / 4;
+#pragma unroll 4
+  for (int idx = lane; idx < NO * kQ; idx += 64) {
+    const int o = idx / kQ, i4 = (idx - o * kQ) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(W + o * NI + i4);
+    dst[(i4 + 0) * STRIDE + o] = v[0];
+    dst[(i4 + 1) * STRIDE + o] = v[1];
+    dst[(i4 + 2) * STRIDE + o] = v[2];
+    dst[(i4 + 3) * STRIDE + o] = v[3];
   }
 }
 
-// x[d] += scale_d * (b[d] + sum_i W[d][i] in_lds[i * 64]) with the input in an LDS column; NI inputs are loaded into
-// registers first (static indices), outputs are produced 4 at a time by a rolled loop over register-resident x --
-// which a rolled loop cannot index, so the update goes through an LDS column of x as well
-template <int NI>
-__device__ __forceinline__ void load_col(float (&v)[NI], const float* col) {
-#pragma unroll
-  for (int i = 0; i < NI; ++i) v[i] = col[i * 64];
+__device__ __forceinline__ void stage_copy(const float* __restrict__ src, float* dst, int n, int lane) {
+  for (int idx = lane * 4; idx < n; idx += 256) *reinterpret_cast<f32x4*>(dst + idx) = *reinterpret_cast<const f32x4*>(src + idx);
 }
 
-// LayerNorm over the lane's D features (eps inside the sqrt, biased variance: nn.LayerNorm)
+// straight copy of n floats (multiple of 4, both sides 16-byte aligned) by LDS-DMA: every piece in flight at once,
+// no registers; retire with s_waitcnt vmcnt(0)
+__device__ __forceinline__ void stage_dma(const float* __restrict__ src, float* dst, int n, int lane) {
+  const int n4 = n / 4;
+  for (int e0 = 0; e0 < n4; e0 += 64) {
+    if (e0 + lane < n4)
+      __builtin_amdgcn_global_load_lds((tf_gbl_ptr_t)(src + (int64_t)(e0 + lane) * 4), (tf_lds_ptr_t)(dst + e0 * 4), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ void stage_dma_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------------------------------- dense layers
+// Y[tok][n] = bias[n] + sum_k X[tok][k] W[k * WS + n]  for the wave's 64 tokens: X = columns acol .. acol + K,
+// Y -> columns ocol .. ocol + N (may overlap X when HOLD: the A fragments are read first), W and bias in LDS.
+template <int K, int N, int WS, bool BIAS, bool HOLD>
+__device__ __forceinline__ void gemm_cols(float* cols, int acol, const float* W, const float* bias, int ocol, int lane) {
+  const int m = lane & 15, kq = lane >> 4;
+  float af[HOLD ? K / 4 : 1][4];
+  if (HOLD) {
+#pragma unroll
+    for (int t = 0; t < K / 4; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) af[t][mt] = cols[(acol + 4 * t + kq) * kCS + 16 * mt + m];
+  }
+#pragma unroll 1
+  for (int nb = 0; nb < N; nb += 16) {
+    const float bv = BIAS ? bias[nb + m] : 0.f;
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){bv, bv, bv, bv};
+#pragma unroll
+    for (int t = 0; t < K / 4; ++t) {
+      const float bw = W[(4 * t + kq) * WS + nb + m];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const float av = HOLD ? af[t][mt] : cols[(acol + 4 * t + kq) * kCS + 16 * mt + m];
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, acc[mt], 0, 0, 0);
+      }
+    }
+    // D[row = token 4 kq + r][col = output m]: four consecutive tokens of one output column per lane
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      *reinterpret_cast<f32x4*>(cols + (ocol + nb + m) * kCS + 16 * mt + 4 * kq) = acc[mt];
+  }
+}
+
+// LayerNorm over the lane's D features (eps inside the sqrt, biased variance: nn.LayerNorm); w, b in LDS; the output
+// goes to the lane's slots of columns hcol ..
 template <int D>
-__device__ __forceinline__ void layer_norm(const float (&x)[D], const float* __restrict__ w,
-                                           const float* __restrict__ b, float (&h)[D], float& mu, float& rstd) {
+__device__ __forceinline__ void layer_norm_to_cols(const float (&x)[D], const float* w, const float* b, float* hcol,
+                                                   float& mu, float& rstd) {
   float s = 0.f;
 #pragma unroll
   for (int d = 0; d < D; ++d) s += x[d];
@@ -122,34 +200,45 @@ __device__ __forceinline__ void layer_norm(const float (&x)[D], const float* __r
   }
   rstd = rsqrtf(q * (1.f / D) + 1e-5f);
 #pragma unroll
-  for (int d = 0; d < D; ++d) h[d] = (x[d] - mu) * rstd * w[d] + b[d];
+  for (int d = 0; d < D; ++d) hcol[d * kCS] = (x[d] - mu) * rstd * w[d] + b[d];
 }
 
-// tokin [B][N][D]: output of input_layer (Linear + GELU); logits [B][n_cls]; save [L][B*S][Sv<D>::total] or null
-// (inference); xfinal [B][D]: the cls token entering last_layer, after dropout (training) or null
-template <int kTD>
+// LDS image of one block's weights for the forward: [K][N] = transposed matrices (rows padded by 4 floats to spread the
+// staging stores), then the small parameters
+template <int D> struct FwdImg {
+  static constexpr int SI = 3 * D + 4, SO = D + 4, S1 = 2 * D + 4, S2 = D + 4;            // row strides
+  static constexpr int win = 0, wo = win + D * SI, w1 = wo + D * SO, w2 = w1 + D * S1, small = w2 + 2 * D * S2;
+  static constexpr int ln1w = small, ln1b = ln1w + D, inb = ln1b + D, ob = inb + 3 * D, ln2w = ob + D, ln2b = ln2w + D,
+                       b1 = ln2b + D, b2 = b1 + 2 * D, total = b2 + D;
+};
+
+// tokin [B][N][D]: output of input_layer (Linear + GELU); logits [B][n_cls]; save [L][gridDim.x][Sv<D>::total][64] or
+// null (inference); xfinal [B][D]: the cls token entering last_layer, after dropout (training) or null
+// kDH = head width (compile time: the attention loops carry no branches); TRAIN: dropout + the record
+template <int kTD, int kDH, bool TRAIN>
 __global__ __launch_bounds__(64) void tail_fused_fwd_kernel(const float* __restrict__ P, TailMeta a,
                                                             const float* __restrict__ tokin,
                                                             float* __restrict__ logits, float* __restrict__ save,
                                                             float* __restrict__ xfinal) {
   constexpr int kTHid = 2 * kTD;
-  // LDS columns of a wave: [feature][lane]
-  constexpr int kColQkv = 0, kColCtx = 3 * kTD, kColMid = 4 * kTD, kColX = 6 * kTD, kColTotal = 7 * kTD;
+  using Img = FwdImg<kTD>;
+  // column regions: q | k | v (the MLP's hidden vector reuses it), and two D-wide regions
+  constexpr int RQ = 0, RA = 3 * kTD, RC = 4 * kTD, kColTotal = 5 * kTD;
   constexpr int kSvXin = Sv<kTD>::xin, kSvLn1 = Sv<kTD>::ln1, kSvQkv = Sv<kTD>::qkv, kSvProb = Sv<kTD>::prob,
                 kSvCtx = Sv<kTD>::ctx, kSvXmid = Sv<kTD>::xmid, kSvLn2 = Sv<kTD>::ln2, kSvHpre = Sv<kTD>::hpre,
                 kSvTotal = Sv<kTD>::total;
-  __shared__ float cols[kColTotal * 64];
+  __shared__ __attribute__((aligned(16))) float wl[Img::total];
+  __shared__ __attribute__((aligned(16))) float cols[kColTotal * kCS];
   const int lane = threadIdx.x;
   const int S = a.S, G = 64 / S;                          // trials per wave
   const int g = lane / S, i = lane - g * S;
   const int64_t b = (int64_t)blockIdx.x * G + g;
   const bool live = g < G && b < a.B;
   const int gs = (g < G ? g : 0) * S;                     // first lane of this token's trial
-  const int64_t bc = live ? b : 0;
-  const int64_t M = a.B * S;
-  const int64_t tok = bc * S + i;                         // global token row
-  const int dh = kTD / a.H;
-  const float scale = 1.f / sqrtf((float)dh);
+  const int64_t bc = live ? b : 0;                        // dead lanes recompute trial 0 (finite values, never stored)
+  const int64_t tok = bc * S + i;                         // global token row (dropout counters)
+  constexpr int kH = kTD / kDH;
+  const float scale = 1.f / sqrtf((float)kDH);
   float* my = cols + lane;
 
   float x[kTD];
@@ -160,107 +249,144 @@ __global__ __launch_bounds__(64) void tail_fused_fwd_kernel(const float* __restr
   }
   for (int l = 0; l < a.L; ++l) {
     const TailLayerOff& wo = a.layer[l];
-    const TailLayerW w = {P + wo.ln1w, P + wo.ln1b, P + wo.inw, P + wo.inb, P + wo.ow, P + wo.ob,
-                          P + wo.ln2w, P + wo.ln2b, P + wo.w1, P + wo.b1, P + wo.w2, P + wo.b2};
-    // this token's record of layer l: [layer][token][field] -- one base address per lane, every field an immediate offset
-    float* sv = (save && live) ? save + ((int64_t)l * M + tok) * kSvTotal : nullptr;
-    float h[kTD], mu, rstd;
-    if (sv) {
+#ifdef TF_TIMING
+    const bool tf_first = l == 1;
+#endif
+    TF_MARK(0);
+    stage_transposed<3 * kTD, kTD, Img::SI>(P + wo.inw, wl + Img::win, lane);
+    stage_transposed<kTD, kTD, Img::SO>(P + wo.ow, wl + Img::wo, lane);
+    stage_transposed<kTHid, kTD, Img::S1>(P + wo.w1, wl + Img::w1, lane);
+    stage_transposed<kTD, kTHid, Img::S2>(P + wo.w2, wl + Img::w2, lane);
+    stage_copy(P + wo.ln1w, wl + Img::ln1w, 2 * kTD, lane);
+    stage_copy(P + wo.inb, wl + Img::inb, 3 * kTD, lane);
+    stage_copy(P + wo.ob, wl + Img::ob, kTD, lane);
+    stage_copy(P + wo.ln2w, wl + Img::ln2w, 2 * kTD, lane);
+    stage_copy(P + wo.b1, wl + Img::b1, 2 * kTD, lane);
+    stage_copy(P + wo.b2, wl + Img::b2, kTD, lane);
+    // this wave's record block of layer l: field f of this lane at sv[f * 64]
+    float* sv = save + (((int64_t)l * gridDim.x + blockIdx.x) * kSvTotal) * 64 + lane;
+    const TfDrop d_attn = tf_drop(a.seed, l, 0, a.p_attn), d_mlp1 = tf_drop(a.seed, l, 1, a.p_mlp),
+                 d_mlp2 = tf_drop(a.seed, l, 2, a.p_mlp);
+    float mu, rstd;
+    if (TRAIN) {
 #pragma unroll
-      for (int d = 0; d < kTD; ++d) sv[kSvXin + d] = x[d];
+      for (int d = 0; d < kTD; ++d) sv[(kSvXin + d) * 64] = x[d];
     }
-    layer_norm<kTD>(x, w.ln1w, w.ln1b, h, mu, rstd);
-    if (sv) { sv[kSvLn1] = mu; sv[kSvLn1 + 1] = rstd; }
-    matvec_to_lds<kTD, 3 * kTD>(h, w.inw, w.inb, my + kColQkv * 64);            // q | k | v columns
     wave_lds_sync();
-    if (sv) {
-      for (int o = 0; o < 3 * kTD; ++o) sv[kSvQkv + o] = my[(kColQkv + o) * 64];
+    TF_MARK(1);
+    layer_norm_to_cols<kTD>(x, wl + Img::ln1w, wl + Img::ln1b, my + RA * kCS, mu, rstd);
+    if (TRAIN) { sv[kSvLn1 * 64] = mu; sv[(kSvLn1 + 1) * 64] = rstd; }
+    wave_lds_sync();
+    TF_MARK(2);
+    gemm_cols<kTD, 3 * kTD, Img::SI, true, true>(cols, RA, wl + Img::win, wl + Img::inb, RQ, lane);   // q | k | v
+    wave_lds_sync();
+    TF_MARK(3);
+    if (TRAIN) {
+#pragma unroll 16
+      for (int o = 0; o < 3 * kTD; ++o) sv[(kSvQkv + o) * 64] = my[(RQ + o) * kCS];
     }
-    // attention: this token's query against the keys / values of its trial (lanes gs .. gs + S - 1)
-    for (int hh = 0; hh < a.H; ++hh) {
-      float qh[8];
+    // attention: this token's query against the keys / values of its trial (lanes gs .. gs + S - 1).  All kTMaxS
+    // positions are computed (positions past S read token 0 and are masked): no control flow inside a head.
+    TF_MARK(4);
+#pragma unroll 2
+    for (int hh = 0; hh < kH; ++hh) {
+      const int qc = RQ + hh * kDH, kc = qc + kTD, vc = kc + kTD;
+      float qh[kDH];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) qh[t] = t < dh ? my[(kColQkv + hh * dh + t) * 64] : 0.f;
+      for (int t = 0; t < kDH; ++t) qh[t] = my[(qc + t) * kCS];
       float sc[kTMaxS];
       float mx = -INFINITY;
 #pragma unroll
       for (int j = 0; j < kTMaxS; ++j) {
+        const int jj = gs + (j < S ? j : 0);
         float d0 = 0.f;
-        if (j < S) {
 #pragma unroll
-          for (int t = 0; t < 8; ++t)
-            if (t < dh) d0 = fmaf(qh[t], cols[(kColQkv + kTD + hh * dh + t) * 64 + gs + j], d0);
-        }
+        for (int t = 0; t < kDH; ++t) d0 = fmaf(qh[t], cols[(kc + t) * kCS + jj], d0);
         sc[j] = j < S ? d0 * scale : -INFINITY;
         mx = fmaxf(mx, sc[j]);
       }
       float den = 0.f;
 #pragma unroll
       for (int j = 0; j < kTMaxS; ++j) {
-        sc[j] = j < S ? expf(sc[j] - mx) : 0.f;
+        sc[j] = expf(sc[j] - mx);                        // exp(-inf) = 0 past S
         den += sc[j];
       }
-      float o[8];
+      float o[kDH];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) o[t] = 0.f;
+      for (int t = 0; t < kDH; ++t) o[t] = 0.f;
 #pragma unroll
       for (int j = 0; j < kTMaxS; ++j) {
-        if (j < S) {
-          const float p = sc[j] / den;
-          if (sv) sv[kSvProb + hh * kTMaxS + j] = p;
-          const float pd = p * tf_keep(a.seed, l, 0, (unsigned long long)((tok * a.H + hh) * kTMaxS + j), a.p_attn);
-#pragma unroll
-          for (int t = 0; t < 8; ++t)
-            if (t < dh) o[t] = fmaf(pd, cols[(kColQkv + 2 * kTD + hh * dh + t) * 64 + gs + j], o[t]);
+        const int jj = gs + (j < S ? j : 0);
+        const float p = sc[j] / den;
+        float pd = p;
+        if (TRAIN) {
+          sv[(kSvProb + hh * kTMaxS + j) * 64] = p;
+          pd *= tf_keep(d_attn, (unsigned long long)((tok * kH + hh) * kTMaxS + j));
         }
+#pragma unroll
+        for (int t = 0; t < kDH; ++t) o[t] = fmaf(pd, cols[(vc + t) * kCS + jj], o[t]);
       }
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
-        if (t < dh) my[(kColCtx + hh * dh + t) * 64] = o[t];
+      for (int t = 0; t < kDH; ++t) my[(RC + hh * kDH + t) * kCS] = o[t];
     }
     wave_lds_sync();
-    {
-      float ctx[kTD];
-      load_col<kTD>(ctx, my + kColCtx * 64);
-      if (sv) {
+    if (TRAIN) {
+#pragma unroll 16
+      for (int d = 0; d < kTD; ++d) sv[(kSvCtx + d) * 64] = my[(RC + d) * kCS];
+    }
+    TF_MARK(5);
+    gemm_cols<kTD, kTD, Img::SO, true, true>(cols, RC, wl + Img::wo, wl + Img::ob, RA, lane);          // output projection
+    wave_lds_sync();
+    TF_MARK(6);
 #pragma unroll
-        for (int d = 0; d < kTD; ++d) sv[kSvCtx + d] = ctx[d];
+    for (int d = 0; d < kTD; ++d) x[d] += my[(RA + d) * kCS];
+    if (TRAIN) {
+#pragma unroll
+      for (int d = 0; d < kTD; ++d) sv[(kSvXmid + d) * 64] = x[d];
+    }
+    layer_norm_to_cols<kTD>(x, wl + Img::ln2w, wl + Img::ln2b, my + RC * kCS, mu, rstd);
+    if (TRAIN) { sv[kSvLn2 * 64] = mu; sv[(kSvLn2 + 1) * 64] = rstd; }
+    wave_lds_sync();
+    TF_MARK(7);
+    gemm_cols<kTD, kTHid, Img::S1, true, true>(cols, RC, wl + Img::w1, wl + Img::b1, RQ, lane);
+    wave_lds_sync();
+    TF_MARK(8);
+#pragma unroll 1
+    for (int o0 = 0; o0 < kTHid; o0 += 16) {             // GELU + dropout in place, 16 elements in flight
+      float pre[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pre[k] = my[(RQ + o0 + k) * kCS];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        float v = tf_gelu(pre[k]);
+        if (TRAIN) {
+          sv[(kSvHpre + o0 + k) * 64] = pre[k];
+          v *= tf_keep(d_mlp1, (unsigned long long)(tok * kTHid + o0 + k));
+        }
+        my[(RQ + o0 + k) * kCS] = v;
       }
-      matvec_to_lds<kTD, kTD>(ctx, w.ow, w.ob, my + kColX * 64);               // attention output projection
-      wave_lds_sync();
-#pragma unroll
-      for (int d = 0; d < kTD; ++d) x[d] += my[(kColX + d) * 64];
-    }
-    if (sv) {
-#pragma unroll
-      for (int d = 0; d < kTD; ++d) sv[kSvXmid + d] = x[d];
-    }
-    layer_norm<kTD>(x, w.ln2w, w.ln2b, h, mu, rstd);
-    if (sv) { sv[kSvLn2] = mu; sv[kSvLn2 + 1] = rstd; }
-    wave_lds_sync();
-    matvec_to_lds<kTD, kTHid>(h, w.w1, w.b1, my + kColMid * 64);
-    wave_lds_sync();
-    {
-      float m[kTHid];
-      load_col<kTHid>(m, my + kColMid * 64);
-#pragma unroll
-      for (int o = 0; o < kTHid; ++o) {
-        if (sv) sv[kSvHpre + o] = m[o];
-        m[o] = tf_gelu(m[o]) * tf_keep(a.seed, l, 1, (unsigned long long)(tok * kTHid + o), a.p_mlp);
-      }
-      matvec_to_lds<kTHid, kTD>(m, w.w2, w.b2, my + kColX * 64);
-      wave_lds_sync();
-#pragma unroll
-      for (int d = 0; d < kTD; ++d)
-        x[d] = fmaf(my[(kColX + d) * 64], tf_keep(a.seed, l, 2, (unsigned long long)(tok * kTD + d), a.p_mlp), x[d]);
     }
     wave_lds_sync();
-  }
-  if (live && i == 0) {
+    TF_MARK(9);
+    gemm_cols<kTHid, kTD, Img::S2, true, true>(cols, RQ, wl + Img::w2, wl + Img::b2, RA, lane);
+    wave_lds_sync();
+    TF_MARK(10);
 #pragma unroll
     for (int d = 0; d < kTD; ++d) {
-      x[d] *= tf_keep(a.seed, kTMaxL, 0, (unsigned long long)(bc * kTD + d), a.p_cls);
-      if (xfinal) xfinal[bc * kTD + d] = x[d];
+      const float kp = TRAIN ? tf_keep(d_mlp2, (unsigned long long)(tok * kTD + d)) : 1.f;
+      x[d] = fmaf(my[(RA + d) * kCS], kp, x[d]);
+    }
+    wave_lds_sync();
+    TF_MARK(11);
+  }
+  if (live && i == 0) {
+    const TfDrop d_cls = tf_drop(a.seed, kTMaxL, 0, a.p_cls);
+#pragma unroll
+    for (int d = 0; d < kTD; ++d) {
+      if (TRAIN) {
+        x[d] *= tf_keep(d_cls, (unsigned long long)(bc * kTD + d));
+        xfinal[bc * kTD + d] = x[d];
+      }
     }
     for (int c = 0; c < a.n_cls; ++c) {
       float acc = P[a.lastb + c];
@@ -272,38 +398,10 @@ __global__ __launch_bounds__(64) void tail_fused_fwd_kernel(const float* __restr
 }
 
 // ----------------------------------------------------------------------------------------------------- backward
-// One launch for the whole tail, the lane <-> token mapping of the forward.  Data gradients are lane-local: the
-// transposed products  d_in[i] = sum_o W[o][i] g[o]  run as a rolled loop over o with g[o] read from the lane's LDS
-// column and row o of W (contiguous) in the scalar file, accumulating all d_in[i] in registers.  Weight gradients
-// are sums over tokens of outer products: the wave's 64 token rows of g and of the layer input already sit in
-// [feature][lane] LDS columns, which IS the A / B operand layout of v_mfma_f32_16x16x4_f32 with the token index as K
-// (lane l supplies feature l & 15 of token 4 s + (l >> 4) in k-step s), so each 16 x 16 tile of dW is 16 MFMAs and the
-// bias / LayerNorm-parameter sums are the same product against a vector of ones.  Each wave leaves its partial sums
-// in its own slab (same layout as the parameter block); tail_fused_reduce_kernel adds the slabs in a fixed order.
-// The column stride is 68 dwords: own-column accesses (lane-contiguous) and the MFMA operand reads
-// ((l & 15) * 68 + (l >> 4) -> bank 4 (l & 15) + (l >> 4)) are both conflict-free.
-constexpr int kBS = 68;
-
-// out[o] = sum_r col[r] * W[r][o], r < NR (rows of W contiguous: NO scalars per row)
-template <int NR, int NO>
-__device__ __forceinline__ void matvecT_from_lds(const float* __restrict__ W, const float* col, float (&out)[NO]) {
-#pragma unroll
-  for (int o = 0; o < NO; ++o) out[o] = 0.f;
-  constexpr int kRows = NO <= 32 ? 2 : 1;                 // weight rows in the SGPR file per iteration
-#pragma unroll 1
-  for (int r = 0; r < NR; r += kRows) {
-    float g[kRows];
-#pragma unroll
-    for (int q = 0; q < kRows; ++q) g[q] = col[(r + q) * kBS];
-#pragma unroll
-    for (int q = 0; q < kRows; ++q) {
-      const float* w = W + (r + q) * NO;
-#pragma unroll
-      for (int o = 0; o < NO; ++o) out[o] = fmaf(w[o], g[q], out[o]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
+// One launch for the whole tail, the lane <-> token mapping of the forward.  Data gradients  dX = G W  are the same
+// column products with the weights as stored ([out][in] = [K][N]); weight gradients are sums over tokens of outer
+// products: 16 MFMAs per 16 x 16 tile with the token index as K, and the bias / LayerNorm-parameter sums are that
+// product against a vector of ones.
 
 // dW[o][i] = sum_tok g[tok][o] in[tok][i] (o < no_valid rows written), db[o] = sum_tok g[tok][o]; NI == 0: sums only
 template <int NO, int NI>
@@ -314,14 +412,14 @@ __device__ __forceinline__ void wgrad_tiles(const float* cols, int gcol, int ico
   for (int ob = 0; ob < NO; ob += 16) {
     float av[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) av[t] = cols[(gcol + ob + m) * kBS + 4 * t + kq];
+    for (int t = 0; t < 16; ++t) av[t] = cols[(gcol + ob + m) * kCS + 4 * t + kq];
     if (NI > 0) {
 #pragma unroll 1
       for (int ib = 0; ib < NI; ib += 16) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 16; ++t)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], cols[(icol + ib + m) * kBS + 4 * t + kq], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], cols[(icol + ib + m) * kCS + 4 * t + kq], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (ob + 4 * kq + r < no_valid) dw[(ob + 4 * kq + r) * NI + ib + m] = acc[r];
@@ -338,32 +436,34 @@ __device__ __forceinline__ void wgrad_tiles(const float* cols, int gcol, int ico
   }
 }
 
-// LayerNorm backward for one token: x (the saved input), statistics, dh = gradient of the output.  Adds the input
-// gradient to dx and leaves [dh * xhat | dh] in the 2 D columns at `pcol` (their sums over tokens are dweight | dbias).
+// LayerNorm backward for one token: xs = the saved input (record rows, 64 apart), dh read from the lane's columns at
+// dhcol.  Adds the input gradient to dx and leaves [dh * xhat | dh] in the 2 D columns at pcol (their sums over tokens
+// are dweight | dbias); pcol may not overlap dhcol.
 template <int D>
-__device__ __forceinline__ void layer_norm_backward(const float* __restrict__ xs, float mu, float rstd,
-                                                    const float* __restrict__ w, const float (&dh)[D], float (&dx)[D],
-                                                    float* pcol) {
+__device__ __forceinline__ void layer_norm_backward(const float* __restrict__ xs, float mu, float rstd, const float* w,
+                                                    const float* dhcol, float (&dx)[D], float* pcol) {
+  float dxh[D];
   float c1 = 0.f, c2 = 0.f;
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    const float xh = (xs[d] - mu) * rstd, dxh = dh[d] * w[d];
-    c1 += dxh;
-    c2 = fmaf(dxh, xh, c2);
-    pcol[d * kBS] = dh[d] * xh;
-    pcol[(D + d) * kBS] = dh[d];
+    const float xh = (xs[d * 64] - mu) * rstd, dh = dhcol[d * kCS];
+    dxh[d] = dh * w[d];
+    c1 += dxh[d];
+    c2 = fmaf(dxh[d], xh, c2);
+    pcol[d * kCS] = dh * xh;
+    pcol[(D + d) * kCS] = dh;
   }
   c1 *= 1.f / D;
   c2 *= 1.f / D;
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    const float xh = (xs[d] - mu) * rstd;
-    dx[d] += rstd * (dh[d] * w[d] - c1 - xh * c2);
+    const float xh = (xs[d * 64] - mu) * rstd;
+    dx[d] += rstd * (dxh[d] - c1 - xh * c2);
   }
 }
 
 // dlogits [B][n_cls] (already scaled by the caller's loss weight); dtokin [B][N][D]; slab [gridDim.x][ptot]
-template <int kTD>
+template <int kTD, int kDH>
 __global__ __launch_bounds__(64) void tail_fused_bwd_kernel(const float* __restrict__ P, TailMeta a,
                                                             const float* __restrict__ save,
                                                             const float* __restrict__ xfinal,
@@ -371,184 +471,188 @@ __global__ __launch_bounds__(64) void tail_fused_bwd_kernel(const float* __restr
                                                             float* __restrict__ dtokin, float* __restrict__ slab,
                                                             int ptot) {
   constexpr int kTHid = 2 * kTD;
-  constexpr int RQ = 0, RA = 3 * kTD, RB = 4 * kTD, RC = 6 * kTD, kColTotal = 7 * kTD;   // column regions
+  // column regions: q | k | v (the MLP's hidden vector and the LayerNorm sums reuse it), two D-wide operand regions;
+  // the attention's probability rows sit in the first 16 columns of RA
+  constexpr int RQ = 0, RA = 3 * kTD, RC = 4 * kTD, RB = RA, RH = RQ, kColTotal = 5 * kTD;
+  constexpr int kLayerFloats = 8 * kTD * kTD + 11 * kTD;   // one block's parameters, copied to LDS as they are
   constexpr int kSvXin = Sv<kTD>::xin, kSvLn1 = Sv<kTD>::ln1, kSvQkv = Sv<kTD>::qkv, kSvProb = Sv<kTD>::prob,
                 kSvCtx = Sv<kTD>::ctx, kSvXmid = Sv<kTD>::xmid, kSvLn2 = Sv<kTD>::ln2, kSvHpre = Sv<kTD>::hpre,
                 kSvTotal = Sv<kTD>::total;
-  static_assert(kTD >= 16 && RB + 16 <= RC, "column regions");
-  __shared__ float cols[kColTotal * kBS];
+  static_assert(kTD >= 16, "column regions");
+  __shared__ __attribute__((aligned(16))) float wl[kLayerFloats];
+  __shared__ __attribute__((aligned(16))) float cols[kColTotal * kCS];
   const int lane = threadIdx.x;
   const int S = a.S, G = 64 / S;
   const int g = lane / S, i = lane - g * S;
   const int64_t b = (int64_t)blockIdx.x * G + g;
   const bool live = g < G && b < a.B;
-  const float lv = live ? 1.f : 0.f;
+  const float lv = live ? 1.f : 0.f;                      // dead lanes carry the forward's (finite) records, weighted by 0
   const int gs = (g < G ? g : 0) * S;
-  const int64_t bc = live ? b : 0;                        // dead lanes read trial 0's (finite) records, weighted by 0
-  const int64_t M = a.B * S;
+  const int64_t bc = live ? b : 0;
   const int64_t tok = bc * S + i;
-  const int dh = kTD / a.H;
-  const float scale = 1.f / sqrtf((float)dh);
+  constexpr int kH = kTD / kDH;
+  const float scale = 1.f / sqrtf((float)kDH);
   float* my = cols + lane;
   float* slabw = slab + (int64_t)blockIdx.x * ptot;
 
+  stage_dma(P + a.layer[a.L - 1].ln1w, wl, kLayerFloats, lane);          // the last block's weights: in flight
   // ---- last_layer: logits = W x0 + b on the cls token after dropout
   float dx[kTD];
   {
     const bool cl = live && i == 0;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) my[(RA + c) * kBS] = (cl && c < a.n_cls) ? dlogits[bc * a.n_cls + c] : 0.f;
+    for (int c = 0; c < 16; ++c) my[(RA + c) * kCS] = (cl && c < a.n_cls) ? dlogits[bc * a.n_cls + c] : 0.f;
 #pragma unroll
-    for (int d = 0; d < kTD; ++d) my[(RC + d) * kBS] = cl ? xfinal[bc * kTD + d] : 0.f;
+    for (int d = 0; d < kTD; ++d) my[(RC + d) * kCS] = cl ? xfinal[bc * kTD + d] : 0.f;
     wave_lds_sync();
     wgrad_tiles<16, kTD>(cols, RA, RC, slabw + a.lastw, slabw + a.lastb, lane, a.n_cls);
 #pragma unroll
     for (int d = 0; d < kTD; ++d) dx[d] = 0.f;
     for (int c = 0; c < a.n_cls; ++c) {
-      const float gl = my[(RA + c) * kBS];
+      const float gl = my[(RA + c) * kCS];
       const float* w = P + a.lastw + c * kTD;
 #pragma unroll
       for (int d = 0; d < kTD; ++d) dx[d] = fmaf(w[d], gl, dx[d]);
     }
+    const TfDrop d_cls = tf_drop(a.seed, kTMaxL, 0, a.p_cls);
 #pragma unroll
-    for (int d = 0; d < kTD; ++d)
-      dx[d] *= tf_keep(a.seed, kTMaxL, 0, (unsigned long long)(bc * kTD + d), a.p_cls);
+    for (int d = 0; d < kTD; ++d) dx[d] *= tf_keep(d_cls, (unsigned long long)(bc * kTD + d));
     wave_lds_sync();
   }
 
   for (int l = a.L - 1; l >= 0; --l) {
     const TailLayerOff& wo = a.layer[l];
-    const float* sv = save + ((int64_t)l * M + tok) * kSvTotal;
+    const float* sv = save + (((int64_t)l * gridDim.x + blockIdx.x) * kSvTotal) * 64 + lane;
+    const int l0 = wo.ln1w;                               // wl + (wo.<tensor> - l0) = that tensor's LDS copy
+    const TfDrop d_attn = tf_drop(a.seed, l, 0, a.p_attn), d_mlp1 = tf_drop(a.seed, l, 1, a.p_mlp),
+                 d_mlp2 = tf_drop(a.seed, l, 2, a.p_mlp);
     // ---- x_out = xmid + drop2(W2 m + b2),  m = drop1(gelu(hpre))
 #pragma unroll
     for (int d = 0; d < kTD; ++d)
-      my[(RA + d) * kBS] = lv * dx[d] * tf_keep(a.seed, l, 2, (unsigned long long)(tok * kTD + d), a.p_mlp);
-#pragma unroll 2
-    for (int o = 0; o < kTHid; ++o)
-      my[(RB + o) * kBS] = tf_gelu(sv[kSvHpre + o]) * tf_keep(a.seed, l, 1, (unsigned long long)(tok * kTHid + o), a.p_mlp);
-    wave_lds_sync();
-    wgrad_tiles<kTD, kTHid>(cols, RA, RB, slabw + wo.w2, slabw + wo.b2, lane, kTD);
-    {
-      float dm[kTHid];
-      matvecT_from_lds<kTD, kTHid>(P + wo.w2, my + RA * kBS, dm);
-      wave_lds_sync();
+      my[(RA + d) * kCS] = lv * dx[d] * tf_keep(d_mlp2, (unsigned long long)(tok * kTD + d));
+#pragma unroll 1
+    for (int o0 = 0; o0 < kTHid; o0 += 16) {
+      float pre[16];
 #pragma unroll
-      for (int o = 0; o < kTHid; ++o) my[(RB + o) * kBS] = dm[o];
+      for (int k = 0; k < 16; ++k) pre[k] = sv[(kSvHpre + o0 + k) * 64];
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        my[(RH + o0 + k) * kCS] = tf_gelu(pre[k]) * tf_keep(d_mlp1, (unsigned long long)(tok * kTHid + o0 + k));
     }
     wave_lds_sync();
-#pragma unroll 2
-    for (int o = 0; o < kTHid; ++o)                       // hpre = W1 h2 + b1: gradient through dropout and GELU
-      my[(RB + o) * kBS] *= tf_gelu_grad(sv[kSvHpre + o]) * tf_keep(a.seed, l, 1, (unsigned long long)(tok * kTHid + o), a.p_mlp);
-    {
-      const float mu = sv[kSvLn2], rstd = sv[kSvLn2 + 1];
-      const float* lw = P + wo.ln2w;
-      const float* lb = P + wo.ln2b;
+    wgrad_tiles<kTD, kTHid>(cols, RA, RH, slabw + wo.w2, slabw + wo.b2, lane, kTD);
+    stage_dma_wait();                                     // this block's weights have landed
+    gemm_cols<kTD, kTHid, kTHid, false, true>(cols, RA, wl + (wo.w2 - l0), nullptr, RH, lane);          // dm = dy2 W2
+    wave_lds_sync();
+#pragma unroll 1
+    for (int o0 = 0; o0 < kTHid; o0 += 16) {              // hpre = W1 h2 + b1: gradient through dropout and GELU
+      float pre[16], dm[16];
 #pragma unroll
-      for (int d = 0; d < kTD; ++d) my[(RC + d) * kBS] = (sv[kSvXmid + d] - mu) * rstd * lw[d] + lb[d];
+      for (int k = 0; k < 16; ++k) {
+        pre[k] = sv[(kSvHpre + o0 + k) * 64];
+        dm[k] = my[(RH + o0 + k) * kCS];
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        my[(RH + o0 + k) * kCS] = dm[k] * tf_gelu_grad(pre[k]) * tf_keep(d_mlp1, (unsigned long long)(tok * kTHid + o0 + k));
+    }
+    {
+      const float mu = sv[kSvLn2 * 64], rstd = sv[(kSvLn2 + 1) * 64];
+      const float* lw = wl + (wo.ln2w - l0);
+      const float* lb = wl + (wo.ln2b - l0);
+#pragma unroll
+      for (int d = 0; d < kTD; ++d) my[(RC + d) * kCS] = (sv[(kSvXmid + d) * 64] - mu) * rstd * lw[d] + lb[d];
       wave_lds_sync();
-      wgrad_tiles<kTHid, kTD>(cols, RB, RC, slabw + wo.w1, slabw + wo.b1, lane, kTHid);
-      float dhv[kTD];
-      matvecT_from_lds<kTHid, kTD>(P + wo.w1, my + RB * kBS, dhv);
-      layer_norm_backward<kTD>(sv + kSvXmid, mu, rstd, lw, dhv, dx, my + RQ * kBS);
+      wgrad_tiles<kTHid, kTD>(cols, RH, RC, slabw + wo.w1, slabw + wo.b1, lane, kTHid);
+      gemm_cols<kTHid, kTD, kTD, false, true>(cols, RH, wl + (wo.w1 - l0), nullptr, RA, lane);         // dh2 = dhpre W1
+      wave_lds_sync();
+      layer_norm_backward<kTD>(sv + kSvXmid * 64, mu, rstd, lw, my + RA * kCS, dx, my + RQ * kCS);
       wave_lds_sync();
       wgrad_tiles<2 * kTD, 0>(cols, RQ, 0, nullptr, slabw + wo.ln2w, lane, 2 * kTD);
     }
     // ---- xmid = xin + Wo ctx + bo
 #pragma unroll
     for (int d = 0; d < kTD; ++d) {
-      my[(RA + d) * kBS] = dx[d];
-      my[(RC + d) * kBS] = sv[kSvCtx + d];
+      my[(RA + d) * kCS] = dx[d];
+      my[(RC + d) * kCS] = sv[(kSvCtx + d) * 64];
     }
     wave_lds_sync();
     wgrad_tiles<kTD, kTD>(cols, RA, RC, slabw + wo.ow, slabw + wo.ob, lane, kTD);
-    {
-      float dctx[kTD];
-      matvecT_from_lds<kTD, kTD>(P + wo.ow, my + RA * kBS, dctx);
-      wave_lds_sync();
-#pragma unroll
-      for (int d = 0; d < kTD; ++d) my[(RC + d) * kBS] = dctx[d];
-    }
-#pragma unroll 4
-    for (int o = 0; o < 3 * kTD; ++o) my[(RQ + o) * kBS] = sv[kSvQkv + o];
+    gemm_cols<kTD, kTD, kTD, false, true>(cols, RA, wl + (wo.ow - l0), nullptr, RC, lane);              // dctx = dxmid Wo
+#pragma unroll 16
+    for (int o = 0; o < 3 * kTD; ++o) my[(RQ + o) * kCS] = sv[(kSvQkv + o) * 64];
     wave_lds_sync();
-    // ---- attention: ctx_i = sum_j drop(p_ij) v_j,  p = softmax(scale q k^T)
-    for (int hh = 0; hh < a.H; ++hh) {
-      const int qc = RQ + hh * dh, kc = RQ + kTD + hh * dh, vc = RQ + 2 * kTD + hh * dh, cc = RC + hh * dh;
-      float dc[8], pr[kTMaxS], dp[kTMaxS];
+    // ---- attention: ctx_i = sum_j drop(p_ij) v_j,  p = softmax(scale q k^T); positions past S are computed on token 0
+    // and masked (the saved probabilities there are 0), so a head carries no control flow
+#pragma unroll 1
+    for (int hh = 0; hh < kH; ++hh) {
+      const int qc = RQ + hh * kDH, kc = qc + kTD, vc = kc + kTD, cc = RC + hh * kDH;
+      float dc[kDH], pr[kTMaxS], dp[kTMaxS];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) dc[t] = t < dh ? my[(cc + t) * kBS] : 0.f;
+      for (int t = 0; t < kDH; ++t) dc[t] = my[(cc + t) * kCS];
       float dot = 0.f;
 #pragma unroll
       for (int j = 0; j < kTMaxS; ++j) {
-        pr[j] = 0.f;
-        dp[j] = 0.f;
-        if (j < S) {
-          pr[j] = sv[kSvProb + hh * kTMaxS + j];
-          const float kp = tf_keep(a.seed, l, 0, (unsigned long long)((tok * a.H + hh) * kTMaxS + j), a.p_attn);
-          float dpd = 0.f;
+        const int jj = gs + (j < S ? j : 0);
+        pr[j] = sv[(kSvProb + hh * kTMaxS + j) * 64];
+        const float kp = tf_keep(d_attn, (unsigned long long)((tok * kH + hh) * kTMaxS + j));
+        float dpd = 0.f;
 #pragma unroll
-          for (int t = 0; t < 8; ++t)
-            if (t < dh) dpd = fmaf(dc[t], cols[(vc + t) * kBS + gs + j], dpd);
-          dp[j] = dpd * kp;
-          dot = fmaf(dp[j], pr[j], dot);
-          my[(RB + j) * kBS] = pr[j] * kp;
-        }
+        for (int t = 0; t < kDH; ++t) dpd = fmaf(dc[t], cols[(vc + t) * kCS + jj], dpd);
+        dp[j] = dpd * kp;
+        dot = fmaf(dp[j], pr[j], dot);
+        my[(RB + j) * kCS] = pr[j] * kp;
       }
-      float dq[8];
+      float dq[kDH];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) dq[t] = 0.f;
+      for (int t = 0; t < kDH; ++t) dq[t] = 0.f;
 #pragma unroll
       for (int j = 0; j < kTMaxS; ++j) {
-        if (j < S) {
-          const float ds = pr[j] * (dp[j] - dot);
-          my[(RB + 8 + j) * kBS] = ds;
+        const int jj = gs + (j < S ? j : 0);
+        const float ds = pr[j] * (dp[j] - dot);
+        my[(RB + 8 + j) * kCS] = ds;
 #pragma unroll
-          for (int t = 0; t < 8; ++t)
-            if (t < dh) dq[t] = fmaf(ds, cols[(kc + t) * kBS + gs + j], dq[t]);
-        }
+        for (int t = 0; t < kDH; ++t) dq[t] = fmaf(ds, cols[(kc + t) * kCS + jj], dq[t]);
       }
       wave_lds_sync();
-      float dk[8], dv[8];
+      float dk[kDH], dv[kDH];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) dk[t] = dv[t] = 0.f;
+      for (int t = 0; t < kDH; ++t) dk[t] = dv[t] = 0.f;
 #pragma unroll
-      for (int ii = 0; ii < kTMaxS; ++ii) {
-        if (ii < S) {                                     // row ii of the trial's probability matrix, this token's column
-          const float pdv = cols[(RB + i) * kBS + gs + ii], dsv = cols[(RB + 8 + i) * kBS + gs + ii];
+      for (int ii = 0; ii < kTMaxS; ++ii) {               // row ii of the trial's probability matrix, this token's column
+        const int li = gs + (ii < S ? ii : 0);
+        const float ok = ii < S ? 1.f : 0.f;
+        const float pdv = ok * cols[(RB + i) * kCS + li], dsv = ok * cols[(RB + 8 + i) * kCS + li];
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            if (t < dh) {
-              dv[t] = fmaf(pdv, cols[(cc + t) * kBS + gs + ii], dv[t]);
-              dk[t] = fmaf(dsv, cols[(qc + t) * kBS + gs + ii], dk[t]);
-            }
-          }
+        for (int t = 0; t < kDH; ++t) {
+          dv[t] = fmaf(pdv, cols[(cc + t) * kCS + li], dv[t]);
+          dk[t] = fmaf(dsv, cols[(qc + t) * kCS + li], dk[t]);
         }
       }
       wave_lds_sync();
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        if (t < dh) {                                     // the head's q / k / v slices become dq / dk / dv
-          my[(qc + t) * kBS] = lv * scale * dq[t];
-          my[(kc + t) * kBS] = lv * scale * dk[t];
-          my[(vc + t) * kBS] = lv * dv[t];
-        }
+      for (int t = 0; t < kDH; ++t) {                     // the head's q / k / v slices become dq / dk / dv
+        my[(qc + t) * kCS] = lv * scale * dq[t];
+        my[(kc + t) * kCS] = lv * scale * dk[t];
+        my[(vc + t) * kCS] = lv * dv[t];
       }
       wave_lds_sync();
     }
     // ---- qkv = Win h1 + bin,  h1 = LN1(xin)
     {
-      const float mu = sv[kSvLn1], rstd = sv[kSvLn1 + 1];
-      const float* lw = P + wo.ln1w;
-      const float* lb = P + wo.ln1b;
+      const float mu = sv[kSvLn1 * 64], rstd = sv[(kSvLn1 + 1) * 64];
+      const float* lw = wl + (wo.ln1w - l0);
+      const float* lb = wl + (wo.ln1b - l0);
 #pragma unroll
-      for (int d = 0; d < kTD; ++d) my[(RA + d) * kBS] = (sv[kSvXin + d] - mu) * rstd * lw[d] + lb[d];
+      for (int d = 0; d < kTD; ++d) my[(RA + d) * kCS] = (sv[(kSvXin + d) * 64] - mu) * rstd * lw[d] + lb[d];
       wave_lds_sync();
       wgrad_tiles<3 * kTD, kTD>(cols, RQ, RA, slabw + wo.inw, slabw + wo.inb, lane, 3 * kTD);
-      float dhv[kTD];
-      matvecT_from_lds<3 * kTD, kTD>(P + wo.inw, my + RQ * kBS, dhv);
-      layer_norm_backward<kTD>(sv + kSvXin, mu, rstd, lw, dhv, dx, my + RB * kBS);
+      gemm_cols<3 * kTD, kTD, kTD, false, false>(cols, RQ, wl + (wo.inw - l0), nullptr, RC, lane);     // dh1 = dqkv Win
       wave_lds_sync();
-      wgrad_tiles<2 * kTD, 0>(cols, RB, 0, nullptr, slabw + wo.ln1w, lane, 2 * kTD);
+      layer_norm_backward<kTD>(sv + kSvXin * 64, mu, rstd, lw, my + RC * kCS, dx, my + RQ * kCS);
+      wave_lds_sync();
+      if (l > 0) stage_dma(P + a.layer[l - 1].ln1w, wl, kLayerFloats, lane);   // next block's weights under the sums
+      wgrad_tiles<2 * kTD, 0>(cols, RQ, 0, nullptr, slabw + wo.ln1w, lane, 2 * kTD);
     }
     wave_lds_sync();
   }
@@ -558,13 +662,13 @@ __global__ __launch_bounds__(64) void tail_fused_bwd_kernel(const float* __restr
     for (int d = 0; d < kTD; ++d) dtokin[(bc * a.N + (i - 1)) * kTD + d] = dx[d];
   }
 #pragma unroll
-  for (int d = 0; d < kTD; ++d) my[(RA + d) * kBS] = dx[d];
+  for (int d = 0; d < kTD; ++d) my[(RA + d) * kCS] = dx[d];
   wave_lds_sync();
   for (int idx = lane; idx < a.n_pos * kTD; idx += 64) {
     const int ii = idx / kTD, d = idx - ii * kTD;
     float sum = 0.f;
     if (ii < S)
-      for (int gg = 0; gg < G; ++gg) sum += cols[(RA + d) * kBS + gg * S + ii];
+      for (int gg = 0; gg < G; ++gg) sum += cols[(RA + d) * kCS + gg * S + ii];
     slabw[a.pos + idx] = sum;
     if (ii == 0) slabw[a.cls + d] = sum;
   }
@@ -598,7 +702,7 @@ using namespace isd;
 
 extern "C" int64_t isd_tail_fused_save_floats(int64_t B, int S, int D, int L) {
   if (B < 0 || S < 1 || S > kTMaxS || L < 1 || L > kTMaxL || (D != 16 && D != 32)) return ISD_ERR_INVALID;
-  return (int64_t)L * (D == 32 ? Sv<32>::total : Sv<16>::total) * B * S;
+  return (int64_t)L * (D == 32 ? Sv<32>::total : Sv<16>::total) * cdiv(B, (int64_t)(64 / S)) * 64;   // [layer][wave][field][lane]
 }
 
 // offsets of the tail's tensors inside the flat block, state_dict order (see TailMeta)
@@ -632,14 +736,14 @@ static int tail_fused_check(const char* who, int N, int S_table, int D, int H, i
   ISD_CHECK_ARG(N >= 0 && N + 1 <= kTMaxS && N + 1 <= S_table,
                 "%s: %d tokens per trial (at most %d with the cls token, positional table of %d)", who, N + 1, kTMaxS,
                 S_table);
-  ISD_CHECK_ARG(H >= 1 && D % H == 0 && D / H <= 8, "%s: num_heads=%d", who, H);
+  ISD_CHECK_ARG(H >= 1 && (D == 4 * H || D == 8 * H), "%s: num_heads=%d (head width 4 or 8)", who, H);
   ISD_CHECK_ARG(L >= 1 && L <= kTMaxL && n_cls >= 1 && n_cls <= kTMaxCls, "%s: L=%d n_cls=%d", who, L, n_cls);
   ISD_CHECK_ARG(B >= 0, "%s: B=%lld", who, (long long)B);
   return ISD_OK;
 }
 
 extern "C" int isd_tail_fused_supported(int N, int D, int H, int L, int hidden, int n_cls) {
-  return (D == 32 || D == 16) && hidden == 2 * D && N >= 0 && N + 1 <= kTMaxS && H >= 1 && D % H == 0 && D / H <= 8 &&
+  return (D == 32 || D == 16) && hidden == 2 * D && N >= 0 && N + 1 <= kTMaxS && H >= 1 && (D == 4 * H || D == 8 * H) &&
          L >= 1 && L <= kTMaxL && n_cls >= 1 && n_cls <= kTMaxCls;
 }
 
@@ -653,14 +757,26 @@ extern "C" int isd_tail_fused_forward(const float* params, const float* tokin, f
                 "isd_tail_fused_forward: dropout probabilities must lie in [0, 1)");
   if (B == 0) return ISD_OK;
   ISD_CHECK_ARG(params && logits && (N == 0 || tokin), "isd_tail_fused_forward: null argument");
+  ISD_CHECK_ARG(((uintptr_t)params & 15) == 0, "isd_tail_fused_forward: the parameter block must be 16-byte aligned");
   TailMeta a = {};
   tail_meta_offsets(a, n_tokens_p1, D, L, n_cls);
   a.B = B; a.N = N; a.S = N + 1; a.H = H; a.L = L; a.n_cls = n_cls; a.n_pos = n_tokens_p1;
   a.p_attn = p_attn; a.p_mlp = p_mlp; a.p_cls = p_cls; a.seed = seed;
   const int G = 64 / a.S;
   const dim3 grid((unsigned)cdiv(B, G));
-  if (D == 32) hipLaunchKernelGGL(tail_fused_fwd_kernel<32>, grid, dim3(64), 0, (hipStream_t)stream, params, a, tokin, logits, save, xfinal);
-  else hipLaunchKernelGGL(tail_fused_fwd_kernel<16>, grid, dim3(64), 0, (hipStream_t)stream, params, a, tokin, logits, save, xfinal);
+  ISD_CHECK_ARG((save && xfinal) || (!save && !xfinal && p_attn == 0.f && p_mlp == 0.f && p_cls == 0.f),
+                "isd_tail_fused_forward: dropout needs the training record (save and xfinal)");
+  const int key = D * 100 + (D / H) * 10 + (save ? 1 : 0);
+#define ISD_TF_FWD(DD, DH, TR)                                                                                  \
+  case DD * 100 + DH * 10 + TR:                                                                                  \
+    hipLaunchKernelGGL((tail_fused_fwd_kernel<DD, DH, TR != 0>), grid, dim3(64), 0, (hipStream_t)stream, params, \
+                       a, tokin, logits, save, xfinal);                                                          \
+    break;
+  switch (key) {
+    ISD_TF_FWD(32, 4, 0) ISD_TF_FWD(32, 4, 1) ISD_TF_FWD(32, 8, 0) ISD_TF_FWD(32, 8, 1)
+    ISD_TF_FWD(16, 4, 0) ISD_TF_FWD(16, 4, 1) ISD_TF_FWD(16, 8, 0) ISD_TF_FWD(16, 8, 1)
+  }
+#undef ISD_TF_FWD
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
@@ -681,14 +797,20 @@ extern "C" int isd_tail_fused_backward(const float* params, const float* save, c
   ISD_CHECK_ARG(B > 0, "isd_tail_fused_backward: empty batch");
   ISD_CHECK_ARG(params && save && xfinal && dlogits && dparams && workspace && (N == 0 || dtokin),
                 "isd_tail_fused_backward: null argument");
+  ISD_CHECK_ARG(((uintptr_t)params & 15) == 0, "isd_tail_fused_backward: the parameter block must be 16-byte aligned");
   TailMeta a = {};
   tail_meta_offsets(a, n_tokens_p1, D, L, n_cls);
   a.B = B; a.N = N; a.S = N + 1; a.H = H; a.L = L; a.n_cls = n_cls; a.n_pos = n_tokens_p1;
   a.p_attn = p_attn; a.p_mlp = p_mlp; a.p_cls = p_cls; a.seed = seed;
   const int ptot = a.lastb + n_cls;
   const int nw = (int)cdiv(B, (int64_t)(64 / a.S));
-  if (D == 32) hipLaunchKernelGGL(tail_fused_bwd_kernel<32>, dim3(nw), dim3(64), 0, (hipStream_t)stream, params, a, save, xfinal, dlogits, dtokin, workspace, ptot);
-  else hipLaunchKernelGGL(tail_fused_bwd_kernel<16>, dim3(nw), dim3(64), 0, (hipStream_t)stream, params, a, save, xfinal, dlogits, dtokin, workspace, ptot);
+#define ISD_TF_BWD(DD, DH)                                                                                        \
+  case DD * 10 + DH:                                                                                              \
+    hipLaunchKernelGGL((tail_fused_bwd_kernel<DD, DH>), dim3(nw), dim3(64), 0, (hipStream_t)stream, params, a, save, \
+                       xfinal, dlogits, dtokin, workspace, ptot);                                                 \
+    break;
+  switch (D * 10 + D / H) { ISD_TF_BWD(32, 4) ISD_TF_BWD(32, 8) ISD_TF_BWD(16, 4) ISD_TF_BWD(16, 8) }
+#undef ISD_TF_BWD
   ISD_LAUNCH_CHECK();
   hipLaunchKernelGGL(tail_fused_reduce_kernel, dim3(cdiv(ptot, 64)), dim3(256), 0, (hipStream_t)stream, workspace, dparams, nw, ptot);
   ISD_LAUNCH_CHECK();

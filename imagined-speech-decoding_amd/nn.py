@@ -1038,12 +1038,14 @@ class FAST(nn.Module):
         if self._tail_fusable(tok):
             c = self.config
             ps = self._tail_params()
-            train = torch.is_grad_enabled() and (tok.requires_grad or any(p.requires_grad for p in ps))
             self._tail_calls += 1
             p_blk = float(self.transformer[0].p) if self.training else 0.0
+            p_cls = float(self.dropout.p) if self.training else 0.0
+            # the training kernel (dropout + the backward's record) whenever a gradient may be asked for or masks are drawn
+            train = (torch.is_grad_enabled() and (tok.requires_grad or any(p.requires_grad for p in ps))) \
+                or p_blk > 0.0 or p_cls > 0.0
             cfg = (self.pos_embedding.shape[1], c.num_heads, len(self.transformer), self.transformer[0].linear[0].out_features,
-                   c.n_classes, p_blk, p_blk, float(self.dropout.p) if self.training else 0.0,
-                   _dropout_seed(self._tail_stream, self._tail_calls), train)
+                   c.n_classes, p_blk, p_blk, p_cls, _dropout_seed(self._tail_stream, self._tail_calls), train)
             return _TailFusedFn.apply(tok, self._tail_flat(ps), cfg, *ps)
         tok = _EmbedFn.apply(tok, self.cls_token, self.pos_embedding[:, :N + 1].contiguous())
         tok = self.transformer(tok)

@@ -22,7 +22,31 @@ def timed(step, n):
     return (time.perf_counter() - t0) / n, out
 
 
+def tail_only():
+    """forward_transformer forward + backward on resident zone features: one launch per direction vs per operator."""
+    for B in (64, 4096):
+        torch.manual_seed(0)
+        net = inn.FAST(fast_config()).cuda().train()
+        feat = torch.randn(B, 5, 8, 32, device="cuda")
+        y = torch.randint(0, 5, (B,), device="cuda")
+        for fused in (True, False):
+            net.fuse_tail = fused
+
+            def step():
+                net.zero_grad(set_to_none=True)
+                loss = inn.token_mean_cross_entropy(net.forward_transformer(feat).unsqueeze(1), y)
+                loss.backward()
+                return loss
+            dt, _ = timed(step, 50)
+            with torch.no_grad():
+                di, _ = timed(lambda: net.forward_transformer(feat), 50)
+            print(f"FAST tail only  B={B} {'one launch per direction' if fused else 'per-operator launches'}: "
+                  f"fwd+bwd {dt*1e3:.3f} ms, inference {di*1e3:.3f} ms")
+
+
 def main():
+    if "--tail" in sys.argv:
+        return tail_only()
     for B, T in ((64, 800), (1024, 512), (4096, 512), (1024, 800)):
         torch.manual_seed(0)
         m = _FastModel(fast_config(seq_len=T)).cuda()
@@ -50,8 +74,9 @@ def main():
         net.eval()
         with torch.no_grad():
             di, _ = timed(lambda: net(x, forward_mode="default"), 20 if B <= 1024 else 5)
-        print(f"FAST default    B={B} T={T}: {dt*1e3:.3f} ms/step, {B/dt:.0f} trials/s, loss {float(loss):.4f} | "
+        print(f"FAST default    B={B} T={T}: {dt*1e3:.3f} ms/step, {B/dt:.0f} trials/s, loss {float(loss.detach()):.4f} | "
               f"inference {di*1e3:.3f} ms, {B/di:.0f} trials/s")
+    tail_only()
 
 
 if __name__ == "__main__":

@@ -6,6 +6,17 @@ import torch
 import isd_amd
 
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg5"
+if which == "tail":                     # FAST's transformer tail, one launch per direction, B = 4096 (512 waves)
+    import isd_amd.nn as inn
+    torch.manual_seed(0)
+    net = inn.FAST(inn.fast_config()).cuda().train()
+    feat = torch.randn(4096, 5, 8, 32, device="cuda")
+    lab = torch.randint(0, 5, (4096,), device="cuda")
+    for _ in range(3):
+        net.zero_grad(set_to_none=True)
+        inn.token_mean_cross_entropy(net.forward_transformer(feat).unsqueeze(1), lab).backward()
+    torch.cuda.synchronize()
+    sys.exit(0)
 if which == "cfg5":
     B, C, T = 128, 128, 4096
     fx = isd_amd.FeatureExtractor(T, 1024.0, isd_amd.BANDS_40, nperseg=1024, noverlap=960)
