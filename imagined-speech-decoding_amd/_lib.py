@@ -72,9 +72,10 @@ SIGNATURES = {
     "isd_tail_fused_param_count": (_i64, [_i, _i, _i, _i]),
     "isd_tail_fused_save_floats": (_i64, [_i64, _i, _i, _i]),
     "isd_tail_fused_workspace_floats": (_i64, [_i64, _i, _i, _i, _i, _i]),
-    "isd_tail_fused_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, C.c_uint64, _p]),
+    "isd_tail_fused_forward": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, C.c_uint64, _p,
+                                    _p]),
     "isd_tail_fused_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f,
-                                     C.c_uint64, _p]),
+                                     C.c_uint64, _p, _p]),
     "isd_linear_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "isd_eegnet_plan_create": (_i, [C.POINTER(_p), _i, _i, _i, _i]),
     "isd_featcnn_supported": (_i, [_p, _i64, _i64, _i]),

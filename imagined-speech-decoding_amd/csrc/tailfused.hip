@@ -67,7 +67,13 @@ struct TailMeta {
   int N, S, H, L, n_cls, n_pos;                          // n_pos = rows of the positional table (>= S)
   float p_attn, p_mlp, p_cls;
   unsigned long long seed;
+  const unsigned long long* seed_dev;                    // optional device-resident step counter mixed into the seed
 };
+
+// the launch's dropout seed: a captured graph replays the same arguments, so its masks advance through *seed_dev
+__device__ __forceinline__ unsigned long long tf_seed(const TailMeta& a) {
+  return a.seed_dev ? a.seed + 0xD1342543DE82EF95ull * *a.seed_dev : a.seed;
+}
 
 // Counter-based dropout: element e of (layer, site) is kept when hash32(e, key(seed, layer, site)) / 2^24 >= p and then
 // scaled by 1 / (1 - p); p = 0 keeps everything with scale 1 through the same arithmetic (no branch).  The key is
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(64) void tail_fused_fwd_kernel(const float* __restr
   constexpr int kH = kTD / kDH;
   const float scale = 1.f / sqrtf((float)kDH);
   float* my = cols + lane;
+  const unsigned long long seed = tf_seed(a);
 
   float x[kTD];
 #pragma unroll
@@ -265,8 +272,8 @@ __global__ __launch_bounds__(64) void tail_fused_fwd_kernel(const float* __restr
     stage_copy(P + wo.b2, wl + Img::b2, kTD, lane);
     // this wave's record block of layer l: field f of this lane at sv[f * 64]
     float* sv = save + (((int64_t)l * gridDim.x + blockIdx.x) * kSvTotal) * 64 + lane;
-    const TfDrop d_attn = tf_drop(a.seed, l, 0, a.p_attn), d_mlp1 = tf_drop(a.seed, l, 1, a.p_mlp),
-                 d_mlp2 = tf_drop(a.seed, l, 2, a.p_mlp);
+    const TfDrop d_attn = tf_drop(seed, l, 0, a.p_attn), d_mlp1 = tf_drop(seed, l, 1, a.p_mlp),
+                 d_mlp2 = tf_drop(seed, l, 2, a.p_mlp);
     float mu, rstd;
     if (TRAIN) {
 #pragma unroll
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(64) void tail_fused_fwd_kernel(const float* __restr
     TF_MARK(11);
   }
   if (live && i == 0) {
-    const TfDrop d_cls = tf_drop(a.seed, kTMaxL, 0, a.p_cls);
+    const TfDrop d_cls = tf_drop(seed, kTMaxL, 0, a.p_cls);
 #pragma unroll
     for (int d = 0; d < kTD; ++d) {
       if (TRAIN) {
@@ -494,6 +501,7 @@ __global__ __launch_bounds__(64) void tail_fused_bwd_kernel(const float* __restr
   const float scale = 1.f / sqrtf((float)kDH);
   float* my = cols + lane;
   float* slabw = slab + (int64_t)blockIdx.x * ptot;
+  const unsigned long long seed = tf_seed(a);
 
   stage_dma(P + a.layer[a.L - 1].ln1w, wl, kLayerFloats, lane);          // the last block's weights: in flight
   // ---- last_layer: logits = W x0 + b on the cls token after dropout
@@ -514,7 +522,7 @@ __global__ __launch_bounds__(64) void tail_fused_bwd_kernel(const float* __restr
 #pragma unroll
       for (int d = 0; d < kTD; ++d) dx[d] = fmaf(w[d], gl, dx[d]);
     }
-    const TfDrop d_cls = tf_drop(a.seed, kTMaxL, 0, a.p_cls);
+    const TfDrop d_cls = tf_drop(seed, kTMaxL, 0, a.p_cls);
 #pragma unroll
     for (int d = 0; d < kTD; ++d) dx[d] *= tf_keep(d_cls, (unsigned long long)(bc * kTD + d));
     wave_lds_sync();
@@ -524,8 +532,8 @@ __global__ __launch_bounds__(64) void tail_fused_bwd_kernel(const float* __restr
     const TailLayerOff& wo = a.layer[l];
     const float* sv = save + (((int64_t)l * gridDim.x + blockIdx.x) * kSvTotal) * 64 + lane;
     const int l0 = wo.ln1w;                               // wl + (wo.<tensor> - l0) = that tensor's LDS copy
-    const TfDrop d_attn = tf_drop(a.seed, l, 0, a.p_attn), d_mlp1 = tf_drop(a.seed, l, 1, a.p_mlp),
-                 d_mlp2 = tf_drop(a.seed, l, 2, a.p_mlp);
+    const TfDrop d_attn = tf_drop(seed, l, 0, a.p_attn), d_mlp1 = tf_drop(seed, l, 1, a.p_mlp),
+                 d_mlp2 = tf_drop(seed, l, 2, a.p_mlp);
     // ---- x_out = xmid + drop2(W2 m + b2),  m = drop1(gelu(hpre))
 #pragma unroll
     for (int d = 0; d < kTD; ++d)
@@ -750,7 +758,7 @@ extern "C" int isd_tail_fused_supported(int N, int D, int H, int L, int hidden, 
 extern "C" int isd_tail_fused_forward(const float* params, const float* tokin, float* logits, float* save,
                                       float* xfinal, int64_t B, int N, int n_tokens_p1, int D, int H, int L,
                                       int hidden, int n_cls, float p_attn, float p_mlp, float p_cls,
-                                      uint64_t seed, void* stream) {
+                                      uint64_t seed, const uint64_t* seed_dev, void* stream) {
   int rc = tail_fused_check("isd_tail_fused_forward", N, n_tokens_p1, D, H, L, hidden, n_cls, B);
   if (rc) return rc;
   ISD_CHECK_ARG(p_attn >= 0.f && p_attn < 1.f && p_mlp >= 0.f && p_mlp < 1.f && p_cls >= 0.f && p_cls < 1.f,
@@ -762,6 +770,7 @@ extern "C" int isd_tail_fused_forward(const float* params, const float* tokin, f
   tail_meta_offsets(a, n_tokens_p1, D, L, n_cls);
   a.B = B; a.N = N; a.S = N + 1; a.H = H; a.L = L; a.n_cls = n_cls; a.n_pos = n_tokens_p1;
   a.p_attn = p_attn; a.p_mlp = p_mlp; a.p_cls = p_cls; a.seed = seed;
+  a.seed_dev = (const unsigned long long*)seed_dev;
   const int G = 64 / a.S;
   const dim3 grid((unsigned)cdiv(B, G));
   ISD_CHECK_ARG((save && xfinal) || (!save && !xfinal && p_attn == 0.f && p_mlp == 0.f && p_cls == 0.f),
@@ -791,7 +800,8 @@ extern "C" int64_t isd_tail_fused_workspace_floats(int64_t B, int N, int n_token
 extern "C" int isd_tail_fused_backward(const float* params, const float* save, const float* xfinal,
                                        const float* dlogits, float* dtokin, float* dparams, float* workspace, int64_t B,
                                        int N, int n_tokens_p1, int D, int H, int L, int hidden, int n_cls, float p_attn,
-                                       float p_mlp, float p_cls, uint64_t seed, void* stream) {
+                                       float p_mlp, float p_cls, uint64_t seed, const uint64_t* seed_dev,
+                                       void* stream) {
   int rc = tail_fused_check("isd_tail_fused_backward", N, n_tokens_p1, D, H, L, hidden, n_cls, B);
   if (rc) return rc;
   ISD_CHECK_ARG(B > 0, "isd_tail_fused_backward: empty batch");
@@ -802,6 +812,7 @@ extern "C" int isd_tail_fused_backward(const float* params, const float* save, c
   tail_meta_offsets(a, n_tokens_p1, D, L, n_cls);
   a.B = B; a.N = N; a.S = N + 1; a.H = H; a.L = L; a.n_cls = n_cls; a.n_pos = n_tokens_p1;
   a.p_attn = p_attn; a.p_mlp = p_mlp; a.p_cls = p_cls; a.seed = seed;
+  a.seed_dev = (const unsigned long long*)seed_dev;
   const int ptot = a.lastb + n_cls;
   const int nw = (int)cdiv(B, (int64_t)(64 / a.S));
 #define ISD_TF_BWD(DD, DH)                                                                                        \

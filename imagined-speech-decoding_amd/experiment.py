@@ -20,6 +20,7 @@ import torch
 
 from .classifier import cosine_scheduler, lr_multiplier
 from .data import DeviceStager
+from .graph import GraphedTrainStep, graph_safe
 from .nn import FAST, fast_config, reset_dropout_streams, token_mean_cross_entropy
 
 
@@ -80,13 +81,14 @@ def predict(model, X, batch_size=256, forward_mode="default"):
 
 
 def train_one_fold(config, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, forward_mode="default", lr=5e-4,
-                   warmup_epochs=10):
+                   warmup_epochs=10, graph=None):
     """One fine-tuning run; returns (best_val_acc, best_state_dict, history).  The fold's trials go to the device
-    once, asynchronously from pinned memory (the validation split uploads under the first training steps)."""
+    once, asynchronously from pinned memory (the validation split uploads under the first training steps).
+    ``graph`` (default: whenever the model allows it, isd_amd.graph.graph_safe): the optimisation step is captured
+    once as a HIP graph and replayed -- at the reference's batch of 64 a step is launch-bound on the host."""
     torch.manual_seed(seed)
     reset_dropout_streams()                              # the fold's masks do not depend on what ran before it
     model = FAST(config).cuda()
-    opt = torch.optim.AdamW(model.parameters(), lr=lr)
     n = len(Xtr)
     bs = min(batch_size, n)
     iters = (n + bs - 1) // bs
@@ -96,23 +98,36 @@ def train_one_fold(config, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, for
     st.put(np.asarray(Xva, dtype=np.float32))
     Xd, yd = st.get()
     Xva = st.get()
+    use_graph = graph_safe(model) if graph is None else bool(graph)
+    if use_graph:
+        opt = torch.optim.AdamW(model.parameters(), lr=torch.tensor(float(lr), device=Xd.device), capturable=True)
+        model.train()
+        gstep = GraphedTrainStep(model, opt, Xd, yd, bs, forward_mode)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=lr)
     gen = torch.Generator().manual_seed(seed)
     best, best_sd, hist, step = -1.0, None, [], 0
     for ep in range(max_epochs):
         model.train()
         order = torch.randperm(n, generator=gen).cuda()
-        tot = 0.0
+        tot = torch.zeros((), device=Xd.device)
+        if use_graph:
+            gstep.loss_sum.zero_()
         for i in range(iters):
             idx = order[i * bs:(i + 1) * bs]
-            for g in opt.param_groups:
-                g["lr"] = lr * lr_multiplier(table, step)
-            opt.zero_grad(set_to_none=True)
-            logits = model(Xd[idx].contiguous(), forward_mode=forward_mode)
-            loss = token_mean_cross_entropy(logits, yd[idx].contiguous())
-            loss.backward()
-            opt.step()
+            if use_graph:
+                gstep.step(idx, lr * lr_multiplier(table, step))
+            else:
+                for g in opt.param_groups:
+                    g["lr"] = lr * lr_multiplier(table, step)
+                opt.zero_grad(set_to_none=True)
+                logits = model(Xd[idx].contiguous(), forward_mode=forward_mode)
+                loss = token_mean_cross_entropy(logits, yd[idx].contiguous())
+                loss.backward()
+                opt.step()
+                tot += loss.detach() * len(idx)          # summed on the device: one host read per epoch
             step += 1
-            tot += float(loss.detach()) * len(idx)
+        tot = float(gstep.loss_sum if use_graph else tot)
         val_acc = accuracy(yva, predict(model, Xva, batch_size, forward_mode))
         hist.append({"loss": tot / n, "val_acc": val_acc})
         if val_acc > best:                                   # ModelCheckpoint(monitor='val_acc', mode='max', top-1)

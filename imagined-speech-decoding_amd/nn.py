@@ -466,7 +466,7 @@ class _TailFusedFn(torch.autograd.Function):
     def forward(ctx, tokin, flat, cfg, *params):
         tokin = _f32c(tokin, "tokens")
         B, N, D = tokin.shape
-        n_pos, H, L, hidden, n_cls, p_attn, p_mlp, p_cls, seed, train = cfg
+        n_pos, H, L, hidden, n_cls, p_attn, p_mlp, p_cls, seed, train, seed_dev = cfg
         L_ = _lib.lib()
         logits = torch.empty((B, n_cls), dtype=torch.float32, device=tokin.device)
         save = xfinal = None
@@ -478,7 +478,7 @@ class _TailFusedFn(torch.autograd.Function):
             _lib.check(L_.isd_tail_fused_forward(flat.data_ptr(), tokin.data_ptr(), logits.data_ptr(),
                                                  save.data_ptr() if train else 0, xfinal.data_ptr() if train else 0,
                                                  B, N, n_pos, D, H, L, hidden, n_cls, p_attn, p_mlp, p_cls, seed,
-                                                 _stream()))
+                                                 0 if seed_dev is None else seed_dev.data_ptr(), _stream()))
         ctx.cfg, ctx.dims = cfg, (B, N, D)
         ctx.shapes = [tuple(p.shape) for p in params]
         if train:
@@ -488,7 +488,7 @@ class _TailFusedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         flat, save, xfinal = ctx.saved_tensors
-        n_pos, H, L, hidden, n_cls, p_attn, p_mlp, p_cls, seed, _ = ctx.cfg
+        n_pos, H, L, hidden, n_cls, p_attn, p_mlp, p_cls, seed, _, seed_dev = ctx.cfg
         B, N, D = ctx.dims
         dlogits = _f32c(dlogits, "dlogits")
         L_ = _lib.lib()
@@ -500,7 +500,7 @@ class _TailFusedFn(torch.autograd.Function):
             _lib.check(L_.isd_tail_fused_backward(flat.data_ptr(), save.data_ptr(), xfinal.data_ptr(),
                                                   dlogits.data_ptr(), dtok.data_ptr(), dflat.data_ptr(), ws.data_ptr(),
                                                   B, N, n_pos, D, H, L, hidden, n_cls, p_attn, p_mlp, p_cls, seed,
-                                                  _stream()))
+                                                  0 if seed_dev is None else seed_dev.data_ptr(), _stream()))
         grads, off = [], 0
         for shp in ctx.shapes:
             n = math.prod(shp)
@@ -987,6 +987,7 @@ class FAST(nn.Module):
         self.dropout = nn.Dropout(config.dropout)
         self.fuse_tail = True               # one launch per direction for the transformer tail where it applies
         self._tail_stream, self._tail_calls = _new_dropout_stream(), 0
+        self.seed_dev = None                # int64 device counter mixed into the tail's dropout seed (graph replay)
 
     def _tail_params(self):
         """The tail's parameters in the order of the fused kernels' flat block (include/isd_hip.h)."""
@@ -1045,7 +1046,8 @@ class FAST(nn.Module):
             train = (torch.is_grad_enabled() and (tok.requires_grad or any(p.requires_grad for p in ps))) \
                 or p_blk > 0.0 or p_cls > 0.0
             cfg = (self.pos_embedding.shape[1], c.num_heads, len(self.transformer), self.transformer[0].linear[0].out_features,
-                   c.n_classes, p_blk, p_blk, p_cls, _dropout_seed(self._tail_stream, self._tail_calls), train)
+                   c.n_classes, p_blk, p_blk, p_cls, _dropout_seed(self._tail_stream, self._tail_calls), train,
+                   self.seed_dev)
             return _TailFusedFn.apply(tok, self._tail_flat(ps), cfg, *ps)
         tok = _EmbedFn.apply(tok, self.cls_token, self.pos_embedding[:, :N + 1].contiguous())
         tok = self.transformer(tok)

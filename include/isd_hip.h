@@ -289,11 +289,14 @@ int isd_attention_backward(const float* qkv, const float* probs, const float* dc
  *   linear.0.{weight [2D][D], bias} | linear.3.{weight [D][2D], bias} | last_layer.{weight [n_cls][D], bias}
  *   (isd_tail_fused_param_count floats).  tokin [B][N][D] = input_layer's output; logits [B][n_cls].
  * Training: `save` (isd_tail_fused_save_floats(B, N+1, D, L) floats) and xfinal [B][D] receive what the backward
- *   needs; both null for inference.  Dropout masks are counter-based (seed); pass the same seed to the backward.
+ *   needs; both null for inference (then every dropout probability must be 0).  Dropout masks are counter-based:
+ *   pass the same seed to the backward.  seed_dev (may be null) points at a device-resident step counter that is
+ *   mixed into the seed at launch: a captured HIP graph replays the same arguments, and advances its masks by
+ *   incrementing that counter inside the graph.
  * Backward: dlogits [B][n_cls] -> dtokin [B][N][D] and dparams (the block's layout, overwritten; positional rows past
  *   N+1 get zeros); workspace = isd_tail_fused_workspace_floats floats (one partial block per wave, summed in a
  *   fixed order: deterministic).
- * Needs dim_token 16 or 32, hidden = 2 dim_token, N + 1 <= 8 tokens, head_dim <= 8, L <= 8, n_cls <= 16
+ * Needs dim_token 16 or 32, hidden = 2 dim_token, N + 1 <= 8 tokens, head width 4 or 8, L <= 8, n_cls <= 16
  * (isd_tail_fused_supported; the per-operator entry points cover everything else).
  * ---------------------------------------------------------------------- */
 int isd_tail_fused_supported(int N, int D, int H, int L, int hidden, int n_cls);
@@ -302,11 +305,11 @@ int64_t isd_tail_fused_save_floats(int64_t B, int S, int D, int L);
 int64_t isd_tail_fused_workspace_floats(int64_t B, int N, int n_pos, int D, int L, int n_cls);
 int isd_tail_fused_forward(const float* params, const float* tokin, float* logits, float* save, float* xfinal,
                            int64_t B, int N, int n_pos, int D, int H, int L, int hidden, int n_cls, float p_attn,
-                           float p_mlp, float p_cls, uint64_t seed, void* stream);
+                           float p_mlp, float p_cls, uint64_t seed, const uint64_t* seed_dev, void* stream);
 int isd_tail_fused_backward(const float* params, const float* save, const float* xfinal, const float* dlogits,
                             float* dtokin, float* dparams, float* workspace, int64_t B, int N, int n_pos, int D, int H,
                             int L, int hidden, int n_cls, float p_attn, float p_mlp, float p_cls, uint64_t seed,
-                            void* stream);
+                            const uint64_t* seed_dev, void* stream);
 
 /* ----------------------------------------------------------------------
  * Whole classifier step on spec-S features in one call (the build-defined classifier of SURVEY 8d:

@@ -237,3 +237,44 @@ def test_fold_packing_over_worker_processes_equals_serial_run(isd, tmp_path):
         assert sa.keys() == sb.keys()
         for k in sa:
             assert rel_err(sb[k].float(), sa[k].float()) < 1e-5, k
+
+
+def test_graphed_training_step_matches_eager_and_advances_dropout(isd):
+    """The optimisation step captured as a HIP graph (isd_amd.graph): with dropout off, a fold trained through graph
+    replays follows the eager run (same batches, same schedule; AdamW capturable vs foreach arithmetic apart); with
+    dropout on, every replay draws new masks through the device-resident step counter."""
+    from isd_amd import experiment as E
+    from isd_amd.graph import GraphedTrainStep, graph_safe
+    import isd_amd.nn as inn
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((40, 64, 800)).astype(np.float32)
+    y = rng.integers(0, 5, 40).astype(np.uint8)
+    cfg = inn.fast_config(dropout=0.0)
+    runs = {}
+    for graph in (False, True):
+        acc, sd, hist = E.train_one_fold(cfg, X[:32], y[:32], X[32:], y[32:], 3, 12, seed=5, graph=graph)
+        runs[graph] = (hist, sd)
+    for he, hg in zip(runs[False][0], runs[True][0]):
+        assert abs(he["loss"] - hg["loss"]) < 2e-3 * max(1.0, abs(he["loss"])), (he, hg)
+    for k, v in runs[False][1].items():
+        assert float((v - runs[True][1][k]).abs().max()) < 5e-3 * max(1.0, float(v.abs().max())), k
+    # dropout: replaying the same batch at learning rate 0 gives a different loss each time, eval mode does not
+    torch.manual_seed(0)
+    m = inn.FAST(inn.fast_config(dropout=0.3)).cuda().train()
+    assert graph_safe(m)
+    Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+    opt = torch.optim.AdamW(m.parameters(), lr=torch.tensor(0.0, device="cuda"), capturable=True)
+    g = GraphedTrainStep(m, opt, Xd, yd, 16)
+    before = [p.detach().clone() for p in m.parameters()]
+    idx = torch.arange(16, device="cuda")
+    losses = []
+    for _ in range(3):
+        g.loss_sum.zero_()
+        g.step(idx, 0.0)
+        losses.append(float(g.loss_sum) / 16)
+    assert len(set(losses)) == 3 and all(np.isfinite(losses))
+    assert int(m.seed_dev) == 3
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))       # lr 0: nothing moved
+    g.step(idx[:5], 0.0)                                                                 # ragged batch: eager, same code
+    assert int(m.seed_dev) == 4
+    assert not graph_safe(inn.FAST(inn.fast_config(head="EEGNet_Encoder")).cuda())

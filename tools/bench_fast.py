@@ -56,26 +56,36 @@ def main():
         dt, out = timed(lambda: tr.step(x, y), 20 if B <= 1024 else 5)
         print(f"FAST train_head B={B} T={T}: {dt*1e3:.3f} ms/step, {B/dt:.0f} trials/s, loss {float(out['loss']):.4f}, "
               f"mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+    from isd_amd.graph import GraphedTrainStep
     for B, T in ((64, 800), (4096, 800), (4096, 512)):
-        torch.manual_seed(0)
-        net = inn.FAST(fast_config(seq_len=T)).cuda().train()
-        opt = torch.optim.AdamW(net.parameters(), lr=5e-4, fused=True)
         x = torch.randn(B, 64, T, device="cuda")
         y = torch.randint(0, 5, (B,), device="cuda")
+        for graph in (False, True):
+            torch.manual_seed(0)
+            net = inn.FAST(fast_config(seq_len=T)).cuda().train()
+            if graph:                           # the whole step as one HIP graph replay (isd_amd.graph)
+                opt = torch.optim.AdamW(net.parameters(), lr=torch.tensor(5e-4, device="cuda"), capturable=True)
+                gs = GraphedTrainStep(net, opt, x, y, B)
+                idx = torch.arange(B, device="cuda")
 
-        def step():
-            opt.zero_grad(set_to_none=True)
-            logits = net(x, forward_mode="default")
-            loss = inn.token_mean_cross_entropy(logits.unsqueeze(1), y)
-            loss.backward()
-            opt.step()
-            return loss
-        dt, loss = timed(step, 20 if B <= 1024 else 5)
-        net.eval()
-        with torch.no_grad():
-            di, _ = timed(lambda: net(x, forward_mode="default"), 20 if B <= 1024 else 5)
-        print(f"FAST default    B={B} T={T}: {dt*1e3:.3f} ms/step, {B/dt:.0f} trials/s, loss {float(loss.detach()):.4f} | "
-              f"inference {di*1e3:.3f} ms, {B/di:.0f} trials/s")
+                def step():
+                    gs.step(idx, 5e-4)
+                    return gs.loss_sum
+            else:
+                opt = torch.optim.AdamW(net.parameters(), lr=5e-4, fused=True)
+
+                def step():
+                    opt.zero_grad(set_to_none=True)
+                    loss = inn.token_mean_cross_entropy(net(x, forward_mode="default"), y)
+                    loss.backward()
+                    opt.step()
+                    return loss
+            dt, loss = timed(step, 20 if B <= 1024 else 5)
+            net.eval()
+            with torch.no_grad():
+                di, _ = timed(lambda: net(x, forward_mode="default"), 20 if B <= 1024 else 5)
+            print(f"FAST default    B={B} T={T} {'graph replay' if graph else 'eager       '}: {dt*1e3:.3f} ms/step, "
+                  f"{B/dt:.0f} trials/s | inference {di*1e3:.3f} ms, {B/di:.0f} trials/s")
     tail_only()
 
 

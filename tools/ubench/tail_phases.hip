@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int it = 0; it < 3; ++it) {
     hipEventRecord(e0, 0);
-    int rc = isd_tail_fused_forward(P, T, Lg, Sv, Xf, B, N, N + 1, D, H, L, 2 * D, ncls, 0.f, 0.f, 0.f, 1, nullptr);
+    int rc = isd_tail_fused_forward(P, T, Lg, Sv, Xf, B, N, N + 1, D, H, L, 2 * D, ncls, 0.f, 0.f, 0.f, 1, nullptr, nullptr);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("rc %d launch %.1f us\n", rc, ms * 1e3);
