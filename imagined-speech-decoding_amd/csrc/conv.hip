@@ -81,10 +81,30 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // threads share one (zone, layer), this is block `bx` of them.
 __device__ __forceinline__ void prep_conv_body(const float* __restrict__ params, const ZoneDesc& zd, int z,
                                                float* __restrict__ wf, float* __restrict__ wt, int F, int layer,
-                                               int64_t zstride, int bf16, int bx, int nbx) {
+                                               int64_t zstride, int bf16, int bx, int nbx, int k32) {
   const int GT = F / 16;
   const int ncg = F / 4;
   const float* W = params + zd.p_off + F * kTaps + F + (int64_t)F * F * zd.cin + (int64_t)layer * F * F * kTaps;
+  if (k32) {
+    // bf16 matrix cores (F = 32): block (k, gt) holds, for lane l, the 8 bf16 W[gt*16 + (l&15)][8 (l>>4) + j][k] --
+    // one v_mfma_f32_16x16x32_bf16 A fragment per tap covers all 32 input channels
+    uint4* wf16 = reinterpret_cast<uint4*>(wf + z * zstride);
+    uint4* wt16 = reinterpret_cast<uint4*>(wt + z * zstride);
+    for (int e = bx * 256 + threadIdx.x; e < kTaps * GT * 64; e += nbx * 256) {
+      const int lane = e & 63, blk = e >> 6;
+      const int gt = blk % GT, k = blk / GT;
+      const int g = gt * 16 + (lane & 15), c0 = 8 * (lane >> 4);
+      float a[8], b[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a[j] = W[(g * F + c0 + j) * kTaps + k];
+        b[j] = W[((c0 + j) * F + g) * kTaps + (kTaps - 1 - k)];
+      }
+      wf16[e] = make_uint4(bf16_pack(a[0], a[1]), bf16_pack(a[2], a[3]), bf16_pack(a[4], a[5]), bf16_pack(a[6], a[7]));
+      wt16[e] = make_uint4(bf16_pack(b[0], b[1]), bf16_pack(b[2], b[3]), bf16_pack(b[4], b[5]), bf16_pack(b[6], b[7]));
+    }
+    return;
+  }
   const int total = ncg * kTaps * GT * 64;
   for (int e = bx * 256 + threadIdx.x; e < total; e += nbx * 256) {
     const int lane = e & 63;
@@ -112,6 +132,7 @@ struct PrepConvArgs {
   float *w3, *w3t, *w4, *w4t;
   int64_t zstride;
   int n_layers;
+  int k32;          // cnn3 / cnn4 as K = 32 bf16 fragments (the bf16 fused kernels) instead of fp32 fragment order
 };
 // `wfrag16` (nullable): the same fused first-layer weights as bf16 MFMA A fragments in "tap-window" order (the
 // bf16 first-layer kernels below): block (cg, gt) holds, for lane l, the 8 bf16
@@ -126,7 +147,8 @@ __global__ __launch_bounds__(256) void prep_fused_kernel(const float* __restrict
   const ZoneDesc zd = zones[z];
   if ((int)blockIdx.x >= nbw + F) {
     const int r = blockIdx.x - (nbw + F), layer = r >> 2;
-    prep_conv_body(params, zd, z, layer ? pc.w4 : pc.w3, layer ? pc.w4t : pc.w3t, F, layer, pc.zstride, bf16, r & 3, 4);
+    prep_conv_body(params, zd, z, layer ? pc.w4 : pc.w3, layer ? pc.w4t : pc.w3t, F, layer, pc.zstride, bf16, r & 3, 4,
+                   pc.k32);
     return;
   }
   const int GT = F / 16;
@@ -1064,6 +1086,402 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a
     fused_wgrad_mma<true>(ga, xz, T1, W, W, 0, wave, NW, nks, q, jl, acc0, accb);
   }
   // ---------------- partial slabs
+  {
+    float* s4 = a.part4 + ((int64_t)blockIdx.x * 4 + ks) * a.slab1 + (int64_t)z * F * F * kTaps;
+    float* s3 = a.part3 + ((int64_t)blockIdx.x * 4 + ks) * a.slab1 + (int64_t)z * F * F * kTaps;
+    float* s0 = a.part0 + ((int64_t)blockIdx.x * NW + wave) * a.slab0 + zd.wg_off;
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int g = gt * 16 + 4 * q + r, c = ct * 16 + jl;
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) {
+          s4[((int64_t)g * F + c) * kTaps + k] = acc4[gt][k][r];
+          s3[((int64_t)g * F + c) * kTaps + k] = acc3[gt][k][r];
+          if (jl < cz) s0[((int64_t)g * cin1 + jl) * kTaps + k] = acc0[gt][k][r];
+        }
+        if (jl < kTaps) s0[((int64_t)g * cin1 + cz) * kTaps + jl] = jl == 0 ? accb[gt][r] : 0.f;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// BASELINE config 3 for the reference-native shape: the fused forward / backward above with bf16 activations on the
+// bf16 matrix cores (scripts/train_fast.py:277 trains under bf16-mixed autocast).
+// Activation and gradient tiles are bf16 [time][32 channels] (64-byte rows, two zero guard rows in front -- the
+// pad-2 convolutions need no masks -- and zero rows behind T1 up to a multiple of 32 steps):
+//  * cnn3 / cnn4 and their data gradients: K = 32 = all input channels of one tap, so a layer is 5 taps x 2 filter
+//    tiles of v_mfma_f32_16x16x32_bf16 per 16-step column tile; the B fragment (8 consecutive channels of one time
+//    step) is ONE 16-byte LDS read, the 64 lanes of a wave reading one contiguous KiB; the A fragments come
+//    pre-packed from prep_fused_kernel (k32).  Results (4 consecutive filters of one step per lane) are packed and
+//    stored as 8 bytes into the next tile.
+//  * weight gradients: K = 32 time steps.  Both operands are columns of [time][channel] tiles, delivered transposed
+//    by ds_read_b64_tr_b16; the input side reads a 12-row window once and the five tap windows are register subsets
+//    (even pairs as read, odd pairs by v_alignbit).
+//  * the first layer (<= 16 raw fp32 channel rows x 5 taps) keeps the fp32 fragments of the fp32 kernels: it is
+//    an eighth of the work and its input is not bf16; its weight gradient packs x to bf16 in registers.
+// HBM traffic per item halves (A2, A3, GELU'(A4) as bf16), LDS per workgroup drops from 150 to 81 / 87 KB.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int fused16_rows(int TT) { return 32 * ((TT + 1) / 2) + 8; }   // tile rows incl. guards
+
+// acc[j][gt] = sum_k W_k[gt] x in(rows tt[j]*16 + . + k): `wfr` = LDS fragments [5][2][64] uint4, `in` = tile bytes
+template <int NJ>
+__device__ __forceinline__ void fused_conv_bf16(const uint4* __restrict__ wfr, const char* __restrict__ in,
+                                                const int (&tt)[NJ], int lane, f32x4 (&acc)[NJ][2]) {
+  const int q = lane >> 4, jl = lane & 15;
+  bf16x8 af[kTaps][2];
+#pragma unroll
+  for (int k = 0; k < kTaps; ++k)
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt) af[k][gt] = __builtin_bit_cast(bf16x8, wfr[(k * 2 + gt) * 64 + lane]);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    bf16x8 bfr[kTaps];
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k)      // output step t, tap k reads input step t + k - 2 = tile row t + k
+      bfr[k] = *reinterpret_cast<const bf16x8*>(in + ((tt[j] * 16 + jl + k) * 64 + q * 16));
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+      acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k][0], bfr[k], acc[j][0], 0, 0, 0);
+      acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k][1], bfr[k], acc[j][1], 0, 0, 0);
+    }
+  }
+}
+
+// accumulator tiles -> bf16 tile rows (4 consecutive filters of one step = 8 bytes per lane and filter tile)
+template <int NW, bool DGELU>
+__device__ __forceinline__ void fused_store_bf16(const f32x4 (&acc)[16 / NW][2], const float* __restrict__ bias,
+                                                 char* __restrict__ tile, int T1, int TT, int wave, int q, int jl) {
+#pragma unroll
+  for (int j = 0; j < 16 / NW; ++j) {
+    const int tt = j * NW + wave;
+    const int t = tt * 16 + jl;
+    if (tt >= TT || t >= T1) continue;
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[j][gt][r] + (bias ? bias[gt * 16 + 4 * q + r] : 0.f);
+        if (DGELU) v[r] = gelu_grad_f(v[r]);
+      }
+      *reinterpret_cast<uint2*>(tile + ((t + 2) * 64 + (gt * 16 + 4 * q) * 2)) =
+          make_uint2(bf16_pack(v[0], v[1]), bf16_pack(v[2], v[3]));
+    }
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_bf16_kernel(FusedFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int F = 32;
+  const int z = blockIdx.y;
+  const ZoneDesc zd = a.zones[z];
+  const int cz = zd.cin, ncg = (cz + 3) / 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
+  const int T1 = a.T1, W = a.W, TT = a.TT;
+  const int R = fused16_rows(TT), tile_f = R * 16;            // tile = R rows x 64 bytes
+  float* xz = smem + 4;                                       // [16][W] fp32
+  char* t2 = reinterpret_cast<char*>(smem + ((4 + 16 * W + 3) & ~3));
+  char* t3 = t2 + tile_f * 4;
+  float* red = reinterpret_cast<float*>(t3 + tile_f * 4);     // [NW][32]
+  float* we = red + NW * F;                                   // [4][5][2][64] fp32 fragments of Weff
+  uint4* w3s = reinterpret_cast<uint4*>(we + 4 * kTaps * 2 * 64);   // [5][2][64] bf16 K = 32 fragments
+  uint4* w4s = w3s + kTaps * 2 * 64;
+  for (int e = threadIdx.x; e < 4 * kTaps * 2 * 64; e += NW * 64) we[e] = (e < ncg * kTaps * 2 * 64) ? a.weff[zd.eff_off + e] : 0.f;
+  for (int e = threadIdx.x; e < kTaps * 2 * 64; e += NW * 64) {
+    w3s[e] = reinterpret_cast<const uint4*>(a.w3 + (int64_t)z * a.wz_stride)[e];
+    w4s[e] = reinterpret_cast<const uint4*>(a.w4 + (int64_t)z * a.wz_stride)[e];
+  }
+  for (int e = cz * W + threadIdx.x; e < 16 * W; e += NW * 64) xz[e] = 0.f;
+  for (int e = threadIdx.x; e < 2 * tile_f; e += NW * 64) reinterpret_cast<float*>(t2)[e] = 0.f;   // guards, rows >= T1
+  const float* bias = a.beff + z * F;
+  constexpr int NJ = 16 / NW;
+  int off0[NJ], ttj[NJ];
+  bool ok0[NJ][kTaps];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    ttj[j] = (j * NW + wave) < TT ? (j * NW + wave) : 0;       // dead slots recompute tile 0 (never stored)
+    off0[j] = ttj[j] * 16 + jl;
+#pragma unroll
+    for (int kk = 0; kk < kTaps; ++kk) ok0[j][kk] = off0[j] + kk < W;
+  }
+  const int n16 = T1 * 4;                                      // 16-byte pieces of a tile's real rows
+  char* a2b = reinterpret_cast<char*>(a.a2);
+  char* a3b = reinterpret_cast<char*>(a.a3);
+  char* a4b = reinterpret_cast<char*>(a.a4);
+
+  for (int64_t item = blockIdx.x; item < a.items; item += gridDim.x) {
+    const int64_t b = item / a.N;
+    const int n = (int)(item - b * a.N);
+    const int64_t abase = (item * a.Z + z) * (int64_t)T1 * 64;   // bytes: [item][zone][t][32] bf16
+    __syncthreads();
+    for (int r = wave; r < cz; r += NW) {
+      const float* src = a.x + (b * a.Ctot + a.chan_idx[zd.idx_off + r]) * (int64_t)a.Tx + (int64_t)n * a.S;
+      for (int t0 = 0; t0 < W; t0 += 64)
+        if (t0 + lane < W)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + t0 + lane), (lds_ptr_t)(xz + r * W + t0), 4, 0, 0);
+    }
+    __syncthreads();
+    f32x4 acc[NJ][2];
+    // ---------------- cnn1 o cnn2 (valid, Cz x 5 taps) on the fp32 fragments
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    fused_conv_mma<NJ>(we + lane, xz + q * W, W, ncg, off0, ok0, acc);
+    fused_store_bf16<NW, false>(acc, bias, t2, T1, TT, wave, q, jl);
+    __syncthreads();
+    if (a.store) {
+      uint4* dst = reinterpret_cast<uint4*>(a2b + abase);
+      const uint4* src = reinterpret_cast<const uint4*>(t2 + 2 * 64);
+      for (int e = threadIdx.x; e < n16; e += NW * 64) dst[e] = src[e];
+    }
+    // ---------------- cnn3 (pad 2)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    fused_conv_bf16<NJ>(w3s, t2, ttj, lane, acc);
+    fused_store_bf16<NW, false>(acc, nullptr, t3, T1, TT, wave, q, jl);
+    __syncthreads();                                   // t3 complete; every read of t2 is done
+    if (a.store) {
+      uint4* dst = reinterpret_cast<uint4*>(a3b + abase);
+      const uint4* src = reinterpret_cast<const uint4*>(t3 + 2 * 64);
+      for (int e = threadIdx.x; e < n16; e += NW * 64) dst[e] = src[e];
+    }
+    // ---------------- cnn4 (pad 2) -> GELU -> mean
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    fused_conv_bf16<NJ>(w4s, t3, ttj, lane, acc);
+    if (a.store == 2) fused_store_bf16<NW, true>(acc, nullptr, t2, T1, TT, wave, q, jl);     // GELU'(A4) for the backward
+    else if (a.store) fused_store_bf16<NW, false>(acc, nullptr, t2, T1, TT, wave, q, jl);
+    float part[2][4];
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int tt = j * NW + wave;
+          if (tt < TT && tt * 16 + jl < T1) sacc += gelu_f(acc[j][gt][r]);
+        }
+        sacc += row_shr<8>(sacc);
+        sacc += row_shr<4>(sacc);
+        sacc += row_shr<2>(sacc);
+        sacc += row_shr<1>(sacc);
+        part[gt][r] = sacc;
+      }
+    if (jl == 15) {
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * F + gt * 16 + 4 * q + r] = part[gt][r];
+    }
+    __syncthreads();
+    if (threadIdx.x < F) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += red[w * F + threadIdx.x];
+      a.feat[(item * a.Z + z) * F + threadIdx.x] = tot / (float)T1;
+    }
+    if (a.store) {
+      uint4* dst = reinterpret_cast<uint4*>(a4b + abase);
+      const uint4* src = reinterpret_cast<const uint4*>(t2 + 2 * 64);
+      for (int e = threadIdx.x; e < n16; e += NW * 64) dst[e] = src[e];
+    }
+  }
+}
+
+// transposed 4-row x 16-column block read of a [row][32] bf16 tile: the lane of column c receives rows r0 .. r0 + 3 of
+// that column, packed (lane 4 r + p of the 16-lane group supplies the address of row r, columns 4 p .. 4 p + 3)
+__device__ __forceinline__ unsigned tr_addr(unsigned tile_base, int row0, int col0, int jl) {
+  return tile_base + (unsigned)(((row0 + (jl >> 2)) * 32 + col0 + 4 * (jl & 3)) * 2);
+}
+
+// acc[gt][k] += sum_t G[t][gt*16 + m] * In[t + k - 2][ct*16 + n] over 32-step blocks s = first, first + stride, ...
+__device__ __forceinline__ void fused_wgrad_bf16(unsigned g_base, unsigned in_base, int ct, int first, int stride,
+                                                 int nkb, int q, int jl, f32x4 (&acc)[2][kTaps]) {
+  for (int s = first; s < nkb; s += stride) {
+    const unsigned ga0 = tr_addr(g_base, 2 + 32 * s + 8 * q, 0, jl);
+    const unsigned ia0 = tr_addr(in_base, 32 * s + 8 * q, ct * 16, jl);
+    uint2 a00, a01, a10, a11, w0, w1, w2;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %7\n\tds_read_b64_tr_b16 %1, %7 offset:256\n\t"
+        "ds_read_b64_tr_b16 %2, %7 offset:32\n\tds_read_b64_tr_b16 %3, %7 offset:288\n\t"
+        "ds_read_b64_tr_b16 %4, %8\n\tds_read_b64_tr_b16 %5, %8 offset:256\n\tds_read_b64_tr_b16 %6, %8 offset:512\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11), "=&v"(w0), "=&v"(w1), "=&v"(w2)
+        : "v"(ga0), "v"(ia0)
+        : "memory");
+    const bf16x8 af0 = __builtin_bit_cast(bf16x8, make_uint4(a00.x, a00.y, a01.x, a01.y));
+    const bf16x8 af1 = __builtin_bit_cast(bf16x8, make_uint4(a10.x, a10.y, a11.x, a11.y));
+    const unsigned pe[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};     // window rows (0,1) (2,3) ... (10,11)
+    unsigned po[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) po[n] = __builtin_amdgcn_alignbit(pe[n + 1], pe[n], 16);   // rows (1,2) (3,4) ...
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+      const int h = k >> 1;
+      const uint4 bw = (k & 1) ? make_uint4(po[h], po[h + 1], po[h + 2], po[h + 3])
+                               : make_uint4(pe[h], pe[h + 1], pe[h + 2], pe[h + 3]);
+      const bf16x8 bfr = __builtin_bit_cast(bf16x8, bw);
+      acc[0][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bfr, acc[0][k], 0, 0, 0);
+      acc[1][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bfr, acc[1][k], 0, 0, 0);
+    }
+  }
+}
+
+// first layer: acc[gt][k] += sum_t G2[t][gt*16 + m] * x[n][t + k], accb[gt] += sum_t G2[t][.]; x = fp32 rows in LDS
+__device__ __forceinline__ void fused_wgrad_x_bf16(unsigned g_base, const float* __restrict__ xz, int W, int first,
+                                                   int stride, int nkb, int q, int jl, f32x4 (&acc)[2][kTaps],
+                                                   f32x4 (&accb)[2]) {
+  const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  for (int s = first; s < nkb; s += stride) {
+    const unsigned ga0 = tr_addr(g_base, 2 + 32 * s + 8 * q, 0, jl);
+    uint2 a00, a01, a10, a11;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:256\n\t"
+        "ds_read_b64_tr_b16 %2, %4 offset:32\n\tds_read_b64_tr_b16 %3, %4 offset:288\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11)
+        : "v"(ga0)
+        : "memory");
+    const bf16x8 af0 = __builtin_bit_cast(bf16x8, make_uint4(a00.x, a00.y, a01.x, a01.y));
+    const bf16x8 af1 = __builtin_bit_cast(bf16x8, make_uint4(a10.x, a10.y, a11.x, a11.y));
+    const float* xr = xz + jl * W + 32 * s + 8 * q;     // samples past a row's end meet zero rows of G2 (finite)
+    float e[12];
+#pragma unroll
+    for (int n = 0; n < 12; ++n) e[n] = xr[n];
+    unsigned pe[6], po[5];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) pe[n] = bf16_pack(e[2 * n], e[2 * n + 1]);
+#pragma unroll
+    for (int n = 0; n < 5; ++n) po[n] = bf16_pack(e[2 * n + 1], e[2 * n + 2]);
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+      const int h = k >> 1;
+      const uint4 bw = (k & 1) ? make_uint4(po[h], po[h + 1], po[h + 2], po[h + 3])
+                               : make_uint4(pe[h], pe[h + 1], pe[h + 2], pe[h + 3]);
+      const bf16x8 bfr = __builtin_bit_cast(bf16x8, bw);
+      acc[0][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bfr, acc[0][k], 0, 0, 0);
+      acc[1][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bfr, acc[1][k], 0, 0, 0);
+    }
+    accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, ones, accb[0], 0, 0, 0);
+    accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, ones, accb[1], 0, 0, 0);
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_bf16_kernel(FusedBwdArgs a) {
+  static_assert(NW == 8, "wave roles below assume 8 waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int F = 32;
+  const int z = blockIdx.y;
+  const ZoneDesc zd = a.zones[z];
+  const int cz = zd.cin, cin1 = cz + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
+  const int T1 = a.T1, W = a.W, TT = a.TT;
+  const int R = fused16_rows(TT), tile_f = R * 16;
+  float* xz = smem + 4;                                       // [16][W] fp32; the zero guard rows of `ga` follow it
+  char* ga = reinterpret_cast<char*>(smem + ((4 + 16 * W + 3) & ~3));
+  char* gb = ga + tile_f * 4;
+  char* at = gb + tile_f * 4;                                 // staged activation (A3, then A2)
+  uint4* w4s = reinterpret_cast<uint4*>(at + tile_f * 4);     // transposed + flipped cnn4 / cnn3 fragments
+  uint4* w3s = w4s + kTaps * 2 * 64;
+  float* dfs = reinterpret_cast<float*>(w3s + kTaps * 2 * 64);   // [32] dfeat of the item / T1
+  for (int e = threadIdx.x; e < kTaps * 2 * 64; e += NW * 64) {
+    w4s[e] = reinterpret_cast<const uint4*>(a.w4t + (int64_t)z * a.wz_stride)[e];
+    w3s[e] = reinterpret_cast<const uint4*>(a.w3t + (int64_t)z * a.wz_stride)[e];
+  }
+  for (int e = cz * W + threadIdx.x; e < 16 * W; e += NW * 64) xz[e] = 0.f;
+  for (int e = threadIdx.x; e < 3 * tile_f; e += NW * 64) reinterpret_cast<float*>(ga)[e] = 0.f;
+  constexpr int NJ = 16 / NW;
+  int ttj[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) ttj[j] = (j * NW + wave) < TT ? (j * NW + wave) : 0;
+  const int ct = wave & 1, ks = wave >> 1;
+  const int nkb = (T1 + 31) >> 5;                             // 32-step blocks of the weight gradients
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem;
+  const unsigned ga_base = smem_base + (unsigned)(ga - reinterpret_cast<char*>(smem));
+  const unsigned gb_base = smem_base + (unsigned)(gb - reinterpret_cast<char*>(smem));
+  const unsigned at_base = smem_base + (unsigned)(at - reinterpret_cast<char*>(smem));
+  f32x4 acc4[2][kTaps], acc3[2][kTaps], acc0[2][kTaps], accb[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    accb[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+      acc4[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc3[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc0[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const int n16 = T1 * 4;
+  const char* a2b = reinterpret_cast<const char*>(a.a2);
+  const char* a3b = reinterpret_cast<const char*>(a.a3);
+  const char* a4b = reinterpret_cast<const char*>(a.a4);
+
+  for (int64_t item = blockIdx.x; item < a.items; item += gridDim.x) {
+    const int64_t b = item / a.N;
+    const int n = (int)(item - b * a.N);
+    const int64_t abase = (item * a.Z + z) * (int64_t)T1 * 64;
+    __syncthreads();                                   // the previous item's tiles are no longer read
+    glds_copy16_strided(reinterpret_cast<const float*>(a4b + abase), reinterpret_cast<float*>(ga + 128), n16, wave * 64,
+                        NW * 64, lane);                // GELU'(A4)
+    glds_copy16_strided(reinterpret_cast<const float*>(a3b + abase), reinterpret_cast<float*>(at + 128), n16, wave * 64,
+                        NW * 64, lane);
+    for (int r = wave; r < cz; r += NW) {
+      const float* src = a.x + (b * a.Ctot + a.chan_idx[zd.idx_off + r]) * (int64_t)a.Tx + (int64_t)n * a.S;
+      for (int t0 = 0; t0 < W; t0 += 64)
+        if (t0 + lane < W)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + t0 + lane), (lds_ptr_t)(xz + r * W + t0), 4, 0, 0);
+    }
+    if (threadIdx.x < F) dfs[threadIdx.x] = a.dfeat[(item * a.Z + z) * F + threadIdx.x] / (float)T1;
+    __syncthreads();
+    // G4 = dfeat/T1 * GELU'(A4): 16 bytes = 8 consecutive filters of one step
+    for (int e = threadIdx.x; e < n16; e += NW * 64) {
+      uint4* pv = reinterpret_cast<uint4*>(ga + 128) + e;
+      const uint4 v = *pv;
+      const float* d = dfs + (e & 3) * 8;
+      *pv = make_uint4(bf16_pack(bf16_lo(v.x) * d[0], bf16_hi(v.x) * d[1]), bf16_pack(bf16_lo(v.y) * d[2], bf16_hi(v.y) * d[3]),
+                       bf16_pack(bf16_lo(v.z) * d[4], bf16_hi(v.z) * d[5]), bf16_pack(bf16_lo(v.w) * d[6], bf16_hi(v.w) * d[7]));
+    }
+    __syncthreads();                                   // G4, A3 and the x rows are in LDS
+    // ---------------- cnn4: dW4 += G4 (*) A3 ; G3 = W4^T (*) G4 -> gb
+    fused_wgrad_bf16(ga_base, at_base, ct, ks, 4, nkb, q, jl, acc4);
+    {
+      f32x4 acc[NJ][2];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      fused_conv_bf16<NJ>(w4s, ga, ttj, lane, acc);
+      fused_store_bf16<NW, false>(acc, nullptr, gb, T1, TT, wave, q, jl);
+    }
+    __syncthreads();                                   // G3 complete; A3 and G4 are dead
+    glds_copy16_strided(reinterpret_cast<const float*>(a2b + abase), reinterpret_cast<float*>(at + 128), n16, wave * 64,
+                        NW * 64, lane);
+    // ---------------- cnn3 data gradient first (does not need A2): G2 = W3^T (*) G3 -> ga
+    {
+      f32x4 acc[NJ][2];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      fused_conv_bf16<NJ>(w3s, gb, ttj, lane, acc);
+      fused_store_bf16<NW, false>(acc, nullptr, ga, T1, TT, wave, q, jl);
+    }
+    __syncthreads();                                   // G2 complete, A2 landed
+    fused_wgrad_bf16(gb_base, at_base, ct, ks, 4, nkb, q, jl, acc3);
+    // ---------------- cnn1 o cnn2: dWeff += G2 (*) x (valid convolution), dbeff += sum_t G2
+    fused_wgrad_x_bf16(ga_base, xz, W, wave, NW, nkb, q, jl, acc0, accb);
+  }
+  // ---------------- partial slabs (same layout as the fp32 kernel)
   {
     float* s4 = a.part4 + ((int64_t)blockIdx.x * 4 + ks) * a.slab1 + (int64_t)z * F * F * kTaps;
     float* s3 = a.part3 + ((int64_t)blockIdx.x * 4 + ks) * a.slab1 + (int64_t)z * F * F * kTaps;
@@ -2372,11 +2790,23 @@ static int launch_conv(int mode, int bf16, const ConvArgs& a, int n_zones, hipSt
   return ISD_OK;
 }
 
+// the reference-native shape with bf16 activations runs the bf16 fused pair (conv4_fused_*_bf16_kernel)
+static bool fused16_ok(const isd_conv4_plan* p, const Geo& g) {
+  return p->n_layers == 4 && p->F == 32 && p->act_bf16 && p->max_cz <= 16 && g.TT <= 16 && g.TT >= 4;
+}
+static size_t fused16_lds(const isd_conv4_plan* p, const Geo& g, bool bwd) {
+  const size_t tile_f = (size_t)fused16_rows(g.TT) * 16, x_f = (size_t)((4 + 16 * p->W + 3) & ~3);
+  const size_t w16 = (size_t)kTaps * 2 * 64 * 4;
+  return sizeof(float) * (bwd ? x_f + 3 * tile_f + 2 * w16 + 32 + 16
+                              : x_f + 2 * tile_f + 8 * 32 + 4 * kTaps * 2 * 64 + 2 * w16 + 16);
+}
+
 static int launch_prep(const isd_conv4_plan* p, const Geo& g, const float* params, float* ws, hipStream_t st,
                        bool tap16 = false) {
   const int F = p->F;
   const int nbw = (int)cdiv(((int64_t)(p->max_cz + 3) / 4) * 4 * F, 256);
-  PrepConvArgs pc{ws + g.o_w3, ws + g.o_w3t, ws + g.o_w4, ws + g.o_w4t, p->conv_zstride, p->n_layers};
+  PrepConvArgs pc{ws + g.o_w3, ws + g.o_w3t, ws + g.o_w4, ws + g.o_w4t, p->conv_zstride, p->n_layers,
+                  fused16_ok(p, g) && fused16_lds(p, g, true) <= 160 * 1024 ? 1 : 0};
   const int extra = p->n_layers == 4 ? 8 : 0;
   hipLaunchKernelGGL(prep_fused_kernel, dim3(nbw + F + extra, p->Z), dim3(256), 0, st, params, p->d_zones,
                      ws + g.o_eff, ws + g.o_beff, F, nbw, p->act_bf16, pc,
@@ -2491,6 +2921,24 @@ extern "C" int isd_conv4_forward(const isd_conv4_plan* p, const float* x, const 
   const int F = p->F;
   rc = launch_prep(p, g, params, ws, st);
   if (rc) return rc;
+  if (fused16_ok(p, g) && fused16_lds(p, g, true) <= 160 * 1024) {
+    // reference-native shape, bf16 activations: the fused kernel on the bf16 matrix cores
+    FusedFwdArgs fa = {};
+    fa.x = x; fa.weff = ws + g.o_eff; fa.beff = ws + g.o_beff; fa.w3 = ws + g.o_w3; fa.w4 = ws + g.o_w4;
+    fa.a2 = ws + g.o_a2; fa.a3 = ws + g.o_a3; fa.a4 = ws + g.o_a4; fa.feat = feat;
+    fa.zones = p->d_zones; fa.chan_idx = p->d_idx; fa.wz_stride = p->conv_zstride; fa.items = g.items;
+    fa.Z = p->Z; fa.W = p->W; fa.T1 = g.T1; fa.TT = g.TT; fa.store = 2;
+    fa.Ctot = p->Ctot; fa.Tx = (int)T; fa.N = g.N; fa.S = p->S;
+    const size_t lds = fused16_lds(p, g, false);
+    int per_zone = (lds <= 80 * 1024 ? 512 : 256) / p->Z;     // two workgroups per CU when the tiles allow
+    if (per_zone < 1) per_zone = 1;
+    if (per_zone > g.items) per_zone = (int)g.items;
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv4_fused_fwd_bf16_kernel<8>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((conv4_fused_fwd_bf16_kernel<8>), dim3(per_zone, p->Z), dim3(8 * 64), lds, st, fa);
+    ISD_LAUNCH_CHECK();
+    return ISD_OK;
+  }
   if (p->n_layers == 4 && F == 32 && !p->act_bf16 && p->max_cz <= 16 && g.TT <= 16 && (F * g.T1) % 4 == 0 &&
       g.TT >= 4) {
     // reference-native shape: one persistent fused kernel (register-resident weights, activations through LDS)
@@ -2757,6 +3205,38 @@ static int conv4_backward_impl(const isd_conv4_plan* p, const float* x, const fl
   const int F = p->F;
   const int64_t rows = g.items * p->Z * F;
   bool kept_dgelu = false;                                 // the forward of this step ran fused and kept GELU'(A4)
+  if (fused16_ok(p, g) && fused16_lds(p, g, true) <= 160 * 1024) {
+    ISD_CHECK_ARG(!dx, "isd_conv4_backward_x: fp32 activations only");
+    constexpr int NW = 8;
+    const size_t lds = fused16_lds(p, g, true);
+    int per_zone = 256 / p->Z;
+    if (per_zone < 1) per_zone = 1;
+    if (per_zone > g.items) per_zone = (int)g.items;
+    FusedBwdArgs fb = {};
+    fb.x = x; fb.dfeat = dfeat; fb.a2 = ws + g.o_a2; fb.a3 = ws + g.o_a3; fb.a4 = ws + g.o_a4;
+    fb.w3t = ws + g.o_w3t; fb.w4t = ws + g.o_w4t;
+    fb.part4 = ws + g.o_part;
+    fb.part3 = fb.part4 + (int64_t)per_zone * 4 * g.slab1;
+    fb.part0 = fb.part3 + (int64_t)per_zone * 4 * g.slab1;
+    fb.zones = p->d_zones; fb.chan_idx = p->d_idx; fb.wz_stride = p->conv_zstride; fb.items = g.items;
+    fb.slab1 = g.slab1; fb.slab0 = g.slab0;
+    fb.Z = p->Z; fb.W = p->W; fb.T1 = g.T1; fb.TT = g.TT;
+    fb.Ctot = p->Ctot; fb.Tx = (int)T; fb.N = g.N; fb.S = p->S;
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv4_fused_bwd_bf16_kernel<NW>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((conv4_fused_bwd_bf16_kernel<NW>), dim3(per_zone, p->Z), dim3(NW * 64), lds, st, fb);
+    ISD_LAUNCH_CHECK();
+    launch_reduce_slabs(fb.part4, ws + g.o_wg34, g.slab1, per_zone * 4, st);
+    hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 1);
+    launch_reduce_slabs(fb.part3, ws + g.o_wg34, g.slab1, per_zone * 4, st);
+    hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 0);
+    launch_reduce_slabs(fb.part0, ws + g.o_wg, g.slab0, per_zone * NW, st);
+    const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
+    hipLaunchKernelGGL(fused_bwd_kernel, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,
+                       ws + g.o_wg, dparams, F, nb2);
+    ISD_LAUNCH_CHECK();
+    return ISD_OK;
+  }
   if (p->n_layers == 4 && F == 32 && !p->act_bf16 && p->max_cz <= 16 && g.TT <= 16 && (F * g.T1) % 4 == 0 &&
       g.TT >= 4) {
     // reference-native shape: one persistent fused kernel; gradient tiles stay in LDS, weight gradients in registers

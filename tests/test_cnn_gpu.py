@@ -358,3 +358,36 @@ def test_bf16_matrix_core_step_shapes_vs_fp32_path(inn, B, C, T):
     ev = hp16.forward(x, y)
     assert torch.equal(inf["logits"], o16["logits"]) and torch.equal(inf["pred"], o16["pred"])
     assert abs(float(ev["loss"]) - float(o16["loss"])) < 1e-6
+
+
+def test_bf16_fused_raw_eeg_head_vs_fp32(inn):
+    """The reference-native shape (8 zones, windows of 250 samples) with bf16 activations runs the fused forward /
+    backward on the bf16 matrix cores (conv4_fused_fwd_bf16_kernel / conv4_fused_bwd_bf16_kernel: [time][channel] bf16
+    tiles, v_mfma_f32_16x16x32_bf16, transposed LDS reads for the weight gradients).  Stated tolerance against the
+    fp32 kernels on the same parameters: features 2e-2, parameter gradients 5e-2 of the tensor's largest magnitude
+    (scripts/train_fast.py:277 trains under bf16-mixed autocast)."""
+    torch.manual_seed(3)
+    h32 = inn.Head("Conv4Layers", ocnn.ELECTRODES, ocnn.ZONES, 32).cuda()
+    h16 = inn.Head("Conv4Layers", ocnn.ELECTRODES, ocnn.ZONES, 32, act_dtype="bf16").cuda()
+    h16.load_state_dict(h32.state_dict())
+    for B, T in ((3, 250), (37, 512), (2, 800)):             # 1, 3 and 5 windows per trial; items not a multiple of anything
+        x = torch.randn(B, 64, T, device="cuda")
+        n_win = (T - 250) // 125 + 1
+        w = torch.randn(B * n_win, 8, 32, device="cuda")
+        outs = []
+        for h in (h32, h16):
+            h.zero_grad(set_to_none=True)
+            f = h.forward_windows(x, 250, 125)
+            assert f.shape == (B * n_win, 8, 32)
+            (f * w).sum().backward()
+            outs.append((f.detach().cpu(), {k: p.grad.detach().cpu().clone() for k, p in h.named_parameters()}))
+        (f32, g32), (f16, g16) = outs
+        assert 0 < rel_err(f16, f32) < 2e-2, (B, T)
+        for k in g32:
+            assert rel_err(g16[k], g32[k]) < 5e-2, (B, T, k)
+    # the oracle (fp64) agrees with the bf16 features within the same tolerance
+    x = torch.randn(2, 64, 512)
+    p = {"head." + k: v.detach().cpu().double() for k, v in h32.state_dict().items()}
+    ref = ocnn.forward_head(x.double(), p, list(ocnn.ZONES), ocnn.zone_index_lists(), 250, 125)
+    got = h16.forward_windows(x.cuda(), 250, 125).detach().cpu()
+    assert rel_err(got, ref.reshape(got.shape)) < 2e-2

@@ -47,14 +47,15 @@ def tail_only():
 def main():
     if "--tail" in sys.argv:
         return tail_only()
-    for B, T in ((64, 800), (1024, 512), (4096, 512), (1024, 800)):
+    for B, T, act in ((64, 800, "f32"), (1024, 512, "f32"), (4096, 512, "f32"), (1024, 800, "f32"), (64, 800, "bf16"),
+                      (4096, 512, "bf16"), (1024, 800, "bf16")):
         torch.manual_seed(0)
-        m = _FastModel(fast_config(seq_len=T)).cuda()
+        m = _FastModel(fast_config(seq_len=T, act_dtype=act)).cuda()
         tr = isd_amd.Trainer(m)
         x = torch.randn(B, 64, T, device="cuda")
         y = torch.randint(0, 5, (B,), device="cuda")
         dt, out = timed(lambda: tr.step(x, y), 20 if B <= 1024 else 5)
-        print(f"FAST train_head B={B} T={T}: {dt*1e3:.3f} ms/step, {B/dt:.0f} trials/s, loss {float(out['loss']):.4f}, "
+        print(f"FAST train_head {act} B={B} T={T}: {dt*1e3:.3f} ms/step, {B/dt:.0f} trials/s, loss {float(out['loss']):.4f}, "
               f"mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
     from isd_amd.graph import GraphedTrainStep
     for B, T in ((64, 800), (4096, 800), (4096, 512)):
