@@ -100,11 +100,12 @@ def train_one_fold(config, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, for
     Xva = st.get()
     use_graph = graph_safe(model) if graph is None else bool(graph)
     if use_graph:
-        opt = torch.optim.AdamW(model.parameters(), lr=torch.tensor(float(lr), device=Xd.device), capturable=True)
+        opt = torch.optim.AdamW(model.parameters(), lr=torch.tensor(float(lr), device=Xd.device), capturable=True,
+                                fused=True)
         model.train()
         gstep = GraphedTrainStep(model, opt, Xd, yd, bs, forward_mode)
     else:
-        opt = torch.optim.AdamW(model.parameters(), lr=lr)
+        opt = torch.optim.AdamW(model.parameters(), lr=lr, fused=True)
     gen = torch.Generator().manual_seed(seed)
     best, best_sd, hist, step = -1.0, None, [], 0
     for ep in range(max_epochs):
@@ -183,21 +184,31 @@ def run_folds(fold_tasks, workers=0, devices=None):
 
 
 def finetune_per_subject_cv(train_val, test, out_dir, config=None, n_folds=5, max_epochs=200, batch_size=64, seed=42,
-                            forward_mode="default", workers=0, devices=None):
+                            forward_mode="default", workers=0, devices=None, precision="32"):
     """``train_val`` / ``test``: {SID: (X [n,C,T], y)}.  Mirrors scripts/train_fast.py:68-265; returns the summary rows.
     ``workers`` > 0 packs the subject x fold trainings over that many processes / the GPUs in ``devices``
-    (``run_folds``); results do not depend on the packing."""
+    (``run_folds``); results do not depend on the packing.  ``precision``: '32', or 'bf16-mixed' (the reference
+    script's default, scripts/train_fast.py:277): the zone CNN keeps bf16 activations / gradients and runs on the bf16
+    matrix cores, parameters and the transformer tail stay fp32.  A ``config`` that sets ``act_dtype`` wins."""
+
+    def with_precision(cfg):
+        if hasattr(cfg, "act_dtype"):
+            return cfg
+        import copy
+        cfg = copy.copy(cfg)
+        cfg.act_dtype = "bf16" if str(precision).startswith("bf16") else "f32"
+        return cfg
     save_dir = os.path.join(out_dir, "FAST")
     os.makedirs(save_dir, exist_ok=True)
     rows, gp, gt = [], [], []
     fold_tasks = {}
     for sid, (X, y) in train_val.items():
-        cfg = config or fast_config(seq_len=int(X.shape[-1]))
+        cfg = with_precision(config or fast_config(seq_len=int(X.shape[-1])))
         for fi, (tr, va) in enumerate(kfold_indices(len(X), n_folds, seed)):
             fold_tasks[(sid, fi)] = (cfg, X[tr], y[tr], X[va], y[va], max_epochs, batch_size, seed, forward_mode)
     done = run_folds(fold_tasks, workers, devices)
     for sid, (X, y) in train_val.items():
-        cfg = config or fast_config(seq_len=int(X.shape[-1]))
+        cfg = with_precision(config or fast_config(seq_len=int(X.shape[-1])))
         sub_dir = os.path.join(save_dir, f"sub-{sid}")
         os.makedirs(sub_dir, exist_ok=True)
         fold_rows, best_acc, best_sd = [], -1.0, None
@@ -278,6 +289,8 @@ def main(argv=None):
     ap.add_argument("--n_folds", type=int, default=5)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--forward_mode", default="default", choices=["default", "train_head"])
+    ap.add_argument("--precision", default="bf16-mixed", choices=["bf16-mixed", "32"],
+                    help="training precision (scripts/train_fast.py:277 defaults to bf16-mixed)")
     ap.add_argument("--workers", type=int, default=0, help="pack the subject x fold trainings over this many processes")
     ap.add_argument("--devices", type=int, nargs="*", default=None, help="GPUs the workers are bound to (default: all)")
     args = ap.parse_args(argv)
@@ -286,7 +299,7 @@ def main(argv=None):
     tv = load_standardized(args.data)
     te = load_standardized(args.test) if args.test else {}
     rows = finetune_per_subject_cv(tv, te, args.output_dir, None, args.n_folds, args.epochs, args.batch_size, args.seed,
-                                   args.forward_mode, args.workers, args.devices)
+                                   args.forward_mode, args.workers, args.devices, args.precision)
     per, summary = process_results(args.output_dir)
     print(summary if summary else rows)
 

@@ -258,6 +258,11 @@ def test_graphed_training_step_matches_eager_and_advances_dropout(isd):
         assert abs(he["loss"] - hg["loss"]) < 2e-3 * max(1.0, abs(he["loss"])), (he, hg)
     for k, v in runs[False][1].items():
         assert float((v - runs[True][1][k]).abs().max()) < 5e-3 * max(1.0, float(v.abs().max())), k
+    # bf16-mixed (the reference script's default precision): the zone CNN on the bf16 matrix cores, inside the graph
+    acc16, sd16, h16 = E.train_one_fold(inn.fast_config(dropout=0.0, act_dtype="bf16"), X[:32], y[:32], X[32:], y[32:], 3,
+                                        12, seed=5)
+    for he, hb in zip(runs[False][0], h16):
+        assert abs(he["loss"] - hb["loss"]) < 5e-2, (he, hb)
     # dropout: replaying the same batch at learning rate 0 gives a different loss each time, eval mode does not
     torch.manual_seed(0)
     m = inn.FAST(inn.fast_config(dropout=0.3)).cuda().train()

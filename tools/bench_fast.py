@@ -58,14 +58,14 @@ def main():
         print(f"FAST train_head {act} B={B} T={T}: {dt*1e3:.3f} ms/step, {B/dt:.0f} trials/s, loss {float(out['loss']):.4f}, "
               f"mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
     from isd_amd.graph import GraphedTrainStep
-    for B, T in ((64, 800), (4096, 800), (4096, 512)):
+    for B, T, act in ((64, 800, "f32"), (4096, 800, "f32"), (4096, 512, "f32"), (64, 800, "bf16"), (4096, 800, "bf16")):
         x = torch.randn(B, 64, T, device="cuda")
         y = torch.randint(0, 5, (B,), device="cuda")
         for graph in (False, True):
             torch.manual_seed(0)
-            net = inn.FAST(fast_config(seq_len=T)).cuda().train()
+            net = inn.FAST(fast_config(seq_len=T, act_dtype=act)).cuda().train()
             if graph:                           # the whole step as one HIP graph replay (isd_amd.graph)
-                opt = torch.optim.AdamW(net.parameters(), lr=torch.tensor(5e-4, device="cuda"), capturable=True)
+                opt = torch.optim.AdamW(net.parameters(), lr=torch.tensor(5e-4, device="cuda"), capturable=True, fused=True)
                 gs = GraphedTrainStep(net, opt, x, y, B)
                 idx = torch.arange(B, device="cuda")
 
@@ -85,7 +85,7 @@ def main():
             net.eval()
             with torch.no_grad():
                 di, _ = timed(lambda: net(x, forward_mode="default"), 20 if B <= 1024 else 5)
-            print(f"FAST default    B={B} T={T} {'graph replay' if graph else 'eager       '}: {dt*1e3:.3f} ms/step, "
+            print(f"FAST default {act:>4} B={B} T={T} {'graph replay' if graph else 'eager       '}: {dt*1e3:.3f} ms/step, "
                   f"{B/dt:.0f} trials/s | inference {di*1e3:.3f} ms, {B/di:.0f} trials/s")
     tail_only()
 
