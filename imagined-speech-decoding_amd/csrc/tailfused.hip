@@ -123,10 +123,10 @@ __device__ __forceinline__ float tf_gelu_grad(float x) {
 // ------------------------------------------------------------------------------------------- staging the weights
 // dst[i * STRIDE + o] = W[o][i]
 template <int NO, int NI, int STRIDE>
-__device__ __forceinline__ void stage_transposed(const float* __restrict__ W, float* dst, int lane) {
+__device__ __forceinline__ void stage_transposed(const float* __restrict__ W, float* dst, int tid) {
   constexpr int kQ = NI / 4;
 #pragma unroll 4
-  for (int idx = lane; idx < NO * kQ; idx += 64) {
+  for (int idx = tid; idx < NO * kQ; idx += 256) {
     const int o = idx / kQ, i4 = (idx - o * kQ) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(W + o * NI + i4);
     dst[(i4 + 0) * STRIDE + o] = v[0];
@@ -136,15 +136,15 @@ __device__ __forceinline__ void stage_transposed(const float* __restrict__ W, fl
   }
 }
 
-__device__ __forceinline__ void stage_copy(const float* __restrict__ src, float* dst, int n, int lane) {
-  for (int idx = lane * 4; idx < n; idx += 256) *reinterpret_cast<f32x4*>(dst + idx) = *reinterpret_cast<const f32x4*>(src + idx);
+__device__ __forceinline__ void stage_copy(const float* __restrict__ src, float* dst, int n, int tid) {
+  for (int idx = tid * 4; idx < n; idx += 1024) *reinterpret_cast<f32x4*>(dst + idx) = *reinterpret_cast<const f32x4*>(src + idx);
 }
 
 // straight copy of n floats (multiple of 4, both sides 16-byte aligned) by LDS-DMA: every piece in flight at once,
 // no registers; retire with s_waitcnt vmcnt(0)
-__device__ __forceinline__ void stage_dma(const float* __restrict__ src, float* dst, int n, int lane) {
-  const int n4 = n / 4;
-  for (int e0 = 0; e0 < n4; e0 += 64) {
+__device__ __forceinline__ void stage_dma(const float* __restrict__ src, float* dst, int n, int tid) {
+  const int n4 = n / 4, lane = tid & 63;
+  for (int e0 = (tid >> 6) * 64; e0 < n4; e0 += 256) {    // a wave moves 1 KiB pieces; dst base is wave-uniform
     if (e0 + lane < n4)
       __builtin_amdgcn_global_load_lds((tf_gbl_ptr_t)(src + (int64_t)(e0 + lane) * 4), (tf_lds_ptr_t)(dst + e0 * 4), 16, 0, 0);
   }
@@ -154,59 +154,65 @@ __device__ __forceinline__ void stage_dma_wait() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// ------------------------------------------------------------------------------------------- dense layers
-// Y[tok][n] = bias[n] + sum_k X[tok][k] W[k * WS + n]  for the wave's 64 tokens: X = columns acol .. acol + K,
-// Y -> columns ocol .. ocol + N (may overlap X when HOLD: the A fragments are read first), W and bias in LDS.
+// ------------------------------------------------------------------------------------------- the workgroup
+// FOUR waves share the 64 tokens of a workgroup (one token per lane in every wave) and its LDS columns; the four SIMDs
+// of a CU work on the same tokens: a dense layer gives each wave one 16-token row tile, elementwise work gives wave w
+// the w-th quarter of the features, attention gives it every fourth head, a weight gradient every fourth tile.
+// (One wave per workgroup ran every phase as one dependent chain on one SIMD: 120 / 385 us at any batch size.)
+constexpr int kNW = 4;
+
+// Y[tok][n] = bias[n] + sum_k X[tok][k] W[k * WS + n] for the 16 tokens of row tile `mt`: X = columns acol .. acol + K,
+// Y -> columns ocol .. ocol + N, W and bias in LDS.  HOLD keeps the K / 4 A fragments in registers.
 template <int K, int N, int WS, bool BIAS, bool HOLD>
-__device__ __forceinline__ void gemm_cols(float* cols, int acol, const float* W, const float* bias, int ocol, int lane) {
+__device__ __forceinline__ void gemm_cols(float* cols, int acol, const float* W, const float* bias, int ocol, int lane,
+                                          int mt) {
   const int m = lane & 15, kq = lane >> 4;
-  float af[HOLD ? K / 4 : 1][4];
+  float af[HOLD ? K / 4 : 1];
   if (HOLD) {
 #pragma unroll
-    for (int t = 0; t < K / 4; ++t)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) af[t][mt] = cols[(acol + 4 * t + kq) * kCS + 16 * mt + m];
+    for (int t = 0; t < K / 4; ++t) af[t] = cols[(acol + 4 * t + kq) * kCS + 16 * mt + m];
   }
-#pragma unroll 1
+#pragma unroll 2
   for (int nb = 0; nb < N; nb += 16) {
     const float bv = BIAS ? bias[nb + m] : 0.f;
-    f32x4 acc[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){bv, bv, bv, bv};
+    f32x4 acc = {bv, bv, bv, bv};
 #pragma unroll
     for (int t = 0; t < K / 4; ++t) {
       const float bw = W[(4 * t + kq) * WS + nb + m];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const float av = HOLD ? af[t][mt] : cols[(acol + 4 * t + kq) * kCS + 16 * mt + m];
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, acc[mt], 0, 0, 0);
-      }
+      const float av = HOLD ? af[t] : cols[(acol + 4 * t + kq) * kCS + 16 * mt + m];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, acc, 0, 0, 0);
     }
     // D[row = token 4 kq + r][col = output m]: four consecutive tokens of one output column per lane
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-      *reinterpret_cast<f32x4*>(cols + (ocol + nb + m) * kCS + 16 * mt + 4 * kq) = acc[mt];
+    *reinterpret_cast<f32x4*>(cols + (ocol + nb + m) * kCS + 16 * mt + 4 * kq) = acc;
   }
 }
 
-// LayerNorm over the lane's D features (eps inside the sqrt, biased variance: nn.LayerNorm); w, b in LDS; the output
-// goes to the lane's slots of columns hcol ..
-template <int D>
-__device__ __forceinline__ void layer_norm_to_cols(const float (&x)[D], const float* w, const float* b, float* hcol,
-                                                   float& mu, float& rstd) {
+// per-token sum of one value over the four waves (each holds a feature quarter): scratch = 4 free columns
+__device__ __forceinline__ float wg_sum4(float* cols, int c0, int wave, int lane, float v) {
+  cols[(c0 + wave) * kCS + lane] = v;
+  __syncthreads();
+  return (cols[c0 * kCS + lane] + cols[(c0 + 1) * kCS + lane]) + (cols[(c0 + 2) * kCS + lane] + cols[(c0 + 3) * kCS + lane]);
+}
+
+// LayerNorm of the token's D features, this thread holding FS = D / 4 of them (eps inside the sqrt, biased variance:
+// nn.LayerNorm); w, b = this thread's slice of the LDS copies; output to the thread's slots of columns hcol ..;
+// scratch = 8 free columns.  Two barriers inside.
+template <int D, int FS>
+__device__ __forceinline__ void layer_norm_to_cols(const float (&x)[FS], const float* w, const float* b, float* hcol,
+                                                   float* cols, int scratch, int wave, int lane, float& mu, float& rstd) {
   float s = 0.f;
 #pragma unroll
-  for (int d = 0; d < D; ++d) s += x[d];
-  mu = s * (1.f / D);
+  for (int d = 0; d < FS; ++d) s += x[d];
+  mu = wg_sum4(cols, scratch, wave, lane, s) * (1.f / D);
   float q = 0.f;
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < FS; ++d) {
     const float c = x[d] - mu;
     q = fmaf(c, c, q);
   }
-  rstd = rsqrtf(q * (1.f / D) + 1e-5f);
+  rstd = rsqrtf(wg_sum4(cols, scratch + 4, wave, lane, q) * (1.f / D) + 1e-5f);
 #pragma unroll
-  for (int d = 0; d < D; ++d) hcol[d * kCS] = (x[d] - mu) * rstd * w[d] + b[d];
+  for (int d = 0; d < FS; ++d) hcol[d * kCS] = (x[d] - mu) * rstd * w[d] + b[d];
 }
 
 // LDS image of one block's weights for the forward: [K][N] = transposed matrices (rows padded by 4 floats to spread the
@@ -218,41 +224,42 @@ template <int D> struct FwdImg {
                        b1 = ln2b + D, b2 = b1 + 2 * D, total = b2 + D;
 };
 
-// tokin [B][N][D]: output of input_layer (Linear + GELU); logits [B][n_cls]; save [L][gridDim.x][Sv<D>::total][64] or
-// null (inference); xfinal [B][D]: the cls token entering last_layer, after dropout (training) or null
+// tokin [B][N][D]: output of input_layer (Linear + GELU); logits [B][n_cls]; save [L][gridDim.x][Sv<D>::total][64]
+// and xfinal [B][D] (the cls token entering last_layer, after dropout) with TRAIN
 // kDH = head width (compile time: the attention loops carry no branches); TRAIN: dropout + the record
 template <int kTD, int kDH, bool TRAIN>
-__global__ __launch_bounds__(64) void tail_fused_fwd_kernel(const float* __restrict__ P, TailMeta a,
-                                                            const float* __restrict__ tokin,
-                                                            float* __restrict__ logits, float* __restrict__ save,
-                                                            float* __restrict__ xfinal) {
-  constexpr int kTHid = 2 * kTD;
+__global__ __launch_bounds__(kNW * 64) void tail_fused_fwd_kernel(const float* __restrict__ P, TailMeta a,
+                                                                  const float* __restrict__ tokin,
+                                                                  float* __restrict__ logits, float* __restrict__ save,
+                                                                  float* __restrict__ xfinal) {
+  constexpr int kTHid = 2 * kTD, FS = kTD / kNW, HS = kTHid / kNW;
   using Img = FwdImg<kTD>;
-  // column regions: q | k | v (the MLP's hidden vector reuses it), and two D-wide regions
+  // column regions: q | k | v (the MLP's hidden vector and LayerNorm scratch reuse it), and two D-wide regions
   constexpr int RQ = 0, RA = 3 * kTD, RC = 4 * kTD, kColTotal = 5 * kTD;
   constexpr int kSvXin = Sv<kTD>::xin, kSvLn1 = Sv<kTD>::ln1, kSvQkv = Sv<kTD>::qkv, kSvProb = Sv<kTD>::prob,
                 kSvCtx = Sv<kTD>::ctx, kSvXmid = Sv<kTD>::xmid, kSvLn2 = Sv<kTD>::ln2, kSvHpre = Sv<kTD>::hpre,
                 kSvTotal = Sv<kTD>::total;
   __shared__ __attribute__((aligned(16))) float wl[Img::total];
   __shared__ __attribute__((aligned(16))) float cols[kColTotal * kCS];
-  const int lane = threadIdx.x;
-  const int S = a.S, G = 64 / S;                          // trials per wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = a.S, G = 64 / S;                          // trials per workgroup
   const int g = lane / S, i = lane - g * S;
   const int64_t b = (int64_t)blockIdx.x * G + g;
   const bool live = g < G && b < a.B;
   const int gs = (g < G ? g : 0) * S;                     // first lane of this token's trial
-  const int64_t bc = live ? b : 0;                        // dead lanes recompute trial 0 (finite values, never stored)
+  const int64_t bc = live ? b : 0;                        // dead lanes recompute trial 0 (finite values, never used)
   const int64_t tok = bc * S + i;                         // global token row (dropout counters)
   constexpr int kH = kTD / kDH;
   const float scale = 1.f / sqrtf((float)kDH);
   float* my = cols + lane;
   const unsigned long long seed = tf_seed(a);
+  const int f0 = FS * wave, h0 = HS * wave;               // this thread's feature / hidden-feature quarter
 
-  float x[kTD];
+  float x[FS];
 #pragma unroll
-  for (int d = 0; d < kTD; ++d) {
-    const float base = i == 0 ? P[a.cls + d] : tokin[(bc * a.N + (i - 1)) * kTD + d];
-    x[d] = base + P[a.pos + i * kTD + d];
+  for (int d = 0; d < FS; ++d) {
+    const float base = i == 0 ? P[a.cls + f0 + d] : tokin[(bc * a.N + (i - 1)) * kTD + f0 + d];
+    x[d] = base + P[a.pos + i * kTD + f0 + d];
   }
   for (int l = 0; l < a.L; ++l) {
     const TailLayerOff& wo = a.layer[l];
@@ -260,43 +267,45 @@ __global__ __launch_bounds__(64) void tail_fused_fwd_kernel(const float* __restr
     const bool tf_first = l == 1;
 #endif
     TF_MARK(0);
-    stage_transposed<3 * kTD, kTD, Img::SI>(P + wo.inw, wl + Img::win, lane);
-    stage_transposed<kTD, kTD, Img::SO>(P + wo.ow, wl + Img::wo, lane);
-    stage_transposed<kTHid, kTD, Img::S1>(P + wo.w1, wl + Img::w1, lane);
-    stage_transposed<kTD, kTHid, Img::S2>(P + wo.w2, wl + Img::w2, lane);
-    stage_copy(P + wo.ln1w, wl + Img::ln1w, 2 * kTD, lane);
-    stage_copy(P + wo.inb, wl + Img::inb, 3 * kTD, lane);
-    stage_copy(P + wo.ob, wl + Img::ob, kTD, lane);
-    stage_copy(P + wo.ln2w, wl + Img::ln2w, 2 * kTD, lane);
-    stage_copy(P + wo.b1, wl + Img::b1, 2 * kTD, lane);
-    stage_copy(P + wo.b2, wl + Img::b2, kTD, lane);
-    // this wave's record block of layer l: field f of this lane at sv[f * 64]
+    stage_transposed<3 * kTD, kTD, Img::SI>(P + wo.inw, wl + Img::win, tid);
+    stage_transposed<kTD, kTD, Img::SO>(P + wo.ow, wl + Img::wo, tid);
+    stage_transposed<kTHid, kTD, Img::S1>(P + wo.w1, wl + Img::w1, tid);
+    stage_transposed<kTD, kTHid, Img::S2>(P + wo.w2, wl + Img::w2, tid);
+    stage_copy(P + wo.ln1w, wl + Img::ln1w, 2 * kTD, tid);
+    stage_copy(P + wo.inb, wl + Img::inb, 3 * kTD, tid);
+    stage_copy(P + wo.ob, wl + Img::ob, kTD, tid);
+    stage_copy(P + wo.ln2w, wl + Img::ln2w, 2 * kTD, tid);
+    stage_copy(P + wo.b1, wl + Img::b1, 2 * kTD, tid);
+    stage_copy(P + wo.b2, wl + Img::b2, kTD, tid);
+    // this workgroup's record block of layer l: field f of this lane at sv[f * 64]
     float* sv = save + (((int64_t)l * gridDim.x + blockIdx.x) * kSvTotal) * 64 + lane;
     const TfDrop d_attn = tf_drop(seed, l, 0, a.p_attn), d_mlp1 = tf_drop(seed, l, 1, a.p_mlp),
                  d_mlp2 = tf_drop(seed, l, 2, a.p_mlp);
     float mu, rstd;
     if (TRAIN) {
 #pragma unroll
-      for (int d = 0; d < kTD; ++d) sv[(kSvXin + d) * 64] = x[d];
+      for (int d = 0; d < FS; ++d) sv[(kSvXin + f0 + d) * 64] = x[d];
     }
-    wave_lds_sync();
+    __syncthreads();                                      // weights staged; the previous block's columns are dead
     TF_MARK(1);
-    layer_norm_to_cols<kTD>(x, wl + Img::ln1w, wl + Img::ln1b, my + RA * kCS, mu, rstd);
-    if (TRAIN) { sv[kSvLn1 * 64] = mu; sv[(kSvLn1 + 1) * 64] = rstd; }
-    wave_lds_sync();
+    layer_norm_to_cols<kTD, FS>(x, wl + Img::ln1w + f0, wl + Img::ln1b + f0, my + (RA + f0) * kCS, cols, RC, wave, lane, mu,
+                                rstd);
+    if (TRAIN && wave == 0) { sv[kSvLn1 * 64] = mu; sv[(kSvLn1 + 1) * 64] = rstd; }
+    __syncthreads();
     TF_MARK(2);
-    gemm_cols<kTD, 3 * kTD, Img::SI, true, true>(cols, RA, wl + Img::win, wl + Img::inb, RQ, lane);   // q | k | v
-    wave_lds_sync();
+    gemm_cols<kTD, 3 * kTD, Img::SI, true, true>(cols, RA, wl + Img::win, wl + Img::inb, RQ, lane, wave);   // q | k | v
+    __syncthreads();
     TF_MARK(3);
     if (TRAIN) {
-#pragma unroll 16
-      for (int o = 0; o < 3 * kTD; ++o) sv[(kSvQkv + o) * 64] = my[(RQ + o) * kCS];
+#pragma unroll
+      for (int o = 0; o < 3 * FS; ++o) sv[(kSvQkv + 3 * f0 + o) * 64] = my[(RQ + 3 * f0 + o) * kCS];
     }
-    // attention: this token's query against the keys / values of its trial (lanes gs .. gs + S - 1).  All kTMaxS
-    // positions are computed (positions past S read token 0 and are masked): no control flow inside a head.
+    // attention: this token's query against the keys / values of its trial (lanes gs .. gs + S - 1), every fourth head
+    // per wave.  All kTMaxS positions are computed (positions past S read token 0 and are masked): no control flow
+    // inside a head.
     TF_MARK(4);
-#pragma unroll 2
-    for (int hh = 0; hh < kH; ++hh) {
+#pragma unroll 1
+    for (int hh = wave; hh < kH; hh += kNW) {
       const int qc = RQ + hh * kDH, kc = qc + kTD, vc = kc + kTD;
       float qh[kDH];
 #pragma unroll
@@ -336,105 +345,113 @@ __global__ __launch_bounds__(64) void tail_fused_fwd_kernel(const float* __restr
 #pragma unroll
       for (int t = 0; t < kDH; ++t) my[(RC + hh * kDH + t) * kCS] = o[t];
     }
-    wave_lds_sync();
+    __syncthreads();
     if (TRAIN) {
-#pragma unroll 16
-      for (int d = 0; d < kTD; ++d) sv[(kSvCtx + d) * 64] = my[(RC + d) * kCS];
+#pragma unroll
+      for (int d = 0; d < FS; ++d) sv[(kSvCtx + f0 + d) * 64] = my[(RC + f0 + d) * kCS];
     }
     TF_MARK(5);
-    gemm_cols<kTD, kTD, Img::SO, true, true>(cols, RC, wl + Img::wo, wl + Img::ob, RA, lane);          // output projection
-    wave_lds_sync();
+    gemm_cols<kTD, kTD, Img::SO, true, true>(cols, RC, wl + Img::wo, wl + Img::ob, RA, lane, wave);         // output projection
+    __syncthreads();
     TF_MARK(6);
 #pragma unroll
-    for (int d = 0; d < kTD; ++d) x[d] += my[(RA + d) * kCS];
+    for (int d = 0; d < FS; ++d) x[d] += my[(RA + f0 + d) * kCS];
     if (TRAIN) {
 #pragma unroll
-      for (int d = 0; d < kTD; ++d) sv[(kSvXmid + d) * 64] = x[d];
+      for (int d = 0; d < FS; ++d) sv[(kSvXmid + f0 + d) * 64] = x[d];
     }
-    layer_norm_to_cols<kTD>(x, wl + Img::ln2w, wl + Img::ln2b, my + RC * kCS, mu, rstd);
-    if (TRAIN) { sv[kSvLn2 * 64] = mu; sv[(kSvLn2 + 1) * 64] = rstd; }
-    wave_lds_sync();
+    layer_norm_to_cols<kTD, FS>(x, wl + Img::ln2w + f0, wl + Img::ln2b + f0, my + (RC + f0) * kCS, cols, RQ, wave, lane, mu,
+                                rstd);
+    if (TRAIN && wave == 0) { sv[kSvLn2 * 64] = mu; sv[(kSvLn2 + 1) * 64] = rstd; }
+    __syncthreads();
     TF_MARK(7);
-    gemm_cols<kTD, kTHid, Img::S1, true, true>(cols, RC, wl + Img::w1, wl + Img::b1, RQ, lane);
-    wave_lds_sync();
+    gemm_cols<kTD, kTHid, Img::S1, true, true>(cols, RC, wl + Img::w1, wl + Img::b1, RQ, lane, wave);
+    __syncthreads();
     TF_MARK(8);
-#pragma unroll 1
-    for (int o0 = 0; o0 < kTHid; o0 += 16) {             // GELU + dropout in place, 16 elements in flight
-      float pre[16];
+    {                                                     // GELU + dropout in place on this thread's hidden quarter
+      float pre[HS];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) pre[k] = my[(RQ + o0 + k) * kCS];
+      for (int k = 0; k < HS; ++k) pre[k] = my[(RQ + h0 + k) * kCS];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
+      for (int k = 0; k < HS; ++k) {
         float v = tf_gelu(pre[k]);
         if (TRAIN) {
-          sv[(kSvHpre + o0 + k) * 64] = pre[k];
-          v *= tf_keep(d_mlp1, (unsigned long long)(tok * kTHid + o0 + k));
+          sv[(kSvHpre + h0 + k) * 64] = pre[k];
+          v *= tf_keep(d_mlp1, (unsigned long long)(tok * kTHid + h0 + k));
         }
-        my[(RQ + o0 + k) * kCS] = v;
+        my[(RQ + h0 + k) * kCS] = v;
       }
     }
-    wave_lds_sync();
+    __syncthreads();
     TF_MARK(9);
-    gemm_cols<kTHid, kTD, Img::S2, true, true>(cols, RQ, wl + Img::w2, wl + Img::b2, RA, lane);
-    wave_lds_sync();
+    gemm_cols<kTHid, kTD, Img::S2, true, true>(cols, RQ, wl + Img::w2, wl + Img::b2, RA, lane, wave);
+    __syncthreads();
     TF_MARK(10);
 #pragma unroll
-    for (int d = 0; d < kTD; ++d) {
-      const float kp = TRAIN ? tf_keep(d_mlp2, (unsigned long long)(tok * kTD + d)) : 1.f;
-      x[d] = fmaf(my[(RA + d) * kCS], kp, x[d]);
+    for (int d = 0; d < FS; ++d) {
+      const float kp = TRAIN ? tf_keep(d_mlp2, (unsigned long long)(tok * kTD + f0 + d)) : 1.f;
+      x[d] = fmaf(my[(RA + f0 + d) * kCS], kp, x[d]);
     }
-    wave_lds_sync();
     TF_MARK(11);
   }
-  if (live && i == 0) {
+  // ---- last_layer on the cls tokens: the four feature quarters meet in the RC columns
+  __syncthreads();
+  {
     const TfDrop d_cls = tf_drop(seed, kTMaxL, 0, a.p_cls);
 #pragma unroll
-    for (int d = 0; d < kTD; ++d) {
-      if (TRAIN) {
-        x[d] *= tf_keep(d_cls, (unsigned long long)(bc * kTD + d));
-        xfinal[bc * kTD + d] = x[d];
-      }
+    for (int d = 0; d < FS; ++d) {
+      if (TRAIN) x[d] *= tf_keep(d_cls, (unsigned long long)(bc * kTD + f0 + d));
+      my[(RC + f0 + d) * kCS] = x[d];
     }
-    for (int c = 0; c < a.n_cls; ++c) {
-      float acc = P[a.lastb + c];
+  }
+  __syncthreads();
+  if (live && i == 0) {
+    if (TRAIN) {
 #pragma unroll
-      for (int d = 0; d < kTD; ++d) acc = fmaf(P[a.lastw + c * kTD + d], x[d], acc);
+      for (int d = 0; d < FS; ++d) xfinal[bc * kTD + f0 + d] = x[d];
+    }
+    for (int c = wave; c < a.n_cls; c += kNW) {
+      float acc = P[a.lastb + c];
+#pragma unroll 8
+      for (int d = 0; d < kTD; ++d) acc = fmaf(P[a.lastw + c * kTD + d], my[(RC + d) * kCS], acc);
       logits[bc * a.n_cls + c] = acc;
     }
   }
 }
 
 // ----------------------------------------------------------------------------------------------------- backward
-// One launch for the whole tail, the lane <-> token mapping of the forward.  Data gradients  dX = G W  are the same
-// column products with the weights as stored ([out][in] = [K][N]); weight gradients are sums over tokens of outer
-// products: 16 MFMAs per 16 x 16 tile with the token index as K, and the bias / LayerNorm-parameter sums are that
-// product against a vector of ones.
+// One launch for the whole tail, the thread <-> (token, feature quarter) mapping of the forward.  Data gradients
+// dX = G W  are the same column products with the weights as stored ([out][in] = [K][N]); weight gradients are sums
+// over tokens of outer products: 16 MFMAs per 16 x 16 tile with the token index as K, every fourth tile per wave, and
+// the bias / LayerNorm-parameter sums are that product against a vector of ones.
 
 // dW[o][i] = sum_tok g[tok][o] in[tok][i] (o < no_valid rows written), db[o] = sum_tok g[tok][o]; NI == 0: sums only
 template <int NO, int NI>
 __device__ __forceinline__ void wgrad_tiles(const float* cols, int gcol, int icol, float* __restrict__ dw,
-                                            float* __restrict__ db, int lane, int no_valid) {
+                                            float* __restrict__ db, int lane, int wave, int no_valid) {
   const int m = lane & 15, kq = lane >> 4;
+  constexpr int n_ib = NI / 16, n_ob = NO / 16;
+  if (NI > 0) {
 #pragma unroll 1
-  for (int ob = 0; ob < NO; ob += 16) {
-    float av[16];
+    for (int t = wave; t < n_ob * n_ib; t += kNW) {
+      const int ob = (t / (n_ib > 0 ? n_ib : 1)) * 16, ib = (t % (n_ib > 0 ? n_ib : 1)) * 16;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 16; ++t) av[t] = cols[(gcol + ob + m) * kCS + 4 * t + kq];
-    if (NI > 0) {
-#pragma unroll 1
-      for (int ib = 0; ib < NI; ib += 16) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < 16; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cols[(gcol + ob + m) * kCS + 4 * s + kq],
+                                                   cols[(icol + ib + m) * kCS + 4 * s + kq], acc, 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], cols[(icol + ib + m) * kCS + 4 * t + kq], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (ob + 4 * kq + r < no_valid) dw[(ob + 4 * kq + r) * NI + ib + m] = acc[r];
-      }
+      for (int r = 0; r < 4; ++r)
+        if (ob + 4 * kq + r < no_valid) dw[(ob + 4 * kq + r) * NI + ib + m] = acc[r];
     }
+  }
+#pragma unroll 1
+  for (int t = (wave + n_ob * n_ib) % kNW; t < n_ob; t += kNW) {       // the sums start where the tiles left off
+    const int ob = t * 16;
     f32x4 accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 16; ++t) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], 1.f, accb, 0, 0, 0);
+    for (int s = 0; s < 16; ++s)
+      accb = __builtin_amdgcn_mfma_f32_16x16x4f32(cols[(gcol + ob + m) * kCS + 4 * s + kq], 1.f, accb, 0, 0, 0);
     if (m == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -443,44 +460,44 @@ __device__ __forceinline__ void wgrad_tiles(const float* cols, int gcol, int ico
   }
 }
 
-// LayerNorm backward for one token: xs = the saved input (record rows, 64 apart), dh read from the lane's columns at
-// dhcol.  Adds the input gradient to dx and leaves [dh * xhat | dh] in the 2 D columns at pcol (their sums over tokens
-// are dweight | dbias); pcol may not overlap dhcol.
-template <int D>
+// LayerNorm backward for one token, this thread holding FS of its D features: xs = the saved input (record rows, 64
+// apart, this thread's slice), w = its slice of the LDS weight, dh read from its slots of columns dhcol.  Adds the
+// input gradient to dx and leaves [dh * xhat | dh] in its slots of the 2 D columns at pcol (their sums over tokens
+// are dweight | dbias).  scratch = 8 free columns; two barriers inside.
+template <int D, int FS>
 __device__ __forceinline__ void layer_norm_backward(const float* __restrict__ xs, float mu, float rstd, const float* w,
-                                                    const float* dhcol, float (&dx)[D], float* pcol) {
-  float dxh[D];
+                                                    const float* dhcol, float (&dx)[FS], float* pcol, float* cols,
+                                                    int scratch, int wave, int lane) {
+  float dxh[FS], xh[FS];
   float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const float xh = (xs[d * 64] - mu) * rstd, dh = dhcol[d * kCS];
+  for (int d = 0; d < FS; ++d) {
+    const float dh = dhcol[d * kCS];
+    xh[d] = (xs[d * 64] - mu) * rstd;
     dxh[d] = dh * w[d];
     c1 += dxh[d];
-    c2 = fmaf(dxh[d], xh, c2);
-    pcol[d * kCS] = dh * xh;
+    c2 = fmaf(dxh[d], xh[d], c2);
+    pcol[d * kCS] = dh * xh[d];
     pcol[(D + d) * kCS] = dh;
   }
-  c1 *= 1.f / D;
-  c2 *= 1.f / D;
+  c1 = wg_sum4(cols, scratch, wave, lane, c1) * (1.f / D);
+  c2 = wg_sum4(cols, scratch + 4, wave, lane, c2) * (1.f / D);
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const float xh = (xs[d * 64] - mu) * rstd;
-    dx[d] += rstd * (dxh[d] - c1 - xh * c2);
-  }
+  for (int d = 0; d < FS; ++d) dx[d] += rstd * (dxh[d] - c1 - xh[d] * c2);
 }
 
 // dlogits [B][n_cls] (already scaled by the caller's loss weight); dtokin [B][N][D]; slab [gridDim.x][ptot]
 template <int kTD, int kDH>
-__global__ __launch_bounds__(64) void tail_fused_bwd_kernel(const float* __restrict__ P, TailMeta a,
-                                                            const float* __restrict__ save,
-                                                            const float* __restrict__ xfinal,
-                                                            const float* __restrict__ dlogits,
-                                                            float* __restrict__ dtokin, float* __restrict__ slab,
-                                                            int ptot) {
-  constexpr int kTHid = 2 * kTD;
-  // column regions: q | k | v (the MLP's hidden vector and the LayerNorm sums reuse it), two D-wide operand regions;
-  // the attention's probability rows sit in the first 16 columns of RA
-  constexpr int RQ = 0, RA = 3 * kTD, RC = 4 * kTD, RB = RA, RH = RQ, kColTotal = 5 * kTD;
+__global__ __launch_bounds__(kNW * 64) void tail_fused_bwd_kernel(const float* __restrict__ P, TailMeta a,
+                                                                  const float* __restrict__ save,
+                                                                  const float* __restrict__ xfinal,
+                                                                  const float* __restrict__ dlogits,
+                                                                  float* __restrict__ dtokin, float* __restrict__ slab,
+                                                                  int ptot) {
+  constexpr int kTHid = 2 * kTD, FS = kTD / kNW, HS = kTHid / kNW;
+  // column regions: q | k | v (the MLP's hidden vector and the LayerNorm sums reuse it), two D-wide operand regions,
+  // and 16 columns per wave for the attention's probability rows
+  constexpr int RQ = 0, RA = 3 * kTD, RC = 4 * kTD, RB = 5 * kTD, RH = RQ, kColTotal = 5 * kTD + 16 * kNW;
   constexpr int kLayerFloats = 8 * kTD * kTD + 11 * kTD;   // one block's parameters, copied to LDS as they are
   constexpr int kSvXin = Sv<kTD>::xin, kSvLn1 = Sv<kTD>::ln1, kSvQkv = Sv<kTD>::qkv, kSvProb = Sv<kTD>::prob,
                 kSvCtx = Sv<kTD>::ctx, kSvXmid = Sv<kTD>::xmid, kSvLn2 = Sv<kTD>::ln2, kSvHpre = Sv<kTD>::hpre,
@@ -488,7 +505,7 @@ __global__ __launch_bounds__(64) void tail_fused_bwd_kernel(const float* __restr
   static_assert(kTD >= 16, "column regions");
   __shared__ __attribute__((aligned(16))) float wl[kLayerFloats];
   __shared__ __attribute__((aligned(16))) float cols[kColTotal * kCS];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int S = a.S, G = 64 / S;
   const int g = lane / S, i = lane - g * S;
   const int64_t b = (int64_t)blockIdx.x * G + g;
@@ -502,30 +519,33 @@ __global__ __launch_bounds__(64) void tail_fused_bwd_kernel(const float* __restr
   float* my = cols + lane;
   float* slabw = slab + (int64_t)blockIdx.x * ptot;
   const unsigned long long seed = tf_seed(a);
+  const int f0 = FS * wave, h0 = HS * wave;
 
-  stage_dma(P + a.layer[a.L - 1].ln1w, wl, kLayerFloats, lane);          // the last block's weights: in flight
+  stage_dma(P + a.layer[a.L - 1].ln1w, wl, kLayerFloats, tid);           // the last block's weights: in flight
   // ---- last_layer: logits = W x0 + b on the cls token after dropout
-  float dx[kTD];
+  float dx[FS];
   {
     const bool cl = live && i == 0;
+    if (wave == 0) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) my[(RA + c) * kCS] = (cl && c < a.n_cls) ? dlogits[bc * a.n_cls + c] : 0.f;
+      for (int c = 0; c < 16; ++c) my[(RA + c) * kCS] = (cl && c < a.n_cls) ? dlogits[bc * a.n_cls + c] : 0.f;
+    }
 #pragma unroll
-    for (int d = 0; d < kTD; ++d) my[(RC + d) * kCS] = cl ? xfinal[bc * kTD + d] : 0.f;
-    wave_lds_sync();
-    wgrad_tiles<16, kTD>(cols, RA, RC, slabw + a.lastw, slabw + a.lastb, lane, a.n_cls);
+    for (int d = 0; d < FS; ++d) my[(RC + f0 + d) * kCS] = cl ? xfinal[bc * kTD + f0 + d] : 0.f;
+    __syncthreads();
+    wgrad_tiles<16, kTD>(cols, RA, RC, slabw + a.lastw, slabw + a.lastb, lane, wave, a.n_cls);
 #pragma unroll
-    for (int d = 0; d < kTD; ++d) dx[d] = 0.f;
+    for (int d = 0; d < FS; ++d) dx[d] = 0.f;
     for (int c = 0; c < a.n_cls; ++c) {
       const float gl = my[(RA + c) * kCS];
-      const float* w = P + a.lastw + c * kTD;
+      const float* w = P + a.lastw + c * kTD + f0;
 #pragma unroll
-      for (int d = 0; d < kTD; ++d) dx[d] = fmaf(w[d], gl, dx[d]);
+      for (int d = 0; d < FS; ++d) dx[d] = fmaf(w[d], gl, dx[d]);
     }
     const TfDrop d_cls = tf_drop(seed, kTMaxL, 0, a.p_cls);
 #pragma unroll
-    for (int d = 0; d < kTD; ++d) dx[d] *= tf_keep(d_cls, (unsigned long long)(bc * kTD + d));
-    wave_lds_sync();
+    for (int d = 0; d < FS; ++d) dx[d] *= tf_keep(d_cls, (unsigned long long)(bc * kTD + f0 + d));
+    __syncthreads();
   }
 
   for (int l = a.L - 1; l >= 0; --l) {
@@ -536,143 +556,139 @@ __global__ __launch_bounds__(64) void tail_fused_bwd_kernel(const float* __restr
                  d_mlp2 = tf_drop(seed, l, 2, a.p_mlp);
     // ---- x_out = xmid + drop2(W2 m + b2),  m = drop1(gelu(hpre))
 #pragma unroll
-    for (int d = 0; d < kTD; ++d)
-      my[(RA + d) * kCS] = lv * dx[d] * tf_keep(d_mlp2, (unsigned long long)(tok * kTD + d));
-#pragma unroll 1
-    for (int o0 = 0; o0 < kTHid; o0 += 16) {
-      float pre[16];
+    for (int d = 0; d < FS; ++d)
+      my[(RA + f0 + d) * kCS] = lv * dx[d] * tf_keep(d_mlp2, (unsigned long long)(tok * kTD + f0 + d));
+    float pre[HS];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) pre[k] = sv[(kSvHpre + o0 + k) * 64];
+    for (int k = 0; k < HS; ++k) pre[k] = sv[(kSvHpre + h0 + k) * 64];
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
-        my[(RH + o0 + k) * kCS] = tf_gelu(pre[k]) * tf_keep(d_mlp1, (unsigned long long)(tok * kTHid + o0 + k));
-    }
-    wave_lds_sync();
-    wgrad_tiles<kTD, kTHid>(cols, RA, RH, slabw + wo.w2, slabw + wo.b2, lane, kTD);
-    stage_dma_wait();                                     // this block's weights have landed
-    gemm_cols<kTD, kTHid, kTHid, false, true>(cols, RA, wl + (wo.w2 - l0), nullptr, RH, lane);          // dm = dy2 W2
-    wave_lds_sync();
-#pragma unroll 1
-    for (int o0 = 0; o0 < kTHid; o0 += 16) {              // hpre = W1 h2 + b1: gradient through dropout and GELU
-      float pre[16], dm[16];
+    for (int k = 0; k < HS; ++k)
+      my[(RH + h0 + k) * kCS] = tf_gelu(pre[k]) * tf_keep(d_mlp1, (unsigned long long)(tok * kTHid + h0 + k));
+    __syncthreads();
+    wgrad_tiles<kTD, kTHid>(cols, RA, RH, slabw + wo.w2, slabw + wo.b2, lane, wave, kTD);
+    stage_dma_wait();                                     // this thread's pieces of the block's weights have landed
+    __syncthreads();                                      // ... everyone's; and m is no longer read
+    gemm_cols<kTD, kTHid, kTHid, false, true>(cols, RA, wl + (wo.w2 - l0), nullptr, RH, lane, wave);    // dm = dy2 W2
+    __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        pre[k] = sv[(kSvHpre + o0 + k) * 64];
-        dm[k] = my[(RH + o0 + k) * kCS];
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k)
-        my[(RH + o0 + k) * kCS] = dm[k] * tf_gelu_grad(pre[k]) * tf_keep(d_mlp1, (unsigned long long)(tok * kTHid + o0 + k));
-    }
+    for (int k = 0; k < HS; ++k)                          // hpre = W1 h2 + b1: gradient through dropout and GELU
+      my[(RH + h0 + k) * kCS] *= tf_gelu_grad(pre[k]) * tf_keep(d_mlp1, (unsigned long long)(tok * kTHid + h0 + k));
     {
       const float mu = sv[kSvLn2 * 64], rstd = sv[(kSvLn2 + 1) * 64];
-      const float* lw = wl + (wo.ln2w - l0);
-      const float* lb = wl + (wo.ln2b - l0);
+      const float* lw = wl + (wo.ln2w - l0) + f0;
+      const float* lb = wl + (wo.ln2b - l0) + f0;
 #pragma unroll
-      for (int d = 0; d < kTD; ++d) my[(RC + d) * kCS] = (sv[(kSvXmid + d) * 64] - mu) * rstd * lw[d] + lb[d];
-      wave_lds_sync();
-      wgrad_tiles<kTHid, kTD>(cols, RH, RC, slabw + wo.w1, slabw + wo.b1, lane, kTHid);
-      gemm_cols<kTHid, kTD, kTD, false, true>(cols, RH, wl + (wo.w1 - l0), nullptr, RA, lane);         // dh2 = dhpre W1
-      wave_lds_sync();
-      layer_norm_backward<kTD>(sv + kSvXmid * 64, mu, rstd, lw, my + RA * kCS, dx, my + RQ * kCS);
-      wave_lds_sync();
-      wgrad_tiles<2 * kTD, 0>(cols, RQ, 0, nullptr, slabw + wo.ln2w, lane, 2 * kTD);
+      for (int d = 0; d < FS; ++d) my[(RC + f0 + d) * kCS] = (sv[(kSvXmid + f0 + d) * 64] - mu) * rstd * lw[d] + lb[d];
+      __syncthreads();
+      wgrad_tiles<kTHid, kTD>(cols, RH, RC, slabw + wo.w1, slabw + wo.b1, lane, wave, kTHid);
+      gemm_cols<kTHid, kTD, kTD, false, true>(cols, RH, wl + (wo.w1 - l0), nullptr, RA, lane, wave);    // dh2 = dhpre W1
+      __syncthreads();
+      layer_norm_backward<kTD, FS>(sv + (kSvXmid + f0) * 64, mu, rstd, lw, my + (RA + f0) * kCS, dx, my + (RQ + f0) * kCS,
+                                   cols, RC, wave, lane);
+      __syncthreads();
+      wgrad_tiles<2 * kTD, 0>(cols, RQ, 0, nullptr, slabw + wo.ln2w, lane, wave, 2 * kTD);
     }
     // ---- xmid = xin + Wo ctx + bo
 #pragma unroll
-    for (int d = 0; d < kTD; ++d) {
-      my[(RA + d) * kCS] = dx[d];
-      my[(RC + d) * kCS] = sv[(kSvCtx + d) * 64];
+    for (int d = 0; d < FS; ++d) {
+      my[(RA + f0 + d) * kCS] = dx[d];
+      my[(RC + f0 + d) * kCS] = sv[(kSvCtx + f0 + d) * 64];
     }
-    wave_lds_sync();
-    wgrad_tiles<kTD, kTD>(cols, RA, RC, slabw + wo.ow, slabw + wo.ob, lane, kTD);
-    gemm_cols<kTD, kTD, kTD, false, true>(cols, RA, wl + (wo.ow - l0), nullptr, RC, lane);              // dctx = dxmid Wo
-#pragma unroll 16
-    for (int o = 0; o < 3 * kTD; ++o) my[(RQ + o) * kCS] = sv[(kSvQkv + o) * 64];
-    wave_lds_sync();
-    // ---- attention: ctx_i = sum_j drop(p_ij) v_j,  p = softmax(scale q k^T); positions past S are computed on token 0
-    // and masked (the saved probabilities there are 0), so a head carries no control flow
+    __syncthreads();
+    wgrad_tiles<kTD, kTD>(cols, RA, RC, slabw + wo.ow, slabw + wo.ob, lane, wave, kTD);
+    __syncthreads();                                      // ctx is dead, the LayerNorm sums are taken
+    gemm_cols<kTD, kTD, kTD, false, true>(cols, RA, wl + (wo.ow - l0), nullptr, RC, lane, wave);        // dctx = dxmid Wo
+#pragma unroll
+    for (int o = 0; o < 3 * FS; ++o) my[(RQ + 3 * f0 + o) * kCS] = sv[(kSvQkv + 3 * f0 + o) * 64];
+    __syncthreads();
+    // ---- attention: ctx_i = sum_j drop(p_ij) v_j,  p = softmax(scale q k^T); every fourth head per wave, positions
+    // past S computed on token 0 and masked (the saved probabilities there are 0): a head carries no control flow.
+    // The hand-overs inside a head are between lanes of this wave only (its own 16 columns at rb).
+    {
+      const int rb = RB + 16 * wave;
 #pragma unroll 1
-    for (int hh = 0; hh < kH; ++hh) {
-      const int qc = RQ + hh * kDH, kc = qc + kTD, vc = kc + kTD, cc = RC + hh * kDH;
-      float dc[kDH], pr[kTMaxS], dp[kTMaxS];
+      for (int hh = wave; hh < kH; hh += kNW) {
+        const int qc = RQ + hh * kDH, kc = qc + kTD, vc = kc + kTD, cc = RC + hh * kDH;
+        float dc[kDH], pr[kTMaxS], dp[kTMaxS];
 #pragma unroll
-      for (int t = 0; t < kDH; ++t) dc[t] = my[(cc + t) * kCS];
-      float dot = 0.f;
+        for (int t = 0; t < kDH; ++t) dc[t] = my[(cc + t) * kCS];
+        float dot = 0.f;
 #pragma unroll
-      for (int j = 0; j < kTMaxS; ++j) {
-        const int jj = gs + (j < S ? j : 0);
-        pr[j] = sv[(kSvProb + hh * kTMaxS + j) * 64];
-        const float kp = tf_keep(d_attn, (unsigned long long)((tok * kH + hh) * kTMaxS + j));
-        float dpd = 0.f;
+        for (int j = 0; j < kTMaxS; ++j) {
+          const int jj = gs + (j < S ? j : 0);
+          pr[j] = sv[(kSvProb + hh * kTMaxS + j) * 64];
+          const float kp = tf_keep(d_attn, (unsigned long long)((tok * kH + hh) * kTMaxS + j));
+          float dpd = 0.f;
 #pragma unroll
-        for (int t = 0; t < kDH; ++t) dpd = fmaf(dc[t], cols[(vc + t) * kCS + jj], dpd);
-        dp[j] = dpd * kp;
-        dot = fmaf(dp[j], pr[j], dot);
-        my[(RB + j) * kCS] = pr[j] * kp;
-      }
-      float dq[kDH];
-#pragma unroll
-      for (int t = 0; t < kDH; ++t) dq[t] = 0.f;
-#pragma unroll
-      for (int j = 0; j < kTMaxS; ++j) {
-        const int jj = gs + (j < S ? j : 0);
-        const float ds = pr[j] * (dp[j] - dot);
-        my[(RB + 8 + j) * kCS] = ds;
-#pragma unroll
-        for (int t = 0; t < kDH; ++t) dq[t] = fmaf(ds, cols[(kc + t) * kCS + jj], dq[t]);
-      }
-      wave_lds_sync();
-      float dk[kDH], dv[kDH];
-#pragma unroll
-      for (int t = 0; t < kDH; ++t) dk[t] = dv[t] = 0.f;
-#pragma unroll
-      for (int ii = 0; ii < kTMaxS; ++ii) {               // row ii of the trial's probability matrix, this token's column
-        const int li = gs + (ii < S ? ii : 0);
-        const float ok = ii < S ? 1.f : 0.f;
-        const float pdv = ok * cols[(RB + i) * kCS + li], dsv = ok * cols[(RB + 8 + i) * kCS + li];
-#pragma unroll
-        for (int t = 0; t < kDH; ++t) {
-          dv[t] = fmaf(pdv, cols[(cc + t) * kCS + li], dv[t]);
-          dk[t] = fmaf(dsv, cols[(qc + t) * kCS + li], dk[t]);
+          for (int t = 0; t < kDH; ++t) dpd = fmaf(dc[t], cols[(vc + t) * kCS + jj], dpd);
+          dp[j] = dpd * kp;
+          dot = fmaf(dp[j], pr[j], dot);
+          my[(rb + j) * kCS] = pr[j] * kp;
         }
-      }
-      wave_lds_sync();
+        float dq[kDH];
 #pragma unroll
-      for (int t = 0; t < kDH; ++t) {                     // the head's q / k / v slices become dq / dk / dv
-        my[(qc + t) * kCS] = lv * scale * dq[t];
-        my[(kc + t) * kCS] = lv * scale * dk[t];
-        my[(vc + t) * kCS] = lv * dv[t];
+        for (int t = 0; t < kDH; ++t) dq[t] = 0.f;
+#pragma unroll
+        for (int j = 0; j < kTMaxS; ++j) {
+          const int jj = gs + (j < S ? j : 0);
+          const float ds = pr[j] * (dp[j] - dot);
+          my[(rb + 8 + j) * kCS] = ds;
+#pragma unroll
+          for (int t = 0; t < kDH; ++t) dq[t] = fmaf(ds, cols[(kc + t) * kCS + jj], dq[t]);
+        }
+        wave_lds_sync();
+        float dk[kDH], dv[kDH];
+#pragma unroll
+        for (int t = 0; t < kDH; ++t) dk[t] = dv[t] = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < kTMaxS; ++ii) {             // row ii of the trial's probability matrix, this token's column
+          const int li = gs + (ii < S ? ii : 0);
+          const float ok = ii < S ? 1.f : 0.f;
+          const float pdv = ok * cols[(rb + i) * kCS + li], dsv = ok * cols[(rb + 8 + i) * kCS + li];
+#pragma unroll
+          for (int t = 0; t < kDH; ++t) {
+            dv[t] = fmaf(pdv, cols[(cc + t) * kCS + li], dv[t]);
+            dk[t] = fmaf(dsv, cols[(qc + t) * kCS + li], dk[t]);
+          }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < kDH; ++t) {                   // the head's q / k / v slices become dq / dk / dv
+          my[(qc + t) * kCS] = lv * scale * dq[t];
+          my[(kc + t) * kCS] = lv * scale * dk[t];
+          my[(vc + t) * kCS] = lv * dv[t];
+        }
+        wave_lds_sync();
       }
-      wave_lds_sync();
     }
     // ---- qkv = Win h1 + bin,  h1 = LN1(xin)
     {
       const float mu = sv[kSvLn1 * 64], rstd = sv[(kSvLn1 + 1) * 64];
-      const float* lw = wl + (wo.ln1w - l0);
-      const float* lb = wl + (wo.ln1b - l0);
+      const float* lw = wl + (wo.ln1w - l0) + f0;
+      const float* lb = wl + (wo.ln1b - l0) + f0;
 #pragma unroll
-      for (int d = 0; d < kTD; ++d) my[(RA + d) * kCS] = (sv[(kSvXin + d) * 64] - mu) * rstd * lw[d] + lb[d];
-      wave_lds_sync();
-      wgrad_tiles<3 * kTD, kTD>(cols, RQ, RA, slabw + wo.inw, slabw + wo.inb, lane, 3 * kTD);
-      gemm_cols<3 * kTD, kTD, kTD, false, false>(cols, RQ, wl + (wo.inw - l0), nullptr, RC, lane);     // dh1 = dqkv Win
-      wave_lds_sync();
-      layer_norm_backward<kTD>(sv + kSvXin * 64, mu, rstd, lw, my + RC * kCS, dx, my + RQ * kCS);
-      wave_lds_sync();
-      if (l > 0) stage_dma(P + a.layer[l - 1].ln1w, wl, kLayerFloats, lane);   // next block's weights under the sums
-      wgrad_tiles<2 * kTD, 0>(cols, RQ, 0, nullptr, slabw + wo.ln1w, lane, 2 * kTD);
+      for (int d = 0; d < FS; ++d) my[(RA + f0 + d) * kCS] = (sv[(kSvXin + f0 + d) * 64] - mu) * rstd * lw[d] + lb[d];
+      __syncthreads();                                    // dqkv and h1 complete
+      wgrad_tiles<3 * kTD, kTD>(cols, RQ, RA, slabw + wo.inw, slabw + wo.inb, lane, wave, 3 * kTD);
+      gemm_cols<3 * kTD, kTD, kTD, false, false>(cols, RQ, wl + (wo.inw - l0), nullptr, RC, lane, wave);   // dh1 = dqkv Win
+      __syncthreads();
+      layer_norm_backward<kTD, FS>(sv + (kSvXin + f0) * 64, mu, rstd, lw, my + (RC + f0) * kCS, dx, my + (RQ + f0) * kCS,
+                                   cols, RA, wave, lane);
+      __syncthreads();
+      if (l > 0) stage_dma(P + a.layer[l - 1].ln1w, wl, kLayerFloats, tid);   // next block's weights under the sums
+      wgrad_tiles<2 * kTD, 0>(cols, RQ, 0, nullptr, slabw + wo.ln1w, lane, wave, 2 * kTD);
     }
-    wave_lds_sync();
+    __syncthreads();
   }
   // ---- tokens = cat(cls, tokin) + pos
   if (live && i > 0) {
 #pragma unroll
-    for (int d = 0; d < kTD; ++d) dtokin[(bc * a.N + (i - 1)) * kTD + d] = dx[d];
+    for (int d = 0; d < FS; ++d) dtokin[(bc * a.N + (i - 1)) * kTD + f0 + d] = dx[d];
   }
 #pragma unroll
-  for (int d = 0; d < kTD; ++d) my[(RA + d) * kCS] = dx[d];
-  wave_lds_sync();
-  for (int idx = lane; idx < a.n_pos * kTD; idx += 64) {
+  for (int d = 0; d < FS; ++d) my[(RA + f0 + d) * kCS] = dx[d];
+  __syncthreads();
+  for (int idx = tid; idx < a.n_pos * kTD; idx += kNW * 64) {
     const int ii = idx / kTD, d = idx - ii * kTD;
     float sum = 0.f;
     if (ii < S)
@@ -778,7 +794,7 @@ extern "C" int isd_tail_fused_forward(const float* params, const float* tokin, f
   const int key = D * 100 + (D / H) * 10 + (save ? 1 : 0);
 #define ISD_TF_FWD(DD, DH, TR)                                                                                  \
   case DD * 100 + DH * 10 + TR:                                                                                  \
-    hipLaunchKernelGGL((tail_fused_fwd_kernel<DD, DH, TR != 0>), grid, dim3(64), 0, (hipStream_t)stream, params, \
+    hipLaunchKernelGGL((tail_fused_fwd_kernel<DD, DH, TR != 0>), grid, dim3(256), 0, (hipStream_t)stream, params, \
                        a, tokin, logits, save, xfinal);                                                          \
     break;
   switch (key) {
@@ -817,7 +833,7 @@ extern "C" int isd_tail_fused_backward(const float* params, const float* save, c
   const int nw = (int)cdiv(B, (int64_t)(64 / a.S));
 #define ISD_TF_BWD(DD, DH)                                                                                        \
   case DD * 10 + DH:                                                                                              \
-    hipLaunchKernelGGL((tail_fused_bwd_kernel<DD, DH>), dim3(nw), dim3(64), 0, (hipStream_t)stream, params, a, save, \
+    hipLaunchKernelGGL((tail_fused_bwd_kernel<DD, DH>), dim3(nw), dim3(256), 0, (hipStream_t)stream, params, a, save, \
                        xfinal, dlogits, dtokin, workspace, ptot);                                                 \
     break;
   switch (D * 10 + D / H) { ISD_TF_BWD(32, 4) ISD_TF_BWD(32, 8) ISD_TF_BWD(16, 4) ISD_TF_BWD(16, 8) }
