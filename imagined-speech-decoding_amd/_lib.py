@@ -87,6 +87,7 @@ SIGNATURES = {
     "isd_paperhead_workspace_bytes": (_i64, [_p, _i64]),
     "isd_paperhead_forward": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _p]),
     "isd_paperhead_backward": (_i, [_p, _p, _p, _p, _p, _p, _i64, _p]),
+    "isd_paperhead_backward_x": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "isd_cvblock_plan_create": (_i, [C.POINTER(_p), _i, _i, _i]),
     "isd_cvblock_flat_dim": (_i64, [_p]),
     "isd_eegnet_plan_destroy": (_i, [_p]),
@@ -95,6 +96,7 @@ SIGNATURES = {
     "isd_eegnet_workspace_bytes": (_i64, [_p, _i64]),
     "isd_eegnet_forward": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _f, C.c_uint64, _p]),
     "isd_eegnet_backward": (_i, [_p, _p, _p, _p, _p, _p, _i64, _f, C.c_uint64, _p]),
+    "isd_eegnet_backward_x": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, C.c_uint64, _p]),
     "isd_eegnet_forward_stage": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _f, C.c_uint64, _i, _p]),
     "isd_eegnet_backward_stage": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _f, C.c_uint64, _i, _p]),
     "isd_eegnet_sync_block": (_i, [_p, _i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),

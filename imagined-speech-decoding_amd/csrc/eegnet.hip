@@ -693,21 +693,22 @@ __global__ __launch_bounds__(256) void eeg_bwd3_sums_kernel(const float* __restr
 // all-reduce that follows adds the ranks' copies
 __global__ void eeg_bwd_bn_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
                                        const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N,
-                                       int which, double gs) {
+                                       int which, double gs, int bn_train) {
   const int h = threadIdx.x;
   if (h >= kF2) return;
+  const double inv = bn_train ? 1.0 / N : 0.0;           // running statistics do not depend on the batch: no mean terms
   if (which == 3) {
     dparams[off.g3 + h] = (float)(st->dy3x[h] * gs);
     dparams[off.b3 + h] = (float)(st->dy3s[h] * gs);
     co->cA3[h] = params[off.g3 + h] / co->sig3[h];
-    co->cB3[h] = (float)(st->dy3s[h] / N);
-    co->cC3[h] = (float)(st->dy3x[h] / N);
+    co->cB3[h] = (float)(st->dy3s[h] * inv);
+    co->cC3[h] = (float)(st->dy3x[h] * inv);
   } else {
     dparams[off.g2 + h] = (float)(st->dy2x[h] * gs);
     dparams[off.b2 + h] = (float)(st->dy2s[h] * gs);
     co->cA2[h] = params[off.g2 + h] / co->sig2[h];
-    co->cB2[h] = (float)(st->dy2s[h] / N);
-    co->cC2[h] = (float)(st->dy2x[h] / N);
+    co->cB2[h] = (float)(st->dy2s[h] * inv);
+    co->cC2[h] = (float)(st->dy2x[h] * inv);
   }
 }
 
@@ -989,7 +990,7 @@ __global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restr
                                                             float* __restrict__ dparams,
                                                             const EegStats* __restrict__ st,
                                                             const EegCoef* __restrict__ co, EegOff off, int C, int K,
-                                                            double N1, int separable, double gs) {
+                                                            double N1, int separable, double gs, int bn_train) {
   const float* Wt = params + off.Wt;
   if (separable) {
     for (int e = threadIdx.x; e < kF2 * kF2; e += 256) dparams[off.Wp + e] = (float)st->dWp[e / kF2][e % kF2];
@@ -1011,14 +1012,84 @@ __global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restr
     const int f = e / K, k = e - f * K;
     const double sig = co->sig1[f], mu = co->mu1[f];
     const double t1 = st->T1[2 * f][k] + st->T1[2 * f + 1][k];
-    const double meanD = SD[f] / N1;
-    const double meanDa = (SU[f] - mu * SD[f]) / (sig * N1);
+    const double meanD = bn_train ? SD[f] / N1 : 0.0;
+    const double meanDa = bn_train ? (SU[f] - mu * SD[f]) / (sig * N1) : 0.0;
     double wg = 0.0;
     for (int k2 = 0; k2 < K; ++k2) wg += (double)Wt[f * K + k2] * co->G[k2][k];
     const double val = ((double)params[off.g1 + f] / sig) *
                        (t1 - meanD * N1 * co->m[k] - (meanDa / sig) * (N1 * wg - mu * N1 * co->m[k]));
     dparams[off.Wt + e] = (float)(val * gs);
   }
+}
+
+// Gradient w.r.t. the input trials (what the attribution scripts differentiate).  With a1[f,c,t'] = (Wt_f * xpad_c)[t'],
+// BN1 and the depthwise spatial layer:
+//   dx[b,c,t] = sum_g s1[f] Ws[g,c] v[b,g,t]                                        (v: eeg_bwd_corr_kernel)
+//             - sum_f sum_k Wt[f,k] ( c3_f a1[b,f,c,t-k+P] + c2_f )  over 0 <= t-k+P < Tp,      batch statistics only:
+//   c3_f = g1_f meanDa_f / sig1_f^2,  c2_f = (g1_f / sig1_f) meanD_f - c3_f mu1_f   (BatchNorm's mean / variance paths;
+//   meanD, meanDa as in eeg_bwd_final_kernel).  One workgroup per (row, 256-sample segment): the row segment with a
+//   64-sample halo in LDS, per filter the a1 values the segment's outputs touch, then the transposed filter.
+__global__ __launch_bounds__(256) void eeg_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                                                         const float* __restrict__ params, float* __restrict__ dx,
+                                                         const EegStats* __restrict__ st, const EegCoef* __restrict__ co,
+                                                         EegOff off, int C, int K, int T, int Tp, double N1,
+                                                         int bn_train) {
+  __shared__ float xs[256 + 2 * kMaxK];                  // x[s0 - K + j]
+  __shared__ float tmp[256 + kMaxK];                     // c3 a1[t'] + c2 for t' = s0 - (K - 1 - P) + u, 0 outside [0, Tp)
+  __shared__ float wt[kMaxK];
+  __shared__ float c2s[kF1], c3s[kF1];
+  const int64_t row = blockIdx.x;                        // b * C + c
+  const int64_t b = row / C;
+  const int c = (int)(row - b * C);
+  const int s0 = blockIdx.y * 256, tid = threadIdx.x, P = K / 2;
+  const int t = s0 + tid;
+  const float* Ws = params + off.Ws;
+  float acc = 0.f;
+  if (t < T) {
+    const float* vr = v + b * kF2 * (int64_t)T + t;
+#pragma unroll
+    for (int g = 0; g < kF2; ++g) acc = fmaf(co->s1[g >> 1] * Ws[g * C + c], vr[(int64_t)g * T], acc);
+  }
+  if (bn_train) {
+    if (tid < kF1) {
+      const int f = tid;
+      const double sd = (double)co->wsum[2 * f] * st->Sd[2 * f] + (double)co->wsum[2 * f + 1] * st->Sd[2 * f + 1];
+      const double su = st->Su[2 * f] + st->Su[2 * f + 1];
+      const double sig = co->sig1[f], mu = co->mu1[f], g1 = params[off.g1 + f];
+      const double meanD = sd / N1, meanDa = (su - mu * sd) / (sig * N1);
+      const double c3 = g1 * meanDa / (sig * sig);
+      c3s[f] = (float)c3;
+      c2s[f] = (float)(g1 / sig * meanD - c3 * mu);
+    }
+    const float* xr = x + row * (int64_t)T;
+    for (int j = tid; j < 256 + 2 * K; j += 256) {
+      const int tt = s0 - K + j;
+      xs[j] = (tt >= 0 && tt < T) ? xr[tt] : 0.f;
+    }
+    const int u_lo = s0 - (K - 1 - P);                    // t' of tmp[0]
+    for (int f = 0; f < kF1; ++f) {
+      __syncthreads();                                   // xs / coefficients ready; previous filter's tmp consumed
+      if (tid < K) wt[tid] = params[off.Wt + f * K + tid];
+      __syncthreads();
+      for (int u = tid; u < 256 + K; u += 256) {
+        const int tp = u_lo + u;
+        float a = 0.f;
+        if (tp >= 0 && tp < Tp) {
+          // a1[t'] = sum_k Wt[k] x[t' + k - P];  xs index of x[t' - P] is t' - P - s0 + K
+          const float* xw = xs + (tp - P - s0 + K);
+          for (int k = 0; k < K; ++k) a = fmaf(wt[k], xw[k], a);
+          a = fmaf(c3s[f], a, c2s[f]);
+        }
+        tmp[u] = a;
+      }
+      __syncthreads();
+      // t' = t - k + P  ->  u = t' - u_lo = tid - k + K - 1
+      float sub = 0.f;
+      for (int k = 0; k < K; ++k) sub = fmaf(wt[k], tmp[tid - k + K - 1], sub);
+      acc -= sub;
+    }
+  }
+  if (t < T) dx[row * (int64_t)T + t] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1352,6 +1423,10 @@ static int eeg_forward_stage(const isd_eegnet_plan* p, int stage, const float* x
   const int C = p->C, K = p->K, T = p->T, Tp = p->Tp, T2 = p->T2, T2p = p->T2p, T3 = p->T3;
   const int64_t rows = B * C;
   const double wd = (double)world;
+  // `training` bit 0: BatchNorm uses batch statistics; bit 1: eval-mode statistics, but keep what a backward pass
+  // needs (input attributions differentiate the eval-mode network)
+  const int keep = training != 0;
+  training &= 1;
   if (stage == 0) {
     ISD_HIP_TRY(hipMemsetAsync(S, 0, sizeof(EegStats), st));
     if (training) {
@@ -1402,7 +1477,7 @@ static int eeg_forward_stage(const isd_eegnet_plan* p, int stage, const float* x
                          ws + w.a4, S, B, T2, T2p, training);
     } else {
       hipLaunchKernelGGL(eeg_sep_kernel, dim3((unsigned)cdiv(T2p, 256), (unsigned)B), dim3(256), 0, st, ws + w.p2,
-                         params + p->off.Wd, params + p->off.Wp, training ? ws + w.a3 : nullptr, ws + w.a4, S, T2, T2p,
+                         params + p->off.Wd, params + p->off.Wp, keep ? ws + w.a3 : nullptr, ws + w.a4, S, T2, T2p,
                          training);
     }
     ISD_LAUNCH_CHECK();
@@ -1442,7 +1517,7 @@ extern "C" int isd_eegnet_forward(const isd_eegnet_plan* p, const float* x, cons
   if (rc || B == 0) return rc;
   for (int stage = 0; stage < 4 && rc == ISD_OK; ++stage)
     rc = eeg_forward_stage(p, stage, x, params, buffers, out, (float*)workspace, B, training, momentum, eps,
-                           training ? dropout_p : 0.f, seed, 1, (hipStream_t)stream, stream);
+                           (training & 1) ? dropout_p : 0.f, seed, 1, (hipStream_t)stream, stream);
   return rc;
 }
 
@@ -1454,12 +1529,12 @@ extern "C" int isd_eegnet_forward_stage(const isd_eegnet_plan* p, int stage, con
   if (rc || B == 0) return rc;
   ISD_CHECK_ARG(stage >= 0 && stage < 4, "isd_eegnet_forward_stage: stage=%d not in [0,4)", stage);
   return eeg_forward_stage(p, stage, x, params, buffers, out, (float*)workspace, B, training, momentum, eps,
-                           training ? dropout_p : 0.f, seed, world, (hipStream_t)stream, stream);
+                           (training & 1) ? dropout_p : 0.f, seed, world, (hipStream_t)stream, stream);
 }
 
 static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* x, const float* params,
                               const float* dout, float* dparams, float* ws, int64_t B, float dropout_p, uint64_t seed,
-                              int world, hipStream_t st, void* stream) {
+                              int world, hipStream_t st, void* stream, int bn_train = 1) {
   const EegWs w = eeg_layout(p, B);
   EegStats* S = (EegStats*)(ws + w.stats);
   EegCoef* Cf = (EegCoef*)(ws + w.coef);
@@ -1482,7 +1557,7 @@ static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* 
   }
   if (stage == 1) {
     hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
-                       (double)B * (double)T2p * wd, 3, gs);
+                       (double)B * (double)T2p * wd, 3, gs, bn_train);
     if (p->cv) {
       hipLaunchKernelGGL(cv_bwd_da4_kernel, dim3((unsigned)cdiv(rows16 * T2p, 256)), dim3(256), 0, st, ws + w.a4,
                          ws + w.dpooled, Cf, ws + w.da4, rows16 * T2p, T2p, T3, p->P2, dropout_p, seed);
@@ -1508,7 +1583,7 @@ static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* 
   }
   if (stage == 2) {
     hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
-                       (double)B * (double)Tp * wd, 2, gs);
+                       (double)B * (double)Tp * wd, 2, gs, bn_train);
     hipLaunchKernelGGL(eeg_bwd_bn2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st, ws + w.dy2,
                        ws + w.u, Cf, S, Tp);
     {
@@ -1529,7 +1604,7 @@ static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* 
   // the stage-1 gradients are assembled from GLOBAL sums (BatchNorm's backward couples the whole batch): every rank
   // computes the same global gradient, pre-divided by the world size; the separable weights are local sums
   hipLaunchKernelGGL(eeg_bwd_final_kernel, dim3(1), dim3(256), 0, st, params, dparams, S, Cf, p->off, C, K,
-                     (double)(B * C) * (double)Tp * wd, !p->cv, gs);
+                     (double)(B * C) * (double)Tp * wd, !p->cv, gs, bn_train);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
@@ -1551,6 +1626,33 @@ extern "C" int isd_eegnet_backward(const isd_eegnet_plan* p, const float* x, con
     rc = eeg_backward_stage(p, stage, x, params, dout, dparams, (float*)workspace, B, dropout_p, seed, 1,
                             (hipStream_t)stream, stream);
   return rc;
+}
+
+// Parameter gradients AND the gradient w.r.t. the input trials.  `training` as in the forward that preceded it:
+// 1 = batch statistics (BatchNorm's mean / variance paths contribute to dx), 2 = eval-mode statistics with the
+// activations kept (isd_eegnet_forward(..., training = 2, ...): what attribution methods differentiate).
+extern "C" int isd_eegnet_backward_x(const isd_eegnet_plan* p, const float* x, const float* params, const float* dout,
+                                     float* dparams, float* dx, void* workspace, int64_t B, int training,
+                                     float dropout_p, uint64_t seed, void* stream) {
+  int rc = eeg_backward_check(p, x, params, dout, dparams, workspace, B, 1);
+  if (rc) return rc;
+  ISD_CHECK_ARG(dx, "isd_eegnet_backward_x: null dx");
+  ISD_CHECK_ARG(training == 1 || training == 2, "isd_eegnet_backward_x: training=%d (1: batch statistics, 2: eval + kept)",
+                training);
+  const int bn_train = training & 1;
+  hipStream_t st = (hipStream_t)stream;
+  for (int stage = 0; stage < 4 && rc == ISD_OK; ++stage)
+    rc = eeg_backward_stage(p, stage, x, params, dout, dparams, (float*)workspace, B, bn_train ? dropout_p : 0.f, seed, 1,
+                            st, stream, bn_train);
+  if (rc) return rc;
+  float* ws = (float*)workspace;
+  const EegWs w = eeg_layout(p, B);
+  ISD_CHECK_ARG(B * p->C <= 0x7fffffffLL, "isd_eegnet_backward_x: too many rows");
+  hipLaunchKernelGGL(eeg_bwd_dx_kernel, dim3((unsigned)(B * p->C), (unsigned)cdiv(p->T, 256)), dim3(256), 0, st, x,
+                     ws + w.v, params, dx, (const EegStats*)(ws + w.stats), (const EegCoef*)(ws + w.coef), p->off, p->C,
+                     p->K, p->T, p->Tp, (double)(B * p->C) * (double)p->Tp, bn_train);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
 }
 
 extern "C" int isd_eegnet_backward_stage(const isd_eegnet_plan* p, int stage, const float* x, const float* params,

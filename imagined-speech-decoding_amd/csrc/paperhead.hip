@@ -224,14 +224,16 @@ __global__ __launch_bounds__(256) void ph_bwd_pool_kernel(const float* __restric
 }
 
 __global__ void ph_bwd_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
-                                   const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N) {
+                                   const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N,
+                                   int bn_train) {
   const int o = threadIdx.x;
   if (o >= g.Fo[l]) return;
+  const double inv = bn_train ? 1.0 / N : 0.0;           // running statistics do not depend on the batch: no mean terms
   dparams[g.g[l] + o] = (float)st->d2[l][o];
   dparams[g.b[l] + o] = (float)st->d1[l][o];
   co->cA[l][o] = params[g.g[l] + o] * co->isg[l][o];
-  co->cB[l][o] = (float)(st->d1[l][o] / N);
-  co->cC[l][o] = (float)(st->d2[l][o] / N);
+  co->cB[l][o] = (float)(st->d1[l][o] * inv);
+  co->cC[l][o] = (float)(st->d2[l][o] * inv);
 }
 
 // dy = cA (dyh - cB - xhat cC) in place
@@ -498,8 +500,8 @@ extern "C" int isd_paperhead_forward(const isd_paperhead_plan* p, const float* x
   return ISD_OK;
 }
 
-extern "C" int isd_paperhead_backward(const isd_paperhead_plan* p, const float* x, const float* params,
-                                      const float* dout, float* dparams, void* workspace, int64_t B, void* stream) {
+static int ph_backward_impl(const isd_paperhead_plan* p, const float* x, const float* params, const float* dout,
+                            float* dparams, float* dx, void* workspace, int64_t B, int bn_train, void* stream) {
   ISD_CHECK_ARG(p, "isd_paperhead_backward: null plan");
   ISD_CHECK_ARG(B >= 1, "isd_paperhead_backward: B=%lld", (long long)B);
   ISD_CHECK_ARG(x && params && dout && dparams && workspace, "isd_paperhead_backward: null argument");
@@ -518,7 +520,7 @@ extern "C" int isd_paperhead_backward(const isd_paperhead_plan* p, const float* 
                        l == 3 ? (const float*)nullptr : ws + w.da[l], l == 3 ? dout : (const float*)nullptr, Cf,
                        ws + w.dy[l], S, B, l, g.Fo[l], g.To[l], g.Tp[l]);
     hipLaunchKernelGGL(ph_bwd_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, g, l,
-                       (double)B * (double)g.To[l]);
+                       (double)B * (double)g.To[l], bn_train);
     const int64_t ny = B * g.Fo[l] * g.To[l];
     hipLaunchKernelGGL(ph_bwd_bn_kernel, dim3((unsigned)cdiv(ny, 256)), dim3(256), 0, st, ws + w.dy[l], ws + w.y[l], Cf,
                        ny, l, g.Fo[l], g.To[l]);
@@ -534,6 +536,9 @@ extern "C" int isd_paperhead_backward(const isd_paperhead_plan* p, const float* 
       hipLaunchKernelGGL(ph_reduce_kernel, dim3(1), dim3(256), 0, st, ws + w.pbias, slabs, (int64_t)g.Fo[0],
                          ws + w.dbeff);
       hipLaunchKernelGGL(ph_bwd_l1_kernel, dim3(1), dim3(256), 0, st, params, dparams, ws + w.dweff, ws + w.dbeff, g);
+      if (dx)   // the fused first layer is one C -> F1 three-tap convolution: its data gradient is the input gradient
+        hipLaunchKernelGGL(ph_bwd_dgrad_kernel, dim3((unsigned)cdiv(B * g.Ti[0], 256), (unsigned)n_ctile), dim3(256), 0,
+                           st, ws + w.dy[0], ws + w.wb[0], dx, B, g.Ci[0], g.Cp[0], g.Ti[0], g.To[0], g.Fo[0]);
     } else {
       hipLaunchKernelGGL(ph_bwd_dgrad_kernel, dim3((unsigned)cdiv(B * g.Ti[l], 256), (unsigned)n_ctile), dim3(256), 0, st,
                          ws + w.dy[l], ws + w.wb[l], ws + w.da[l - 1], B, g.Ci[l], g.Cp[l], g.Ti[l], g.To[l], g.Fo[l]);
@@ -541,4 +546,18 @@ extern "C" int isd_paperhead_backward(const isd_paperhead_plan* p, const float* 
   }
   ISD_LAUNCH_CHECK();
   return ISD_OK;
+}
+
+extern "C" int isd_paperhead_backward(const isd_paperhead_plan* p, const float* x, const float* params,
+                                      const float* dout, float* dparams, void* workspace, int64_t B, void* stream) {
+  return ph_backward_impl(p, x, params, dout, dparams, nullptr, workspace, B, 1, stream);
+}
+
+// The same plus dx [B][C][T].  training: 1 = the forward used batch statistics, 0 = running statistics (eval mode: what
+// attribution methods differentiate; every activation the backward needs is kept by the forward in both modes).
+extern "C" int isd_paperhead_backward_x(const isd_paperhead_plan* p, const float* x, const float* params,
+                                        const float* dout, float* dparams, float* dx, void* workspace, int64_t B,
+                                        int training, void* stream) {
+  ISD_CHECK_ARG(dx, "isd_paperhead_backward_x: null dx");
+  return ph_backward_impl(p, x, params, dout, dparams, dx, workspace, B, training ? 1 : 0, stream);
 }

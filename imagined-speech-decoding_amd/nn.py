@@ -231,7 +231,7 @@ def eegnet_forward(plan, x, flat, bufs, out, ws, training, momentum, eps, dropou
     stages and the fp64 sum block of each stage is all-reduced in between.  Returns the world size that was used
     (pass it to ``eegnet_backward``)."""
     L, B, st = _lib.lib(), x.shape[0], _stream()
-    dist, world = _bn_sync_world(sync, training)
+    dist, world = _bn_sync_world(sync, int(training) == 1)      # training: 0 eval, 1 batch statistics, 2 eval + keep
     args = (x.data_ptr(), flat.data_ptr(), bufs.data_ptr(), out.data_ptr(), ws.data_ptr(), B, int(training),
             float(momentum), float(eps), float(dropout_p), int(seed))
     if world == 1:
@@ -266,32 +266,45 @@ def eegnet_backward(plan, x, flat, dout, dflat, ws, dropout_p, seed, world=1):
 
 
 class _EEGNetFn(torch.autograd.Function):
+    """EEGNet_Encoder / CVBlock.  Differentiable w.r.t. the parameters and -- single device -- the input trials, in
+    train mode (batch statistics: BatchNorm's mean / variance paths are part of the input gradient) and in eval mode
+    (running statistics: what attribution methods differentiate; the forward then keeps its activations)."""
+
     @staticmethod
     def forward(ctx, x, flat, bufs, plan, training, momentum, eps, dropout_p, seed, sync):
         x, flat = _f32c(x, "x"), _f32c(flat, "params")
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("gradient w.r.t. the EEG input is not provided by the HIP EEGNet head")
         B = x.shape[0]
         out = torch.empty((B, plan.F), dtype=torch.float32, device=x.device)
         ws = torch.empty(max(int(_lib.lib().isd_eegnet_workspace_bytes(plan._h, B)) // 4, 1), dtype=torch.float32,
                          device=x.device)
+        want_bwd = any(ctx.needs_input_grad[:2])
+        mode = 1 if training else (2 if want_bwd else 0)     # 2: eval-mode statistics, activations kept for backward
         with torch.cuda.device(x.device):
-            world = eegnet_forward(plan, x, flat, bufs, out, ws, training, momentum, eps, dropout_p, seed, sync)
-        ctx.plan, ctx.ws, ctx.dp, ctx.seed, ctx.training, ctx.world = plan, ws, float(dropout_p), int(seed), training, world
+            world = eegnet_forward(plan, x, flat, bufs, out, ws, mode, momentum, eps, dropout_p, seed, sync)
+        ctx.plan, ctx.ws, ctx.dp, ctx.seed, ctx.mode, ctx.world = plan, ws, float(dropout_p), int(seed), mode, world
         ctx.save_for_backward(x, flat)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, flat = ctx.saved_tensors
-        if not ctx.training:
-            raise RuntimeError("EEGNet_Encoder backward needs a train-mode forward (batch statistics)")
         dflat = torch.empty_like(flat)
         dout = _f32c(dout, "dout")
+        dx = None
         with torch.cuda.device(x.device):
-            eegnet_backward(ctx.plan, x, flat, dout, dflat, ctx.ws, ctx.dp, ctx.seed, ctx.world)
+            if ctx.needs_input_grad[0] or ctx.mode == 2:
+                if ctx.world != 1:
+                    raise NotImplementedError("the input gradient of the BatchNorm heads is single-device")
+                dx = torch.empty_like(x)
+                _lib.check(_lib.lib().isd_eegnet_backward_x(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dout.data_ptr(),
+                                                            dflat.data_ptr(), dx.data_ptr(), ctx.ws.data_ptr(), x.shape[0],
+                                                            ctx.mode, ctx.dp, ctx.seed, _stream()))
+                if not ctx.needs_input_grad[0]:
+                    dx = None
+            else:
+                eegnet_backward(ctx.plan, x, flat, dout, dflat, ctx.ws, ctx.dp, ctx.seed, ctx.world)
         ctx.ws = None
-        return None, dflat, None, None, None, None, None, None, None, None
+        return dx, dflat, None, None, None, None, None, None, None, None
 
 
 class PaperHeadPlan:
@@ -311,11 +324,12 @@ class PaperHeadPlan:
 
 
 class _PaperHeadFn(torch.autograd.Function):
+    """HeadConv_Paper_Version: parameter gradients and the input gradient, after a train-mode (batch statistics) or an
+    eval-mode (running statistics) forward."""
+
     @staticmethod
     def forward(ctx, x, flat, bufs, plan, training, momentum, eps):
         x, flat = _f32c(x, "x"), _f32c(flat, "params")
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("gradient w.r.t. the EEG input is not provided by the HIP HeadConv_Paper_Version")
         B = x.shape[0]
         out = torch.empty((B, plan.F), dtype=torch.float32, device=x.device)
         ws = torch.empty(max(int(_lib.lib().isd_paperhead_workspace_bytes(plan._h, B)) // 4, 1), dtype=torch.float32,
@@ -331,15 +345,22 @@ class _PaperHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, flat = ctx.saved_tensors
-        if not ctx.training:
-            raise RuntimeError("HeadConv_Paper_Version backward needs a train-mode forward (batch statistics)")
         dflat = torch.empty_like(flat)
         dout = _f32c(dout, "dout")
+        dx = None
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().isd_paperhead_backward(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dout.data_ptr(),
-                                                         dflat.data_ptr(), ctx.ws.data_ptr(), x.shape[0], _stream()))
+            if ctx.needs_input_grad[0] or not ctx.training:
+                dx = torch.empty_like(x)
+                _lib.check(_lib.lib().isd_paperhead_backward_x(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dout.data_ptr(),
+                                                               dflat.data_ptr(), dx.data_ptr(), ctx.ws.data_ptr(),
+                                                               x.shape[0], int(ctx.training), _stream()))
+                if not ctx.needs_input_grad[0]:
+                    dx = None
+            else:
+                _lib.check(_lib.lib().isd_paperhead_backward(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dout.data_ptr(),
+                                                             dflat.data_ptr(), ctx.ws.data_ptr(), x.shape[0], _stream()))
         ctx.ws = None
-        return None, dflat, None, None, None, None, None
+        return dx, dflat, None, None, None, None, None
 
 
 class _LinearResFn(torch.autograd.Function):

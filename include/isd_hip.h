@@ -240,6 +240,13 @@ int isd_eegnet_forward(const isd_eegnet_plan* plan, const float* x, const float*
 int isd_eegnet_backward(const isd_eegnet_plan* plan, const float* x, const float* params, const float* dout,
                         float* dparams, void* workspace, int64_t B, float dropout_p, uint64_t seed,
                         void* stream);
+/* The same plus the gradient w.r.t. the input trials, dx [B][C][T] (fast.py:203-210 asks for an autograd-differentiable
+ * encoder; the attribution scripts differentiate the network w.r.t. x).  `training` = the value the forward was called
+ * with: 1 (batch statistics: BatchNorm's mean / variance paths reach dx) or 2 (isd_eegnet_forward(..., training = 2):
+ * eval-mode statistics with the activations kept for this call -- what attribution methods use).  Single device. */
+int isd_eegnet_backward_x(const isd_eegnet_plan* plan, const float* x, const float* params, const float* dout,
+                          float* dparams, float* dx, void* workspace, int64_t B, int training, float dropout_p,
+                          uint64_t seed, void* stream);
 /* Synchronised BatchNorm under data parallelism (the reference's heads use plain nn.BatchNorm2d on one
  * device, fast.py:46-63,133-159, so the single-device batch statistics are what a sharded batch must reproduce).
  * The forward and backward passes above are four stages each (0..3); after stages 0, 1 and 2 a block of fp64 batch
@@ -349,6 +356,10 @@ int isd_paperhead_forward(const isd_paperhead_plan* plan, const float* x, const 
                           float* out, void* workspace, int64_t B, int training, float momentum, float eps, void* stream);
 int isd_paperhead_backward(const isd_paperhead_plan* plan, const float* x, const float* params, const float* dout,
                            float* dparams, void* workspace, int64_t B, void* stream);
+/* ... plus the gradient w.r.t. the input trials dx [B][C][T]; training = 1 after a batch-statistics forward, 0 after an
+ * eval-mode forward (running statistics). */
+int isd_paperhead_backward_x(const isd_paperhead_plan* plan, const float* x, const float* params, const float* dout,
+                             float* dparams, float* dx, void* workspace, int64_t B, int training, void* stream);
 
 #ifdef __cplusplus
 }

@@ -154,5 +154,14 @@ def test_fast_with_registry_heads_vs_oracle(inn, head, enc):
         want = p[k].grad
         tol = 2e-4 * max(float(want.abs().max()), 5e-2 * scale)
         assert float((q.grad.cpu().double() - want).abs().max()) < tol + 1e-7, k
+    # input attributions: the eval-mode network differentiated w.r.t. the trials, end to end (zones own their channels,
+    # overlapping windows add, BatchNorm on its running statistics)
+    m.eval()
+    xg = x.cuda().requires_grad_()
+    m(xg)[:, 1].sum().backward()
+    p2 = {k: v.detach().cpu().clone().double() for k, v in m.state_dict().items()}
+    xr = x.double().requires_grad_()
+    ocnn.default_logits(xr, p2, names, idx, 4, 1, encoder=getattr(ocnn, enc), training=False)[:, 1].sum().backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < 2e-4
     with pytest.raises(KeyError):
         inn.FAST(inn.fast_config(electrodes, zones, head="NoSuchHead"))

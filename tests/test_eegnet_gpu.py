@@ -99,3 +99,54 @@ def test_eegnet_dropout_is_unbiased_and_deterministic_per_seed(inn):
     assert float((outs.mean(0) - ref).abs().mean() / ref.abs().mean()) < 0.2
     with pytest.raises(Exception):
         inn.EEGNet_Encoder(8, 32).cuda()(torch.randn(2, 8, 20, device="cuda"))   # too short for the pooling
+
+
+@pytest.mark.parametrize("kind,C,T,K,B", [("eegnet", 6, 250, 64, 3), ("eegnet", 9, 333, 32, 5), ("eegnet", 3, 700, 64, 2),
+                                          ("eegnet", 5, 65, 64, 4), ("cvblock", 7, 250, 0, 3), ("paper", 6, 250, 0, 4),
+                                          ("paper", 17, 300, 0, 2)])
+@pytest.mark.parametrize("train", [True, False])
+def test_bn_heads_input_gradient_vs_oracle(inn, kind, C, T, K, B, train):
+    """d loss / d x of EEGNet_Encoder, CVBlock and HeadConv_Paper_Version (the head contract of fast.py:203-210 asks for an autograd-differentiable
+    encoder; the attribution scripts differentiate w.r.t. the trials): train mode -- BatchNorm's batch-mean / variance
+    paths included -- and eval mode (running statistics: the backward follows an eval-mode forward that kept its
+    activations), with the parameter gradients of both, against the oracle's autograd in fp64."""
+    torch.manual_seed(C + T + int(train))
+    if kind == "eegnet":
+        m = inn.EEGNet_Encoder(C, 16, kernel_length=K, dropout=0.0).cuda()
+        ref = lambda xx, pp, tr: ocnn.eegnet_encoder(xx, pp, training=tr, kernel_length=K)
+    elif kind == "cvblock":
+        m = inn.CVBlock(C, 16, dropout=0.0).cuda()
+        ref = lambda xx, pp, tr: ocnn.cvblock(xx, pp, training=tr)
+    else:
+        m = inn.HeadConv_Paper_Version(C, 16).cuda()
+        ref = lambda xx, pp, tr: ocnn.headconv_paper(xx, pp, training=tr)
+    with torch.no_grad():
+        for bn in m._bns():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+            bn.running_mean.uniform_(-0.2, 0.2)
+            bn.running_var.uniform_(0.5, 2.0)
+    p = {k: v.detach().cpu().clone().double() for k, v in m.state_dict().items()}
+    for k, v in p.items():
+        if "running" not in k and "num_batches" not in k:
+            v.requires_grad_()
+    x = torch.randn(B, C, T)
+    w = torch.randn(B, 16)
+    m.train(train)
+    xg = x.cuda().requires_grad_()
+    y = m(xg)
+    (y * w.cuda()).sum().backward()
+    xr = x.double().requires_grad_()
+    yr = ref(xr, p, train)
+    (yr * w.double()).sum().backward()
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-4
+    assert rel_err(xg.grad.cpu(), xr.grad) < 2e-4
+    scale = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
+    for k, q in m.named_parameters():
+        assert _grad_err(q.grad.cpu().numpy(), p[k].grad.numpy(), scale) < 2e-4, k
+    # the parameter-only backward (no input gradient requested) is unchanged by the new path
+    m.zero_grad(set_to_none=True)
+    if train:
+        (m(x.cuda()) * w.cuda()).sum().backward()
+        for k, q in m.named_parameters():
+            assert _grad_err(q.grad.cpu().numpy(), p[k].grad.numpy(), scale) < 2e-4, k
