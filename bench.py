@@ -354,12 +354,17 @@ def main():
         if os.path.exists(tf):
             try:
                 table = json.load(open(tf))
-                ent = table.get(roof["kernel"].split(" ")[0])
-                roof["traffic"] = ent["bytes_per_launch"] if ent and B == ent.get("trials_per_launch", 4096) else None
+                def measured(ent, trials):
+                    # PMC bytes of the pass the table was measured on; every trial is independent, so an entry may give
+                    # bytes per trial instead (measured on a smaller batch of the same shape)
+                    if not ent:
+                        return None
+                    if "bytes_per_trial" in ent:
+                        return int(round(ent["bytes_per_trial"] * trials))
+                    return ent["bytes_per_launch"] if trials == ent.get("trials_per_launch", 4096) else None
+                roof["traffic"] = measured(table.get(roof["kernel"].split(" ")[0]), B)
                 if roof_hbm:
-                    ent = table.get(roof_hbm["kernel"].split(" ")[0])
-                    if ent and ent.get("trials_per_launch", 4096) == roof_hbm["trials_per_pass"]:
-                        roof_hbm["traffic"] = ent["bytes_per_launch"]
+                    roof_hbm["traffic"] = measured(table.get(roof_hbm["kernel"].split(" ")[0]), roof_hbm["trials_per_pass"])
             except Exception:
                 pass
         line = {

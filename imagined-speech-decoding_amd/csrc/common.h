@@ -73,6 +73,30 @@ __device__ __forceinline__ double read_lane(double v, int src) {
 // LDS hand-over between the lanes of ONE wave (workgroups of 64 threads): LDS operations of a wave execute in
 // order, so it is enough to wait for the outstanding LDS operations and to keep the compiler from moving accesses
 // across this point.  Unlike __syncthreads() this does not drain vmcnt: global stores and loads stay in flight.
+// GELU (erf form, nn.GELU's default) and its derivative through  erfc(|z|) = t (a1 + t (a2 + ...)) exp(-z^2),
+// t = 1 / (1 + p |z|)  (Abramowitz & Stegun 7.1.26, absolute error 1.5e-7 -- the fp32 rounding level of the
+// activation).  libm's erff is ~100 instructions per element and, where an activation tile ends in GELU and GELU',
+// was the larger part of the kernel's vector work.  cdf = 0.5 (1 + erf(x / sqrt 2)),  ez = exp(-x^2 / 2).
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& ez) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  ez = __expf(-z * z);
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f),
+                              0.254829592f);
+  const float c = 0.5f * poly * ez;                      // 0.5 erfc(|z|)
+  cdf = x < 0.f ? c : 1.f - c;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  float cdf, ez;
+  gelu_parts(x, cdf, ez);
+  return x * cdf;
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  float cdf, ez;
+  gelu_parts(x, cdf, ez);
+  return fmaf(x * 0.39894228040143267794f, ez, cdf);
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();

@@ -72,10 +72,8 @@ template <> struct Act<bf16_t> {
   static __device__ __forceinline__ float rnd(float v) { return bf16_round(v); }
 };
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
-}
+__device__ __forceinline__ float gelu_f(float x) { return gelu_fast(x); }               // common.h: A&S erf, 1.5e-7
+__device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_fast(x); }
 
 // cnn3 / cnn4 weights [F][F][5] -> frag order, forward and transposed+flipped (dgrad) copies; `nbx` blocks of 256
 // threads share one (zone, layer), this is block `bx` of them.

@@ -97,28 +97,8 @@ __device__ __forceinline__ float tf_keep(const TfDrop& d, unsigned long long e) 
   return (float)(h >> 8) * (1.f / 16777216.f) >= d.p ? d.inv : 0.f;
 }
 
-// GELU (erf form, nn.GELU's default) and its derivative.  erfc(|z|) = t (a1 + t (a2 + ...)) exp(-z^2), t = 1 / (1 + p |z|)
-// (Abramowitz & Stegun 7.1.26, absolute error 1.5e-7 -- the fp32 rounding level of the activation); libm's erff is
-// ~100 instructions per element and was half of the kernel's vector work.
-__device__ __forceinline__ void tf_gelu_parts(float x, float& cdf, float& ez) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
-  ez = __expf(-z * z);                                   // exp(-x^2 / 2)
-  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f),
-                              0.254829592f);
-  const float c = 0.5f * poly * ez;                      // 0.5 erfc(|z|)
-  cdf = x < 0.f ? c : 1.f - c;                           // 0.5 (1 + erf(x / sqrt 2))
-}
-__device__ __forceinline__ float tf_gelu(float x) {
-  float cdf, ez;
-  tf_gelu_parts(x, cdf, ez);
-  return x * cdf;
-}
-__device__ __forceinline__ float tf_gelu_grad(float x) {
-  float cdf, ez;
-  tf_gelu_parts(x, cdf, ez);
-  return fmaf(x * 0.39894228040143267794f, ez, cdf);
-}
+__device__ __forceinline__ float tf_gelu(float x) { return gelu_fast(x); }             // common.h: A&S erf, 1.5e-7
+__device__ __forceinline__ float tf_gelu_grad(float x) { return gelu_grad_fast(x); }
 
 // ------------------------------------------------------------------------------------------- staging the weights
 // dst[i * STRIDE + o] = W[o][i]
