@@ -90,6 +90,7 @@ SIGNATURES = {
     "isd_paperhead_backward_x": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "isd_cvblock_plan_create": (_i, [C.POINTER(_p), _i, _i, _i]),
     "isd_cvblock_flat_dim": (_i64, [_p]),
+    "isd_eegnet_plan_set_seed_counter": (_i, [_p, _p]),
     "isd_eegnet_plan_destroy": (_i, [_p]),
     "isd_eegnet_param_count": (_i64, [_p]),
     "isd_eegnet_buffer_count": (_i64, [_p]),

@@ -72,6 +72,9 @@ struct EegCoef {
   float mu3[kF2], sig3[kF2], A3[kF2], B3[kF2];   // y3 = A3 a4 + B3
   float cA3[kF2], cB3[kF2], cC3[kF2];            // da4 = cA3 (dy3 - cB3 - xhat3 cC3)
   float cA2[kF2], cB2[kF2], cC2[kF2];
+  // added to the dropout seed of every kernel of this pass (forward and backward): 0, or a multiple of the plan's
+  // device-resident step counter, so that a captured graph -- which replays the same seed argument -- draws new masks
+  unsigned long long seed_add;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -350,8 +353,10 @@ __global__ __launch_bounds__(64) void eeg_stats_derive_kernel(EegStats* __restri
 __global__ __launch_bounds__(256) void eeg_finalize1_kernel(const float* __restrict__ params, float* __restrict__ bufs,
                                                             const EegStats* __restrict__ st, EegCoef* __restrict__ co,
                                                             EegOff off, int C, int K, int T, int64_t rows,
-                                                            int training, float momentum, float eps) {
+                                                            int training, float momentum, float eps,
+                                                            const unsigned long long* __restrict__ seed_dev) {
   const int P = K / 2;
+  if (threadIdx.x == 0) co->seed_add = seed_dev ? 0xD1342543DE82EF95ull * *seed_dev : 0ull;
   const double N1 = (double)rows * (double)(T + 2 * P - K + 1);
   const float* Wt = params + off.Wt;
   const float* Ws = params + off.Ws;
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(256) void eeg_pool2_kernel(const float* __restrict_
   const float* ur = u + (int64_t)bg * Tp + P1 * v;
   float s = 0.f;
   for (int r = 0; r < P1; ++r) s += elu_f(fmaf(A, ur[r], Bc));
-  p2[(int64_t)bg * T2 + v] = s / (float)P1 * drop_scale(seed, (uint64_t)bg * T2 + v, dp);
+  p2[(int64_t)bg * T2 + v] = s / (float)P1 * drop_scale(seed + co->seed_add, (uint64_t)bg * T2 + v, dp);
 }
 
 // a3[b,g,w] = sum_k Wd[g,k] p2pad[b,g,w+k];  a4[b,h,w] = sum_g Wp[h,g] a3[b,g,w];  BN3 sums.
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(256) void eeg_pool3_kernel(const float* __restrict_
   const float* ar = a4 + row * T2p;
   float s = 0.f;
   for (int w = lane; w < 8 * T3; w += 64)
-    s += elu_f(fmaf(A, ar[w], Bc)) * drop_scale(seed ^ 0x5bd1e995u, (uint64_t)row * T3 + (w >> 3), dp);
+    s += elu_f(fmaf(A, ar[w], Bc)) * drop_scale((seed + co->seed_add) ^ 0x5bd1e995u, (uint64_t)row * T3 + (w >> 3), dp);
   s = wave_sum(s);
   if (lane == 0) pooled[row] = T3 > 0 ? s / (float)(8 * T3) : 0.f;
 }
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(256) void eeg_bwd3_sums_kernel(const float* __restr
   float s1 = 0.f, s2 = 0.f;
   for (int w = lane; w < 8 * T3; w += 64) {
     const float av = ar[w];
-    const float dy = de * drop_scale(seed ^ 0x5bd1e995u, (uint64_t)row * T3 + (w >> 3), dp) *
+    const float dy = de * drop_scale((seed + co->seed_add) ^ 0x5bd1e995u, (uint64_t)row * T3 + (w >> 3), dp) *
                      elu_grad_f(fmaf(A, av, Bc));
     s1 += dy;
     s2 += dy * (av - mu) * isg;
@@ -727,7 +732,7 @@ __global__ __launch_bounds__(256) void eeg_bwd_sep_kernel(const float* __restric
     const int64_t row = (int64_t)b * kF2 + h;
     const float av = a4[row * T2p + w];
     const float de = (w < 8 * T3 && T3 > 0)
-                         ? dpooled[row] / (float)(8 * T3) * drop_scale(seed ^ 0x5bd1e995u, (uint64_t)row * T3 + (w >> 3), dp)
+                         ? dpooled[row] / (float)(8 * T3) * drop_scale((seed + co->seed_add) ^ 0x5bd1e995u, (uint64_t)row * T3 + (w >> 3), dp)
                          : 0.f;
     const float dy = de * elu_grad_f(fmaf(co->A3[h], av, co->B3[h]));
     const float xh = (av - co->mu3[h]) / co->sig3[h];
@@ -797,7 +802,7 @@ __global__ __launch_bounds__(256) void eeg_bwd_pool2_kernel(const float* __restr
       } else {
         dp = da3[(int64_t)bg * T2 + v];                 // CVBlock: dp2 already formed by cv_bwd_dp2_kernel
       }
-      dp *= drop_scale(seed, (uint64_t)bg * T2 + v, dpr);
+      dp *= drop_scale(seed + co->seed_add, (uint64_t)bg * T2 + v, dpr);
       const float uv = u[(int64_t)bg * Tp + tp];
       const float y2 = fmaf(co->A2[g], uv, co->B2[g]);
       dy = dp / (float)P1 * elu_grad_f(y2);
@@ -1161,14 +1166,14 @@ __global__ __launch_bounds__(256) void cv_pool3_kernel(const float* __restrict__
   const float* ar = a4 + row * T2p + P2 * v;
   float s = 0.f;
   for (int r = 0; r < P2; ++r) s += elu_f(fmaf(A, ar[r], Bc));
-  p3[e] = s / (float)P2 * drop_scale(seed ^ 0x5bd1e995u, (uint64_t)e, dp);
+  p3[e] = s / (float)P2 * drop_scale((seed + co->seed_add) ^ 0x5bd1e995u, (uint64_t)e, dp);
 }
 
 __device__ __forceinline__ float cv_dy3(const float* __restrict__ dp3, const EegCoef* __restrict__ co, int64_t row,
                                         int h, int w, float av, int T3, int P2, float dp, uint64_t seed) {
   if (w >= P2 * T3) return 0.f;
   const int64_t e = row * T3 + w / P2;
-  const float de = dp3[e] / (float)P2 * drop_scale(seed ^ 0x5bd1e995u, (uint64_t)e, dp);
+  const float de = dp3[e] / (float)P2 * drop_scale((seed + co->seed_add) ^ 0x5bd1e995u, (uint64_t)e, dp);
   return de * elu_grad_f(fmaf(co->A3[h], av, co->B3[h]));
 }
 
@@ -1289,6 +1294,7 @@ struct isd_eegnet_plan {
   int cv;          // 0: EEGNet_Encoder, 1: CVBlock
   int P1, P2;      // AvgPool widths of the two stages
   EegOff off;
+  const unsigned long long* seed_dev;   // optional device-resident dropout step counter (isd_eegnet_plan_set_seed_counter)
 };
 
 static inline int64_t al64(int64_t v) { return (v + 63) / 64 * 64; }
@@ -1342,6 +1348,12 @@ static int eeg_plan_create(isd_eegnet_plan** out, int in_channels, int feature_d
   f.bl = o; o += feature_dim;
   f.total = o;
   *out = p;
+  return ISD_OK;
+}
+
+extern "C" int isd_eegnet_plan_set_seed_counter(isd_eegnet_plan* p, const uint64_t* seed_dev) {
+  ISD_CHECK_ARG(p, "isd_eegnet_plan_set_seed_counter: null plan");
+  p->seed_dev = (const unsigned long long*)seed_dev;
   return ISD_OK;
 }
 
@@ -1457,7 +1469,7 @@ static int eeg_forward_stage(const isd_eegnet_plan* p, int stage, const float* x
   }
   if (stage == 1) {
     hipLaunchKernelGGL(eeg_finalize1_kernel, dim3(1), dim3(256), 0, st, params, buffers, S, Cf, p->off, C, K, T,
-                       rows * world, training, momentum, eps);
+                       rows * world, training, momentum, eps, p->seed_dev);
     hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(T, 16), (unsigned)B), dim3(256), 0, st, x,
                        params + p->off.Ws, ws + w.z, C, T, (int)cdiv(T, 16));
     hipLaunchKernelGGL(eeg_tconv_kernel, dim3(row_blocks(Tp, B * kF2), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.z,

@@ -13,13 +13,20 @@ from .nn import token_mean_cross_entropy
 
 
 def graph_safe(model):
-    """True when every dropout mask of ``model`` advances through device memory: the fused transformer tail does
-    (``seed_dev``); the per-operator blocks and the BatchNorm heads take their seeds by value and would replay one
-    mask for ever."""
+    """True when every dropout mask of ``model`` advances through device memory: the fused transformer tail
+    (``seed_dev``), ``EEGNet_Encoder`` / ``CVBlock`` zones (``set_seed_counter``); ``Conv4Layers`` and
+    ``HeadConv_Paper_Version`` draw none.  The per-operator transformer blocks take their seeds by value and would
+    replay one mask for ever."""
     from . import nn as inn
     from . import _lib
-    if not isinstance(model, inn.FAST) or not model.fuse_tail or not getattr(model.head, "fused", False):
-        return False                                           # Head.fused: every zone a Conv4Layers (no dropout)
+    if not isinstance(model, inn.FAST) or not model.fuse_tail:
+        return False
+    if not model.head.fused and not all(isinstance(e, (inn.EEGNet_Encoder, inn.CVBlock, inn.HeadConv_Paper_Version))
+                                        for e in model.head.encoders.values()):
+        return False                                           # an unknown registered head: cannot vouch for its masks
+    import torch.distributed as dist
+    if not model.head.fused and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return False                                           # synchronised BatchNorm exchanges sums between stages
     c = model.config
     return bool(_lib.lib().isd_tail_fused_supported(model.n_tokens, c.dim_token, c.num_heads, len(model.transformer),
                                                     2 * c.dim_token, c.n_classes))
@@ -43,6 +50,9 @@ class GraphedTrainStep:
         self.loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
         self.lr = g0["lr"]
         model.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        for enc in getattr(model.head, "encoders", {}).values():
+            if hasattr(enc, "set_seed_counter"):
+                enc.set_seed_counter(model.seed_dev)
         # warm-up steps build plans, workspaces and optimizer state; the training itself must not see them
         params = [p for g in opt.param_groups for p in g["params"]]
         keep = [p.detach().clone() for p in params]

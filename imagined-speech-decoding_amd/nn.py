@@ -195,6 +195,12 @@ class EEGNetPlan:
                                                          int(kernel_length), int(T)))
         self.n_params = int(_lib.lib().isd_eegnet_param_count(self._h))
         self.F = int(feature_dim)
+        self._seed_dev = None
+
+    def set_seed_counter(self, counter):
+        """``counter``: int64 device tensor (or None) mixed into every pass's dropout seed (graph replay)."""
+        self._seed_dev = counter                          # keeps the tensor alive
+        _lib.check(_lib.lib().isd_eegnet_plan_set_seed_counter(self._h, 0 if counter is None else counter.data_ptr()))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -724,7 +730,15 @@ class _BNStackMixin(_FlatParamMixin):
         plan = self._plans.get(T)
         if plan is None:
             plan = self._plans[T] = self._make_plan(T)
+            if getattr(self, "_seed_dev", None) is not None:
+                plan.set_seed_counter(self._seed_dev)
         return plan
+
+    def set_seed_counter(self, counter):
+        """Device-resident dropout step counter (int64 tensor, or None): see ``isd_amd.graph``."""
+        self._seed_dev = counter
+        for plan in self._plans.values():
+            plan.set_seed_counter(counter)
 
     def _run(self, x):
         plan = self._plan_for(x.shape[-1])
@@ -897,6 +911,7 @@ class Head(nn.Module, _FlatParamMixin):
                                    else HEAD_REGISTRY[head](len(ch_names), feature_dim))
         self.feature_dim = feature_dim
         self._plans = {}
+        self._zone_streams = {}
 
     def _ordered_params(self):
         if not self.fused:
@@ -920,12 +935,24 @@ class Head(nn.Module, _FlatParamMixin):
 
     def _per_zone(self, xw):
         """Registry heads other than Conv4Layers: one encoder call per zone on its gathered channels (fast.py:210)."""
+        # The zones are independent until the stack: each runs on its own HIP stream (forked from / joined to the
+        # caller's), so their short kernels overlap on the GPU and, in a captured graph, form parallel branches.
+        main = torch.cuda.current_stream(xw.device)
+        streams = self._zone_streams.get(xw.device)
+        if streams is None:
+            streams = self._zone_streams[xw.device] = [torch.cuda.Stream(xw.device) for _ in self.encoders]
         outs = []
-        for area, enc in self.encoders.items():
+        for (area, enc), st in zip(self.encoders.items(), streams):
             idx = self.index_dict[area]
             if idx.device != xw.device:
                 idx = self.index_dict[area] = idx.to(xw.device)
-            outs.append(enc(xw.index_select(1, idx)))
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs.append(enc(xw.index_select(1, idx)))
+            xw.record_stream(st)
+        for st, o in zip(streams, outs):
+            main.wait_stream(st)
+            o.record_stream(main)
         return torch.stack(outs, dim=1)
 
     def forward_windows(self, x, window_len, slide_step):

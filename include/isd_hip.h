@@ -230,6 +230,10 @@ int isd_eegnet_plan_create(isd_eegnet_plan** out, int in_channels, int feature_d
  *   projector.weight [F, 16*T3] | projector.bias [F];  buffer block as above (bn1, bn2, bn3). */
 int isd_cvblock_plan_create(isd_eegnet_plan** out, int in_channels, int dim_token, int T);
 int64_t isd_cvblock_flat_dim(const isd_eegnet_plan* plan);
+/* Optional device-resident dropout step counter (uint64): when set, every pass mixes its current value into the dropout
+ * seed, so a captured HIP graph -- which replays the same seed argument -- draws new masks by incrementing the counter
+ * inside the graph.  Null (the default) = the seed argument alone. */
+int isd_eegnet_plan_set_seed_counter(isd_eegnet_plan* plan, const uint64_t* seed_dev);
 int isd_eegnet_plan_destroy(isd_eegnet_plan* plan);
 int64_t isd_eegnet_param_count(const isd_eegnet_plan* plan);
 int64_t isd_eegnet_buffer_count(const isd_eegnet_plan* plan);

@@ -282,4 +282,56 @@ def test_graphed_training_step_matches_eager_and_advances_dropout(isd):
     assert all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))       # lr 0: nothing moved
     g.step(idx[:5], 0.0)                                                                 # ragged batch: eager, same code
     assert int(m.seed_dev) == 4
-    assert not graph_safe(inn.FAST(inn.fast_config(head="EEGNet_Encoder")).cuda())
+    m.fuse_tail = False
+    assert not graph_safe(m)                                  # per-operator blocks take their dropout seeds by value
+
+
+@pytest.mark.parametrize("head", ["EEGNet_Encoder", "HeadConv_Paper_Version"])
+def test_graphed_step_with_batchnorm_heads(isd, head):
+    """The BatchNorm heads inside the captured step: the zones run on forked HIP streams (parallel branches of the
+    graph), running statistics and num_batches_tracked update on the device, and EEGNet's dropout masks advance through
+    the plan's device-resident counter.  Dropout off: the replayed fold follows the eager one."""
+    from isd_amd import experiment as E
+    from isd_amd.graph import GraphedTrainStep, graph_safe
+    import isd_amd.nn as inn
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((30, 64, 800)).astype(np.float32)
+    y = rng.integers(0, 5, 30).astype(np.uint8)
+    cfg = inn.fast_config(dropout=0.0, head=head)
+    hist = {}
+    for graph in (False, True):
+        hist[graph] = E.train_one_fold(_no_head_dropout(cfg), X[:24], y[:24], X[24:], y[24:], 2, 12, seed=7, graph=graph)[2]
+    for he, hg in zip(hist[False], hist[True]):
+        assert abs(he["loss"] - hg["loss"]) < 5e-3 * max(1.0, abs(he["loss"])), (head, he, hg)
+    # masks: EEGNet zones draw dropout (0.25) -- replays at learning rate 0 differ, the counter advances
+    if head == "EEGNet_Encoder":
+        torch.manual_seed(0)
+        m = inn.FAST(inn.fast_config(dropout=0.0, head=head)).cuda().train()
+        assert graph_safe(m)
+        Xd, yd = torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()
+        opt = torch.optim.AdamW(m.parameters(), lr=torch.tensor(0.0, device="cuda"), capturable=True, fused=True)
+        g = GraphedTrainStep(m, opt, Xd, yd, 16)
+        idx = torch.arange(16, device="cuda")
+        losses = []
+        for _ in range(3):
+            g.loss_sum.zero_()
+            g.step(idx, 0.0)
+            losses.append(float(g.loss_sum) / 16)
+        assert len(set(losses)) == 3 and all(np.isfinite(losses)) and int(m.seed_dev) == 3
+        nbt = next(iter(m.head.encoders.values())).temporal_conv[1].num_batches_tracked
+        assert int(nbt) >= 3                                      # BatchNorm bookkeeping advanced inside the replays
+
+
+def _no_head_dropout(cfg):
+    """A config whose BatchNorm zone encoders are built without dropout (the registry constructors take none)."""
+    import copy
+    import isd_amd.nn as inn
+    cfg = copy.copy(cfg)
+
+    class _Quiet(inn.EEGNet_Encoder):
+        def __init__(self, c, f):
+            super().__init__(c, f, dropout=0.0)
+    if cfg.head == "EEGNet_Encoder":
+        inn.register_head("EEGNet_Encoder_nodrop", _Quiet)
+        cfg.head = "EEGNet_Encoder_nodrop"
+    return cfg

@@ -44,9 +44,43 @@ def tail_only():
                   f"fwd+bwd {dt*1e3:.3f} ms, inference {di*1e3:.3f} ms")
 
 
+def heads():
+    """FAST 'default' step at the reference's batch with each registry head (fast.py:203), eager and graph replay."""
+    from isd_amd.graph import GraphedTrainStep, graph_safe
+    B, T = 64, 800
+    x = torch.randn(B, 64, T, device="cuda")
+    y = torch.randint(0, 5, (B,), device="cuda")
+    for head in ("Conv4Layers", "EEGNet_Encoder", "CVBlock", "HeadConv_Paper_Version"):
+        for graph in (False, True):
+            torch.manual_seed(0)
+            net = inn.FAST(fast_config(seq_len=T, head=head)).cuda().train()
+            if graph and not graph_safe(net):
+                print(f"FAST default head={head:<22} B={B}: not graph-safe")
+                continue
+            if graph:
+                opt = torch.optim.AdamW(net.parameters(), lr=torch.tensor(5e-4, device="cuda"), capturable=True, fused=True)
+                gs = GraphedTrainStep(net, opt, x, y, B)
+                idx = torch.arange(B, device="cuda")
+
+                def step():
+                    gs.step(idx, 5e-4)
+            else:
+                opt = torch.optim.AdamW(net.parameters(), lr=5e-4, fused=True)
+
+                def step():
+                    opt.zero_grad(set_to_none=True)
+                    inn.token_mean_cross_entropy(net(x, forward_mode="default"), y).backward()
+                    opt.step()
+            dt, _ = timed(step, 20)
+            print(f"FAST default head={head:<22} B={B} {'graph replay' if graph else 'eager       '}: {dt*1e3:.3f} ms/step, "
+                  f"{B/dt:.0f} trials/s")
+
+
 def main():
     if "--tail" in sys.argv:
         return tail_only()
+    if "--heads" in sys.argv:
+        return heads()
     for B, T, act in ((64, 800, "f32"), (1024, 512, "f32"), (4096, 512, "f32"), (1024, 800, "f32"), (64, 800, "bf16"),
                       (4096, 512, "bf16"), (1024, 800, "bf16")):
         torch.manual_seed(0)

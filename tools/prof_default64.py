@@ -7,7 +7,7 @@ import isd_amd.nn as inn
 
 torch.manual_seed(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-net = inn.FAST(inn.fast_config()).cuda().train()
+net = inn.FAST(inn.fast_config(head=os.environ.get("ISD_PROF_HEAD", "Conv4Layers"))).cuda().train()
 opt = torch.optim.AdamW(net.parameters(), lr=5e-4, fused=True)
 x = torch.randn(B, 64, 800, device="cuda")
 y = torch.randint(0, 5, (B,), device="cuda")
