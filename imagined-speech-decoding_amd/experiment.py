@@ -103,8 +103,19 @@ def train_one_fold(config, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, for
         opt = torch.optim.AdamW(model.parameters(), lr=torch.tensor(float(lr), device=Xd.device), capturable=True,
                                 fused=True)
         model.train()
-        gstep = GraphedTrainStep(model, opt, Xd, yd, bs, forward_mode)
-    else:
+        try:
+            gstep = GraphedTrainStep(model, opt, Xd, yd, bs, forward_mode)
+        except RuntimeError as e:                        # a capture the runtime refuses: train eagerly, say so
+            if graph:
+                raise
+            import warnings
+            warnings.warn(f"HIP-graph capture of the training step failed ({e}); continuing with eager launches")
+            torch.cuda.synchronize()
+            use_graph = False
+            torch.manual_seed(seed)
+            reset_dropout_streams()
+            model = FAST(config).cuda()
+    if not use_graph:
         opt = torch.optim.AdamW(model.parameters(), lr=lr, fused=True)
     gen = torch.Generator().manual_seed(seed)
     best, best_sd, hist, step = -1.0, None, [], 0
