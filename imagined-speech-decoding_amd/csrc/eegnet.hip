@@ -494,33 +494,47 @@ __global__ __launch_bounds__(256) void eeg_spatial_kernel(const float* __restric
 }
 
 // u[b,g,t'] = sum_k Wt[f,k] zpad[b,g,t'+k]; per-g sums of u and u^2 (fp64 atomics).  grid (ceil(Tp/256), B*16)
+// KT: the filter length as a compile-time constant (16 / 32 / 64: fully unrolled tap loops without a test per tap -- a
+// run-time bound left every LDS read in its own basic block behind its own wait), 0 = any length
+template <int KT>
 __global__ __launch_bounds__(256) void eeg_tconv_kernel(const float* __restrict__ z, const float* __restrict__ Wt,
-                                                        float* __restrict__ u, EegStats* __restrict__ st, int K, int T,
-                                                        int Tp, int want_stats) {
+                                                        float* __restrict__ u, EegStats* __restrict__ st, int Krt, int T,
+                                                        int Tp, int want_stats, int n_rows) {
+  const int K = KT ? KT : Krt;
   __shared__ float red[4];
   __shared__ float zs[256 + kMaxK];                    // zpad[tp0 .. tp0 + 256 + K): the tile's inputs, staged once
-  const int bg = blockIdx.y, g = bg & (kF2 - 1), f = g >> 1, P = K / 2;
-  const float* zr = z + (int64_t)bg * T;
-  const float* w = Wt + f * K;
-  // a workgroup strides over its row: the per-row sums reach the 16 fp64 accumulators through one atomic per
-  // workgroup, and 35 k workgroups queueing on 16 addresses were what the kernel spent its time on (0.37 ms).
+  // A workgroup strides over its row AND over every gridDim.y-th row (gridDim.y is a multiple of 16, so they share the
+  // filter): the sums reach the 16 fp64 accumulators through one atomic pair per workgroup.  35 k workgroups queueing
+  // on 16 addresses were what the kernel spent its time on at the stress shape (0.37 ms), and 5 k short rows per zone
+  // what the zone heads spent theirs on (57 us per launch for 1.3 M outputs).
   // Each tile of 256 outputs reads its 256 + K inputs through LDS (one global read per input instead of K
   // bounds-checked ones per output: the raw stress head went 1.96 -> 1.79 ms).
+  const int g = blockIdx.y & (kF2 - 1), f = g >> 1, P = K / 2;
+  const float* w = Wt + f * K;
   float t1 = 0.f, t2 = 0.f;
-  for (int tp0 = blockIdx.x * 256; tp0 < Tp; tp0 += gridDim.x * 256) {
-    __syncthreads();                                    // the previous tile's readers are done
-    for (int j = threadIdx.x; j < 256 + K; j += 256) {
-      const int t = tp0 + j - P;
-      zs[j] = (t >= 0 && t < T) ? zr[t] : 0.f;
-    }
-    __syncthreads();
-    const int tp = tp0 + threadIdx.x;
-    if (tp < Tp) {
-      float acc = 0.f;
-      for (int k = 0; k < K; ++k) acc = fmaf(w[k], zs[threadIdx.x + k], acc);
-      u[(int64_t)bg * Tp + tp] = acc;
-      t1 += acc;
-      t2 = fmaf(acc, acc, t2);
+  for (int bg = blockIdx.y; bg < n_rows; bg += gridDim.y) {
+    const float* zr = z + (int64_t)bg * T;
+    for (int tp0 = blockIdx.x * 256; tp0 < Tp; tp0 += gridDim.x * 256) {
+      __syncthreads();                                  // the previous tile's readers are done
+      for (int j = threadIdx.x; j < 256 + K; j += 256) {
+        const int t = tp0 + j - P;
+        const float zv = zr[t < 0 ? 0 : (t < T ? t : T - 1)];
+        zs[j] = (t >= 0 && t < T) ? zv : 0.f;
+      }
+      __syncthreads();
+      const int tp = tp0 + threadIdx.x;
+      if (tp < Tp) {
+        float acc = 0.f;
+        if (KT) {
+#pragma unroll
+          for (int k = 0; k < (KT ? KT : 1); ++k) acc = fmaf(w[k], zs[threadIdx.x + k], acc);
+        } else {
+          for (int k = 0; k < K; ++k) acc = fmaf(w[k], zs[threadIdx.x + k], acc);
+        }
+        u[(int64_t)bg * Tp + tp] = acc;
+        t1 += acc;
+        t2 = fmaf(acc, acc, t2);
+      }
     }
   }
   if (want_stats) {
@@ -582,43 +596,61 @@ __global__ __launch_bounds__(256) void eeg_pool2_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void eeg_sep_kernel(const float* __restrict__ p2, const float* __restrict__ Wd,
                                                       const float* __restrict__ Wp, float* __restrict__ a3out,
                                                       float* __restrict__ a4, EegStats* __restrict__ st, int T2,
-                                                      int T2p, int want_stats) {
+                                                      int T2p, int want_stats, int B) {
   __shared__ float red[4];
-  const int b = blockIdx.y;
+  // a workgroup walks every gridDim.y-th trial and keeps its 32 per-channel sums in registers: one round of block
+  // sums and atomics per workgroup instead of one per trial (short windows: 63 live threads, 32 block sums each)
   const int w = blockIdx.x * 256 + threadIdx.x;
   const bool live = w < T2p;
-  float a3[kF2], o[kF2];
+  float s1[kF2], s2[kF2];
 #pragma unroll
-  for (int g = 0; g < kF2; ++g) {
-    float acc = 0.f;
-    if (live) {
-      const float* pr = p2 + ((int64_t)b * kF2 + g) * T2;
+  for (int h = 0; h < kF2; ++h) s1[h] = s2[h] = 0.f;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    float a3[kF2];
 #pragma unroll
-      for (int k = 0; k < kK2; ++k) {
-        const int v = w + k - kP2;
-        if (v >= 0 && v < T2) acc = fmaf(Wd[g * kK2 + k], pr[v], acc);
+    for (int g = 0; g < kF2; ++g) {
+      float acc = 0.f;
+      if (live) {
+        const float* pr = p2 + ((int64_t)b * kF2 + g) * T2;
+#pragma unroll
+        for (int k = 0; k < kK2; ++k) {                 // clamped address + select: no branch around the load, so the
+          const int v = w + k - kP2;                    // 16 loads of a channel go out together
+          const float pv = pr[v < 0 ? 0 : (v < T2 ? v : T2 - 1)];
+          acc = fmaf(Wd[g * kK2 + k], (v >= 0 && v < T2) ? pv : 0.f, acc);
+        }
+        if (a3out) a3out[((int64_t)b * kF2 + g) * T2p + w] = acc;
       }
-      if (a3out) a3out[((int64_t)b * kF2 + g) * T2p + w] = acc;
+      a3[g] = acc;
     }
-    a3[g] = acc;
-  }
-#pragma unroll
-  for (int h = 0; h < kF2; ++h) {
-    float acc = 0.f;
-#pragma unroll
-    for (int g = 0; g < kF2; ++g) acc = fmaf(Wp[h * kF2 + g], a3[g], acc);
-    o[h] = acc;
-    if (live) a4[((int64_t)b * kF2 + h) * T2p + w] = acc;
-  }
-  if (want_stats) {
 #pragma unroll
     for (int h = 0; h < kF2; ++h) {
-      const float s1 = block_sum(live ? o[h] : 0.f, red);
-      const float s2 = block_sum(live ? o[h] * o[h] : 0.f, red);
-      if (threadIdx.x == 0) {
-        atomicAdd(&st->a1[h], (double)s1);
-        atomicAdd(&st->a2[h], (double)s2);
+      float acc = 0.f;
+#pragma unroll
+      for (int g = 0; g < kF2; ++g) acc = fmaf(Wp[h * kF2 + g], a3[g], acc);
+      if (live) {
+        a4[((int64_t)b * kF2 + h) * T2p + w] = acc;
+        s1[h] += acc;
+        s2[h] = fmaf(acc, acc, s2[h]);
       }
+    }
+  }
+  if (want_stats) {
+    // the 32 sums in one round: wave sums, one barrier, 32 threads finish (32 block_sum calls were 64 barriers)
+    __shared__ float part[4][2 * kF2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int h = 0; h < kF2; ++h) {
+      const float t1 = wave_sum(s1[h]), t2 = wave_sum(s2[h]);
+      if (lane == 0) {
+        part[wv][h] = t1;
+        part[wv][kF2 + h] = t2;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kF2) {
+      const float tot = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+      if (threadIdx.x < kF2) atomicAdd(&st->a1[threadIdx.x], (double)tot);
+      else atomicAdd(&st->a2[threadIdx.x - kF2], (double)tot);
     }
   }
 }
@@ -670,20 +702,23 @@ __global__ __launch_bounds__(256) void eeg_bwd3_sums_kernel(const float* __restr
                                                             const float* __restrict__ dpooled,
                                                             const EegCoef* __restrict__ co, EegStats* __restrict__ st,
                                                             int64_t rows, int T2p, int T3, float dp, uint64_t seed) {
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // gridDim.x is a multiple of 4: a wave's rows (every 4 gridDim.x-th) share h, and it sends ONE atomic pair
+  const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (row >= rows) return;
-  const int h = (int)(row & (kF2 - 1));
+  if (row0 >= rows) return;
+  const int h = (int)(row0 & (kF2 - 1));
   const float A = co->A3[h], Bc = co->B3[h], mu = co->mu3[h], isg = 1.f / co->sig3[h];
-  const float de = T3 > 0 ? dpooled[row] / (float)(8 * T3) : 0.f;
-  const float* ar = a4 + row * T2p;
   float s1 = 0.f, s2 = 0.f;
-  for (int w = lane; w < 8 * T3; w += 64) {
-    const float av = ar[w];
-    const float dy = de * drop_scale((seed + co->seed_add) ^ 0x5bd1e995u, (uint64_t)row * T3 + (w >> 3), dp) *
-                     elu_grad_f(fmaf(A, av, Bc));
-    s1 += dy;
-    s2 += dy * (av - mu) * isg;
+  for (int64_t row = row0; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float de = T3 > 0 ? dpooled[row] / (float)(8 * T3) : 0.f;
+    const float* ar = a4 + row * T2p;
+    for (int w = lane; w < 8 * T3; w += 64) {
+      const float av = ar[w];
+      const float dy = de * drop_scale((seed + co->seed_add) ^ 0x5bd1e995u, (uint64_t)row * T3 + (w >> 3), dp) *
+                       elu_grad_f(fmaf(A, av, Bc));
+      s1 += dy;
+      s2 += dy * (av - mu) * isg;
+    }
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
@@ -755,24 +790,36 @@ __global__ __launch_bounds__(256) void eeg_bwd_sepw_kernel(const float* __restri
                                                            EegStats* __restrict__ st, int B, int T2, int T2p) {
   __shared__ float red[4];
   const int o = blockIdx.x;
-  float s = 0.f;
+  // thread = (trial b0 + 4 j, step w0 + 64 i): no 64-bit division per element, two independent accumulators
+  const int b0 = threadIdx.x >> 6, w0 = threadIdx.x & 63;
+  float sa = 0.f, sb = 0.f;
   if (o < kF2 * kF2) {
     const int h = o / kF2, g = o - h * kF2;
-    for (int64_t e = threadIdx.x; e < (int64_t)B * T2p; e += 256) {
-      const int64_t b = e / T2p;
-      const int w = (int)(e - b * T2p);
-      s = fmaf(da4[(b * kF2 + h) * T2p + w], a3[(b * kF2 + g) * T2p + w], s);
+    for (int b = b0; b < B; b += 8) {
+      const bool two = b + 4 < B;
+      const float* d0 = da4 + ((int64_t)b * kF2 + h) * T2p;
+      const float* a0 = a3 + ((int64_t)b * kF2 + g) * T2p;
+      const float* d1 = da4 + ((int64_t)(two ? b + 4 : b) * kF2 + h) * T2p;
+      const float* a1 = a3 + ((int64_t)(two ? b + 4 : b) * kF2 + g) * T2p;
+      for (int w = w0; w < T2p; w += 64) {
+        sa = fmaf(d0[w], a0[w], sa);
+        sb = fmaf(two ? d1[w] : 0.f, a1[w], sb);
+      }
     }
   } else {
     const int o2 = o - kF2 * kF2;
     const int g = o2 / kK2, k = o2 - g * kK2;
-    for (int64_t e = threadIdx.x; e < (int64_t)B * T2p; e += 256) {
-      const int64_t b = e / T2p;
-      const int w = (int)(e - b * T2p);
-      const int v = w + k - kP2;
-      if (v >= 0 && v < T2) s = fmaf(da3[(b * kF2 + g) * T2p + w], p2[(b * kF2 + g) * T2 + v], s);
+    for (int b = b0; b < B; b += 4) {
+      const float* d0 = da3 + ((int64_t)b * kF2 + g) * T2p;
+      const float* p0 = p2 + ((int64_t)b * kF2 + g) * T2;
+      for (int w = w0; w < T2p; w += 64) {
+        const int v = w + k - kP2;
+        const float pv = p0[v < 0 ? 0 : (v < T2 ? v : T2 - 1)];
+        sa = fmaf(d0[w], (v >= 0 && v < T2) ? pv : 0.f, sa);
+      }
     }
   }
+  const float s = sa + sb;
   const float tot = block_sum(s, red);
   if (threadIdx.x == 0) {
     if (o < kF2 * kF2) st->dWp[o / kF2][o % kF2] = (double)tot;
@@ -784,10 +831,12 @@ __global__ __launch_bounds__(256) void eeg_bwd_sepw_kernel(const float* __restri
 __global__ __launch_bounds__(256) void eeg_bwd_pool2_kernel(const float* __restrict__ da3, const float* __restrict__ Wd,
                                                             const float* __restrict__ u, const EegCoef* __restrict__ co,
                                                             float* __restrict__ dy2, EegStats* __restrict__ st, int Tp,
-                                                            int T2, int T2p, int P1, float dpr, uint64_t seed) {
+                                                            int T2, int T2p, int P1, float dpr, uint64_t seed,
+                                                            int n_rows) {
   __shared__ float red[4];
-  const int bg = blockIdx.y, g = bg & (kF2 - 1);
+  const int g = blockIdx.y & (kF2 - 1);                 // gridDim.y is a multiple of 16: the rows of a workgroup share g
   float t1 = 0.f, t2 = 0.f;
+  for (int bg = blockIdx.y; bg < n_rows; bg += gridDim.y)
   for (int tp = blockIdx.x * 256 + threadIdx.x; tp < Tp; tp += gridDim.x * 256) {   // one atomic pair per workgroup
     float dy = 0.f, xh = 0.f;
     const int v = tp / P1;
@@ -797,7 +846,8 @@ __global__ __launch_bounds__(256) void eeg_bwd_pool2_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < kK2; ++k) {
           const int w = v - k + kP2;
-          if (w >= 0 && w < T2p) dp = fmaf(Wd[g * kK2 + k], da3[(int64_t)bg * T2p + w], dp);
+          const float dv = da3[(int64_t)bg * T2p + (w < 0 ? 0 : (w < T2p ? w : T2p - 1))];
+          dp = fmaf(Wd[g * kK2 + k], (w >= 0 && w < T2p) ? dv : 0.f, dp);
         }
       } else {
         dp = da3[(int64_t)bg * T2 + v];                 // CVBlock: dp2 already formed by cv_bwd_dp2_kernel
@@ -824,10 +874,11 @@ __global__ __launch_bounds__(256) void eeg_bwd_pool2_kernel(const float* __restr
 // da2 = cA2 (dy2 - cB2 - xhat2 cC2) in place; Sd = sum da2, Su = sum da2*u
 __global__ __launch_bounds__(256) void eeg_bwd_bn2_kernel(float* __restrict__ dy2, const float* __restrict__ u,
                                                           const EegCoef* __restrict__ co, EegStats* __restrict__ st,
-                                                          int Tp) {
+                                                          int Tp, int n_rows) {
   __shared__ float red[4];
-  const int bg = blockIdx.y, g = bg & (kF2 - 1);
+  const int g = blockIdx.y & (kF2 - 1);                 // gridDim.y is a multiple of 16: the rows of a workgroup share g
   float t1 = 0.f, t2 = 0.f;
+  for (int bg = blockIdx.y; bg < n_rows; bg += gridDim.y)
   for (int tp = blockIdx.x * 256 + threadIdx.x; tp < Tp; tp += gridDim.x * 256) {   // one atomic pair per workgroup
     const float uv = u[(int64_t)bg * Tp + tp];
     const float xh = (co->s1[g >> 1] * uv + co->o1[g >> 1] * co->wsum[g] - co->mu2[g]) / co->sig2[g];
@@ -849,48 +900,65 @@ __global__ __launch_bounds__(256) void eeg_bwd_bn2_kernel(float* __restrict__ dy
 // grid (B*16, segments): a workgroup takes kCorrSeg time steps of its row (with the whole row in LDS -- 33 KiB at
 // T = 4096 -- a CU held 4 of these one-wave workgroups and the kernel was the slowest of the raw stress head).
 constexpr int kCorrSeg = 1024;
+template <int KT>
 __global__ __launch_bounds__(64) void eeg_bwd_corr_kernel(const float* __restrict__ da2, const float* __restrict__ z,
                                                           const float* __restrict__ Wt, float* __restrict__ v,
-                                                          EegStats* __restrict__ st, int K, int T, int Tp) {
+                                                          EegStats* __restrict__ st, int Krt, int T, int Tp, int n_rows) {
+  const int K = KT ? KT : Krt;
+  constexpr int KA = KT ? KT : kMaxK;                   // accumulators kept
   extern __shared__ float sm[];                         // z[s0 - P + j], j < L + K + 64;  da2[s0 - K + j], j < L + 2K + 64
-  const int bg = blockIdx.x, g = bg & (kF2 - 1), f = g >> 1, P = K / 2, lane = threadIdx.x;
+  // gridDim.x is a multiple of 16: the rows of a workgroup (every gridDim.x-th) share g, their K lag sums stay in
+  // registers and reach the fp64 accumulators once per workgroup (5 k rows x 64 lags on 1 k addresses were 0.15 ms)
+  const int g = blockIdx.x & (kF2 - 1), f = g >> 1, P = K / 2, lane = threadIdx.x;
   const int s0 = blockIdx.y * kCorrSeg, L = kCorrSeg;
   float* zp = sm;
   float* dp = sm + L + K + 64;
-  const float* zr = z + (int64_t)bg * T;
-  const float* dr = da2 + (int64_t)bg * Tp;
-  for (int j = lane; j < L + K + 64; j += 64) {
-    const int t = s0 - P + j;
-    zp[j] = (t >= 0 && t < T) ? zr[t] : 0.f;
-  }
-  for (int j = lane; j < L + 2 * K + 64; j += 64) {
-    const int t = s0 - K + j;
-    dp[j] = (t >= 0 && t < Tp) ? dr[t] : 0.f;
-  }
-  wave_lds_sync();
-  float acc[kMaxK];
+  float* w = dp + L + 2 * K + 64;                       // the filter's taps (64 scalars in the SGPR file spilled)
+  for (int k = lane; k < K; k += 64) w[k] = Wt[f * K + k];
+  float acc[KA];
 #pragma unroll
-  for (int k = 0; k < kMaxK; ++k) acc[k] = 0.f;
-  const int n1 = Tp - s0 < L ? Tp - s0 : L;             // t' = s0 + u, u < n1
-  for (int u0 = 0; u0 < n1; u0 += 64) {
-    const float dv = dp[K + u0 + lane];                 // da2[s0 + u0 + lane], 0 beyond Tp
+  for (int k = 0; k < KA; ++k) acc[k] = 0.f;
+  for (int bg = blockIdx.x; bg < n_rows; bg += gridDim.x) {
+    const float* zr = z + (int64_t)bg * T;
+    const float* dr = da2 + (int64_t)bg * Tp;
+    wave_lds_sync();                                    // the previous row's readers are done
+    const int n1 = Tp - s0 < L ? Tp - s0 : L;           // t' = s0 + u, u < n1
+    const int Lr = (n1 + 63) & ~63;                     // what this segment touches (short rows: a fraction of L)
+    // clamped addresses + selects: a branch around each load would serialise them (one L2 round trip per iteration)
+#pragma unroll 4
+    for (int j = lane; j < Lr + K + 64; j += 64) {
+      const int t = s0 - P + j;
+      const float zv = zr[t < 0 ? 0 : (t < T ? t : T - 1)];
+      zp[j] = (t >= 0 && t < T) ? zv : 0.f;
+    }
+#pragma unroll 4
+    for (int j = lane; j < Lr + 2 * K + 64; j += 64) {
+      const int t = s0 - K + j;
+      const float dv = dr[t < 0 ? 0 : (t < Tp ? t : Tp - 1)];
+      dp[j] = (t >= 0 && t < Tp) ? dv : 0.f;
+    }
+    wave_lds_sync();
+    for (int u0 = 0; u0 < n1; u0 += 64) {
+      const float dv = dp[K + u0 + lane];               // da2[s0 + u0 + lane], 0 beyond Tp
 #pragma unroll
-    for (int k = 0; k < kMaxK; ++k)
-      if (k < K) acc[k] = fmaf(dv, zp[u0 + lane + k], acc[k]);    // z[t' + k - P]
+      for (int k = 0; k < KA; ++k)
+        if (KT || k < K) acc[k] = fmaf(dv, zp[u0 + lane + k], acc[k]);    // z[t' + k - P]
+    }
+    const int n2 = T - s0 < L ? T - s0 : L;             // t = s0 + u, u < n2
+    for (int u = lane; u < n2; u += 64) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < KA; ++k)
+        if (KT || k < K) a = fmaf(w[k], dp[K + u - k + P], a);            // da2[t - k + P]
+      v[(int64_t)bg * T + s0 + u] = a;
+    }
   }
 #pragma unroll
-  for (int k = 0; k < kMaxK; ++k) {
-    if (k < K) {
+  for (int k = 0; k < KA; ++k) {
+    if (KT || k < K) {
       const float tot = wave_sum(acc[k]);
       if (lane == 0) atomicAdd(&st->T1[g][k], (double)tot);
     }
-  }
-  const float* w = Wt + f * K;
-  const int n2 = T - s0 < L ? T - s0 : L;               // t = s0 + u, u < n2
-  for (int u = lane; u < n2; u += 64) {
-    float a = 0.f;
-    for (int k = 0; k < K; ++k) a = fmaf(w[k], dp[K + u - k + P], a);   // da2[t - k + P]
-    v[(int64_t)bg * T + s0 + u] = a;
   }
 }
 
@@ -1034,11 +1102,14 @@ __global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restr
 //   c3_f = g1_f meanDa_f / sig1_f^2,  c2_f = (g1_f / sig1_f) meanD_f - c3_f mu1_f   (BatchNorm's mean / variance paths;
 //   meanD, meanDa as in eeg_bwd_final_kernel).  One workgroup per (row, 256-sample segment): the row segment with a
 //   64-sample halo in LDS, per filter the a1 values the segment's outputs touch, then the transposed filter.
+template <int KT>
 __global__ __launch_bounds__(256) void eeg_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ v,
                                                          const float* __restrict__ params, float* __restrict__ dx,
                                                          const EegStats* __restrict__ st, const EegCoef* __restrict__ co,
-                                                         EegOff off, int C, int K, int T, int Tp, double N1,
+                                                         EegOff off, int C, int Krt, int T, int Tp, double N1,
                                                          int bn_train) {
+  const int K = KT ? KT : Krt;
+  constexpr int KA = KT ? KT : kMaxK;
   __shared__ float xs[256 + 2 * kMaxK];                  // x[s0 - K + j]
   __shared__ float tmp[256 + kMaxK];                     // c3 a1[t'] + c2 for t' = s0 - (K - 1 - P) + u, 0 outside [0, Tp)
   __shared__ float wt[kMaxK];
@@ -1082,7 +1153,9 @@ __global__ __launch_bounds__(256) void eeg_bwd_dx_kernel(const float* __restrict
         if (tp >= 0 && tp < Tp) {
           // a1[t'] = sum_k Wt[k] x[t' + k - P];  xs index of x[t' - P] is t' - P - s0 + K
           const float* xw = xs + (tp - P - s0 + K);
-          for (int k = 0; k < K; ++k) a = fmaf(wt[k], xw[k], a);
+#pragma unroll
+          for (int k = 0; k < KA; ++k)
+            if (KT || k < K) a = fmaf(wt[k], xw[k], a);
           a = fmaf(c3s[f], a, c2s[f]);
         }
         tmp[u] = a;
@@ -1090,7 +1163,9 @@ __global__ __launch_bounds__(256) void eeg_bwd_dx_kernel(const float* __restrict
       __syncthreads();
       // t' = t - k + P  ->  u = t' - u_lo = tid - k + K - 1
       float sub = 0.f;
-      for (int k = 0; k < K; ++k) sub = fmaf(wt[k], tmp[tid - k + K - 1], sub);
+#pragma unroll
+      for (int k = 0; k < KA; ++k)
+        if (KT || k < K) sub = fmaf(wt[k], tmp[tid - k + K - 1], sub);
       acc -= sub;
     }
   }
@@ -1404,6 +1479,13 @@ extern "C" int64_t isd_eegnet_workspace_bytes(const isd_eegnet_plan* p, int64_t 
 
 // workgroups per row for the kernels that end in one fp64 atomic per workgroup and statistic: enough of them to
 // fill the chip (~4 k workgroups), no more
+// y-extent of the launches whose workgroups also walk rows: a multiple of 16 (the rows of a workgroup share the filter),
+// about 1 k workgroups in all (64 atomics per accumulator address)
+static unsigned row_groups(int64_t rows16, unsigned per_row) {
+  int64_t want = 1024 / (per_row ? per_row : 1) / 16 * 16;
+  if (want < 16) want = 16;
+  return (unsigned)(rows16 < want ? rows16 : want);
+}
 static unsigned row_blocks(int row_len, int64_t n_rows) {
   const int64_t full = cdiv(row_len, 256);
   int64_t want = cdiv(4096, n_rows > 0 ? n_rows : 1);
@@ -1472,8 +1554,18 @@ static int eeg_forward_stage(const isd_eegnet_plan* p, int stage, const float* x
                        rows * world, training, momentum, eps, p->seed_dev);
     hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(T, 16), (unsigned)B), dim3(256), 0, st, x,
                        params + p->off.Ws, ws + w.z, C, T, (int)cdiv(T, 16));
-    hipLaunchKernelGGL(eeg_tconv_kernel, dim3(row_blocks(Tp, B * kF2), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.z,
-                       params + p->off.Wt, ws + w.u, S, K, T, Tp, training);
+    {
+      const unsigned gx = row_blocks(Tp, B * kF2);
+#define ISD_EEG_K(KERNEL, ...)                          \
+  do {                                                 \
+    if (K == 64) hipLaunchKernelGGL(KERNEL<64>, __VA_ARGS__);      \
+    else if (K == 32) hipLaunchKernelGGL(KERNEL<32>, __VA_ARGS__); \
+    else if (K == 16) hipLaunchKernelGGL(KERNEL<16>, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<0>, __VA_ARGS__);               \
+  } while (0)
+      ISD_EEG_K(eeg_tconv_kernel, dim3(gx, row_groups(B * kF2, gx)), dim3(256), 0, st, ws + w.z, params + p->off.Wt,
+                ws + w.u, S, K, T, Tp, training, (int)(B * kF2));
+    }
     ISD_LAUNCH_CHECK();
     return ISD_OK;
   }
@@ -1488,9 +1580,11 @@ static int eeg_forward_stage(const isd_eegnet_plan* p, int stage, const float* x
       hipLaunchKernelGGL(cv_conv3_kernel, dim3((unsigned)cdiv(B * T2p, 256)), dim3(256), 0, st, ws + w.p2, ws + w.w3f,
                          ws + w.a4, S, B, T2, T2p, training);
     } else {
-      hipLaunchKernelGGL(eeg_sep_kernel, dim3((unsigned)cdiv(T2p, 256), (unsigned)B), dim3(256), 0, st, ws + w.p2,
+      const unsigned gxs = (unsigned)cdiv(T2p, 256);
+      const int64_t gys = 2048 / gxs > 0 ? 2048 / gxs : 1;
+      hipLaunchKernelGGL(eeg_sep_kernel, dim3(gxs, (unsigned)(B < gys ? B : gys)), dim3(256), 0, st, ws + w.p2,
                          params + p->off.Wd, params + p->off.Wp, keep ? ws + w.a3 : nullptr, ws + w.a4, S, T2, T2p,
-                         training);
+                         training, (int)B);
     }
     ISD_LAUNCH_CHECK();
     return ISD_OK;
@@ -1562,8 +1656,8 @@ static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* 
       hipLaunchKernelGGL(cv_bwd3_sums_kernel, dim3((unsigned)cdiv(rows16, 4)), dim3(256), 0, st, ws + w.a4, ws + w.dpooled,
                          Cf, S, rows16, T2p, T3, p->P2, dropout_p, seed);
     else
-      hipLaunchKernelGGL(eeg_bwd3_sums_kernel, dim3((unsigned)cdiv(rows16, 4)), dim3(256), 0, st, ws + w.a4, ws + w.dpooled,
-                         Cf, S, rows16, T2p, T3, dropout_p, seed);
+      hipLaunchKernelGGL(eeg_bwd3_sums_kernel, dim3((unsigned)(rows16 / 4 < 256 ? rows16 / 4 : 256)), dim3(256), 0, st,
+                         ws + w.a4, ws + w.dpooled, Cf, S, rows16, T2p, T3, dropout_p, seed);
     ISD_LAUNCH_CHECK();
     return ISD_OK;
   }
@@ -1579,16 +1673,17 @@ static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* 
                          dparams + p->off.Wd);
       hipLaunchKernelGGL(cv_bwd_dp2_kernel, dim3((unsigned)cdiv(B * T2, 256)), dim3(256), 0, st, ws + w.da4, ws + w.w3b,
                          ws + w.da3, B, T2, T2p);
-      hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st,
-                         ws + w.da3, (const float*)nullptr, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, p->P1, dropout_p,
-                         seed);
+      hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), row_groups(rows16, row_blocks(Tp, rows16))),
+                         dim3(256), 0, st, ws + w.da3, (const float*)nullptr, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p,
+                         p->P1, dropout_p, seed, (int)rows16);
     } else {
       hipLaunchKernelGGL(eeg_bwd_sep_kernel, dim3((unsigned)cdiv(T2p, 256), (unsigned)B), dim3(256), 0, st, ws + w.a4,
                          ws + w.dpooled, params + p->off.Wp, Cf, ws + w.da4, ws + w.da3, T2p, T3, dropout_p, seed);
       hipLaunchKernelGGL(eeg_bwd_sepw_kernel, dim3(kF2 * kF2 + kF2 * kK2), dim3(256), 0, st, ws + w.da4, ws + w.a3,
                          ws + w.da3, ws + w.p2, S, (int)B, T2, T2p);
-      hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st,
-                         ws + w.da3, params + p->off.Wd, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, p->P1, dropout_p, seed);
+      hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), row_groups(rows16, row_blocks(Tp, rows16))),
+                         dim3(256), 0, st, ws + w.da3, params + p->off.Wd, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, p->P1,
+                         dropout_p, seed, (int)rows16);
     }
     ISD_LAUNCH_CHECK();
     return ISD_OK;
@@ -1596,12 +1691,13 @@ static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* 
   if (stage == 2) {
     hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
                        (double)B * (double)Tp * wd, 2, gs, bn_train);
-    hipLaunchKernelGGL(eeg_bwd_bn2_kernel, dim3(row_blocks(Tp, rows16), (unsigned)rows16), dim3(256), 0, st, ws + w.dy2,
-                       ws + w.u, Cf, S, Tp);
+    hipLaunchKernelGGL(eeg_bwd_bn2_kernel, dim3(row_blocks(Tp, rows16), row_groups(rows16, row_blocks(Tp, rows16))),
+                       dim3(256), 0, st, ws + w.dy2, ws + w.u, Cf, S, Tp, (int)rows16);
     {
-      const size_t lds = sizeof(float) * (size_t)((kCorrSeg + K + 64) + (kCorrSeg + 2 * K + 64));
-      hipLaunchKernelGGL(eeg_bwd_corr_kernel, dim3((unsigned)rows16, (unsigned)cdiv(Tp, kCorrSeg)), dim3(64), lds, st,
-                         ws + w.dy2, ws + w.z, params + p->off.Wt, ws + w.v, S, K, T, Tp);
+      const size_t lds = sizeof(float) * (size_t)((kCorrSeg + K + 64) + (kCorrSeg + 2 * K + 64) + kMaxK);
+      const unsigned segs = (unsigned)cdiv(Tp, kCorrSeg);
+      ISD_EEG_K(eeg_bwd_corr_kernel, dim3(row_groups(rows16, segs), segs), dim3(64), lds, st, ws + w.dy2, ws + w.z,
+                params + p->off.Wt, ws + w.v, S, K, T, Tp, (int)rows16);
     }
     const int64_t n_chunks = B * ((T + 255) / 256);
     const int slabs = n_chunks < w.n_slabs ? (int)n_chunks : w.n_slabs;
@@ -1660,9 +1756,10 @@ extern "C" int isd_eegnet_backward_x(const isd_eegnet_plan* p, const float* x, c
   float* ws = (float*)workspace;
   const EegWs w = eeg_layout(p, B);
   ISD_CHECK_ARG(B * p->C <= 0x7fffffffLL, "isd_eegnet_backward_x: too many rows");
-  hipLaunchKernelGGL(eeg_bwd_dx_kernel, dim3((unsigned)(B * p->C), (unsigned)cdiv(p->T, 256)), dim3(256), 0, st, x,
-                     ws + w.v, params, dx, (const EegStats*)(ws + w.stats), (const EegCoef*)(ws + w.coef), p->off, p->C,
-                     p->K, p->T, p->Tp, (double)(B * p->C) * (double)p->Tp, bn_train);
+  const int K = p->K;
+  ISD_EEG_K(eeg_bwd_dx_kernel, dim3((unsigned)(B * p->C), (unsigned)cdiv(p->T, 256)), dim3(256), 0, st, x, ws + w.v, params,
+            dx, (const EegStats*)(ws + w.stats), (const EegCoef*)(ws + w.coef), p->off, p->C, p->K, p->T, p->Tp,
+            (double)(B * p->C) * (double)p->Tp, bn_train);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
