@@ -56,6 +56,12 @@ __device__ __forceinline__ float row_shl(float v) {
   int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true);
   return __int_as_float(r);
 }
+// DPP rotate right by N inside the 16-lane row (lane i reads lane (i - N) mod 16): dpp_ctrl row_ror:N
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+  int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, true);
+  return __int_as_float(r);
+}
 // DPP shift right by one lane across the WHOLE wave (gfx9 wave_shr:1; lane 0 gets 0): joins neighbouring chunks of a
 // row that spans two or four 16-lane DPP rows
 __device__ __forceinline__ float wave_shr1(float v) {

@@ -140,7 +140,9 @@ __device__ __forceinline__ void scan_step(double& e1, double& e2, const double* 
 // LDS once per band: as a per-lane global load inside the section they were waited for ~100 instructions after issue,
 // at L2 latency under a saturated write stream (PMC: the fp32 long-row kernel sat in s_waitcnt for half of its wave
 // cycles).
-template <typename VT, int GPR>
+// CARRY (with GPR == 1): every 16-lane group walks its own row in 512-sample passes; (c1, c2) is the state entering the
+// group's pass and comes back, on lane 15 of the group, as the state leaving it (P c + the group's own end state).
+template <typename VT, int GPR, bool CARRY = false>
 __device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& sc, const double* Qsec,
                                         int lane, double& c1, double& c2) {
   // in-chunk recursion from zero state, both halves side by side; sA = final state of the first half,
@@ -189,6 +191,16 @@ __device__ __forceinline__ void section(typename VOps<VT>::Arr& v, const FbSec& 
   scan_step<8>(e1, e2, sm.Mp[3]);
   double i1 = row_shr<1>(e1);                          // exclusive; lane 0 of each 16-lane row -> 0
   double i2 = row_shr<1>(e2);
+  if (GPR == 1 && CARRY) {
+    const double2* Q2 = reinterpret_cast<const double2*>(Qsec + (lane & 15) * 4);      // M^i of this lane
+    const double2 Qa = Q2[0], Qb = Q2[1];
+    i1 = fma(Qa.x, c1, fma(Qa.y, c2, i1));
+    i2 = fma(Qb.x, c1, fma(Qb.y, c2, i2));
+    const double n1 = fma(sm.P[0], c1, fma(sm.P[1], c2, e1));    // meaningful on lane 15: M^16 c + the group's end state
+    const double n2 = fma(sm.P[2], c1, fma(sm.P[3], c2, e2));
+    c1 = n1;
+    c2 = n2;
+  }
   if (GPR > 1) {
     // group totals (wave-uniform) and the serial chain over the 4 groups of the wave
     double E1[4], E2[4];
@@ -835,6 +847,169 @@ void fused_long_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict_
   }
 }
 
+// The same extraction with FOUR ROWS PER WAVE (rows of a multiple of 512 samples, at most 16 blocks per frame): every
+// 16-lane group walks its own row in 512-sample passes and carries its section states from pass to pass.  In
+// fused_long_kernel the wave's four groups hold consecutive quarters of one 2048-sample pass and their end states are
+// chained serially per section -- 16 v_readlane, 16 uniform fp64 FMAs and 12 selects on top of the 136-instruction
+// section body of a kernel that is VALU-issue bound (PMC: 1 447 vector instructions per band and pass, 100 % of the
+// launch at 4 cycles each).  Groups that own their rows need none of it: the carry is two doubles per (section,
+// group) in LDS.  The frames are finished as the row streams by: a frame is the sum of nblk consecutive block sums,
+// so after every pass the eight frames whose last block just arrived are formed from a 32-block ring per (row, bin)
+// -- keeping all 64 blocks of four rows until the end of the band cost 10 KiB of LDS and two waves per SIMD.
+template <typename VT, int KB>
+__global__ __launch_bounds__(64)
+void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
+                        const double* __restrict__ Qtab, const float2* __restrict__ blk,
+                        const float* __restrict__ x, float* __restrict__ feat, int C,
+                        int T, int nb, int ns, int J, int log2_nblk, int n_bins_max,
+                        float scale2, FusedBands fbnd, int mode, float eps,
+                        const int* __restrict__ bmap, int nb_out, int n_rows) {
+  using O = VOps<VT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane0 = threadIdx.x;
+  const int n_iter = T / kSeg;                                             // 512-sample passes
+  const int n_blocks = T >> 6;                                             // 64-sample blocks of a row
+  float2* ring = reinterpret_cast<float2*>(smem_raw);                      // [4 rows][KB][32]: block m at m & 31
+  float2* tw = ring + 4 * KB * 32;                                         // [64]  e^{-2 pi i u / nblk}
+  double* carry = reinterpret_cast<double*>(tw + 64);                      // [kMaxSec][4 groups][2]
+  double* Qlds = carry + kMaxSec * 8;                                      // [kMaxSec][16][4] the band's per-lane M^i
+  // id = 8 kLongShare q + 8 w + c  <->  row quad = 8 q + c, band subset w (the sharers of a quad run on one XCD)
+  const int id = blockIdx.x;
+  const int quad = (id / (8 * kLongShare)) * 8 + (id & 7);
+  const int share = (id >> 3) % kLongShare;
+  if (quad * 4 >= n_rows) return;
+  const int nblk = 1 << log2_nblk, half = nblk >> 1;
+  if (lane0 < nblk) {
+    float sn, cs;
+    sincospif(2.f * (float)lane0 / (float)nblk, &sn, &cs);
+    tw[lane0] = make_float2(cs, -sn);
+  }
+  wave_lds_sync();
+  for (int b = share; b < nb; b += kLongShare) {
+    int lane = lane0;                                    // lane-derived addresses are re-formed per band (see above)
+    asm volatile("" : "+v"(lane));
+    const int q = lane >> 4, li = lane & 15;
+    const bool row_ok = quad * 4 + q < n_rows;
+    const int row = row_ok ? quad * 4 + q : n_rows - 1;                    // a missing row recomputes the last one
+    const float* src = x + row * (int64_t)T;
+    const int bt = row / C, ch = row - bt * C;
+    float* out = feat + (((int64_t)bt * nb_out + bmap[b]) * C + ch) * (int64_t)J;
+    const int klo = fbnd.klo[b], khi = fbnd.khi[b];
+    const int k0 = klo - 1, nbin = khi - klo + 1;
+    if (lane < ns * 8) carry[lane] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 2 * KB; ++e) ring[e * 64 + lane] = make_float2(0.f, 0.f);      // 4 x KB x 32 slots
+    stage_q(Qlds, Qtab, b, ns, lane);
+    wave_lds_sync();
+    const auto gain = O::g(bands[b]);
+    for (int it = 0; it <= n_iter; ++it) {
+      if (it == n_iter && !(lane & 1)) {                 // the eight blocks past the end of the row: zeros
+        const int sl = (it * 8 + (li >> 1)) & 31;
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) ring[(q * KB + kk) * 32 + sl] = make_float2(0.f, 0.f);
+      }
+      if (it < n_iter) {
+        typename O::Arr v;
+        {
+          float4 xf[kL / 4];
+          chunk_issue<true>(xf, src, 0, it * 16 + li, T);
+          XArr xs;
+#pragma unroll
+          for (int j = 0; j < kL / 2; ++j) xs[j] = (f2){f4_get(xf[j >> 2], j & 3), f4_get(xf[(j >> 2) + 4], j & 3)};
+          O::from_x(v, xs, gain);
+        }
+        for (int sct = 0; sct < ns; ++sct) {
+          double c1 = carry[(sct * 4 + q) * 2], c2 = carry[(sct * 4 + q) * 2 + 1];
+          section<VT, 1, true>(v, secs[b * ns + sct], Qlds + sct * 64, lane, c1, c2);
+          wave_lds_sync();                              // every lane has read the incoming carry
+          if (li == 15) {
+            carry[(sct * 4 + q) * 2] = c1;
+            carry[(sct * 4 + q) * 2 + 1] = c2;
+          }
+        }
+        float vf[kL];
+#pragma unroll
+        for (int n = 0; n < kL; ++n) vf[n] = (float)O::at(v, n);
+        // half-block DFT sums with block-local phase (this lane's 32 samples start at offset 32*(lane&1) in the block)
+        const int m = it * 8 + (li >> 1);
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+          __builtin_amdgcn_sched_barrier(0);            // one bin's 64 table scalars at a time in the SGPR file
+          const int k = k0 + kk < n_bins_max ? k0 + kk : n_bins_max;
+          const float2* tb = blk + (int64_t)k * 64;
+          f2 acc = {0.f, 0.f};
+#pragma unroll
+          for (int n = 0; n < kL; ++n) acc = __builtin_elementwise_fma((f2){vf[n], vf[n]}, (f2){tb[n].x, tb[n].y}, acc);
+          const float2 ph = tb[kL];                     // e^{-2 pi i k 32 / n}: the odd lane's offset in the block
+          const float px = (lane & 1) ? acc.x * ph.x - acc.y * ph.y : acc.x;
+          const float py = (lane & 1) ? acc.x * ph.y + acc.y * ph.x : acc.y;
+          const float sx = px + row_shl<1>(px), sy = py + row_shl<1>(py);
+          // absolute block phase e^{-2 pi i k m / nblk}, then into the ring
+          const float2 w = tw[((k0 + kk) * m) & (nblk - 1)];
+          if (!(lane & 1)) ring[(q * KB + kk) * 32 + (m & 31)] = make_float2(sx * w.x - sy * w.y, sx * w.y + sy * w.x);
+        }
+      }
+      wave_lds_sync();
+      // frames j = 8 it - 7 .. 8 it: their last block (j + half - 1 <= 8 it + 7) has arrived, or lies past the row.
+      // Lane = (frame j0 + (li & 7), half of the window li >> 3); the two halves meet through one DPP rotation.
+      {
+        const int j = 8 * it - 7 + (li & 7);
+        const int m0 = j - half + (li >> 3) * half;      // this lane's `half` blocks: m0 .. m0 + half - 1
+        // blocks before the row and past its end read as zero because their ring slots ARE zero (cleared at the start
+        // of the band and, for the slots past the end, before the last round): no test per read
+        const float2* rq = ring + q * KB * 32;
+        float2 R[KB];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) R[kk] = make_float2(0.f, 0.f);
+        if (half == 8) {
+#pragma unroll
+          for (int d = 0; d < 8; ++d) {
+            const int sl = (m0 + d) & 31;
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+              const float2 sv = rq[kk * 32 + sl];
+              R[kk].x += sv.x;
+              R[kk].y += sv.y;
+            }
+          }
+        } else {
+          for (int d = 0; d < half; ++d) {
+            const int sl = (m0 + d) & 31;
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+              const float2 sv = rq[kk * 32 + sl];
+              R[kk].x += sv.x;
+              R[kk].y += sv.y;
+            }
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+          R[kk].x += row_ror<8>(R[kk].x);
+          R[kk].y += row_ror<8>(R[kk].y);
+        }
+        const float2 wn = tw[j & (nblk - 1)];                        // e^{-2 pi i j/nblk};  w^j = conj(wn)
+        float acc = 0.f;
+#pragma unroll
+        for (int bq = 0; bq < KB - 2; ++bq) {
+          if (bq < nbin) {
+            const float2 lo = R[bq], mid = R[bq + 1], hi = R[bq + 2];
+            const float sx = hi.x * wn.x + hi.y * wn.y + lo.x * wn.x - lo.y * wn.y;
+            const float sy = hi.y * wn.x - hi.x * wn.y + lo.y * wn.x + lo.x * wn.y;
+            const float vx = 0.5f * mid.x + 0.25f * sx, vy = 0.5f * mid.y + 0.25f * sy;
+            const float pw = (vx * vx + vy * vy) * scale2;
+            acc += mode == ISD_BP_MAGNITUDE ? sqrtf(pw) : pw;
+          }
+        }
+        float r = nbin > 0 ? acc / (float)nbin : 0.f;
+        if (mode == ISD_BP_LOGPOWER) r = logf(r + eps);
+        if (row_ok && li < 8 && j >= 0 && j < J) out[j] = r;
+      }
+      wave_lds_sync();                                   // the ring slots this round read may be overwritten next pass
+    }
+  }
+}
+
 static void mat2_mul(const double* a, const double* b, double* o) {
   double r[4] = {a[0] * b[0] + a[1] * b[2], a[0] * b[1] + a[1] * b[3], a[2] * b[0] + a[3] * b[2],
                  a[2] * b[1] + a[3] * b[3]};
@@ -1095,7 +1270,24 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
   hipLaunchKernelGGL((fused_long_kernel<VT, K, V>), dim3((unsigned)(cdiv(rows, 8) * 8 * kLongShare)), dim3(64), lds, s, \
                      fs.d_sec, fs.d_band, fs.d_Q, st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections, st->J,      \
                      log2_nblk, st->n / 2, st->scale * st->scale, fbnd, mode, eps, fs.d_map, fb->n_bands, (int)rows)
-#define ISD_FL_LAUNCH(VT, K) do { if (vec) ISD_FL_LAUNCH2(VT, K, true); else ISD_FL_LAUNCH2(VT, K, false); } while (0)
+      // rows of whole 512-sample passes covering all 64 blocks: four rows per wave, no cross-group chain
+      const bool rows4 = vec && st->T % kSeg == 0 && log2_nblk <= 4 && log2_nblk >= 1 && getenv("ISD_FUSED_ROWS4_OFF") == nullptr;
+      const size_t lds4 = sizeof(float2) * ((size_t)4 * KB * 32 + 64) + sizeof(double) * (8 * kMaxSec + 64 * kMaxSec);
+#define ISD_FL_LAUNCH4(VT, K)                                                                                         \
+  do {                                                                                                                \
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)fused_rows4_kernel<VT, K>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds4));                                                                      \
+    hipLaunchKernelGGL((fused_rows4_kernel<VT, K>), dim3((unsigned)(cdiv(cdiv(rows, 4), 8) * 8 * kLongShare)), dim3(64),  \
+                       lds4, s, fs.d_sec, fs.d_band, fs.d_Q, st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections,  \
+                       st->J, log2_nblk, st->n / 2, st->scale * st->scale, fbnd, mode, eps, fs.d_map, fb->n_bands,      \
+                       (int)rows);                                                                                    \
+  } while (0)
+#define ISD_FL_LAUNCH(VT, K)                                        \
+  do {                                                              \
+    if (rows4 && K <= 5) ISD_FL_LAUNCH4(VT, (K <= 5 ? K : 5));      \
+    else if (vec) ISD_FL_LAUNCH2(VT, K, true);                      \
+    else ISD_FL_LAUNCH2(VT, K, false);                              \
+  } while (0)
       if (k == 0) {
         if (KB == 4) ISD_FL_LAUNCH(float, 4); else if (KB == 5) ISD_FL_LAUNCH(float, 5);
         else if (KB == 6) ISD_FL_LAUNCH(float, 6); else ISD_FL_LAUNCH(float, 8);
@@ -1104,6 +1296,7 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
         else if (KB == 6) ISD_FL_LAUNCH(double, 6); else ISD_FL_LAUNCH(double, 8);
       }
 #undef ISD_FL_LAUNCH2
+#undef ISD_FL_LAUNCH4
 #undef ISD_FL_LAUNCH
       ISD_LAUNCH_CHECK();
     }
