@@ -151,8 +151,9 @@ def filterbank_hbm_roofline(fx, x, nb, n=4):
                     "mixed": "fb_kernel<float,%d> + fb_kernel<double,%d> (per-band precision)"}[fx.fb.precision]
         launches = launches.replace("%d", "1" if T <= 512 else "2")
     else:
-        launches = {"f32": "fb_long_kernel_f32", "f64": "fb_long_kernel_f64",
-                    "mixed": "fb_long_kernel_f32 + fb_long_kernel_f64 (per-band precision)"}[fx.fb.precision]
+        stem = "fb_rows4_kernel" if xs.shape[-1] % 512 == 0 else "fb_long_kernel"      # csrc/fb.hip fb_launch_t
+        launches = {"f32": f"{stem}_f32", "f64": f"{stem}_f64",
+                    "mixed": f"{stem}_f32 + {stem}_f64 (per-band precision)"}[fx.fb.precision]
     del y
     return {"bound": "hbm", "kernel": launches, "achieved": round(by / (ms * 1e-3) / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -553,6 +553,106 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fb
 }
 #undef ISD_FB_LONG_ARGS
 
+// Long rows of whole 512-sample passes, FOUR ROWS PER WAVE: every 16-lane group walks its own row and carries its
+// section states from pass to pass (two doubles per band, section and group in LDS), so the serial cross-group chain
+// of fb_long_body -- a hundred vector instructions per section in a kernel the PMC shows 87 % VALU-busy -- is gone.
+// kLongShare workgroups share a quad of rows, each taking every kLongShare-th band, and the PASS loop is outermost:
+// a pass of x is read once per workgroup and filtered through all of the workgroup's bands (with the band loop
+// outermost the quad was re-read per band: the PMC showed 2.75 GB through the fabric for a 268 MB input next to the
+// 6.4 GB of filtered output -- the kernel sat at the memory system's limit on traffic it did not need).  The per-lane
+// M^i come straight from global memory (L1-resident, 64 bytes per lane and section).  The filtered pass leaves two
+// rows at a time through the half tile as coalesced float4 stores.
+constexpr int kRows4Bands = (kMaxBands + kLongShare - 1) / kLongShare;      // bands of one workgroup
+template <typename VT, bool PASS_OUTER>
+__device__ __forceinline__ void fb_rows4_body(
+    const FbSec* __restrict__ secs, const FbBand* __restrict__ bands, const double* __restrict__ Qtab,
+    const float* __restrict__ x, float* __restrict__ y, int C, int T, int nb, int ns,
+    const int* __restrict__ bmap, int nb_out, int n_rows) {
+  using O = VOps<VT>;
+  __shared__ __attribute__((aligned(16))) float tile[2 * 16 * kPad];        // 32 chunks: two rows of one pass
+  __shared__ double carry[kRows4Bands * kMaxSec * 8];                       // [band of this workgroup][section][group][2]
+  const int lane = threadIdx.x;
+  const int n_iter = T / kSeg;
+  const int id = blockIdx.x;
+  const int quad = (id / (8 * kLongShare)) * 8 + (id & 7);
+  const int share = (id >> 3) % kLongShare;
+  if (quad * 4 >= n_rows) return;
+  const int64_t bstride = (int64_t)C * T;
+  const int q = lane >> 4, li = lane & 15;
+  const int row = quad * 4 + q < n_rows ? quad * 4 + q : n_rows - 1;
+  const float* src = x + row * (int64_t)T;
+  for (int e = lane; e < kRows4Bands * kMaxSec * 8; e += 64) carry[e] = 0.0;
+  wave_lds_sync();
+  auto load_x = [&](XArr& xs, int it) {
+    float4 xf[kL / 4];
+    chunk_issue<true>(xf, src, 0, it * 16 + li, T);
+#pragma unroll
+    for (int j = 0; j < kL / 2; ++j) xs[j] = (f2){f4_get(xf[j >> 2], j & 3), f4_get(xf[(j >> 2) + 4], j & 3)};
+  };
+  auto filter_store = [&](const XArr& xs, int it, int b, int bi) {
+    typename O::Arr v;
+    O::from_x(v, xs, O::g(bands[b]));
+    double* cb = carry + (bi * kMaxSec * 4 + q) * 2;
+    for (int sct = 0; sct < ns; ++sct) {
+      double c1 = cb[sct * 8], c2 = cb[sct * 8 + 1];
+      section<VT, 1, true>(v, secs[b * ns + sct], Qtab + (int64_t)(b * ns + sct) * 64, lane, c1, c2);
+      wave_lds_sync();                                  // every lane has read the incoming carry
+      if (li == 15) {
+        cb[sct * 8] = c1;
+        cb[sct * 8 + 1] = c2;
+      }
+    }
+    // transposition to coalesced stores: rows 2 h and 2 h + 1 of the quad (32 chunks) at a time
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      wave_lds_sync();                                  // the previous half's readers are done
+      if ((lane >> 5) == h) chunk_to_tile<VT>(tile + (lane & 31) * kPad, v);
+      wave_lds_sync();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int rr = quad * 4 + 2 * h + (k >> 1);     // wave-uniform
+        if (rr >= n_rows) continue;
+        const int bt = rr / C, ch = rr - bt * C;
+        float* dst = y + ((int64_t)bt * nb_out * C + ch) * (int64_t)T + (int64_t)bmap[b] * bstride;
+        const int e = (k * 64 + lane) * 4;              // element inside the half tile: chunk e >> 5, sample e & 31
+        const float4 val = *reinterpret_cast<const float4*>(tile + (e >> 5) * kPad + (e & 31));
+        *reinterpret_cast<float4*>(dst + it * kSeg + (e & (kSeg - 1))) = val;
+      }
+    }
+  };
+  if (PASS_OUTER) {
+    for (int it = 0; it < n_iter; ++it) {
+      XArr xs;
+      load_x(xs, it);
+      int bi = 0;
+      for (int b = share; b < nb; b += kLongShare, ++bi) filter_store(xs, it, b, bi);
+    }
+  } else {
+    // fp64: the 16 registers of a pass of x held across the bands cost the instance a wave per SIMD (184 VGPRs, 1.62 ->
+    // 1.87 ms per 128 stress trials); it re-reads the pass per band instead
+    int bi = 0;
+    for (int b = share; b < nb; b += kLongShare, ++bi) {
+      for (int it = 0; it < n_iter; ++it) {
+        XArr xs;
+        load_x(xs, it);
+        filter_store(xs, it, b, bi);
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(64) void fb_rows4_kernel_f32(
+    const FbSec* __restrict__ secs, const FbBand* __restrict__ bands, const double* __restrict__ Qtab,
+    const float* __restrict__ x, float* __restrict__ y, int C, int T, int nb, int ns,
+    const int* __restrict__ bmap, int nb_out, int n_rows) {
+  fb_rows4_body<float, true>(secs, bands, Qtab, x, y, C, T, nb, ns, bmap, nb_out, n_rows);
+}
+__global__ __launch_bounds__(64) void fb_rows4_kernel_f64(
+    const FbSec* __restrict__ secs, const FbBand* __restrict__ bands, const double* __restrict__ Qtab,
+    const float* __restrict__ x, float* __restrict__ y, int C, int T, int nb, int ns,
+    const int* __restrict__ bmap, int nb_out, int n_rows) {
+  fb_rows4_body<double, false>(secs, bands, Qtab, x, y, C, T, nb, ns, bmap, nb_out, n_rows);
+}
+
 struct FusedBands {
   int klo[kMaxBands];
   int khi[kMaxBands];
@@ -1171,6 +1271,17 @@ static int fb_launch_t(const isd_fb_plan* p, const FbSet& fs, const float* x, fl
   if (T <= 2 * kSeg) return fb_launch<VT, 2>(p, fs, x, y, R, C, T, st);
   const int vec = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  if (vec && T % kSeg == 0 && getenv("ISD_FUSED_ROWS4_OFF") == nullptr) {   // four rows per wave, group-local carries
+    const dim3 grid4((unsigned)(cdiv(cdiv(R, 4), 8) * 8 * kLongShare));
+    if (std::is_same<VT, float>::value)
+      hipLaunchKernelGGL(fb_rows4_kernel_f32, grid4, dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y, C, T, fs.nb,
+                         p->n_sections, fs.d_map, p->n_bands, (int)R);
+    else
+      hipLaunchKernelGGL(fb_rows4_kernel_f64, grid4, dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y, C, T, fs.nb,
+                         p->n_sections, fs.d_map, p->n_bands, (int)R);
+    ISD_LAUNCH_CHECK();
+    return ISD_OK;
+  }
   const dim3 grid((unsigned)(cdiv(R, 8) * 8 * kLongShare));
 #define ISD_FBL(K) hipLaunchKernelGGL(K, grid, dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y, C, T, fs.nb, \
                                       p->n_sections, fs.d_map, p->n_bands, (int)R)
