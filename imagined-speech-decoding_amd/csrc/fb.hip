@@ -1122,6 +1122,12 @@ using namespace isd;
 
 extern "C" int isd_fb_plan_destroy(isd_fb_plan* p);
 
+// ISD_FUSED_ROWS4_OFF=1 sends long rows to the one-row-per-wave kernels (A/B measurements); read once
+static bool rows4_enabled() {
+  static const bool on = getenv("ISD_FUSED_ROWS4_OFF") == nullptr;
+  return on;
+}
+
 extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections, const double* a12,
                                   const double* gain, int precision) {
   ISD_CHECK_ARG(out && a12 && gain, "isd_fb_plan_create: null argument");
@@ -1271,7 +1277,7 @@ static int fb_launch_t(const isd_fb_plan* p, const FbSet& fs, const float* x, fl
   if (T <= 2 * kSeg) return fb_launch<VT, 2>(p, fs, x, y, R, C, T, st);
   const int vec = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  if (vec && T % kSeg == 0 && getenv("ISD_FUSED_ROWS4_OFF") == nullptr) {   // four rows per wave, group-local carries
+  if (vec && T % kSeg == 0 && rows4_enabled()) {   // four rows per wave, group-local carries
     const dim3 grid4((unsigned)(cdiv(cdiv(R, 4), 8) * 8 * kLongShare));
     if (std::is_same<VT, float>::value)
       hipLaunchKernelGGL(fb_rows4_kernel_f32, grid4, dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y, C, T, fs.nb,
@@ -1382,7 +1388,7 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
                      fs.d_sec, fs.d_band, fs.d_Q, st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections, st->J,      \
                      log2_nblk, st->n / 2, st->scale * st->scale, fbnd, mode, eps, fs.d_map, fb->n_bands, (int)rows)
       // rows of whole 512-sample passes covering all 64 blocks: four rows per wave, no cross-group chain
-      const bool rows4 = vec && st->T % kSeg == 0 && log2_nblk <= 4 && log2_nblk >= 1 && getenv("ISD_FUSED_ROWS4_OFF") == nullptr;
+      const bool rows4 = vec && st->T % kSeg == 0 && log2_nblk <= 4 && log2_nblk >= 1 && rows4_enabled();
       const size_t lds4 = sizeof(float2) * ((size_t)4 * KB * 32 + 64) + sizeof(double) * (8 * kMaxSec + 64 * kMaxSec);
 #define ISD_FL_LAUNCH4(VT, K)                                                                                         \
   do {                                                                                                                \
