@@ -31,8 +31,10 @@ struct PhGeo {
 };
 
 struct PhStats {
-  double s1[4][kPhMaxF], s2[4][kPhMaxF];    // sum y, sum y^2
-  double d1[4][kPhMaxF], d2[4][kPhMaxF];    // sum dyhat, sum dyhat*xhat
+  // per layer one contiguous block of batch sums (under data parallelism it is all-reduced before the layer's
+  // normalisation / BatchNorm backward: synchronised BatchNorm)
+  double s[4][2][kPhMaxF];                  // [layer][sum y | sum y^2]
+  double d[4][2][kPhMaxF];                  // [layer][sum dyhat | sum dyhat*xhat]
 };
 struct PhCoef {
   float A[4][kPhMaxF], Bc[4][kPhMaxF], mu[4][kPhMaxF], isg[4][kPhMaxF];
@@ -148,8 +150,8 @@ __global__ void ph_finalize_kernel(const float* __restrict__ params, float* __re
   if (o >= g.Fo[l]) return;
   double mu, var;
   if (training) {
-    mu = st->s1[l][o] / N;
-    var = st->s2[l][o] / N - mu * mu;
+    mu = st->s[l][0][o] / N;
+    var = st->s[l][1][o] / N - mu * mu;
     if (var < 0.0) var = 0.0;
     bufs[g.rm[l] + o] = (1.f - momentum) * bufs[g.rm[l] + o] + momentum * (float)mu;
     bufs[g.rv[l] + o] = (1.f - momentum) * bufs[g.rv[l] + o] + momentum * (float)(var * N / (N > 1.0 ? N - 1.0 : 1.0));
@@ -218,22 +220,22 @@ __global__ __launch_bounds__(256) void ph_bwd_pool_kernel(const float* __restric
   const float r1 = ph_block_sum(s1, red);
   const float r2 = ph_block_sum(s2, red);
   if (threadIdx.x == 0) {
-    atomicAdd(&st->d1[l][o], (double)r1);
-    atomicAdd(&st->d2[l][o], (double)r2);
+    atomicAdd(&st->d[l][0][o], (double)r1);
+    atomicAdd(&st->d[l][1][o], (double)r2);
   }
 }
 
 __global__ void ph_bwd_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
                                    const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N,
-                                   int bn_train) {
+                                   int bn_train, double gs) {
   const int o = threadIdx.x;
   if (o >= g.Fo[l]) return;
   const double inv = bn_train ? 1.0 / N : 0.0;           // running statistics do not depend on the batch: no mean terms
-  dparams[g.g[l] + o] = (float)st->d2[l][o];
-  dparams[g.b[l] + o] = (float)st->d1[l][o];
+  dparams[g.g[l] + o] = (float)(st->d[l][1][o] * gs);    // global sums on every rank: pre-divided by the world size
+  dparams[g.b[l] + o] = (float)(st->d[l][0][o] * gs);
   co->cA[l][o] = params[g.g[l] + o] * co->isg[l][o];
-  co->cB[l][o] = (float)(st->d1[l][o] * inv);
-  co->cC[l][o] = (float)(st->d2[l][o] * inv);
+  co->cB[l][o] = (float)(st->d[l][0][o] * inv);
+  co->cC[l][o] = (float)(st->d[l][1][o] * inv);
 }
 
 // dy = cA (dyh - cB - xhat cC) in place
@@ -461,66 +463,113 @@ extern "C" int64_t isd_paperhead_workspace_bytes(const isd_paperhead_plan* p, in
   return ph_layout(p->g, B).total * 4;
 }
 
-extern "C" int isd_paperhead_forward(const isd_paperhead_plan* p, const float* x, const float* params, float* buffers,
-                                     float* out, void* workspace, int64_t B, int training, float momentum, float eps,
-                                     void* stream) {
-  ISD_CHECK_ARG(p, "isd_paperhead_forward: null plan");
-  ISD_CHECK_ARG(B >= 0 && B <= (int64_t)1 << 26, "isd_paperhead_forward: B=%lld", (long long)B);
-  if (B == 0) return ISD_OK;
-  ISD_CHECK_ARG(x && params && buffers && out && workspace, "isd_paperhead_forward: null argument");
+// Forward / backward in stages (synchronised BatchNorm): between two stages one layer's block of fp64
+// batch sums sits complete in the workspace (isd_paperhead_sync_block); under data parallelism the caller all-reduces
+// it there and passes the world size.
+//   forward  stage 0: weight preparation, conv 1                          -> sums of layer 1
+//            stage s = 1..3: BN + GELU + pool of layer s, conv s + 1      -> sums of layer s + 1
+//            stage 4: BN + GELU + pool of layer 4, mean over time
+//   backward stage 0: pool routing / GELU' of layer 4                     -> BN backward sums of layer 4
+//            stage k = 1..3: BN backward, weight + data gradient of layer 5 - k, pool routing of layer 4 - k -> its sums
+//            stage 4: BN backward and gradients of layer 1 (and dx)
+static int ph_forward_stage(const isd_paperhead_plan* p, int stage, const float* x, const float* params, float* buffers,
+                            float* out, float* ws, int64_t B, int training, float momentum, float eps, int world,
+                            hipStream_t st) {
   const PhGeo& g = p->g;
-  hipStream_t st = (hipStream_t)stream;
-  float* ws = (float*)workspace;
   const PhWs w = ph_layout(g, B);
   PhStats* S = (PhStats*)(ws + w.stats);
   PhCoef* Cf = (PhCoef*)(ws + w.coef);
-  ISD_HIP_TRY(hipMemsetAsync(S, 0, sizeof(PhStats), st));
-  for (int l = 0; l < 4; ++l) {
-    const int nmax = (g.Fp[l] > g.Fo[l] ? g.Fp[l] : g.Fo[l]) * g.Cp[l] * 3;
-    hipLaunchKernelGGL(ph_prep_kernel, dim3((unsigned)cdiv(nmax, 256)), dim3(256), 0, st, params, ws, ws, ws + w.beff, g,
-                       l, w.wf[l], w.wb[l]);
+  if (stage == 0) {
+    ISD_HIP_TRY(hipMemsetAsync(S, 0, sizeof(PhStats), st));
+    for (int l = 0; l < 4; ++l) {
+      const int nmax = (g.Fp[l] > g.Fo[l] ? g.Fp[l] : g.Fo[l]) * g.Cp[l] * 3;
+      hipLaunchKernelGGL(ph_prep_kernel, dim3((unsigned)cdiv(nmax, 256)), dim3(256), 0, st, params, ws, ws, ws + w.beff,
+                         g, l, w.wf[l], w.wb[l]);
+    }
   }
-  const float* in = x;
-  for (int l = 0; l < 4; ++l) {
-    const int64_t n = B * g.To[l];
-    const unsigned gx = (unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
-    hipLaunchKernelGGL(ph_conv_kernel, dim3(gx, (unsigned)(g.Fp[l] / 16)), dim3(256), 0, st, in, ws + w.wf[l],
-                       l == 0 ? ws + w.beff : (const float*)nullptr, ws + w.y[l], S->s1[l], S->s2[l], B, g.Ci[l], g.Ti[l],
-                       g.To[l], g.Fo[l], g.Fp[l], training);
+  if (stage > 0) {
+    const int l = stage - 1;
     hipLaunchKernelGGL(ph_finalize_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, g, l,
-                       (double)B * (double)g.To[l], training, momentum, eps);
+                       (double)B * (double)g.To[l] * (double)world, training, momentum, eps);
     const int64_t np = B * g.Fo[l] * g.Tp[l];
     hipLaunchKernelGGL(ph_pool_kernel, dim3((unsigned)cdiv(np, 256)), dim3(256), 0, st, ws + w.y[l], Cf, ws + w.a[l], np,
                        l, g.Fo[l], g.To[l], g.Tp[l]);
-    in = ws + w.a[l];
   }
-  hipLaunchKernelGGL(ph_mean_kernel, dim3((unsigned)cdiv(B * g.F, 256)), dim3(256), 0, st, ws + w.a[3], out, B * g.F,
-                     g.Tp[3]);
+  if (stage < 4) {
+    const int l = stage;
+    const float* in = l == 0 ? x : ws + w.a[l - 1];
+    const int64_t n = B * g.To[l];
+    const unsigned gx = (unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
+    hipLaunchKernelGGL(ph_conv_kernel, dim3(gx, (unsigned)(g.Fp[l] / 16)), dim3(256), 0, st, in, ws + w.wf[l],
+                       l == 0 ? ws + w.beff : (const float*)nullptr, ws + w.y[l], S->s[l][0], S->s[l][1], B, g.Ci[l],
+                       g.Ti[l], g.To[l], g.Fo[l], g.Fp[l], training);
+  } else {
+    hipLaunchKernelGGL(ph_mean_kernel, dim3((unsigned)cdiv(B * g.F, 256)), dim3(256), 0, st, ws + w.a[3], out, B * g.F,
+                       g.Tp[3]);
+  }
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
 
-static int ph_backward_impl(const isd_paperhead_plan* p, const float* x, const float* params, const float* dout,
-                            float* dparams, float* dx, void* workspace, int64_t B, int bn_train, void* stream) {
-  ISD_CHECK_ARG(p, "isd_paperhead_backward: null plan");
-  ISD_CHECK_ARG(B >= 1, "isd_paperhead_backward: B=%lld", (long long)B);
-  ISD_CHECK_ARG(x && params && dout && dparams && workspace, "isd_paperhead_backward: null argument");
+static int ph_forward_check(const isd_paperhead_plan* p, const float* x, const float* params, float* buffers, float* out,
+                            void* workspace, int64_t B, int world) {
+  ISD_CHECK_ARG(p, "isd_paperhead_forward: null plan");
+  ISD_CHECK_ARG(B >= 0 && B <= (int64_t)1 << 26, "isd_paperhead_forward: B=%lld", (long long)B);
+  ISD_CHECK_ARG(B == 0 || (x && params && buffers && out && workspace), "isd_paperhead_forward: null argument");
+  ISD_CHECK_ARG(world >= 1 && world <= 65536, "isd_paperhead_forward: world=%d", world);
+  return ISD_OK;
+}
+
+extern "C" int isd_paperhead_forward(const isd_paperhead_plan* p, const float* x, const float* params, float* buffers,
+                                     float* out, void* workspace, int64_t B, int training, float momentum, float eps,
+                                     void* stream) {
+  int rc = ph_forward_check(p, x, params, buffers, out, workspace, B, 1);
+  if (rc || B == 0) return rc;
+  for (int stage = 0; stage < 5 && rc == ISD_OK; ++stage)
+    rc = ph_forward_stage(p, stage, x, params, buffers, out, (float*)workspace, B, training, momentum, eps, 1,
+                          (hipStream_t)stream);
+  return rc;
+}
+
+extern "C" int isd_paperhead_forward_stage(const isd_paperhead_plan* p, int stage, const float* x, const float* params,
+                                           float* buffers, float* out, void* workspace, int64_t B, int training,
+                                           float momentum, float eps, int world, void* stream) {
+  int rc = ph_forward_check(p, x, params, buffers, out, workspace, B, world);
+  if (rc || B == 0) return rc;
+  ISD_CHECK_ARG(stage >= 0 && stage < 5, "isd_paperhead_forward_stage: stage=%d not in [0,5)", stage);
+  return ph_forward_stage(p, stage, x, params, buffers, out, (float*)workspace, B, training, momentum, eps, world,
+                          (hipStream_t)stream);
+}
+
+// The fp64 sums that are complete after `stage` (0..3) of the forward (backward = 0: sums of layer stage + 1) or of the
+// backward (backward = 1: sums of layer 4 - stage): byte offset from the workspace base and number of doubles.
+extern "C" int isd_paperhead_sync_block(const isd_paperhead_plan* p, int64_t B, int backward, int stage,
+                                        int64_t* byte_offset, int64_t* n_doubles) {
+  ISD_CHECK_ARG(p && byte_offset && n_doubles, "isd_paperhead_sync_block: null argument");
+  ISD_CHECK_ARG(stage >= 0 && stage < 4 && B >= 0, "isd_paperhead_sync_block: stage=%d not in [0,4)", stage);
+  const PhWs w = ph_layout(p->g, B);
+  const size_t lo = backward ? offsetof(PhStats, d) + sizeof(double) * 2 * kPhMaxF * (3 - stage)
+                             : offsetof(PhStats, s) + sizeof(double) * 2 * kPhMaxF * stage;
+  *byte_offset = w.stats * 4 + (int64_t)lo;
+  *n_doubles = 2 * kPhMaxF;
+  return ISD_OK;
+}
+
+static int ph_backward_stage(const isd_paperhead_plan* p, int stage, const float* x, const float* params,
+                             const float* dout, float* dparams, float* dx, float* ws, int64_t B, int bn_train, int world,
+                             hipStream_t st) {
   const PhGeo& g = p->g;
-  hipStream_t st = (hipStream_t)stream;
-  float* ws = (float*)workspace;
   const PhWs w = ph_layout(g, B);
   PhStats* S = (PhStats*)(ws + w.stats);
   PhCoef* Cf = (PhCoef*)(ws + w.coef);
-  ISD_HIP_TRY(hipMemsetAsync((char*)S + offsetof(PhStats, d1), 0, sizeof(PhStats) - offsetof(PhStats, d1), st));
   const int slabs = B < kPhSlabs ? (int)B : kPhSlabs;
-  for (int l = 3; l >= 0; --l) {
-    const int64_t np = B * g.Tp[l];
-    const unsigned gx = (unsigned)(cdiv(np, 256) < 256 ? cdiv(np, 256) : 256);
-    hipLaunchKernelGGL(ph_bwd_pool_kernel, dim3(gx, (unsigned)g.Fo[l]), dim3(256), 0, st, ws + w.y[l],
-                       l == 3 ? (const float*)nullptr : ws + w.da[l], l == 3 ? dout : (const float*)nullptr, Cf,
-                       ws + w.dy[l], S, B, l, g.Fo[l], g.To[l], g.Tp[l]);
+  if (stage == 0)
+    ISD_HIP_TRY(hipMemsetAsync((char*)S + offsetof(PhStats, d), 0, sizeof(PhStats) - offsetof(PhStats, d), st));
+  if (stage > 0) {
+    // the layer whose BatchNorm sums are complete: BN backward, weight gradient, data gradient
+    const int l = 4 - stage;
     hipLaunchKernelGGL(ph_bwd_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, g, l,
-                       (double)B * (double)g.To[l], bn_train);
+                       (double)B * (double)g.To[l] * (double)world, bn_train, 1.0 / (double)world);
     const int64_t ny = B * g.Fo[l] * g.To[l];
     hipLaunchKernelGGL(ph_bwd_bn_kernel, dim3((unsigned)cdiv(ny, 256)), dim3(256), 0, st, ws + w.dy[l], ws + w.y[l], Cf,
                        ny, l, g.Fo[l], g.To[l]);
@@ -544,8 +593,40 @@ static int ph_backward_impl(const isd_paperhead_plan* p, const float* x, const f
                          ws + w.dy[l], ws + w.wb[l], ws + w.da[l - 1], B, g.Ci[l], g.Cp[l], g.Ti[l], g.To[l], g.Fo[l]);
     }
   }
+  if (stage < 4) {
+    // max-pool routing + GELU' of the next layer down, and its BatchNorm backward sums
+    const int l = 3 - stage;
+    const int64_t np = B * g.Tp[l];
+    const unsigned gx = (unsigned)(cdiv(np, 256) < 256 ? cdiv(np, 256) : 256);
+    hipLaunchKernelGGL(ph_bwd_pool_kernel, dim3(gx, (unsigned)g.Fo[l]), dim3(256), 0, st, ws + w.y[l],
+                       l == 3 ? (const float*)nullptr : ws + w.da[l], l == 3 ? dout : (const float*)nullptr, Cf,
+                       ws + w.dy[l], S, B, l, g.Fo[l], g.To[l], g.Tp[l]);
+  }
   ISD_LAUNCH_CHECK();
   return ISD_OK;
+}
+
+static int ph_backward_impl(const isd_paperhead_plan* p, const float* x, const float* params, const float* dout,
+                            float* dparams, float* dx, void* workspace, int64_t B, int bn_train, void* stream) {
+  ISD_CHECK_ARG(p, "isd_paperhead_backward: null plan");
+  ISD_CHECK_ARG(B >= 1, "isd_paperhead_backward: B=%lld", (long long)B);
+  ISD_CHECK_ARG(x && params && dout && dparams && workspace, "isd_paperhead_backward: null argument");
+  int rc = ISD_OK;
+  for (int stage = 0; stage < 5 && rc == ISD_OK; ++stage)
+    rc = ph_backward_stage(p, stage, x, params, dout, dparams, dx, (float*)workspace, B, bn_train, 1, (hipStream_t)stream);
+  return rc;
+}
+
+extern "C" int isd_paperhead_backward_stage(const isd_paperhead_plan* p, int stage, const float* x, const float* params,
+                                            const float* dout, float* dparams, void* workspace, int64_t B, int world,
+                                            void* stream) {
+  ISD_CHECK_ARG(p, "isd_paperhead_backward_stage: null plan");
+  ISD_CHECK_ARG(B >= 1, "isd_paperhead_backward_stage: B=%lld", (long long)B);
+  ISD_CHECK_ARG(x && params && dout && dparams && workspace, "isd_paperhead_backward_stage: null argument");
+  ISD_CHECK_ARG(stage >= 0 && stage < 5, "isd_paperhead_backward_stage: stage=%d not in [0,5)", stage);
+  ISD_CHECK_ARG(world >= 1 && world <= 65536, "isd_paperhead_backward_stage: world=%d", world);
+  return ph_backward_stage(p, stage, x, params, dout, dparams, nullptr, (float*)workspace, B, 1, world,
+                           (hipStream_t)stream);
 }
 
 extern "C" int isd_paperhead_backward(const isd_paperhead_plan* p, const float* x, const float* params,

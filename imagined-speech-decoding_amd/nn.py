@@ -331,20 +331,32 @@ class PaperHeadPlan:
 
 class _PaperHeadFn(torch.autograd.Function):
     """HeadConv_Paper_Version: parameter gradients and the input gradient, after a train-mode (batch statistics) or an
-    eval-mode (running statistics) forward."""
+    eval-mode (running statistics) forward.  With torch.distributed initialised (world > 1) the four BatchNorm layers
+    use the statistics of the GLOBAL batch: the pass runs in stages and each layer's fp64 sum block is all-reduced in
+    between, as for EEGNet_Encoder / CVBlock."""
 
     @staticmethod
-    def forward(ctx, x, flat, bufs, plan, training, momentum, eps):
+    def forward(ctx, x, flat, bufs, plan, training, momentum, eps, sync):
         x, flat = _f32c(x, "x"), _f32c(flat, "params")
         B = x.shape[0]
+        L = _lib.lib()
         out = torch.empty((B, plan.F), dtype=torch.float32, device=x.device)
-        ws = torch.empty(max(int(_lib.lib().isd_paperhead_workspace_bytes(plan._h, B)) // 4, 1), dtype=torch.float32,
+        ws = torch.empty(max(int(L.isd_paperhead_workspace_bytes(plan._h, B)) // 4, 1), dtype=torch.float32,
                          device=x.device)
+        dist, world = _bn_sync_world(sync, training)
+        args = (x.data_ptr(), flat.data_ptr(), bufs.data_ptr(), out.data_ptr(), ws.data_ptr(), B, int(training),
+                float(momentum), float(eps))
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().isd_paperhead_forward(plan._h, x.data_ptr(), flat.data_ptr(), bufs.data_ptr(),
-                                                        out.data_ptr(), ws.data_ptr(), B, int(training),
-                                                        float(momentum), float(eps), _stream()))
-        ctx.plan, ctx.ws, ctx.training = plan, ws, training
+            if world == 1:
+                _lib.check(L.isd_paperhead_forward(plan._h, *args, _stream()))
+            else:
+                off, n = C.c_int64(), C.c_int64()
+                for stage in range(5):
+                    _lib.check(L.isd_paperhead_forward_stage(plan._h, stage, *args, world, _stream()))
+                    if stage < 4:
+                        _lib.check(L.isd_paperhead_sync_block(plan._h, B, 0, stage, C.byref(off), C.byref(n)))
+                        _all_reduce_block(dist, ws, off.value, n.value)
+        ctx.plan, ctx.ws, ctx.training, ctx.world = plan, ws, training, world
         ctx.save_for_backward(x, flat)
         return out
 
@@ -354,19 +366,32 @@ class _PaperHeadFn(torch.autograd.Function):
         dflat = torch.empty_like(flat)
         dout = _f32c(dout, "dout")
         dx = None
+        L, B = _lib.lib(), x.shape[0]
         with torch.cuda.device(x.device):
             if ctx.needs_input_grad[0] or not ctx.training:
+                if ctx.world != 1:
+                    raise NotImplementedError("the input gradient of the BatchNorm heads is single-device")
                 dx = torch.empty_like(x)
-                _lib.check(_lib.lib().isd_paperhead_backward_x(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dout.data_ptr(),
-                                                               dflat.data_ptr(), dx.data_ptr(), ctx.ws.data_ptr(),
-                                                               x.shape[0], int(ctx.training), _stream()))
+                _lib.check(L.isd_paperhead_backward_x(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dout.data_ptr(),
+                                                      dflat.data_ptr(), dx.data_ptr(), ctx.ws.data_ptr(), B,
+                                                      int(ctx.training), _stream()))
                 if not ctx.needs_input_grad[0]:
                     dx = None
+            elif ctx.world == 1:
+                _lib.check(L.isd_paperhead_backward(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dout.data_ptr(),
+                                                    dflat.data_ptr(), ctx.ws.data_ptr(), B, _stream()))
             else:
-                _lib.check(_lib.lib().isd_paperhead_backward(ctx.plan._h, x.data_ptr(), flat.data_ptr(), dout.data_ptr(),
-                                                             dflat.data_ptr(), ctx.ws.data_ptr(), x.shape[0], _stream()))
+                import torch.distributed as dist
+                off, n = C.c_int64(), C.c_int64()
+                for stage in range(5):
+                    _lib.check(L.isd_paperhead_backward_stage(ctx.plan._h, stage, x.data_ptr(), flat.data_ptr(),
+                                                              dout.data_ptr(), dflat.data_ptr(), ctx.ws.data_ptr(), B,
+                                                              ctx.world, _stream()))
+                    if stage < 4:
+                        _lib.check(L.isd_paperhead_sync_block(ctx.plan._h, B, 1, stage, C.byref(off), C.byref(n)))
+                        _all_reduce_block(dist, ctx.ws, off.value, n.value)
         ctx.ws = None
-        return dx, dflat, None, None, None, None, None
+        return dx, dflat, None, None, None, None, None, None
 
 
 class _LinearResFn(torch.autograd.Function):
@@ -840,7 +865,6 @@ class CVBlock(nn.Module, _BNStackMixin):
 class HeadConv_Paper_Version(nn.Module, _BNStackMixin):
     """Drop-in for the reference's ``HeadConv_Paper_Version(in_channels, feature_dim=32)`` (fast.py:170-196); same
     parameter / buffer names, ``forward(x[B', C, T]) -> [B', feature_dim]``."""
-    _warned = False
 
     def __init__(self, in_channels, feature_dim=32):
         super().__init__()
@@ -874,17 +898,12 @@ class HeadConv_Paper_Version(nn.Module, _BNStackMixin):
             plan = self._plans[T] = PaperHeadPlan(self.in_channels, self.feature_dim, T)
         flat = self.flat_params()
         theta = torch.cat([p.reshape(-1) for p in self._ordered_params()]) if torch.is_grad_enabled() else flat
-        if self.training and _bn_sync_world(True, True)[1] > 1 and not HeadConv_Paper_Version._warned:
-            import warnings
-            HeadConv_Paper_Version._warned = True
-            warnings.warn("HeadConv_Paper_Version normalises with per-replica batch statistics under data parallelism "
-                          "(EEGNet_Encoder and CVBlock synchronise theirs): results differ from single-device training")
         if self.training:
             for b in self._bns():
                 b.num_batches_tracked += 1
         bn = self.norm1
         return _PaperHeadFn.apply(x, theta, self.flat_buffers(), plan, self.training,
-                                  0.1 if bn.momentum is None else bn.momentum, bn.eps)
+                                  0.1 if bn.momentum is None else bn.momentum, bn.eps, getattr(self, "sync_bn", True))
 
 
 class Head(nn.Module, _FlatParamMixin):

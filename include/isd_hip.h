@@ -364,6 +364,17 @@ int isd_paperhead_backward(const isd_paperhead_plan* plan, const float* x, const
  * eval-mode forward (running statistics). */
 int isd_paperhead_backward_x(const isd_paperhead_plan* plan, const float* x, const float* params, const float* dout,
                              float* dparams, float* dx, void* workspace, int64_t B, int training, void* stream);
+/* Synchronised BatchNorm under data parallelism, as for the EEGNet head: forward stages 0..4 and backward stages 0..4;
+ * after stage s < 4 one layer's block of fp64 batch sums (isd_paperhead_sync_block) is complete in the workspace and
+ * the caller all-reduces it (SUM) before the next stage; `world` scales the counts and pre-divides the gamma / beta
+ * gradients, which every rank assembles from global sums. */
+int isd_paperhead_forward_stage(const isd_paperhead_plan* plan, int stage, const float* x, const float* params,
+                                float* buffers, float* out, void* workspace, int64_t B, int training, float momentum,
+                                float eps, int world, void* stream);
+int isd_paperhead_backward_stage(const isd_paperhead_plan* plan, int stage, const float* x, const float* params,
+                                 const float* dout, float* dparams, void* workspace, int64_t B, int world, void* stream);
+int isd_paperhead_sync_block(const isd_paperhead_plan* plan, int64_t B, int backward, int stage, int64_t* byte_offset,
+                             int64_t* n_doubles);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 """GPU: synchronised BatchNorm and the RCCL path.
 
-* Two ranks (gloo rendezvous, both on cuda:0) each hold half of a batch; EEGNet_Encoder / CVBlock with the fp64 sum
+* Two ranks (gloo rendezvous, both on cuda:0) each hold half of a batch; EEGNet_Encoder / CVBlock /
+  HeadConv_Paper_Version with the fp64 sum
   blocks all-reduced between the stages must reproduce the single-process result on the whole batch (SURVEY.md 8e;
   the reference's heads use nn.BatchNorm2d on one device, fast.py:46-63,133-159): outputs, running statistics, and
   parameter gradients after the gradient all-reduce.
@@ -30,7 +31,8 @@ def _free_port():
 def _head(kind):
     import isd_amd.nn as inn
     torch.manual_seed(7)
-    m = (inn.EEGNet_Encoder(6, 16, dropout=0.0) if kind == "eegnet" else inn.CVBlock(6, 16, dropout=0.0)).cuda()
+    m = (inn.EEGNet_Encoder(6, 16, dropout=0.0) if kind == "eegnet" else
+         inn.CVBlock(6, 16, dropout=0.0) if kind == "cvblock" else inn.HeadConv_Paper_Version(6, 16)).cuda()
     with torch.no_grad():
         for bn in m._bns():
             bn.weight.uniform_(0.5, 1.5)
@@ -62,7 +64,7 @@ def _syncbn_worker(rank, world, port, kind, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["eegnet", "cvblock"])
+@pytest.mark.parametrize("kind", ["eegnet", "cvblock", "paper"])
 def test_synchronised_batchnorm_two_ranks_equal_single_process(kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
