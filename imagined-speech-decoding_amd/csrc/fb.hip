@@ -1277,7 +1277,7 @@ static int fb_launch_t(const isd_fb_plan* p, const FbSet& fs, const float* x, fl
   if (T <= 2 * kSeg) return fb_launch<VT, 2>(p, fs, x, y, R, C, T, st);
   const int vec = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  if (vec && T % kSeg == 0 && rows4_enabled()) {   // four rows per wave, group-local carries
+  if (vec && T % kSeg == 0 && fs.nb <= kMaxBands && rows4_enabled()) {   // four rows per wave, group-local carries (carry slots for kMaxBands bands)
     const dim3 grid4((unsigned)(cdiv(cdiv(R, 4), 8) * 8 * kLongShare));
     if (std::is_same<VT, float>::value)
       hipLaunchKernelGGL(fb_rows4_kernel_f32, grid4, dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y, C, T, fs.nb,
