@@ -192,6 +192,10 @@ def test_extract_features_numpy_in_numpy_out(isd):
     (4096, 1024.0, 1024, 960, odsp.BANDS_40[20:24]),    # fp32 bands only
     (3000, 1024.0, 1024, 960, odsp.BANDS_40[:3]),       # ragged row: last pass and last block partial
     (1500, 512.0, 256, 192, [("a", 6.0, 10.0), ("b", 20.0, 24.0)]),   # one pass, 4 blocks per frame
+    # whole 512-sample passes: four rows per wave (fused_rows4_kernel / fb_rows4_kernel), 3 and 4 passes, rows shorter
+    # than 64 blocks, 16 and 4 blocks per frame; 15 rows = a ragged last quad
+    (1536, 1024.0, 1024, 960, odsp.BANDS_40[:5]),
+    (2048, 512.0, 256, 192, [("a", 6.0, 10.0), ("b", 20.0, 24.0), ("c", 30.0, 38.0)]),
 ])
 def test_fused_long_rows_vs_oracle_and_two_kernel_path(isd, T, fs, nperseg, noverlap, bands):
     X, _ = odsp.synth_trials(3, 5, T, fs, seed=T)
