@@ -276,8 +276,26 @@ __device__ __forceinline__ void stage_q(double* Qlds, const double* __restrict__
 
 // Cooperative (whole wave) coalesced load of the 4 groups' 512-sample segments into the
 // padded chunk-major LDS tile.  gbase[g] < 0 marks an absent group.
+// FULL: every group present, whole 512-sample segments, 16-byte aligned rows -- eight loads back to back, no tests
+template <bool FULL = false>
 __device__ __forceinline__ void tile_load(float* tile, const float* __restrict__ x, int lane,
                                           const int64_t (&gbase)[4], const int (&gt0)[4], int T, bool vec) {
+  if (FULL) {
+    float4 val[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        val[g * 2 + k] = *reinterpret_cast<const float4*>(x + gbase[g] + gt0[g] + (k * 64 + lane) * 4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = (k * 64 + lane) * 4;
+        *reinterpret_cast<float4*>(tile + (g * 16 + (e >> 5)) * kPad + (e & 31)) = val[g * 2 + k];
+      }
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -301,8 +319,27 @@ __device__ __forceinline__ void tile_load(float* tile, const float* __restrict__
   }
 }
 
+// FULL: every group present, whole 512-sample segments, 16-byte aligned rows -- no test stands between the eight
+// tile reads and the eight stores
+template <bool FULL = false>
 __device__ __forceinline__ void tile_store(const float* tile, float* __restrict__ y, int lane,
                                            const int64_t (&gbase)[4], const int (&gt0)[4], int T, bool vec) {
+  if (FULL) {
+    float4 val[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = (k * 64 + lane) * 4;
+        val[g * 2 + k] = *reinterpret_cast<const float4*>(tile + (g * 16 + (e >> 5)) * kPad + (e & 31));
+      }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        *reinterpret_cast<float4*>(y + gbase[g] + gt0[g] + (k * 64 + lane) * 4) = val[g * 2 + k];
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -325,10 +362,11 @@ __device__ __forceinline__ void tile_store(const float* tile, float* __restrict_
 }
 
 // Load the lane's chunk through the LDS tile (coalesced global reads, chunk-major registers).
+template <bool FULL = false>
 __device__ __forceinline__ void load_chunks(XArr& xs, float* tile, const float* __restrict__ x, int lane,
                                             const int64_t (&xbase)[4], const int (&gt0)[4], int T, bool vec) {
   wave_lds_sync();
-  tile_load(tile, x, lane, xbase, gt0, T, vec);
+  tile_load<FULL>(tile, x, lane, xbase, gt0, T, vec);
   wave_lds_sync();
   const float* src = tile + lane * kPad;              // (q*16 + i) == lane
 #pragma unroll
@@ -364,7 +402,7 @@ __device__ __forceinline__ void chunk_to_tile(float* dst, const typename VOps<VT
 
 // Rows of at most 1024 samples.  One wave per workgroup; GPR = 16-lane groups per row (1: T<=512, 2: T<=1024);
 // the wave serves 4/GPR rows.  The input chunk stays in registers (fp32) for all bands.
-template <typename VT, int GPR>
+template <typename VT, int GPR, bool FULL = false>
 __global__ __launch_bounds__(64) void fb_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                                                 const double* __restrict__ Qtab, const float* __restrict__ x,
                                                 float* __restrict__ y, int R, int C, int T, int nb, int ns,
@@ -388,7 +426,7 @@ __global__ __launch_bounds__(64) void fb_kernel(const FbSec* __restrict__ secs, 
   }
   const int64_t bstride = (int64_t)C * T;
   XArr xs;
-  load_chunks(xs, tile, x, lane, xbase, gt0, T, vec != 0);
+  load_chunks<FULL>(xs, tile, x, lane, xbase, gt0, T, vec != 0);
   for (int b = 0; b < nb; ++b) {
     typename O::Arr v;
     O::from_x(v, xs, O::g(bands[b]));
@@ -403,7 +441,7 @@ __global__ __launch_bounds__(64) void fb_kernel(const FbSec* __restrict__ secs, 
     const int64_t boff = (int64_t)bmap[b] * bstride;
 #pragma unroll
     for (int g = 0; g < 4; ++g) ybase[g] = yrow[g] < 0 ? -1 : yrow[g] + boff;
-    tile_store(tile, y, lane, ybase, gt0, T, vec != 0);
+    tile_store<FULL>(tile, y, lane, ybase, gt0, T, vec != 0);
   }
 }
 
@@ -563,7 +601,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fb
 // M^i come straight from global memory (L1-resident, 64 bytes per lane and section).  The filtered pass leaves two
 // rows at a time through the half tile as coalesced float4 stores.
 constexpr int kRows4Bands = (kMaxBands + kLongShare - 1) / kLongShare;      // bands of one workgroup
-template <typename VT, bool PASS_OUTER>
+template <typename VT, bool PASS_OUTER, bool FULLQ>
 __device__ __forceinline__ void fb_rows4_body(
     const FbSec* __restrict__ secs, const FbBand* __restrict__ bands, const double* __restrict__ Qtab,
     const float* __restrict__ x, float* __restrict__ y, int C, int T, int nb, int ns,
@@ -583,6 +621,12 @@ __device__ __forceinline__ void fb_rows4_body(
   const float* src = x + row * (int64_t)T;
   for (int e = lane; e < kRows4Bands * kMaxSec * 8; e += 64) carry[e] = 0.0;
   wave_lds_sync();
+  int64_t ybase[4];                                     // band 0 of each row of the quad (wave-uniform)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rr = quad * 4 + r < n_rows ? quad * 4 + r : n_rows - 1;
+    ybase[r] = ((int64_t)(rr / C) * nb_out * C + (rr % C)) * (int64_t)T;
+  }
   auto load_x = [&](XArr& xs, int it) {
     float4 xf[kL / 4];
     chunk_issue<true>(xf, src, 0, it * 16 + li, T);
@@ -608,15 +652,21 @@ __device__ __forceinline__ void fb_rows4_body(
       wave_lds_sync();                                  // the previous half's readers are done
       if ((lane >> 5) == h) chunk_to_tile<VT>(tile + (lane & 31) * kPad, v);
       wave_lds_sync();
+      // the four tile reads first, then the four stores (a test between a read and its store leaves each pair in
+      // its own basic block behind its own wait); rows past the end are a whole quad's tail: wave-uniform
+      float4 val[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int rr = quad * 4 + 2 * h + (k >> 1);     // wave-uniform
-        if (rr >= n_rows) continue;
-        const int bt = rr / C, ch = rr - bt * C;
-        float* dst = y + ((int64_t)bt * nb_out * C + ch) * (int64_t)T + (int64_t)bmap[b] * bstride;
         const int e = (k * 64 + lane) * 4;              // element inside the half tile: chunk e >> 5, sample e & 31
-        const float4 val = *reinterpret_cast<const float4*>(tile + (e >> 5) * kPad + (e & 31));
-        *reinterpret_cast<float4*>(dst + it * kSeg + (e & (kSeg - 1))) = val;
+        val[k] = *reinterpret_cast<const float4*>(tile + (e >> 5) * kPad + (e & 31));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int rr = quad * 4 + 2 * h + (k >> 1);
+        if (!FULLQ && rr >= n_rows) continue;
+        const int64_t rbase = FULLQ ? ybase[2 * h + (k >> 1)] : ((int64_t)(rr / C) * nb_out * C + (rr % C)) * (int64_t)T;
+        float* dst = y + rbase + (int64_t)bmap[b] * bstride;
+        *reinterpret_cast<float4*>(dst + it * kSeg + (((k * 64 + lane) * 4) & (kSeg - 1))) = val[k];
       }
     }
   };
@@ -640,17 +690,19 @@ __device__ __forceinline__ void fb_rows4_body(
     }
   }
 }
+template <bool FULLQ>
 __global__ __launch_bounds__(64) void fb_rows4_kernel_f32(
     const FbSec* __restrict__ secs, const FbBand* __restrict__ bands, const double* __restrict__ Qtab,
     const float* __restrict__ x, float* __restrict__ y, int C, int T, int nb, int ns,
     const int* __restrict__ bmap, int nb_out, int n_rows) {
-  fb_rows4_body<float, true>(secs, bands, Qtab, x, y, C, T, nb, ns, bmap, nb_out, n_rows);
+  fb_rows4_body<float, true, FULLQ>(secs, bands, Qtab, x, y, C, T, nb, ns, bmap, nb_out, n_rows);
 }
+template <bool FULLQ>
 __global__ __launch_bounds__(64) void fb_rows4_kernel_f64(
     const FbSec* __restrict__ secs, const FbBand* __restrict__ bands, const double* __restrict__ Qtab,
     const float* __restrict__ x, float* __restrict__ y, int C, int T, int nb, int ns,
     const int* __restrict__ bmap, int nb_out, int n_rows) {
-  fb_rows4_body<double, false>(secs, bands, Qtab, x, y, C, T, nb, ns, bmap, nb_out, n_rows);
+  fb_rows4_body<double, false, FULLQ>(secs, bands, Qtab, x, y, C, T, nb, ns, bmap, nb_out, n_rows);
 }
 
 struct FusedBands {
@@ -725,7 +777,7 @@ __device__ __forceinline__ void zero_past_end(XArr& vf, int i, int T) {
 // Band aggregation of materialised filtered signals y[B][nb][C][T] (nperseg 64 / hop 32, T <= 512):
 // same chunk layout as the filterbank (coalesced float4 loads through the LDS tile), direct DFT of
 // each row's own band bins.  HBM-bound: reads nb*C*T*4 bytes per trial, writes nb*C*J*4.
-template <bool MAG>
+template <bool MAG, bool FULL = false>
 __global__ __launch_bounds__(64) void bandpower_direct_kernel(const float2* __restrict__ dft,
                                                               const float* __restrict__ y, float* __restrict__ feat,
                                                               int R, int C, int T, int nb, int J, float scale2,
@@ -751,7 +803,7 @@ __global__ __launch_bounds__(64) void bandpower_direct_kernel(const float2* __re
     }
   }
   XArr vf;
-  load_chunks(vf, tile, y, lane, xbase, gt0, T, vec != 0);
+  load_chunks<FULL>(vf, tile, y, lane, xbase, gt0, T, vec != 0);
   if (T < kSeg) zero_past_end(vf, i, T);
   const int row = row0 + (lane >> 4);
   const int band = (row / C) % nb;
@@ -1264,8 +1316,12 @@ static int fb_launch(const isd_fb_plan* p, const FbSet& fs, const float* x, floa
   const int64_t items = cdiv(R, (int64_t)(4 / GPR));
   const int vec = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  hipLaunchKernelGGL((fb_kernel<VT, GPR>), dim3((unsigned)items), dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y,
-                     (int)R, C, T, fs.nb, p->n_sections, vec, fs.d_map, p->n_bands);
+  if (vec && T == GPR * kSeg && R % (4 / GPR) == 0)   // whole waves of whole segments: the branch-free store path
+    hipLaunchKernelGGL((fb_kernel<VT, GPR, true>), dim3((unsigned)items), dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x,
+                       y, (int)R, C, T, fs.nb, p->n_sections, vec, fs.d_map, p->n_bands);
+  else
+    hipLaunchKernelGGL((fb_kernel<VT, GPR>), dim3((unsigned)items), dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y,
+                       (int)R, C, T, fs.nb, p->n_sections, vec, fs.d_map, p->n_bands);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
@@ -1279,12 +1335,12 @@ static int fb_launch_t(const isd_fb_plan* p, const FbSet& fs, const float* x, fl
                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
   if (vec && T % kSeg == 0 && fs.nb <= kMaxBands && rows4_enabled()) {   // four rows per wave, group-local carries (carry slots for kMaxBands bands)
     const dim3 grid4((unsigned)(cdiv(cdiv(R, 4), 8) * 8 * kLongShare));
-    if (std::is_same<VT, float>::value)
-      hipLaunchKernelGGL(fb_rows4_kernel_f32, grid4, dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y, C, T, fs.nb,
-                         p->n_sections, fs.d_map, p->n_bands, (int)R);
-    else
-      hipLaunchKernelGGL(fb_rows4_kernel_f64, grid4, dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y, C, T, fs.nb,
-                         p->n_sections, fs.d_map, p->n_bands, (int)R);
+#define ISD_R4(K) hipLaunchKernelGGL(K, grid4, dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y, C, T, fs.nb, \
+                                     p->n_sections, fs.d_map, p->n_bands, (int)R)
+    const bool fullq = R % 4 == 0;
+    if (std::is_same<VT, float>::value) { if (fullq) ISD_R4(fb_rows4_kernel_f32<true>); else ISD_R4(fb_rows4_kernel_f32<false>); }
+    else { if (fullq) ISD_R4(fb_rows4_kernel_f64<true>); else ISD_R4(fb_rows4_kernel_f64<false>); }
+#undef ISD_R4
     ISD_LAUNCH_CHECK();
     return ISD_OK;
   }
@@ -1438,12 +1494,13 @@ int isd::bandpower_direct(const isd_stft_plan* st, const float* y, float* feat, 
   const int64_t items = cdiv(R, 4);
   ISD_CHECK_ARG(R <= kMaxRows, "isd_stft_bandpower: too many rows (%lld)", (long long)R);
   const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  if (mode == ISD_BP_MAGNITUDE)
-    hipLaunchKernelGGL(bandpower_direct_kernel<true>, dim3((unsigned)items), dim3(64), 0, stream, st->d_dft, y, feat,
-                       (int)R, C, st->T, nb, st->J, st->scale * st->scale, fbnd, mode, eps, vec);
-  else
-    hipLaunchKernelGGL(bandpower_direct_kernel<false>, dim3((unsigned)items), dim3(64), 0, stream, st->d_dft, y, feat,
-                       (int)R, C, st->T, nb, st->J, st->scale * st->scale, fbnd, mode, eps, vec);
+  const bool full = vec && st->T == kSeg && R % 4 == 0;        // whole waves of whole segments: branch-free loads
+#define ISD_BPD(M, F) hipLaunchKernelGGL((bandpower_direct_kernel<M, F>), dim3((unsigned)items), dim3(64), 0, stream, \
+                                         st->d_dft, y, feat, (int)R, C, st->T, nb, st->J, st->scale * st->scale, fbnd, \
+                                         mode, eps, vec)
+  if (mode == ISD_BP_MAGNITUDE) { if (full) ISD_BPD(true, true); else ISD_BPD(true, false); }
+  else { if (full) ISD_BPD(false, true); else ISD_BPD(false, false); }
+#undef ISD_BPD
   ISD_LAUNCH_CHECK();
   return ISD_OK;
 }
