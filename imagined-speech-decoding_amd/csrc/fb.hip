@@ -296,6 +296,31 @@ __device__ __forceinline__ void tile_load(float* tile, const float* __restrict__
       }
     return;
   }
+  if (vec) {
+    // T % 4 == 0, aligned rows: a float4 lies wholly inside its row or wholly outside.  Outside ones read x[0..3]
+    // (always there) and are zeroed by a select, so the eight loads still issue back to back (a test around each
+    // load would give each its own basic block and its own wait).
+    float4 val[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int t = gt0[g] + (k * 64 + lane) * 4;
+        const bool ok = gbase[g] >= 0 && t < T;
+        val[g * 2 + k] = *reinterpret_cast<const float4*>(x + (ok ? gbase[g] + t : (int64_t)0));
+      }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = (k * 64 + lane) * 4;
+        const bool ok = gbase[g] >= 0 && gt0[g] + e < T;
+        float4 v = val[g * 2 + k];
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        *reinterpret_cast<float4*>(tile + (g * 16 + (e >> 5)) * kPad + (e & 31)) = v;
+      }
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -338,6 +363,24 @@ __device__ __forceinline__ void tile_store(const float* tile, float* __restrict_
 #pragma unroll
       for (int k = 0; k < 2; ++k)
         *reinterpret_cast<float4*>(y + gbase[g] + gt0[g] + (k * 64 + lane) * 4) = val[g * 2 + k];
+    return;
+  }
+  if (vec) {                                          // all tile reads first, then the (predicated) stores
+    float4 val[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = (k * 64 + lane) * 4;
+        val[g * 2 + k] = *reinterpret_cast<const float4*>(tile + (g * 16 + (e >> 5)) * kPad + (e & 31));
+      }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int t = gt0[g] + (k * 64 + lane) * 4;
+        if (gbase[g] >= 0 && t < T) *reinterpret_cast<float4*>(y + gbase[g] + t) = val[g * 2 + k];
+      }
     return;
   }
 #pragma unroll
@@ -829,7 +872,7 @@ __global__ __launch_bounds__(64) void bandpower_direct_kernel(const float2* __re
 // Everything that does not depend on the band (the row's trial / channel split -- an integer division -- and its
 // output address) is computed once in front of the band loop: inside it the compiler does not hoist them out of the
 // `row < R` branch, and they were a tenth of the loop's instructions.
-template <typename VT, bool MAG, int GPR>
+template <typename VT, bool MAG, int GPR, bool FULL>
 __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                                                    const double* __restrict__ Qtab,
                                                    const float2* __restrict__ dft, const float* __restrict__ x,
@@ -858,7 +901,7 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
   const int64_t bstride = (int64_t)C * J;
   const bool st0 = row_ok && i < J, st16 = row_ok && i == LPR - 1 && J == LPR + 1;
   XArr xs;
-  load_chunks(xs, tile, x, lane, xbase, gt0, T, vec != 0);
+  load_chunks<FULL>(xs, tile, x, lane, xbase, gt0, T, vec != 0);
   for (int b = 0; b < nb; ++b) {
     typename O::Arr v;
     O::from_x(v, xs, O::g(bands[b]));
@@ -868,7 +911,7 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
     }
     XArr vf;                                          // fp32 copy for the DFT (the chunk itself when VT is fp32)
     O::to_f32(v, vf);
-    if (T < LPR * kL) zero_past_end(vf, i, T);
+    if (!FULL && T < LPR * kL) zero_past_end(vf, i, T);   // FULL: T == LPR * kL
     float o0, o16;
     band_reduce_pairs<MAG, GPR>(vf, dft, fbnd.klo[b], fbnd.khi[b], false, 0, 0, scale2, o0, o16, i == 0);
     const float inv = fbnd.inv[b];
@@ -1383,12 +1426,16 @@ static int fused_launch(const isd_fb_plan* fb, const FbSet& fs, const isd_stft_p
   const bool two = st->T > kSeg;                          // rows of 513..1024 samples: two 16-lane groups per row
   const int64_t items = cdiv(R, two ? 2 : 4);
   const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-#define ISD_FUSED(M, G)                                                                                              \
-  hipLaunchKernelGGL((fused_kernel<VT, M, G>), dim3((unsigned)items), dim3(64), 0, stream, fs.d_sec, fs.d_band, fs.d_Q, \
-                     st->d_dft, x, feat, (int)R, C, st->T, fs.nb, fb->n_sections, st->J, st->scale * st->scale, fbnd,  \
-                     mode, eps, vec, fs.d_map, fb->n_bands)
+  const int gpr = two ? 2 : 1;
+  const bool full = vec && st->T == gpr * kSeg && R % (4 / gpr) == 0;   // whole waves of whole segments (tile_load<FULL>)
+#define ISD_FUSED3(M, G, F)                                                                                          \
+  hipLaunchKernelGGL((fused_kernel<VT, M, G, F>), dim3((unsigned)items), dim3(64), 0, stream, fs.d_sec, fs.d_band,   \
+                     fs.d_Q, st->d_dft, x, feat, (int)R, C, st->T, fs.nb, fb->n_sections, st->J,                     \
+                     st->scale * st->scale, fbnd, mode, eps, vec, fs.d_map, fb->n_bands)
+#define ISD_FUSED(M, G) do { if (full) ISD_FUSED3(M, G, true); else ISD_FUSED3(M, G, false); } while (0)
   if (mode == ISD_BP_MAGNITUDE) { if (two) ISD_FUSED(true, 2); else ISD_FUSED(true, 1); }
   else { if (two) ISD_FUSED(false, 2); else ISD_FUSED(false, 1); }
+#undef ISD_FUSED3
 #undef ISD_FUSED
   ISD_LAUNCH_CHECK();
   return ISD_OK;
