@@ -41,6 +41,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(PKG_DIR, "build", os.path.basename(src) + ".o")
         objs.append(obj)
         cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        cmd += os.environ.get("ISD_HIPCC_FLAGS", "").split()          # e.g. -DISD_CF_TIMING (tools/conv_phases.py)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         jobs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

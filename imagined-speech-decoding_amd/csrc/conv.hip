@@ -1121,6 +1121,12 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a
 //    an eighth of the work and its input is not bf16; its weight gradient packs x to bf16 in registers.
 // HBM traffic per item halves (A2, A3, GELU'(A4) as bf16), LDS per workgroup drops from 150 to 81 / 87 KB.
 // ---------------------------------------------------------------------------------------
+#ifdef ISD_CF_TIMING                  // tools/conv_phases.py: shader-clock stamps of wave 0 of one workgroup, its 5th item
+__device__ long long cf_times[32];
+#define CF_MARK(k) do { if (blockIdx.x == 1 && blockIdx.y == 6 && threadIdx.x == 0 && item == blockIdx.x + 4 * (int64_t)gridDim.x) cf_times[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CF_MARK(k) do { } while (0)
+#endif
 __host__ __device__ __forceinline__ int fused16_rows(int TT) { return 32 * ((TT + 1) / 2) + 8; }   // tile rows incl. guards
 
 // acc[j][gt] = sum_k W_k[gt] x in(rows tt[j]*16 + . + k): `wfr` = LDS fragments [5][2][64] uint4, `in` = tile bytes
@@ -1128,28 +1134,23 @@ template <int NJ>
 __device__ __forceinline__ void fused_conv_bf16(const uint4* __restrict__ wfr, const char* __restrict__ in,
                                                 const int (&tt)[NJ], int lane, f32x4 (&acc)[NJ][2]) {
   const int q = lane >> 4, jl = lane & 15;
-  bf16x8 af[kTaps][2];
 #pragma unroll
-  for (int k = 0; k < kTaps; ++k)
+  for (int k = 0; k < kTaps; ++k) {      // tap-outer: two weight fragments live at a time, not ten
+    const bf16x8 a0 = __builtin_bit_cast(bf16x8, wfr[(k * 2 + 0) * 64 + lane]);
+    const bf16x8 a1 = __builtin_bit_cast(bf16x8, wfr[(k * 2 + 1) * 64 + lane]);
 #pragma unroll
-    for (int gt = 0; gt < 2; ++gt) af[k][gt] = __builtin_bit_cast(bf16x8, wfr[(k * 2 + gt) * 64 + lane]);
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    bf16x8 bfr[kTaps];
-#pragma unroll
-    for (int k = 0; k < kTaps; ++k)      // output step t, tap k reads input step t + k - 2 = tile row t + k
-      bfr[k] = *reinterpret_cast<const bf16x8*>(in + ((tt[j] * 16 + jl + k) * 64 + q * 16));
-#pragma unroll
-    for (int k = 0; k < kTaps; ++k) {
-      acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k][0], bfr[k], acc[j][0], 0, 0, 0);
-      acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k][1], bfr[k], acc[j][1], 0, 0, 0);
+    for (int j = 0; j < NJ; ++j) {       // output step t, tap k reads input step t + k - 2 = tile row t + k
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(in + ((tt[j] * 16 + jl + k) * 64 + q * 16));
+      acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[j][0], 0, 0, 0);
+      acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[j][1], 0, 0, 0);
     }
   }
 }
 
 // accumulator tiles -> bf16 tile rows (4 consecutive filters of one step = 8 bytes per lane and filter tile)
+// `bias`: the lane's 8 filter biases in registers ([filter tile][r]) or null
 template <int NW, bool DGELU>
-__device__ __forceinline__ void fused_store_bf16(const f32x4 (&acc)[16 / NW][2], const float* __restrict__ bias,
+__device__ __forceinline__ void fused_store_bf16(const f32x4 (&acc)[16 / NW][2], const float (*bias)[4],
                                                  char* __restrict__ tile, int T1, int TT, int wave, int q, int jl) {
 #pragma unroll
   for (int j = 0; j < 16 / NW; ++j) {
@@ -1161,7 +1162,7 @@ __device__ __forceinline__ void fused_store_bf16(const f32x4 (&acc)[16 / NW][2],
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = acc[j][gt][r] + (bias ? bias[gt * 16 + 4 * q + r] : 0.f);
+        v[r] = acc[j][gt][r] + (bias ? bias[gt][r] : 0.f);
         if (DGELU) v[r] = gelu_grad_f(v[r]);
       }
       *reinterpret_cast<uint2*>(tile + ((t + 2) * 64 + (gt * 16 + 4 * q) * 2)) =
@@ -1170,8 +1171,41 @@ __device__ __forceinline__ void fused_store_bf16(const f32x4 (&acc)[16 / NW][2],
   }
 }
 
+// cnn1 o cnn2 on the bf16 matrix cores: K = 32 = 2 taps x 16 channels.  `xt` = bf16 [time][16 channels] (32-byte rows),
+// `wfr` = [3 tap pairs][2 filter tiles][64] fragments (tap 5 and channels >= cz are zero).  The B fragment of lane
+// (step jl, k group q) is the 16-byte half (q & 1) of row step + 2 p + (q >> 1).
+template <int NJ>
+__device__ __forceinline__ void fused_conv1_bf16(const uint4* __restrict__ wfr, const char* __restrict__ xt,
+                                                 const int (&tt)[NJ], int lane, f32x4 (&acc)[NJ][2]) {
+  const int q = lane >> 4, jl = lane & 15;
+  bf16x8 af[3][2];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt) af[p][gt] = __builtin_bit_cast(bf16x8, wfr[(p * 2 + gt) * 64 + lane]);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    bf16x8 bfr[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      bfr[p] = *reinterpret_cast<const bf16x8*>(xt + ((tt[j] * 16 + jl + 2 * p + (q >> 1)) * 32 + (q & 1) * 16));
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p][0], bfr[p], acc[j][0], 0, 0, 0);
+      acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p][1], bfr[p], acc[j][1], 0, 0, 0);
+    }
+  }
+}
+
+// Per item: the wave's two x channels (2 wave, 2 wave + 1) are fetched into registers ONE ITEM AHEAD and written,
+// packed to bf16 pairs, straight into the [time][16 ch] tile `xt` (it borrows the front of t3, idle between cnn4's
+// reads and cnn3's stores) -> cnn1 o cnn2 -> t2 -> cnn3 -> t3 -> cnn4 -> GELU / GELU' (one erf evaluation for both)
+// -> row means.  Phase stamps (tools/conv_phases.py) of the version that staged fp32 x rows by LDS-DMA at the top of
+// the item and ran the first layer on the fp32 matrix cores: 12 200 of 37 300 cycles in the first layer (80 % of the
+// item's matrix-pipe time for an eighth of its flops), 4 800 exposed on the x fetch (3 200 of them a dependent
+// channel-index load), 5 600 in two erf passes.
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_bf16_kernel(FusedFwdArgs a) {
+__global__ __launch_bounds__(NW * 64, 4) void conv4_fused_fwd_bf16_kernel(FusedFwdArgs a) {   // 2 workgroups per CU
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int F = 32;
   const int z = blockIdx.y;
@@ -1180,57 +1214,107 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_bf16_kernel(FusedFwdA
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
   const int T1 = a.T1, W = a.W, TT = a.TT;
   const int R = fused16_rows(TT), tile_f = R * 16;            // tile = R rows x 64 bytes
-  float* xz = smem + 4;                                       // [16][W] fp32
-  char* t2 = reinterpret_cast<char*>(smem + ((4 + 16 * W + 3) & ~3));
+  char* t2 = reinterpret_cast<char*>(smem);
   char* t3 = t2 + tile_f * 4;
+  char* xt = t3;                                              // [TT * 16 + 8][16] bf16
   float* red = reinterpret_cast<float*>(t3 + tile_f * 4);     // [NW][32]
-  float* we = red + NW * F;                                   // [4][5][2][64] fp32 fragments of Weff
-  uint4* w3s = reinterpret_cast<uint4*>(we + 4 * kTaps * 2 * 64);   // [5][2][64] bf16 K = 32 fragments
+  float* bls = red + NW * F;                                  // [32] beff: read per item from LDS -- as registers
+                                                              // loaded before the loop the compiler waited for ALL
+                                                              // vector memory (the x fetch included) at their use
+  uint4* w1s = reinterpret_cast<uint4*>(bls + F);             // [3][2][64] bf16 K = 32 fragments of Weff
+  uint4* w3s = w1s + 3 * 2 * 64;                              // [5][2][64]
   uint4* w4s = w3s + kTaps * 2 * 64;
-  for (int e = threadIdx.x; e < 4 * kTaps * 2 * 64; e += NW * 64) we[e] = (e < ncg * kTaps * 2 * 64) ? a.weff[zd.eff_off + e] : 0.f;
+  for (int e = threadIdx.x; e < 3 * 2 * 64; e += NW * 64) {
+    const int l = e & 63, gt = (e >> 6) & 1, p = e >> 7, tap = 2 * p + (l >> 5);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int ch = ((l >> 4) & 1) * 8 + i;
+      v[i] = (ch < 4 * ncg && tap < kTaps)
+                 ? a.weff[zd.eff_off + (((ch >> 2) * kTaps + tap) * 2 + gt) * 64 + (ch & 3) * 16 + (l & 15)] : 0.f;
+    }
+    w1s[e] = make_uint4(bf16_pack(v[0], v[1]), bf16_pack(v[2], v[3]), bf16_pack(v[4], v[5]), bf16_pack(v[6], v[7]));
+  }
   for (int e = threadIdx.x; e < kTaps * 2 * 64; e += NW * 64) {
     w3s[e] = reinterpret_cast<const uint4*>(a.w3 + (int64_t)z * a.wz_stride)[e];
     w4s[e] = reinterpret_cast<const uint4*>(a.w4 + (int64_t)z * a.wz_stride)[e];
   }
-  for (int e = cz * W + threadIdx.x; e < 16 * W; e += NW * 64) xz[e] = 0.f;
   for (int e = threadIdx.x; e < 2 * tile_f; e += NW * 64) reinterpret_cast<float*>(t2)[e] = 0.f;   // guards, rows >= T1
-  const float* bias = a.beff + z * F;
+  if (threadIdx.x < F) bls[threadIdx.x] = a.beff[z * F + threadIdx.x];
   constexpr int NJ = 16 / NW;
-  int off0[NJ], ttj[NJ];
-  bool ok0[NJ][kTaps];
+  int ttj[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    ttj[j] = (j * NW + wave) < TT ? (j * NW + wave) : 0;       // dead slots recompute tile 0 (never stored)
-    off0[j] = ttj[j] * 16 + jl;
-#pragma unroll
-    for (int kk = 0; kk < kTaps; ++kk) ok0[j][kk] = off0[j] + kk < W;
-  }
+  for (int j = 0; j < NJ; ++j) ttj[j] = (j * NW + wave) < TT ? (j * NW + wave) : 0;   // dead slots recompute tile 0
   const int n16 = T1 * 4;                                      // 16-byte pieces of a tile's real rows
   char* a2b = reinterpret_cast<char*>(a.a2);
   char* a3b = reinterpret_cast<char*>(a.a3);
   char* a4b = reinterpret_cast<char*>(a.a4);
-
-  for (int64_t item = blockIdx.x; item < a.items; item += gridDim.x) {
-    const int64_t b = item / a.N;
-    const int n = (int)(item - b * a.N);
-    const int64_t abase = (item * a.Z + z) * (int64_t)T1 * 64;   // bytes: [item][zone][t][32] bf16
-    __syncthreads();
-    for (int r = wave; r < cz; r += NW) {
-      const float* src = a.x + (b * a.Ctot + a.chan_idx[zd.idx_off + r]) * (int64_t)a.Tx + (int64_t)n * a.S;
-      for (int t0 = 0; t0 < W; t0 += 64)
-        if (t0 + lane < W)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + t0 + lane), (lds_ptr_t)(xz + r * W + t0), 4, 0, 0);
+  // this wave's x channels: their row indices once (as a load per item the fetch waited for it first)
+  static_assert(NW == 8, "16 channels = two per wave");
+  const bool has0 = 2 * wave < cz, has1 = 2 * wave + 1 < cz;
+  const int64_t ch0 = a.chan_idx[zd.idx_off + (has0 ? 2 * wave : 0)];
+  const int64_t ch1 = a.chan_idx[zd.idx_off + (has1 ? 2 * wave + 1 : 0)];
+  const int nitems = (int)a.items, N = a.N;
+  constexpr int XC = 5;                                        // 64-step chunks: W <= 16 * 16 + 4
+  float xr[2][XC];
+  int tcl[XC];
+#pragma unroll
+  for (int c = 0; c < XC; ++c) tcl[c] = c * 64 + lane < W ? c * 64 + lane : W - 1;   // clamped: no test around a load
+  auto fetch_x = [&](int item) {
+    const int b = item / N, n = item - b * N;
+    const float* s0 = a.x + ((int64_t)b * a.Ctot + ch0) * (int64_t)a.Tx + (int64_t)n * a.S;
+    const float* s1 = a.x + ((int64_t)b * a.Ctot + ch1) * (int64_t)a.Tx + (int64_t)n * a.S;
+#pragma unroll
+    for (int c = 0; c < XC - 1; ++c) {
+      xr[0][c] = s0[tcl[c]];
+      xr[1][c] = s1[tcl[c]];
     }
-    __syncthreads();
+    if (W > (XC - 1) * 64) {
+      xr[0][XC - 1] = s0[tcl[XC - 1]];
+      xr[1][XC - 1] = s1[tcl[XC - 1]];
+    }
+  };
+  // x -> xt: bf16 pairs (channels 2 wave, 2 wave + 1) of step t; absent channels and steps >= W: zero
+  auto write_xt = [&]() {
+#pragma unroll
+    for (int c = 0; c < XC; ++c) {
+      const int t = c * 64 + lane;
+      const bool in = t < W;
+      const unsigned pr = bf16_pack(has0 && in ? xr[0][c] : 0.f, has1 && in ? xr[1][c] : 0.f);
+      if (t < TT * 16 + 8) *reinterpret_cast<unsigned*>(xt + t * 32 + wave * 4) = pr;
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < XC; ++c) xr[0][c] = xr[1][c] = 0.f;
+  if ((int)blockIdx.x < nitems) fetch_x(blockIdx.x);
+  __syncthreads();
+  write_xt();
+
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int64_t abase = ((int64_t)item * a.Z + z) * (int64_t)T1 * 64;   // bytes: [item][zone][t][32] bf16
+    CF_MARK(0);
+    CF_MARK(1);
+    __syncthreads();                                   // xt complete; the previous item's readers of t2 are done
+    CF_MARK(2);
+    if (item + (int)gridDim.x < nitems) fetch_x(item + gridDim.x);
+    CF_MARK(3);
     f32x4 acc[NJ][2];
-    // ---------------- cnn1 o cnn2 (valid, Cz x 5 taps) on the fp32 fragments
+    // ---------------- cnn1 o cnn2 (valid, Cz x 5 taps)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    fused_conv_mma<NJ>(we + lane, xz + q * W, W, ncg, off0, ok0, acc);
-    fused_store_bf16<NW, false>(acc, bias, t2, T1, TT, wave, q, jl);
-    __syncthreads();
+    fused_conv1_bf16<NJ>(w1s, xt, ttj, lane, acc);
+    CF_MARK(4);
+    {
+      const float4 b0 = *reinterpret_cast<const float4*>(bls + 4 * q), b1 = *reinterpret_cast<const float4*>(bls + 16 + 4 * q);
+      const float bias[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+      fused_store_bf16<NW, false>(acc, bias, t2, T1, TT, wave, q, jl);
+    }
+    CF_MARK(5);
+    __syncthreads();                                   // t2 complete; every read of xt (= front of t3) is done
+    CF_MARK(6);
+    if (threadIdx.x < 8) reinterpret_cast<uint4*>(t3)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);   // t3's guard rows
     if (a.store) {
       uint4* dst = reinterpret_cast<uint4*>(a2b + abase);
       const uint4* src = reinterpret_cast<const uint4*>(t2 + 2 * 64);
@@ -1241,33 +1325,53 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_bf16_kernel(FusedFwdA
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    CF_MARK(7);
     fused_conv_bf16<NJ>(w3s, t2, ttj, lane, acc);
+    CF_MARK(8);
     fused_store_bf16<NW, false>(acc, nullptr, t3, T1, TT, wave, q, jl);
+    CF_MARK(9);
     __syncthreads();                                   // t3 complete; every read of t2 is done
+    CF_MARK(10);
     if (a.store) {
       uint4* dst = reinterpret_cast<uint4*>(a3b + abase);
       const uint4* src = reinterpret_cast<const uint4*>(t3 + 2 * 64);
       for (int e = threadIdx.x; e < n16; e += NW * 64) dst[e] = src[e];
     }
-    // ---------------- cnn4 (pad 2) -> GELU -> mean
+    // ---------------- cnn4 (pad 2) -> GELU -> mean; GELU'(A4) (or A4) into t2 for the backward
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    CF_MARK(11);
     fused_conv_bf16<NJ>(w4s, t3, ttj, lane, acc);
-    if (a.store == 2) fused_store_bf16<NW, true>(acc, nullptr, t2, T1, TT, wave, q, jl);     // GELU'(A4) for the backward
-    else if (a.store) fused_store_bf16<NW, false>(acc, nullptr, t2, T1, TT, wave, q, jl);
-    float part[2][4];
+    CF_MARK(12);
+    float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int tt = j * NW + wave, t = tt * 16 + jl;
+      const bool live = tt < TT && t < T1;
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt) {
+        float keep[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float u = acc[j][gt][r];
+          float cdf, ez;
+          gelu_parts(u, cdf, ez);                      // one erf for GELU and GELU'
+          part[gt][r] += live ? u * cdf : 0.f;
+          keep[r] = a.store == 2 ? fmaf(u * 0.39894228040143267794f, ez, cdf) : u;
+        }
+        if (live && a.store)
+          *reinterpret_cast<uint2*>(t2 + ((t + 2) * 64 + (gt * 16 + 4 * q) * 2)) =
+              make_uint2(bf16_pack(keep[0], keep[1]), bf16_pack(keep[2], keep[3]));
+      }
+    }
+    CF_MARK(13);
 #pragma unroll
     for (int gt = 0; gt < 2; ++gt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int tt = j * NW + wave;
-          if (tt < TT && tt * 16 + jl < T1) sacc += gelu_f(acc[j][gt][r]);
-        }
+        float sacc = part[gt][r];
         sacc += row_shr<8>(sacc);
         sacc += row_shr<4>(sacc);
         sacc += row_shr<2>(sacc);
@@ -1280,18 +1384,24 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_bf16_kernel(FusedFwdA
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave * F + gt * 16 + 4 * q + r] = part[gt][r];
     }
-    __syncthreads();
+    CF_MARK(14);
+    __syncthreads();                                   // row sums in `red`; every read of t3 is done
+    CF_MARK(15);
+    // the next item's x (fetched after this item's first barrier) into xt = the idle front of t3, BEFORE this item's
+    // last stores are issued: the wait for the fetch is a wait for everything issued before it, too
+    if (item + (int)gridDim.x < nitems) write_xt();
     if (threadIdx.x < F) {
       float tot = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) tot += red[w * F + threadIdx.x];
-      a.feat[(item * a.Z + z) * F + threadIdx.x] = tot / (float)T1;
+      a.feat[((int64_t)item * a.Z + z) * F + threadIdx.x] = tot / (float)T1;
     }
     if (a.store) {
       uint4* dst = reinterpret_cast<uint4*>(a4b + abase);
       const uint4* src = reinterpret_cast<const uint4*>(t2 + 2 * 64);
       for (int e = threadIdx.x; e < n16; e += NW * 64) dst[e] = src[e];
     }
+    CF_MARK(16);
   }
 }
 
@@ -2796,7 +2906,7 @@ static size_t fused16_lds(const isd_conv4_plan* p, const Geo& g, bool bwd) {
   const size_t tile_f = (size_t)fused16_rows(g.TT) * 16, x_f = (size_t)((4 + 16 * p->W + 3) & ~3);
   const size_t w16 = (size_t)kTaps * 2 * 64 * 4;
   return sizeof(float) * (bwd ? x_f + 3 * tile_f + 2 * w16 + 32 + 16
-                              : x_f + 2 * tile_f + 8 * 32 + 4 * kTaps * 2 * 64 + 2 * w16 + 16);
+                              : 2 * tile_f + 8 * 32 + 3 * 2 * 64 * 4 + 2 * w16 + 16);
 }
 
 static int launch_prep(const isd_conv4_plan* p, const Geo& g, const float* params, float* ws, hipStream_t st,
@@ -3342,3 +3452,9 @@ extern "C" int isd_conv4_backward_x(const isd_conv4_plan* p, const float* x, con
   ISD_CHECK_ARG(dx || B == 0, "isd_conv4_backward_x: null dx");
   return conv4_backward_impl(p, x, params, dfeat, dparams, dx, workspace, B, T, stream);
 }
+
+#ifdef ISD_CF_TIMING
+extern "C" int isd_debug_conv_marks(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(isd::cf_times), sizeof(long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
