@@ -1444,32 +1444,29 @@ __device__ __forceinline__ void fused_wgrad_bf16(unsigned g_base, unsigned in_ba
   }
 }
 
-// first layer: acc[gt][k] += sum_t G2[t][gt*16 + m] * x[n][t + k], accb[gt] += sum_t G2[t][.]; x = fp32 rows in LDS
-__device__ __forceinline__ void fused_wgrad_x_bf16(unsigned g_base, const float* __restrict__ xz, int W, int first,
-                                                   int stride, int nkb, int q, int jl, f32x4 (&acc)[2][kTaps],
-                                                   f32x4 (&accb)[2]) {
+// first layer: acc[gt][k] += sum_t G2[t][gt*16 + m] * x[n][t + k], accb[gt] += sum_t G2[t][.]; x = the bf16
+// [time][16 channels] tile (32-byte rows, row = step: a valid convolution has no guard rows)
+__device__ __forceinline__ void fused_wgrad_x_bf16(unsigned g_base, unsigned xt_base, int first, int stride, int nkb,
+                                                   int q, int jl, f32x4 (&acc)[2][kTaps], f32x4 (&accb)[2]) {
   const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   for (int s = first; s < nkb; s += stride) {
     const unsigned ga0 = tr_addr(g_base, 2 + 32 * s + 8 * q, 0, jl);
-    uint2 a00, a01, a10, a11;
+    const unsigned ia0 = xt_base + (unsigned)(((32 * s + 8 * q + (jl >> 2)) * 16 + 4 * (jl & 3)) * 2);
+    uint2 a00, a01, a10, a11, w0, w1, w2;
     asm volatile(
-        "ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:256\n\t"
-        "ds_read_b64_tr_b16 %2, %4 offset:32\n\tds_read_b64_tr_b16 %3, %4 offset:288\n\t"
+        "ds_read_b64_tr_b16 %0, %7\n\tds_read_b64_tr_b16 %1, %7 offset:256\n\t"
+        "ds_read_b64_tr_b16 %2, %7 offset:32\n\tds_read_b64_tr_b16 %3, %7 offset:288\n\t"
+        "ds_read_b64_tr_b16 %4, %8\n\tds_read_b64_tr_b16 %5, %8 offset:128\n\tds_read_b64_tr_b16 %6, %8 offset:256\n\t"
         "s_waitcnt lgkmcnt(0)"
-        : "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11)
-        : "v"(ga0)
+        : "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11), "=&v"(w0), "=&v"(w1), "=&v"(w2)
+        : "v"(ga0), "v"(ia0)
         : "memory");
     const bf16x8 af0 = __builtin_bit_cast(bf16x8, make_uint4(a00.x, a00.y, a01.x, a01.y));
     const bf16x8 af1 = __builtin_bit_cast(bf16x8, make_uint4(a10.x, a10.y, a11.x, a11.y));
-    const float* xr = xz + jl * W + 32 * s + 8 * q;     // samples past a row's end meet zero rows of G2 (finite)
-    float e[12];
+    const unsigned pe[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};     // window steps (0,1) (2,3) ... (10,11)
+    unsigned po[5];
 #pragma unroll
-    for (int n = 0; n < 12; ++n) e[n] = xr[n];
-    unsigned pe[6], po[5];
-#pragma unroll
-    for (int n = 0; n < 6; ++n) pe[n] = bf16_pack(e[2 * n], e[2 * n + 1]);
-#pragma unroll
-    for (int n = 0; n < 5; ++n) po[n] = bf16_pack(e[2 * n + 1], e[2 * n + 2]);
+    for (int n = 0; n < 5; ++n) po[n] = __builtin_amdgcn_alignbit(pe[n + 1], pe[n], 16);   // steps (1,2) (3,4) ...
 #pragma unroll
     for (int k = 0; k < kTaps; ++k) {
       const int h = k >> 1;
@@ -1484,6 +1481,19 @@ __device__ __forceinline__ void fused_wgrad_x_bf16(unsigned g_base, const float*
   }
 }
 
+// 16 bytes per lane, global -> LDS (base + 16 lane), issued behind the compiler's back: as the builtin, every later
+// ds_write of the kernel would first wait for it (the LDS-DMA hazard tracking cannot tell the tiles apart), and a
+// fetch issued one item ahead would be waited for a few instructions later.  The consumer waits with
+// __builtin_amdgcn_s_waitcnt (vmcnt 0) + a workgroup barrier.  `lds_base` must be wave-uniform.
+__device__ __forceinline__ void dma16_async(const void* src_lane, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(src_lane) : "memory");
+}
+
+// One item ahead: GELU'(A4), A3 and A2 of the next item stream into the other tile set by LDS-DMA and its x channels
+// and dfeat row into registers while this item computes (one workgroup per CU: the 120 weight-gradient accumulators
+// leave two waves per SIMD, and 147 of the 160 KB of LDS pay for the second set).  Fetched at the top of the item the
+// three tiles, the x rows behind a dependent channel-index load and dfeat cost the item their whole latency.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_bf16_kernel(FusedBwdArgs a) {
   static_assert(NW == 8, "wave roles below assume 8 waves");
@@ -1494,20 +1504,19 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_bf16_kernel(FusedBwdA
   const int cz = zd.cin, cin1 = cz + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
   const int T1 = a.T1, W = a.W, TT = a.TT;
-  const int R = fused16_rows(TT), tile_f = R * 16;
-  float* xz = smem + 4;                                       // [16][W] fp32; the zero guard rows of `ga` follow it
-  char* ga = reinterpret_cast<char*>(smem + ((4 + 16 * W + 3) & ~3));
-  char* gb = ga + tile_f * 4;
-  char* at = gb + tile_f * 4;                                 // staged activation (A3, then A2)
-  uint4* w4s = reinterpret_cast<uint4*>(at + tile_f * 4);     // transposed + flipped cnn4 / cnn3 fragments
+  const int R = fused16_rows(TT), tile_f = R * 16, tile_b = tile_f * 4;
+  // LDS: set 0 {tA, tB, tC}, set 1 {tA, tB, tC}, gb, xt, w4s, w3s.   tA: GELU'(A4) -> G4 -> G2;  tB: A3;  tC: A2
+  char* sets = reinterpret_cast<char*>(smem);
+  char* gb = sets + 6 * tile_b;
+  const int xt_rows = 32 * ((TT + 1) / 2) + 16;               // the last 32-step block's 12-step window stays inside
+  char* xt = gb + tile_b;                                     // [xt_rows][16] bf16 (rows past W: zeros)
+  uint4* w4s = reinterpret_cast<uint4*>(xt + xt_rows * 32);   // transposed + flipped cnn4 / cnn3 fragments
   uint4* w3s = w4s + kTaps * 2 * 64;
-  float* dfs = reinterpret_cast<float*>(w3s + kTaps * 2 * 64);   // [32] dfeat of the item / T1
   for (int e = threadIdx.x; e < kTaps * 2 * 64; e += NW * 64) {
     w4s[e] = reinterpret_cast<const uint4*>(a.w4t + (int64_t)z * a.wz_stride)[e];
     w3s[e] = reinterpret_cast<const uint4*>(a.w3t + (int64_t)z * a.wz_stride)[e];
   }
-  for (int e = cz * W + threadIdx.x; e < 16 * W; e += NW * 64) xz[e] = 0.f;
-  for (int e = threadIdx.x; e < 3 * tile_f; e += NW * 64) reinterpret_cast<float*>(ga)[e] = 0.f;
+  for (int e = threadIdx.x; e < 7 * tile_f + xt_rows * 8; e += NW * 64) smem[e] = 0.f;   // guards, rows >= T1
   constexpr int NJ = 16 / NW;
   int ttj[NJ];
 #pragma unroll
@@ -1515,9 +1524,8 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_bf16_kernel(FusedBwdA
   const int ct = wave & 1, ks = wave >> 1;
   const int nkb = (T1 + 31) >> 5;                             // 32-step blocks of the weight gradients
   const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem;
-  const unsigned ga_base = smem_base + (unsigned)(ga - reinterpret_cast<char*>(smem));
-  const unsigned gb_base = smem_base + (unsigned)(gb - reinterpret_cast<char*>(smem));
-  const unsigned at_base = smem_base + (unsigned)(at - reinterpret_cast<char*>(smem));
+  const unsigned gb_base = smem_base + 6 * tile_b;
+  const unsigned xt_base = gb_base + tile_b;
   f32x4 acc4[2][kTaps], acc3[2][kTaps], acc0[2][kTaps], accb[2];
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
@@ -1529,52 +1537,96 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_bf16_kernel(FusedBwdA
       acc0[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
-  const int n16 = T1 * 4;
+  const int n16 = T1 * 4;                                      // 16-byte pieces of a tile's real rows
   const char* a2b = reinterpret_cast<const char*>(a.a2);
   const char* a3b = reinterpret_cast<const char*>(a.a3);
   const char* a4b = reinterpret_cast<const char*>(a.a4);
+  const bool has0 = 2 * wave < cz, has1 = 2 * wave + 1 < cz;   // this wave's x channels: 2 wave, 2 wave + 1
+  const int64_t ch0 = a.chan_idx[zd.idx_off + (has0 ? 2 * wave : 0)];
+  const int64_t ch1 = a.chan_idx[zd.idx_off + (has1 ? 2 * wave + 1 : 0)];
+  const int nitems = (int)a.items, N = a.N;
+  const float inv_t1 = 1.f / (float)T1;
+  constexpr int XC = 5;                                        // 64-step chunks: W <= 16 * 16 + 4
+  float xr[2][XC];
+  float4 dr[2];                                                // dfeat[8 (tid & 3) .. + 8]: the filters of this thread's pieces
+  int tcl[XC];
+#pragma unroll
+  for (int c = 0; c < XC; ++c) {
+    tcl[c] = c * 64 + lane < W ? c * 64 + lane : W - 1;        // clamped: no test around a load
+    xr[0][c] = xr[1][c] = 0.f;
+  }
+  auto prefetch = [&](int item, int set) {
+    const int64_t abase = ((int64_t)item * a.Z + z) * (int64_t)T1 * 64;
+    const unsigned tA = smem_base + (unsigned)(set * 3 * tile_b) + 128;          // past the two guard rows
+#pragma unroll 1
+    for (int e0 = wave * 64; e0 < n16; e0 += NW * 64)
+      if (e0 + lane < n16) {
+        const int64_t o = abase + (int64_t)(e0 + lane) * 16;
+        dma16_async(a4b + o, tA + e0 * 16);
+        dma16_async(a3b + o, tA + tile_b + e0 * 16);
+        dma16_async(a2b + o, tA + 2 * tile_b + e0 * 16);
+      }
+    const int b = item / N, n = item - b * N;
+    const float* s0 = a.x + ((int64_t)b * a.Ctot + ch0) * (int64_t)a.Tx + (int64_t)n * a.S;
+    const float* s1 = a.x + ((int64_t)b * a.Ctot + ch1) * (int64_t)a.Tx + (int64_t)n * a.S;
+#pragma unroll
+    for (int c = 0; c < XC - 1; ++c) {
+      xr[0][c] = s0[tcl[c]];
+      xr[1][c] = s1[tcl[c]];
+    }
+    if (W > (XC - 1) * 64) {
+      xr[0][XC - 1] = s0[tcl[XC - 1]];
+      xr[1][XC - 1] = s1[tcl[XC - 1]];
+    }
+    const float4* dp = reinterpret_cast<const float4*>(a.dfeat + ((int64_t)item * a.Z + z) * F + (threadIdx.x & 3) * 8);
+    dr[0] = dp[0];
+    dr[1] = dp[1];
+  };
+  dr[0] = dr[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();                                             // the zero fill is done before the first DMA lands
+  if ((int)blockIdx.x < nitems) prefetch(blockIdx.x, 0);
 
-  for (int64_t item = blockIdx.x; item < a.items; item += gridDim.x) {
-    const int64_t b = item / a.N;
-    const int n = (int)(item - b * a.N);
-    const int64_t abase = (item * a.Z + z) * (int64_t)T1 * 64;
-    __syncthreads();                                   // the previous item's tiles are no longer read
-    glds_copy16_strided(reinterpret_cast<const float*>(a4b + abase), reinterpret_cast<float*>(ga + 128), n16, wave * 64,
-                        NW * 64, lane);                // GELU'(A4)
-    glds_copy16_strided(reinterpret_cast<const float*>(a3b + abase), reinterpret_cast<float*>(at + 128), n16, wave * 64,
-                        NW * 64, lane);
-    for (int r = wave; r < cz; r += NW) {
-      const float* src = a.x + (b * a.Ctot + a.chan_idx[zd.idx_off + r]) * (int64_t)a.Tx + (int64_t)n * a.S;
-      for (int t0 = 0; t0 < W; t0 += 64)
-        if (t0 + lane < W)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + t0 + lane), (lds_ptr_t)(xz + r * W + t0), 4, 0, 0);
+  int set = 0;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x, set ^= 1) {
+    char* tA = sets + set * 3 * tile_b;
+    char* tB = tA + tile_b;
+    const unsigned tA_base = smem_base + (unsigned)(set * 3 * tile_b), tC_base = tA_base + 2 * tile_b;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's share of the item's fetch has landed
+    __syncthreads();                                   // ... everyone's; the previous item's tiles are no longer read
+    // ---------------- x -> xt: bf16 pairs (channels 2 wave, 2 wave + 1) of step t; absent channels, steps >= W: zero
+#pragma unroll
+    for (int c = 0; c < XC; ++c) {
+      const int t = c * 64 + lane;
+      const bool in = t < W;
+      const unsigned pr = bf16_pack(has0 && in ? xr[0][c] : 0.f, has1 && in ? xr[1][c] : 0.f);
+      if (t < TT * 16 + 8) *reinterpret_cast<unsigned*>(xt + t * 32 + wave * 4) = pr;
     }
-    if (threadIdx.x < F) dfs[threadIdx.x] = a.dfeat[(item * a.Z + z) * F + threadIdx.x] / (float)T1;
-    __syncthreads();
-    // G4 = dfeat/T1 * GELU'(A4): 16 bytes = 8 consecutive filters of one step
-    for (int e = threadIdx.x; e < n16; e += NW * 64) {
-      uint4* pv = reinterpret_cast<uint4*>(ga + 128) + e;
-      const uint4 v = *pv;
-      const float* d = dfs + (e & 3) * 8;
-      *pv = make_uint4(bf16_pack(bf16_lo(v.x) * d[0], bf16_hi(v.x) * d[1]), bf16_pack(bf16_lo(v.y) * d[2], bf16_hi(v.y) * d[3]),
-                       bf16_pack(bf16_lo(v.z) * d[4], bf16_hi(v.z) * d[5]), bf16_pack(bf16_lo(v.w) * d[6], bf16_hi(v.w) * d[7]));
+    // ---------------- G4 = dfeat/T1 * GELU'(A4), in place: 16 bytes = 8 consecutive filters of one step
+    {
+      const float d[8] = {dr[0].x * inv_t1, dr[0].y * inv_t1, dr[0].z * inv_t1, dr[0].w * inv_t1,
+                          dr[1].x * inv_t1, dr[1].y * inv_t1, dr[1].z * inv_t1, dr[1].w * inv_t1};
+      for (int e = threadIdx.x; e < n16; e += NW * 64) {       // e & 3 == threadIdx.x & 3
+        uint4* pv = reinterpret_cast<uint4*>(tA + 128) + e;
+        const uint4 v = *pv;
+        *pv = make_uint4(bf16_pack(bf16_lo(v.x) * d[0], bf16_hi(v.x) * d[1]), bf16_pack(bf16_lo(v.y) * d[2], bf16_hi(v.y) * d[3]),
+                         bf16_pack(bf16_lo(v.z) * d[4], bf16_hi(v.z) * d[5]), bf16_pack(bf16_lo(v.w) * d[6], bf16_hi(v.w) * d[7]));
+      }
     }
-    __syncthreads();                                   // G4, A3 and the x rows are in LDS
+    if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x, set ^ 1);
+    __syncthreads();                                   // G4 and xt are complete
     // ---------------- cnn4: dW4 += G4 (*) A3 ; G3 = W4^T (*) G4 -> gb
-    fused_wgrad_bf16(ga_base, at_base, ct, ks, 4, nkb, q, jl, acc4);
+    fused_wgrad_bf16(tA_base, tA_base + tile_b, ct, ks, 4, nkb, q, jl, acc4);
     {
       f32x4 acc[NJ][2];
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      fused_conv_bf16<NJ>(w4s, ga, ttj, lane, acc);
+      fused_conv_bf16<NJ>(w4s, tA, ttj, lane, acc);
       fused_store_bf16<NW, false>(acc, nullptr, gb, T1, TT, wave, q, jl);
     }
-    __syncthreads();                                   // G3 complete; A3 and G4 are dead
-    glds_copy16_strided(reinterpret_cast<const float*>(a2b + abase), reinterpret_cast<float*>(at + 128), n16, wave * 64,
-                        NW * 64, lane);
-    // ---------------- cnn3 data gradient first (does not need A2): G2 = W3^T (*) G3 -> ga
+    __syncthreads();                                   // G3 complete; G4 is dead
+    // ---------------- cnn3: G2 = W3^T (*) G3 -> tA
     {
       f32x4 acc[NJ][2];
 #pragma unroll
@@ -1582,12 +1634,12 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_bf16_kernel(FusedBwdA
 #pragma unroll
         for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       fused_conv_bf16<NJ>(w3s, gb, ttj, lane, acc);
-      fused_store_bf16<NW, false>(acc, nullptr, ga, T1, TT, wave, q, jl);
+      fused_store_bf16<NW, false>(acc, nullptr, tA, T1, TT, wave, q, jl);
     }
-    __syncthreads();                                   // G2 complete, A2 landed
-    fused_wgrad_bf16(gb_base, at_base, ct, ks, 4, nkb, q, jl, acc3);
+    __syncthreads();                                   // G2 complete
+    fused_wgrad_bf16(gb_base, tC_base, ct, ks, 4, nkb, q, jl, acc3);
     // ---------------- cnn1 o cnn2: dWeff += G2 (*) x (valid convolution), dbeff += sum_t G2
-    fused_wgrad_x_bf16(ga_base, xz, W, wave, NW, nkb, q, jl, acc0, accb);
+    fused_wgrad_x_bf16(tA_base, xt_base, wave, NW, nkb, q, jl, acc0, accb);
   }
   // ---------------- partial slabs (same layout as the fp32 kernel)
   {
@@ -2903,10 +2955,13 @@ static bool fused16_ok(const isd_conv4_plan* p, const Geo& g) {
   return p->n_layers == 4 && p->F == 32 && p->act_bf16 && p->max_cz <= 16 && g.TT <= 16 && g.TT >= 4;
 }
 static size_t fused16_lds(const isd_conv4_plan* p, const Geo& g, bool bwd) {
-  const size_t tile_f = (size_t)fused16_rows(g.TT) * 16, x_f = (size_t)((4 + 16 * p->W + 3) & ~3);
+  (void)p;
+  const size_t tile_f = (size_t)fused16_rows(g.TT) * 16;
   const size_t w16 = (size_t)kTaps * 2 * 64 * 4;
-  return sizeof(float) * (bwd ? x_f + 3 * tile_f + 2 * w16 + 32 + 16
-                              : 2 * tile_f + 8 * 32 + 3 * 2 * 64 * 4 + 2 * w16 + 16);
+  // backward: two sets of {GELU'(A4) / G4 / G2, A3, A2} + G3 + the bf16 x tile + two weight fragment sets
+  // forward: t2, t3 (its front doubles as the bf16 x tile), row sums, bias, three weight fragment sets
+  return sizeof(float) * (bwd ? 7 * tile_f + (size_t)(32 * ((g.TT + 1) / 2) + 16) * 8 + 2 * w16 + 16
+                              : 2 * tile_f + 8 * 32 + 32 + 3 * 2 * 64 * 4 + 2 * w16 + 16);
 }
 
 static int launch_prep(const isd_conv4_plan* p, const Geo& g, const float* params, float* ws, hipStream_t st,
