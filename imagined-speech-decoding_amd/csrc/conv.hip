@@ -1591,8 +1591,10 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_bf16_kernel(FusedBwdA
     char* tA = sets + set * 3 * tile_b;
     char* tB = tA + tile_b;
     const unsigned tA_base = smem_base + (unsigned)(set * 3 * tile_b), tC_base = tA_base + 2 * tile_b;
+    CF_MARK(17);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's share of the item's fetch has landed
     __syncthreads();                                   // ... everyone's; the previous item's tiles are no longer read
+    CF_MARK(18);
     // ---------------- x -> xt: bf16 pairs (channels 2 wave, 2 wave + 1) of step t; absent channels, steps >= W: zero
 #pragma unroll
     for (int c = 0; c < XC; ++c) {
@@ -1601,6 +1603,7 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_bf16_kernel(FusedBwdA
       const unsigned pr = bf16_pack(has0 && in ? xr[0][c] : 0.f, has1 && in ? xr[1][c] : 0.f);
       if (t < TT * 16 + 8) *reinterpret_cast<unsigned*>(xt + t * 32 + wave * 4) = pr;
     }
+    CF_MARK(19);
     // ---------------- G4 = dfeat/T1 * GELU'(A4), in place: 16 bytes = 8 consecutive filters of one step
     {
       const float d[8] = {dr[0].x * inv_t1, dr[0].y * inv_t1, dr[0].z * inv_t1, dr[0].w * inv_t1,
@@ -1612,10 +1615,14 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_bf16_kernel(FusedBwdA
                          bf16_pack(bf16_lo(v.z) * d[4], bf16_hi(v.z) * d[5]), bf16_pack(bf16_lo(v.w) * d[6], bf16_hi(v.w) * d[7]));
       }
     }
+    CF_MARK(20);
     if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x, set ^ 1);
+    CF_MARK(21);
     __syncthreads();                                   // G4 and xt are complete
+    CF_MARK(22);
     // ---------------- cnn4: dW4 += G4 (*) A3 ; G3 = W4^T (*) G4 -> gb
     fused_wgrad_bf16(tA_base, tA_base + tile_b, ct, ks, 4, nkb, q, jl, acc4);
+    CF_MARK(23);
     {
       f32x4 acc[NJ][2];
 #pragma unroll
@@ -1625,7 +1632,9 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_bf16_kernel(FusedBwdA
       fused_conv_bf16<NJ>(w4s, tA, ttj, lane, acc);
       fused_store_bf16<NW, false>(acc, nullptr, gb, T1, TT, wave, q, jl);
     }
+    CF_MARK(24);
     __syncthreads();                                   // G3 complete; G4 is dead
+    CF_MARK(25);
     // ---------------- cnn3: G2 = W3^T (*) G3 -> tA
     {
       f32x4 acc[NJ][2];
@@ -1636,10 +1645,14 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_bf16_kernel(FusedBwdA
       fused_conv_bf16<NJ>(w3s, gb, ttj, lane, acc);
       fused_store_bf16<NW, false>(acc, nullptr, tA, T1, TT, wave, q, jl);
     }
+    CF_MARK(26);
     __syncthreads();                                   // G2 complete
+    CF_MARK(27);
     fused_wgrad_bf16(gb_base, tC_base, ct, ks, 4, nkb, q, jl, acc3);
+    CF_MARK(28);
     // ---------------- cnn1 o cnn2: dWeff += G2 (*) x (valid convolution), dbeff += sum_t G2
     fused_wgrad_x_bf16(tA_base, xt_base, wave, NW, nkb, q, jl, acc0, accb);
+    CF_MARK(29);
   }
   // ---------------- partial slabs (same layout as the fp32 kernel)
   {

@@ -31,3 +31,10 @@ names = ["x registers -> bf16 xt tile", "barrier", "fetch next item's x", "cnn1.
 for k, n in enumerate(names):
     print(f"{n:36s} {t[k + 1] - t[k]:8d} clk")
 print(f"{'item total':36s} {t[16] - t[0]:8d} clk (shader clock cycles)")
+bnames = ["wait for the fetched tiles + barrier", "x registers -> bf16 xt tile", "G4 = dfeat/T1 * GELU'(A4)",
+          "fetch next item (DMA + registers)", "barrier", "dW4 (G4 x A3)", "G3 = W4^T * G4, store", "barrier",
+          "G2 = W3^T * G3, store", "barrier", "dW3 (G3 x A2)", "dWeff, dbeff (G2 x x)"]
+print("backward (conv4_fused_bwd_bf16_kernel):")
+for k, n in enumerate(bnames):
+    print(f"{n:36s} {t[18 + k] - t[17 + k]:8d} clk")
+print(f"{'item total (without the loop edge)':36s} {t[29] - t[17]:8d} clk")
