@@ -1018,9 +1018,13 @@ void fused_long_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict_
         __builtin_amdgcn_sched_barrier(0);              // one bin's 64 table scalars at a time in the SGPR file
         const int k = k0 + kk < n_bins_max ? k0 + kk : n_bins_max;
         const float2* tb = blk + (int64_t)k * 64;
-        f2 acc = {0.f, 0.f};
+        f2 acc = {0.f, 0.f}, acc_b = {0.f, 0.f};
 #pragma unroll
-        for (int n = 0; n < kL; ++n) acc = __builtin_elementwise_fma((f2){vf[n], vf[n]}, (f2){tb[n].x, tb[n].y}, acc);
+        for (int n = 0; n < kL; n += 2) {             // two chains: a dependent v_pk_fma costs a wait state each
+            acc = __builtin_elementwise_fma((f2){vf[n], vf[n]}, (f2){tb[n].x, tb[n].y}, acc);
+            acc_b = __builtin_elementwise_fma((f2){vf[n + 1], vf[n + 1]}, (f2){tb[n + 1].x, tb[n + 1].y}, acc_b);
+          }
+          acc += acc_b;
         const float2 ph = tb[kL];                       // e^{-2 pi i k 32 / n}: the odd lane's offset in the block
         P[kk] = (lane & 1) ? make_float2(acc.x * ph.x - acc.y * ph.y, acc.x * ph.y + acc.y * ph.x)
                            : make_float2(acc.x, acc.y);
@@ -1132,9 +1136,13 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
           __builtin_amdgcn_sched_barrier(0);            // one bin's 64 table scalars at a time in the SGPR file
           const int k = k0 + kk < n_bins_max ? k0 + kk : n_bins_max;
           const float2* tb = blk + (int64_t)k * 64;
-          f2 acc = {0.f, 0.f};
+          f2 acc = {0.f, 0.f}, acc_b = {0.f, 0.f};
 #pragma unroll
-          for (int n = 0; n < kL; ++n) acc = __builtin_elementwise_fma((f2){vf[n], vf[n]}, (f2){tb[n].x, tb[n].y}, acc);
+          for (int n = 0; n < kL; n += 2) {             // two chains: a dependent v_pk_fma costs a wait state each
+            acc = __builtin_elementwise_fma((f2){vf[n], vf[n]}, (f2){tb[n].x, tb[n].y}, acc);
+            acc_b = __builtin_elementwise_fma((f2){vf[n + 1], vf[n + 1]}, (f2){tb[n + 1].x, tb[n + 1].y}, acc_b);
+          }
+          acc += acc_b;
           const float2 ph = tb[kL];                     // e^{-2 pi i k 32 / n}: the odd lane's offset in the block
           const float px = (lane & 1) ? acc.x * ph.x - acc.y * ph.y : acc.x;
           const float py = (lane & 1) ? acc.x * ph.y + acc.y * ph.x : acc.y;

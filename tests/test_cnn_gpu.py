@@ -385,6 +385,24 @@ def test_bf16_fused_raw_eeg_head_vs_fp32(inn):
         assert 0 < rel_err(f16, f32) < 2e-2, (B, T)
         for k in g32:
             assert rel_err(g16[k], g32[k]) < 5e-2, (B, T, k)
+    # other window lengths: 260 samples (T1 = 256: the x fetch takes its fifth 64-step chunk, 16 full column tiles),
+    # 100 samples (6 column tiles, 3 blocks of 32 steps in the weight gradients), many more items than workgroups
+    for B, T, wl, st in ((5, 520, 260, 130), (9, 300, 100, 50), (700, 250, 250, 125)):
+        x = torch.randn(B, 64, T, device="cuda")
+        n_win = (T - wl) // st + 1
+        w = torch.randn(B * n_win, 8, 32, device="cuda")
+        outs = []
+        for h in (h32, h16):
+            h.zero_grad(set_to_none=True)
+            f = h.forward_windows(x, wl, st)
+            (f * w).sum().backward()
+            outs.append((f.detach().cpu(), {k: p.grad.detach().cpu().clone() for k, p in h.named_parameters()}))
+        (f32, g32), (f16, g16) = outs
+        assert 0 < rel_err(f16, f32) < 2e-2, (B, T, wl)
+        for k in g32:
+            assert rel_err(g16[k], g32[k]) < 5e-2, (B, T, wl, k)
+        with torch.no_grad():                                # inference keeps no activations: same features
+            assert torch.equal(h16.forward_windows(x, wl, st).cpu(), f16)
     # the oracle (fp64) agrees with the bf16 features within the same tolerance
     x = torch.randn(2, 64, 512)
     p = {"head." + k: v.detach().cpu().double() for k, v in h32.state_dict().items()}
