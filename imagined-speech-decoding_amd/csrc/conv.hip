@@ -769,6 +769,7 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
   float* we = red + NW * F;                           // [4][5][2][64]   frag-ordered Weff of the zone
   float* w3s = we + 4 * kTaps * 2 * 64;              // [8][5][2][64]
   float* w4s = w3s + 8 * kTaps * 2 * 64;
+  float* bls = w4s + 8 * kTaps * 2 * 64;             // [32] beff (in the 64 floats of slack behind the fragments)
   // ---- weight fragments into LDS once per (persistent) workgroup
   for (int e = threadIdx.x; e < 4 * kTaps * 2 * 64; e += NW * 64) we[e] = (e < ncg * kTaps * 2 * 64) ? a.weff[zd.eff_off + e] : 0.f;
   for (int e = threadIdx.x; e < 8 * kTaps * 2 * 64; e += NW * 64) {
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
     w4s[e] = a.w4[(int64_t)z * a.wz_stride + e];
   }
   for (int e = cz * W + threadIdx.x; e < 16 * W; e += NW * 64) xz[e] = 0.f;   // channel round-up rows stay zero
-  const float* bias = a.beff + z * F;
+  if (threadIdx.x < F) bls[threadIdx.x] = a.beff[z * F + threadIdx.x];   // a global load per item would queue behind the x fetch
   constexpr int NJ = 16 / NW;
   int off0[NJ], off2[NJ];                             // tile column offsets for pad 0 / pad 2 reads
   bool ok0[NJ][kTaps], ok2[NJ][kTaps];
@@ -792,17 +793,53 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
     }
   }
 
-  for (int64_t item = blockIdx.x; item < a.items; item += gridDim.x) {
-    const int64_t b = item / a.N;
-    const int n = (int)(item - b * a.N);
-    __syncthreads();                                   // previous item's tiles are no longer read
-    for (int r = wave; r < cz; r += NW) {               // gather the zone's rows of this window
-      const float* src = a.x + (b * a.Ctot + a.chan_idx[zd.idx_off + r]) * (int64_t)a.Tx + (int64_t)n * a.S;
-      for (int t0 = 0; t0 < W; t0 += 64)                  // dword LDS-DMA: the whole row is in flight at once
-        if (t0 + lane < W)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + t0 + lane), (lds_ptr_t)(xz + r * W + t0), 4, 0, 0);
+  // The wave's two x rows (channels wave, wave + NW) are fetched into registers ONE ITEM AHEAD (right after the
+  // barrier that ends the first layer's reads of xz) and written to xz before the item's last stores are issued;
+  // their channel indices are loaded once.  (Fetched at the top of the item -- behind a dependent channel-index
+  // load -- the rows cost every item their whole latency: see the bf16 twin, tools/conv_phases.py.)
+  static_assert(NW == 8, "16 x rows = two per wave");
+  const bool has0 = wave < cz, has1 = wave + NW < cz;
+  const int64_t ch0 = a.chan_idx[zd.idx_off + (has0 ? wave : 0)];
+  const int64_t ch1 = a.chan_idx[zd.idx_off + (has1 ? wave + NW : 0)];
+  const int nitems = (int)a.items, N = a.N;
+  constexpr int XC = 5;                                 // 64-step chunks: W <= 16 * 16 + 4
+  float xr[2][XC];
+  int tcl[XC];
+#pragma unroll
+  for (int c = 0; c < XC; ++c) {
+    tcl[c] = c * 64 + lane < W ? c * 64 + lane : W - 1;   // clamped: no test around a load
+    xr[0][c] = xr[1][c] = 0.f;
+  }
+  auto fetch_x = [&](int item) {
+    const int b = item / N, n = item - b * N;
+    const float* s0 = a.x + ((int64_t)b * a.Ctot + ch0) * (int64_t)a.Tx + (int64_t)n * a.S;
+    const float* s1 = a.x + ((int64_t)b * a.Ctot + ch1) * (int64_t)a.Tx + (int64_t)n * a.S;
+#pragma unroll
+    for (int c = 0; c < XC - 1; ++c) {
+      xr[0][c] = s0[tcl[c]];
+      xr[1][c] = s1[tcl[c]];
     }
-    __syncthreads();
+    if (W > (XC - 1) * 64) {
+      xr[0][XC - 1] = s0[tcl[XC - 1]];
+      xr[1][XC - 1] = s1[tcl[XC - 1]];
+    }
+  };
+  auto write_xz = [&]() {
+#pragma unroll
+    for (int c = 0; c < XC; ++c) {
+      const int t = c * 64 + lane;
+      if (t < W) {
+        if (has0) xz[wave * W + t] = xr[0][c];
+        if (has1) xz[(wave + NW) * W + t] = xr[1][c];
+      }
+    }
+  };
+  if ((int)blockIdx.x < nitems) fetch_x(blockIdx.x);
+  __syncthreads();
+  write_xz();
+
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    __syncthreads();                                   // xz complete; previous item's tiles are no longer read
     f32x4 acc[16 / NW][2];
     // ---------------- cnn1 o cnn2 (valid, Cz x 5 taps)
 #pragma unroll
@@ -810,10 +847,11 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     fused_conv_mma<NJ>(we + lane, xz + q * W, W, ncg, off0, ok0, acc);   // rows cz..4*ncg-1 of xz are zero
-    fused_layer_store<NW>(acc, bias, t2, T1, TT, wave, q, jl);
-    __syncthreads();
+    fused_layer_store<NW>(acc, bls, t2, T1, TT, wave, q, jl);
+    __syncthreads();                                   // t2 complete; every read of xz is done
+    if (item + (int)gridDim.x < nitems) fetch_x(item + gridDim.x);
     if (a.store) {
-      float4* dst = reinterpret_cast<float4*>(a.a2 + (item * a.Z + z) * (int64_t)(F * T1));
+      float4* dst = reinterpret_cast<float4*>(a.a2 + ((int64_t)item * a.Z + z) * (int64_t)(F * T1));
       const float4* src = reinterpret_cast<const float4*>(t2);
       for (int e = threadIdx.x; e < (F * T1) / 4; e += NW * 64) dst[e] = src[e];
     }
@@ -826,7 +864,7 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
     fused_layer_store<NW>(acc, nullptr, t3, T1, TT, wave, q, jl);
     __syncthreads();                                   // t3 complete; every read of t2 is done
     if (a.store) {
-      float4* dst = reinterpret_cast<float4*>(a.a3 + (item * a.Z + z) * (int64_t)(F * T1));
+      float4* dst = reinterpret_cast<float4*>(a.a3 + ((int64_t)item * a.Z + z) * (int64_t)(F * T1));
       const float4* src = reinterpret_cast<const float4*>(t3);
       for (int e = threadIdx.x; e < (F * T1) / 4; e += NW * 64) dst[e] = src[e];
     }
@@ -836,20 +874,31 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) acc[j][gt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     fused_conv_mma<NJ>(w4s + lane, t3 + q * T1, T1, 8, off2, ok2, acc);
-    // t2 is free: stage A4 for the store -- or GELU'(A4), all the fused backward needs of it (store == 2)
-    if (a.store == 2) fused_layer_store<NW, true>(acc, nullptr, t2, T1, TT, wave, q, jl);
-    else if (a.store) fused_layer_store<NW>(acc, nullptr, t2, T1, TT, wave, q, jl);
-    float part[2][4];
+    // t2 is free: stage A4 for the store -- or GELU'(A4), all the fused backward needs of it (store == 2);
+    // GELU (row means) and GELU' share one erf evaluation
+    float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < 16 / NW; ++j) {
+      const int tt = j * NW + wave, t = tt * 16 + jl;
+      const bool live = tt < TT && t < T1;
+      const int tc = live ? t : 0;
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float u = acc[j][gt][r];
+          float cdf, ez;
+          gelu_parts(u, cdf, ez);
+          part[gt][r] += live ? u * cdf : 0.f;
+          const float keep = a.store == 2 ? fmaf(u * 0.39894228040143267794f, ez, cdf) : u;
+          if (live && a.store) t2[(gt * 16 + 4 * q + r) * T1 + tc] = keep;
+        }
+    }
 #pragma unroll
     for (int gt = 0; gt < 2; ++gt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16 / NW; ++j) {
-          const int tt = j * NW + wave;
-          if (tt < TT && tt * 16 + jl < T1) sacc += gelu_f(acc[j][gt][r]);
-        }
+        float sacc = part[gt][r];
         sacc += row_shr<8>(sacc);
         sacc += row_shr<4>(sacc);
         sacc += row_shr<2>(sacc);
@@ -863,8 +912,9 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
         for (int r = 0; r < 4; ++r) red[wave * F + gt * 16 + 4 * q + r] = part[gt][r];
     }
     __syncthreads();
+    if (item + (int)gridDim.x < nitems) write_xz();       // before this item's last stores: the wait is for the fetch only
     if (threadIdx.x < F)
-      a.feat[(item * a.Z + z) * F + threadIdx.x] =
+      a.feat[((int64_t)item * a.Z + z) * F + threadIdx.x] =
           [&] {
             float tot = 0.f;
 #pragma unroll
@@ -872,7 +922,7 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_fwd_kernel(FusedFwdArgs a
             return tot;
           }() / (float)T1;
     if (a.store) {
-      float4* dst = reinterpret_cast<float4*>(a.a4 + (item * a.Z + z) * (int64_t)(F * T1));
+      float4* dst = reinterpret_cast<float4*>(a.a4 + ((int64_t)item * a.Z + z) * (int64_t)(F * T1));
       const float4* src = reinterpret_cast<const float4*>(t2);
       for (int e = threadIdx.x; e < (F * T1) / 4; e += NW * 64) dst[e] = src[e];
     }
@@ -1023,6 +1073,9 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a
     }
   }
   const int n4 = (F * T1) >> 2;
+  static_assert(NW == 8, "16 x rows = two per wave");
+  const int64_t ch0 = a.chan_idx[zd.idx_off + (wave < cz ? wave : 0)];
+  const int64_t ch1 = a.chan_idx[zd.idx_off + (wave + NW < cz ? wave + NW : 0)];
 
   for (int64_t item = blockIdx.x; item < a.items; item += gridDim.x) {
     const int64_t b = item / a.N;
@@ -1031,8 +1084,8 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a
     __syncthreads();                                   // the previous item's tiles are no longer read
     glds_copy16_strided(a.a4 + abase, ga, n4, wave * 64, NW * 64, lane);      // GELU'(A4), stored by the forward
     glds_copy16_strided(a.a3 + abase, at, n4, wave * 64, NW * 64, lane);
-    for (int r = wave; r < cz; r += NW) {
-      const float* src = a.x + (b * a.Ctot + a.chan_idx[zd.idx_off + r]) * (int64_t)a.Tx + (int64_t)n * a.S;
+    for (int r = wave, i = 0; r < cz; r += NW, ++i) {   // channel indices from registers: as a load here the DMA waited for it
+      const float* src = a.x + (b * a.Ctot + (i ? ch1 : ch0)) * (int64_t)a.Tx + (int64_t)n * a.S;
       for (int t0 = 0; t0 < W; t0 += 64)
         if (t0 + lane < W)
           __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + t0 + lane), (lds_ptr_t)(xz + r * W + t0), 4, 0, 0);
