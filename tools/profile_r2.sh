@@ -6,7 +6,8 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for v in "cfg2:" "cfg2_bf16:--bf16" "cfg2_two_kernel:--two-kernel" "cfg5:--config cfg5"; do
   name=${v%%:*}; flags=${v#*:}
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -- python3 $R/bench.py --no-cpu-baseline $flags > $O/${name}_line.json 2> $O/${name}.err || true
+  python3 $R/bench.py --no-cpu-baseline $flags > $O/${name}_line.json 2> $O/${name}.err || true     # the line: without the profiler
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -- python3 $R/bench.py --no-cpu-baseline $flags > $O/${name}_line_profiled.json 2>> $O/${name}.err || true
   f=$(ls $O/$name/*/*kernel_stats.csv | tail -1); cp $f $O/${name}_kernel_stats.csv
 done
 cd $R
