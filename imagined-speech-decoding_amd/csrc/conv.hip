@@ -1170,9 +1170,12 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a
 //  * weight gradients: K = 32 time steps.  Both operands are columns of [time][channel] tiles, delivered transposed
 //    by ds_read_b64_tr_b16; the input side reads a 12-row window once and the five tap windows are register subsets
 //    (even pairs as read, odd pairs by v_alignbit).
-//  * the first layer (<= 16 raw fp32 channel rows x 5 taps) keeps the fp32 fragments of the fp32 kernels: it is
-//    an eighth of the work and its input is not bf16; its weight gradient packs x to bf16 in registers.
-// HBM traffic per item halves (A2, A3, GELU'(A4) as bf16), LDS per workgroup drops from 150 to 81 / 87 KB.
+//  * the first layer: the wave's two raw fp32 x channels are packed to bf16 pairs into a [time][16 channels] tile
+//    (32-byte rows), K = 32 = 2 taps x 16 channels: 3 MFMAs per filter tile and column tile (the fp32 fragments of the
+//    fp32 kernels took 80 % of the item's matrix-pipe time for an eighth of its flops); its weight gradient is the
+//    same transposed-read contraction as the others.
+// HBM traffic per item halves (A2, A3, GELU'(A4) as bf16); LDS per workgroup: forward 62 KB (two per CU), backward
+// 147 KB (two sets of activation tiles: the next item streams in while this one computes).
 // ---------------------------------------------------------------------------------------
 #ifdef ISD_CF_TIMING                  // tools/conv_phases.py: shader-clock stamps of wave 0 of one workgroup, its 5th item
 __device__ long long cf_times[32];

@@ -1,3 +1,4 @@
+# FAST (raw-EEG model) profiles of round 2: full GPU suite, tools/bench_fast.py tables, rocprofv3 kernel table of train_head bf16 B=4096
 set -e
 R=$PWD
 O=$R/gpurun_out/prof_r2b
@@ -12,5 +13,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/fast_bf16 -- python3 
 f=$(ls $O/fast_bf16/*/*kernel_stats.csv | tail -1); cp $f $O/fast_train_head_bf16_kernel_stats.csv
 find $O -name "*kernel_trace.csv" -size +5M -delete
 cd $R
-python tools/conv_phases.py > $O/conv_phases_note.txt 2>&1 || true
 ls $O
