@@ -269,9 +269,14 @@ __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_gram_kernel(const f
       const bool live = g + h * stride < n_grp && r < rows;
       const float* src = x + (live ? r : 0) * (int64_t)T;
 #pragma unroll
+      for (int t = 0; t < MT; ++t) {                            // clamped address, then selects: no test around a load
+        const int idx = 16 * t + i;
+        y[h][t] = src[idx < T ? idx : T - 1];
+      }
+#pragma unroll
       for (int t = 0; t < MT; ++t) {
         const int idx = 16 * t + i;
-        y[h][t] = !live ? 0.f : (idx < T ? src[idx] : (idx == T ? 1.f : 0.f));
+        y[h][t] = !live ? 0.f : (idx < T ? y[h][t] : (idx == T ? 1.f : 0.f));
       }
     }
 #pragma unroll
@@ -460,16 +465,31 @@ __global__ __launch_bounds__(256) void eeg_spatial_kernel(const float* __restric
 #pragma unroll
   for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int c0 = c_lo;
+  // 64 channels per round: 32 loads in flight, none behind a test (xb is clamped to a valid column; columns past T
+  // are zeroed by a select).  With a branch around each x load and 16 channels per round every round waited out
+  // its own memory latency: 1.8 ms for the 2.7 GB of the stress configuration's features.
+  for (; c0 + 64 <= c_hi; c0 += 64) {
+    float av[16], bv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int c = c0 + 4 * k + q;
+      av[k] = wr[c];
+      bv[k] = xb[(int64_t)c * T];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      acc[k & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], tv ? bv[k] : 0.f, acc[k & 3], 0, 0, 0);
+  }
   for (; c0 + 16 <= c_hi; c0 += 16) {
     float av[4], bv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + 4 * k + q;
       av[k] = wr[c];
-      bv[k] = tv ? xb[(int64_t)c * T] : 0.f;
+      bv[k] = xb[(int64_t)c * T];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bv[k], acc[k], 0, 0, 0);
+    for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], tv ? bv[k] : 0.f, acc[k], 0, 0, 0);
   }
   for (; c0 < c_hi; c0 += 4) {
     const int c = c0 + q;
@@ -490,6 +510,78 @@ __global__ __launch_bounds__(256) void eeg_spatial_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       z[((int64_t)b * kF2 + 4 * q + r) * T + t] = ((sum[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+  }
+}
+
+// The same product for wide inputs (hundreds of channels: the stress configuration's 5120 x 65 feature maps): one
+// workgroup takes NTG consecutive time tiles of a trial, so every x row is read whole by ONE workgroup (with a
+// workgroup per tile the five 64-byte pieces of a 260-byte row went to five workgroups on five XCDs, each pulling the
+// row's cache lines into its own L2) and a Ws fragment serves NTG MFMAs instead of one.
+template <int NTG>
+__global__ __launch_bounds__(256) void eeg_spatial_rows_kernel(const float* __restrict__ x, const float* __restrict__ Ws,
+                                                               float* __restrict__ z, int C, int T) {
+  __shared__ float red[3][NTG][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
+  const int b = blockIdx.y;
+  bool tv[NTG];
+  const float* xb[NTG];
+#pragma unroll
+  for (int j = 0; j < NTG; ++j) {
+    const int t = (blockIdx.x * NTG + j) * 16 + jl;
+    tv[j] = t < T;
+    xb[j] = x + (int64_t)b * C * T + (tv[j] ? t : 0);            // clamped: no test around a load
+  }
+  const float* wr = Ws + jl * C;
+  const int cq = ((C + 15) / 16) * 4;                           // channels per wave, a multiple of 4
+  const int c_lo = wave * cq, c_hi = c_lo + cq < C ? c_lo + cq : C;
+  f32x4 acc[NTG];
+#pragma unroll
+  for (int j = 0; j < NTG; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int c0 = c_lo;
+  for (; c0 + 16 <= c_hi; c0 += 16) {
+    float av[4], bv[4][NTG];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + 4 * k + q;
+      av[k] = wr[c];
+#pragma unroll
+      for (int j = 0; j < NTG; ++j) bv[k][j] = xb[j][(int64_t)c * T];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < NTG; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], tv[j] ? bv[k][j] : 0.f, acc[j], 0, 0, 0);
+  }
+  for (; c0 < c_hi; c0 += 4) {
+    const int c = c0 + q;
+    const bool cv = c < c_hi;
+    const int cc = cv ? c : c_hi - 1;
+    const float a0 = cv ? wr[cc] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NTG; ++j) {
+      const float b0 = xb[j][(int64_t)cc * T];
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, (cv && tv[j]) ? b0 : 0.f, acc[j], 0, 0, 0);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < NTG; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave - 1][j][r][lane] = acc[j][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < NTG; ++j) {
+      const int t = (blockIdx.x * NTG + j) * 16 + jl;
+      if (tv[j]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          z[((int64_t)b * kF2 + 4 * q + r) * T + t] =
+              ((acc[j][r] + red[0][j][r][lane]) + red[1][j][r][lane]) + red[2][j][r][lane];
+      }
+    }
   }
 }
 
@@ -963,7 +1055,34 @@ __global__ __launch_bounds__(64) void eeg_bwd_corr_kernel(const float* __restric
 }
 
 // dWs_raw[g,c] = sum_{b,t} v[b,g,t] x[b,c,t] on the matrix cores; persistent waves, partial slabs.
-// A[g][t] = v, B[t][c] = x; K = 4 time steps per MFMA; a wave owns all C/16 channel tiles (<= 16).
+// A[g][t] = v, B[t][c] = x; K = 4 time steps per MFMA; a wave owns all C/16 channel tiles (<= 16) of its 256 channels.
+// A chunk is kDwsPasses x 16 time steps of one trial.  Lane (q, jl) owns the 4 consecutive steps t0 + 4q .. + 3 of its
+// row (one 16-byte load -- dword alignment is enough, tools/ubench/unaligned_x4.hip -- instead of four scalar ones);
+// MFMA step e contracts element e of every lane, i.e. the K index q stands for time t0 + 4q + e in both operands.
+// The channel tile is the OUTER loop inside a chunk: the five 64-byte pieces of a 260-byte row (the stress
+// configuration's 65 frames) are loaded back to back, so each cache line is used while it is still in the L2.  With
+// the pass outermost a row's lines were revisited ~20 us later, after 25 MB of other waves' rows per XCD had gone
+// through its 4 MB L2: the kernel ran at 2 TB/s whatever the load width.
+typedef float F4U __attribute__((ext_vector_type(4), aligned(4)));   // four floats at any dword address
+constexpr int kDwsPasses = 5;
+__device__ __forceinline__ void dws_load_row(const float* __restrict__ row, int t_lo, int t_hi, int q, bool zero_tail,
+                                             float (&f)[kDwsPasses][4]) {
+#pragma unroll
+  for (int p = 0; p < kDwsPasses; ++p) {
+    const int t0 = t_lo + 16 * p, t = t0 + 4 * q;
+    if (t0 + 16 <= t_hi) {                                  // wave-uniform: every lane's four steps lie inside the row
+      const F4U w = *reinterpret_cast<const F4U*>(row + t);
+      f[p][0] = w.x; f[p][1] = w.y; f[p][2] = w.z; f[p][3] = w.w;
+    } else {                                                // clamped addresses (and selects): no test around a load
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f[p][e] = row[t + e < t_hi ? t + e : t_hi - 1];
+      if (zero_tail) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[p][e] = t + e < t_hi ? f[p][e] : 0.f;
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(64) void eeg_bwd_dws_kernel(const float* __restrict__ v, const float* __restrict__ x,
                                                          float* __restrict__ part, int B, int C, int T) {
   const int lane = threadIdx.x, q = lane >> 4, jl = lane & 15;
@@ -972,45 +1091,32 @@ __global__ __launch_bounds__(64) void eeg_bwd_dws_kernel(const float* __restrict
   f32x4 acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int chunks_per_b = (T + 255) / 256;
+  constexpr int CH = kDwsPasses * 16;
+  const int chunks_per_b = (T + CH - 1) / CH;
   const int64_t n_chunks = (int64_t)B * chunks_per_b;
-  const bool vec = (T & 3) == 0 && ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
   for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
     const int64_t b = ch / chunks_per_b;
-    const int t_lo = (int)(ch - b * chunks_per_b) * 256;
-    const int t_hi = t_lo + 256 < T ? t_lo + 256 : T;
-    const float* vr = v + (b * kF2 + jl) * (int64_t)T;
-    // 16 time steps per pass: lane (q, jl) owns the 4 consecutive steps t0 + 4q .. 4q+3 of its row (one 16-byte
-    // load per operand row instead of four scalar ones); MFMA step s contracts element s of every lane, i.e. the
-    // K index q stands for time t0 + 4q + s in both operands
-    for (int t0 = t_lo; t0 < t_hi; t0 += 16) {
-      const int t = t0 + 4 * q;
-      float af[4] = {0.f, 0.f, 0.f, 0.f};
-      if (vec && t + 3 < t_hi) {
-        const float4 f = *reinterpret_cast<const float4*>(vr + t);
-        af[0] = f.x; af[1] = f.y; af[2] = f.z; af[3] = f.w;
-      } else {
+    const int t_lo = (int)(ch - b * chunks_per_b) * CH;
+    const int t_hi = t_lo + CH < T ? t_lo + CH : T;
+    float af[kDwsPasses][4];                                // steps past the row's end: zero (x there is finite)
+    dws_load_row(v + (b * kF2 + jl) * (int64_t)T, t_lo, t_hi, q, true, af);
+    int ne[kDwsPasses];                                     // MFMA steps of a pass that see any valid time step
 #pragma unroll
-        for (int e = 0; e < 4; ++e) af[e] = t + e < t_hi ? vr[t + e] : 0.f;
-      }
+    for (int p = 0; p < kDwsPasses; ++p) {
+      const int left = t_hi - (t_lo + 16 * p);
+      ne[p] = left >= 4 ? 4 : (left > 0 ? left : 0);
+    }
 #pragma unroll
-      for (int ct = 0; ct < 16; ++ct) {
-        if (ct < n_ctile) {
-          const int c = c_base + ct * 16 + jl;
-          float bf[4] = {0.f, 0.f, 0.f, 0.f};
-          if (c < C) {
-            const float* xr = x + (b * C + c) * (int64_t)T;
-            if (vec && t + 3 < t_hi) {
-              const float4 f = *reinterpret_cast<const float4*>(xr + t);
-              bf[0] = f.x; bf[1] = f.y; bf[2] = f.z; bf[3] = f.w;
-            } else {
+    for (int ct = 0; ct < 16; ++ct) {
+      if (ct < n_ctile) {                                   // wave-uniform
+        const int c = c_base + ct * 16 + jl;
+        float bf[kDwsPasses][4];
+        dws_load_row(x + (b * C + (c < C ? c : C - 1)) * (int64_t)T, t_lo, t_hi, q, false, bf);   // channels past C: never stored
 #pragma unroll
-              for (int e = 0; e < 4; ++e) bf[e] = t + e < t_hi ? xr[t + e] : 0.f;
-            }
-          }
+        for (int p = 0; p < kDwsPasses; ++p)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc[ct], 0, 0, 0);
-        }
+          for (int e = 0; e < 4; ++e)
+            if (e < ne[p]) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[p][e], bf[p][e], acc[ct], 0, 0, 0);
       }
     }
   }
@@ -1552,8 +1658,12 @@ static int eeg_forward_stage(const isd_eegnet_plan* p, int stage, const float* x
   if (stage == 1) {
     hipLaunchKernelGGL(eeg_finalize1_kernel, dim3(1), dim3(256), 0, st, params, buffers, S, Cf, p->off, C, K, T,
                        rows * world, training, momentum, eps, p->seed_dev);
-    hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(T, 16), (unsigned)B), dim3(256), 0, st, x,
-                       params + p->off.Ws, ws + w.z, C, T, (int)cdiv(T, 16));
+    if (C >= 128)                                               // wide inputs: whole rows per workgroup
+      hipLaunchKernelGGL(eeg_spatial_rows_kernel<5>, dim3((unsigned)cdiv(cdiv(T, 16), 5), (unsigned)B), dim3(256), 0, st,
+                         x, params + p->off.Ws, ws + w.z, C, T);
+    else
+      hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(T, 16), (unsigned)B), dim3(256), 0, st, x,
+                         params + p->off.Ws, ws + w.z, C, T, (int)cdiv(T, 16));
     {
       const unsigned gx = row_blocks(Tp, B * kF2);
 #define ISD_EEG_K(KERNEL, ...)                          \
@@ -1699,7 +1809,7 @@ static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* 
       ISD_EEG_K(eeg_bwd_corr_kernel, dim3(row_groups(rows16, segs), segs), dim3(64), lds, st, ws + w.dy2, ws + w.z,
                 params + p->off.Wt, ws + w.v, S, K, T, Tp, (int)rows16);
     }
-    const int64_t n_chunks = B * ((T + 255) / 256);
+    const int64_t n_chunks = B * ((T + kDwsPasses * 16 - 1) / (kDwsPasses * 16));
     const int slabs = n_chunks < w.n_slabs ? (int)n_chunks : w.n_slabs;
     hipLaunchKernelGGL(eeg_bwd_dws_kernel, dim3(slabs, (unsigned)cdiv(C, 256)), dim3(64), 0, st, ws + w.v, x, ws + w.part,
                        (int)B, C, T);
