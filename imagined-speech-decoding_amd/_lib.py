@@ -91,6 +91,10 @@ SIGNATURES = {
     "isd_paperhead_forward_stage": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _i, _p]),
     "isd_paperhead_backward_stage": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "isd_paperhead_sync_block": (_i, [_p, _i64, _i, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "isd_zone_batch_begin": (_i, []),
+    "isd_zone_batch_next": (_i, []),
+    "isd_zone_batch_launch": (_i, [_p]),
+    "isd_zone_batch_abort": (_i, []),
     "isd_cvblock_plan_create": (_i, [C.POINTER(_p), _i, _i, _i]),
     "isd_cvblock_flat_dim": (_i64, [_p]),
     "isd_eegnet_plan_set_seed_counter": (_i, [_p, _p]),

@@ -19,12 +19,19 @@
 // cross-batch reductions accumulate in fp64.  Dropout: inference / p = 0 only (train-mode dropout would
 // break parity with any reference RNG stream).
 #include "common.h"
+#include "zonebatch.h"
 #include <math.h>
 #include <stddef.h>
 #include <string.h>
 #include <vector>
 
 namespace isd {
+
+// every launch of this file goes through zone_launch: issued at once, or recorded for a zone-batched launch (zonebatch.h)
+#define ISD_ZLAUNCH(...)                                    \
+  do {                                                      \
+    if (!zone_launch(__VA_ARGS__)) return ISD_ERR_INVALID;  \
+  } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kF1 = 8, kF2 = 16, kK2 = 16, kP2 = 8, kMaxK = 64;
@@ -129,8 +136,8 @@ constexpr int kStatWaves = 4;                          // waves per workgroup
 //  bulk: D_q and the sum of all samples;  edge: Qh, Qt, Sh, St.
 // The waves of a workgroup meet in LDS (fp32) before ONE set of fp64 global atomics per workgroup: 2048 waves
 // sending 85 atomics per lane to the same ~5 k addresses took 0.15 ms on their own.
-__global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_kernel(const float* __restrict__ x,
-                                                                    EegStats* __restrict__ st, int64_t rows, int T) {
+__device__ __forceinline__ void eeg_stats_kernel_body(const float* __restrict__ x,
+                                                                    EegStats* __restrict__ st, int64_t rows, int T, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float tot[21][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int e = threadIdx.x; e < 21 * 64; e += 64 * kStatWaves) (&tot[0][0])[e] = 0.f;
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_kernel(const float*
   // 256 samples per step: the 17 distinct operands x[s0 + lane + 16 j] are requested together (one load per MFMA
   // operand, issued right before its use, left the loop waiting a full memory latency per 64 samples), then the
   // 20 MFMAs run.  Two rows are in flight at once: short rows (the feature classifier's T = 65) are one step each.
-  const int64_t stride = (int64_t)gridDim.x * kStatWaves;
+  const int64_t stride = (int64_t)zgx * kStatWaves;
   for (int64_t r = (int64_t)blockIdx.x * kStatWaves + wave; r < rows; r += 2 * stride) {
     const float* srcA = x + r * (int64_t)T;
     const bool two = r + stride < rows;                           // wave-uniform
@@ -182,6 +189,12 @@ __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_kernel(const float*
   }
   if (threadIdx.x == 0) atomicAdd(&st->S, (double)tot[20][0]);
 }
+ISD_ZONE_FN(eeg_stats_kernel, 64 * kStatWaves)
+__global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_kernel(const float* __restrict__ x,
+                                                                    EegStats* __restrict__ st, int64_t rows, int T) {
+  eeg_stats_kernel_body(x, st, rows, T, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_stats_kernel)
 
 // Edge sums on the matrix cores.  Per row let y[0..95) be its head window x[0..95) (blockIdx.y = 0) or its tail
 // window x[T-31 .. T+64) (blockIdx.y = 1), zero outside the row.  Everything the zero padding needs is inside the
@@ -190,9 +203,9 @@ __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_kernel(const float*
 // The contraction runs over ROWS: one MFMA step takes 4 rows (k = lane >> 4), A = y[16 mt + i] (2 tiles),
 // B = y[16 nt + i] (6 tiles), 6 loads and 12 MFMAs per 4 rows, 48 accumulator registers.  (The per-lane form --
 // 62 lag products per lane and row behind an LDS window -- held 200+ VGPRs and paid a memory latency per row.)
-__global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_edge_kernel(const float* __restrict__ x,
+__device__ __forceinline__ void eeg_stats_edge_kernel_body(const float* __restrict__ x,
                                                                          EegStats* __restrict__ st, int64_t rows,
-                                                                         int T) {
+                                                                         int T, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float tot[32][96];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
   const int which = blockIdx.y;
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_edge_kernel(const f
 #pragma unroll
     for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int64_t n_grp = (rows + 3) >> 2;
-  const int64_t stride = (int64_t)gridDim.x * kStatWaves;
+  const int64_t stride = (int64_t)zgx * kStatWaves;
   for (int64_t g = (int64_t)blockIdx.x * kStatWaves + wave; g < n_grp; g += 2 * stride) {   // two groups in flight
     float b[2][6];
     bool live[2];
@@ -241,6 +254,13 @@ __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_edge_kernel(const f
   for (int e = threadIdx.x; e < 32 * 96; e += 64 * kStatWaves)
     atomicAdd(&st->Pe[which][e / 96][e % 96], (double)tot[e / 96][e % 96]);
 }
+ISD_ZONE_FN(eeg_stats_edge_kernel, 64 * kStatWaves)
+__global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_edge_kernel(const float* __restrict__ x,
+                                                                         EegStats* __restrict__ st, int64_t rows,
+                                                                         int T) {
+  eeg_stats_edge_kernel_body(x, st, rows, T, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_stats_edge_kernel)
 
 // Short rows (T <= 79, e.g. the 65 frames of the stress features): the whole row fits one Gram matrix.  With
 // y = (x[0..T), 1, 0, ...) padded to 16 MT entries, G[a][j] = sum_rows y[a] y[j] holds every lag product
@@ -248,9 +268,9 @@ __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_edge_kernel(const f
 // loads and MT (MT + 1) / 2 MFMAs (upper-triangular tiles) per 4 rows -- 15 at T = 65 against 64 for the bulk + edge
 // pair, one pass over x instead of two.
 template <int MT>
-__global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_gram_kernel(const float* __restrict__ x,
+__device__ __forceinline__ void eeg_stats_gram_kernel_body(const float* __restrict__ x,
                                                                          EegStats* __restrict__ st, int64_t rows,
-                                                                         int T) {
+                                                                         int T, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float tot[16 * MT][16 * MT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
   for (int e = threadIdx.x; e < 256 * MT * MT; e += 64 * kStatWaves) (&tot[0][0])[e] = 0.f;
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_gram_kernel(const f
 #pragma unroll
     for (int nt = 0; nt < MT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int64_t n_grp = (rows + 3) >> 2;
-  const int64_t stride = (int64_t)gridDim.x * kStatWaves;
+  const int64_t stride = (int64_t)zgx * kStatWaves;
   for (int64_t g = (int64_t)blockIdx.x * kStatWaves + wave; g < n_grp; g += 2 * stride) {   // two groups in flight
     float y[2][MT];
 #pragma unroll
@@ -300,10 +320,22 @@ __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_gram_kernel(const f
     if (j >= a && a <= T && j <= T) atomicAdd(&st->Gs[a][j], (double)tot[a][j]);
   }
 }
+ISD_ZONE_FN_T(eeg_stats_gram_kernel, 64 * kStatWaves, int)
+template <int MT>
+__global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_gram_kernel(const float* __restrict__ x,
+                                                                         EegStats* __restrict__ st, int64_t rows,
+                                                                         int T) {
+  eeg_stats_gram_kernel_body<MT>(x, st, rows, T, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER_T(eeg_stats_gram_kernel, 1)
+ISD_ZONE_REGISTER_T(eeg_stats_gram_kernel, 2)
+ISD_ZONE_REGISTER_T(eeg_stats_gram_kernel, 3)
+ISD_ZONE_REGISTER_T(eeg_stats_gram_kernel, 4)
+ISD_ZONE_REGISTER_T(eeg_stats_gram_kernel, 5)
 
 // Gs -> the quantities eeg_finalize1_kernel consumes (same definitions as eeg_stats_derive_kernel: samples outside
 // the row are zero).  One block of 64 threads (thread = lag d).
-__global__ __launch_bounds__(64) void eeg_stats_gram_derive_kernel(EegStats* __restrict__ st, int T) {
+__device__ __forceinline__ void eeg_stats_gram_derive_kernel_body(EegStats* __restrict__ st, int T, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int d = threadIdx.x;
   double a = 0.0;
   for (int s = 0; s + d < T; ++s) a += st->Gs[s][s + d];
@@ -329,9 +361,14 @@ __global__ __launch_bounds__(64) void eeg_stats_gram_derive_kernel(EegStats* __r
     for (int e = 2; e < 33; ++e) { if (T - (e - 1) >= 0) ts += st->Gs[T - (e - 1)][T]; st->Ts[e] = ts; }
   }
 }
+ISD_ZONE_FN(eeg_stats_gram_derive_kernel, 64)
+__global__ __launch_bounds__(64) void eeg_stats_gram_derive_kernel(EegStats* __restrict__ st, int T) {
+  eeg_stats_gram_derive_kernel_body(st, T, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_stats_gram_derive_kernel)
 
 // raw accumulators -> the quantities eeg_finalize1_kernel consumes.  One block of 64 threads (thread = lag d).
-__global__ __launch_bounds__(64) void eeg_stats_derive_kernel(EegStats* __restrict__ st) {
+__device__ __forceinline__ void eeg_stats_derive_kernel_body(EegStats* __restrict__ st, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int d = threadIdx.x;
   double a = 0.0;
   for (int i = 0; i < 16; ++i) a += st->D[(i + d) >> 4][i * 16 + ((i + d) & 15)];
@@ -353,13 +390,18 @@ __global__ __launch_bounds__(64) void eeg_stats_derive_kernel(EegStats* __restri
     for (int e = 2; e < 33; ++e) { ts += st->Pe[1][31][32 - e]; st->Ts[e] = ts; }
   }
 }
+ISD_ZONE_FN(eeg_stats_derive_kernel, 64)
+__global__ __launch_bounds__(64) void eeg_stats_derive_kernel(EegStats* __restrict__ st) {
+  eeg_stats_derive_kernel_body(st, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_stats_derive_kernel)
 
 // BN1 coefficients.  training: from the x statistics; eval: from the running buffers.  One block.
-__global__ __launch_bounds__(256) void eeg_finalize1_kernel(const float* __restrict__ params, float* __restrict__ bufs,
+__device__ __forceinline__ void eeg_finalize1_kernel_body(const float* __restrict__ params, float* __restrict__ bufs,
                                                             const EegStats* __restrict__ st, EegCoef* __restrict__ co,
                                                             EegOff off, int C, int K, int T, int64_t rows,
                                                             int training, float momentum, float eps,
-                                                            const unsigned long long* __restrict__ seed_dev) {
+                                                            const unsigned long long* __restrict__ seed_dev, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int P = K / 2;
   if (threadIdx.x == 0) co->seed_add = seed_dev ? 0xD1342543DE82EF95ull * *seed_dev : 0ull;
   const double N1 = (double)rows * (double)(T + 2 * P - K + 1);
@@ -444,13 +486,22 @@ __global__ __launch_bounds__(256) void eeg_finalize1_kernel(const float* __restr
     co->o1[f] = params[off.b1 + f] - (float)mu * s1;
   }
 }
+ISD_ZONE_FN(eeg_finalize1_kernel, 256)
+__global__ __launch_bounds__(256) void eeg_finalize1_kernel(const float* __restrict__ params, float* __restrict__ bufs,
+                                                            const EegStats* __restrict__ st, EegCoef* __restrict__ co,
+                                                            EegOff off, int C, int K, int T, int64_t rows,
+                                                            int training, float momentum, float eps,
+                                                            const unsigned long long* __restrict__ seed_dev) {
+  eeg_finalize1_kernel_body(params, bufs, st, co, off, C, K, T, rows, training, momentum, eps, seed_dev, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_finalize1_kernel)
 
 // z[b,g,t] = sum_c Ws[g,c] x[b,c,t] on the matrix cores: M = the 16 rows g, N = 16 time steps, K = 4 channels per
 // MFMA.  One workgroup per (trial, time tile); its four waves take a quarter of the channels each (16 channels =
 // 8 loads and 4 independent MFMA chains per step) and meet in LDS in a fixed order.  (One wave per tile walking
 // all channels left 640 waves on the chip at C = 5120, T = 65: 0.29 ms; the scalar version before it 2.3 ms.)
-__global__ __launch_bounds__(256) void eeg_spatial_kernel(const float* __restrict__ x, const float* __restrict__ Ws,
-                                                          float* __restrict__ z, int C, int T, int n_tiles) {
+__device__ __forceinline__ void eeg_spatial_kernel_body(const float* __restrict__ x, const float* __restrict__ Ws,
+                                                          float* __restrict__ z, int C, int T, int n_tiles, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float red[3][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
   const int tile = blockIdx.x;
@@ -512,14 +563,20 @@ __global__ __launch_bounds__(256) void eeg_spatial_kernel(const float* __restric
       z[((int64_t)b * kF2 + 4 * q + r) * T + t] = ((sum[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
   }
 }
+ISD_ZONE_FN(eeg_spatial_kernel, 256)
+__global__ __launch_bounds__(256) void eeg_spatial_kernel(const float* __restrict__ x, const float* __restrict__ Ws,
+                                                          float* __restrict__ z, int C, int T, int n_tiles) {
+  eeg_spatial_kernel_body(x, Ws, z, C, T, n_tiles, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_spatial_kernel)
 
 // The same product for wide inputs (hundreds of channels: the stress configuration's 5120 x 65 feature maps): one
 // workgroup takes NTG consecutive time tiles of a trial, so every x row is read whole by ONE workgroup (with a
 // workgroup per tile the five 64-byte pieces of a 260-byte row went to five workgroups on five XCDs, each pulling the
 // row's cache lines into its own L2) and a Ws fragment serves NTG MFMAs instead of one.
 template <int NTG>
-__global__ __launch_bounds__(256) void eeg_spatial_rows_kernel(const float* __restrict__ x, const float* __restrict__ Ws,
-                                                               float* __restrict__ z, int C, int T) {
+__device__ __forceinline__ void eeg_spatial_rows_kernel_body(const float* __restrict__ x, const float* __restrict__ Ws,
+                                                               float* __restrict__ z, int C, int T, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float red[3][NTG][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
   const int b = blockIdx.y;
@@ -584,18 +641,25 @@ __global__ __launch_bounds__(256) void eeg_spatial_rows_kernel(const float* __re
     }
   }
 }
+ISD_ZONE_FN_T(eeg_spatial_rows_kernel, 256, int)
+template <int NTG>
+__global__ __launch_bounds__(256) void eeg_spatial_rows_kernel(const float* __restrict__ x, const float* __restrict__ Ws,
+                                                               float* __restrict__ z, int C, int T) {
+  eeg_spatial_rows_kernel_body<NTG>(x, Ws, z, C, T, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER_T(eeg_spatial_rows_kernel, 5)
 
 // u[b,g,t'] = sum_k Wt[f,k] zpad[b,g,t'+k]; per-g sums of u and u^2 (fp64 atomics).  grid (ceil(Tp/256), B*16)
 // KT: the filter length as a compile-time constant (16 / 32 / 64: fully unrolled tap loops without a test per tap -- a
 // run-time bound left every LDS read in its own basic block behind its own wait), 0 = any length
 template <int KT>
-__global__ __launch_bounds__(256) void eeg_tconv_kernel(const float* __restrict__ z, const float* __restrict__ Wt,
+__device__ __forceinline__ void eeg_tconv_kernel_body(const float* __restrict__ z, const float* __restrict__ Wt,
                                                         float* __restrict__ u, EegStats* __restrict__ st, int Krt, int T,
-                                                        int Tp, int want_stats, int n_rows) {
+                                                        int Tp, int want_stats, int n_rows, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int K = KT ? KT : Krt;
   __shared__ float red[4];
   __shared__ float zs[256 + kMaxK];                    // zpad[tp0 .. tp0 + 256 + K): the tile's inputs, staged once
-  // A workgroup strides over its row AND over every gridDim.y-th row (gridDim.y is a multiple of 16, so they share the
+  // A workgroup strides over its row AND over every zgy-th row (zgy is a multiple of 16, so they share the
   // filter): the sums reach the 16 fp64 accumulators through one atomic pair per workgroup.  35 k workgroups queueing
   // on 16 addresses were what the kernel spent its time on at the stress shape (0.37 ms), and 5 k short rows per zone
   // what the zone heads spent theirs on (57 us per launch for 1.3 M outputs).
@@ -604,9 +668,9 @@ __global__ __launch_bounds__(256) void eeg_tconv_kernel(const float* __restrict_
   const int g = blockIdx.y & (kF2 - 1), f = g >> 1, P = K / 2;
   const float* w = Wt + f * K;
   float t1 = 0.f, t2 = 0.f;
-  for (int bg = blockIdx.y; bg < n_rows; bg += gridDim.y) {
+  for (int bg = blockIdx.y; bg < n_rows; bg += zgy) {
     const float* zr = z + (int64_t)bg * T;
-    for (int tp0 = blockIdx.x * 256; tp0 < Tp; tp0 += gridDim.x * 256) {
+    for (int tp0 = blockIdx.x * 256; tp0 < Tp; tp0 += zgx * 256) {
       __syncthreads();                                  // the previous tile's readers are done
       for (int j = threadIdx.x; j < 256 + K; j += 256) {
         const int t = tp0 + j - P;
@@ -638,10 +702,21 @@ __global__ __launch_bounds__(256) void eeg_tconv_kernel(const float* __restrict_
     }
   }
 }
+ISD_ZONE_FN_T(eeg_tconv_kernel, 256, int)
+template <int KT>
+__global__ __launch_bounds__(256) void eeg_tconv_kernel(const float* __restrict__ z, const float* __restrict__ Wt,
+                                                        float* __restrict__ u, EegStats* __restrict__ st, int Krt, int T,
+                                                        int Tp, int want_stats, int n_rows) {
+  eeg_tconv_kernel_body<KT>(z, Wt, u, st, Krt, T, Tp, want_stats, n_rows, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER_T(eeg_tconv_kernel, 64)
+ISD_ZONE_REGISTER_T(eeg_tconv_kernel, 32)
+ISD_ZONE_REGISTER_T(eeg_tconv_kernel, 16)
+ISD_ZONE_REGISTER_T(eeg_tconv_kernel, 0)
 
-__global__ void eeg_finalize2_kernel(const float* __restrict__ params, float* __restrict__ bufs,
+__device__ __forceinline__ void eeg_finalize2_kernel_body(const float* __restrict__ params, float* __restrict__ bufs,
                                      const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N2,
-                                     int training, float momentum, float eps) {
+                                     int training, float momentum, float eps, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int g = threadIdx.x;
   if (g >= kF2) return;
   const int f = g >> 1;
@@ -668,11 +743,18 @@ __global__ void eeg_finalize2_kernel(const float* __restrict__ params, float* __
   co->A2[g] = (float)(g2 * (double)s1 / sig2);
   co->B2[g] = (float)(b2 + g2 * ((double)c1 - mu2) / sig2);
 }
+ISD_ZONE_FN(eeg_finalize2_kernel, 1024)
+__global__ void eeg_finalize2_kernel(const float* __restrict__ params, float* __restrict__ bufs,
+                                     const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N2,
+                                     int training, float momentum, float eps) {
+  eeg_finalize2_kernel_body(params, bufs, st, co, off, N2, training, momentum, eps, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_finalize2_kernel)
 
 // p2[b,g,v] = mean_{r<P1} ELU(A2 u[b,g,P1 v+r] + B2)   (P1 = 4 EEGNet, 8 CVBlock)
-__global__ __launch_bounds__(256) void eeg_pool2_kernel(const float* __restrict__ u, const EegCoef* __restrict__ co,
+__device__ __forceinline__ void eeg_pool2_kernel_body(const float* __restrict__ u, const EegCoef* __restrict__ co,
                                                         float* __restrict__ p2, int Tp, int T2, int P1, float dp,
-                                                        uint64_t seed) {
+                                                        uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int bg = blockIdx.y, g = bg & (kF2 - 1);
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v >= T2) return;
@@ -682,22 +764,29 @@ __global__ __launch_bounds__(256) void eeg_pool2_kernel(const float* __restrict_
   for (int r = 0; r < P1; ++r) s += elu_f(fmaf(A, ur[r], Bc));
   p2[(int64_t)bg * T2 + v] = s / (float)P1 * drop_scale(seed + co->seed_add, (uint64_t)bg * T2 + v, dp);
 }
+ISD_ZONE_FN(eeg_pool2_kernel, 256)
+__global__ __launch_bounds__(256) void eeg_pool2_kernel(const float* __restrict__ u, const EegCoef* __restrict__ co,
+                                                        float* __restrict__ p2, int Tp, int T2, int P1, float dp,
+                                                        uint64_t seed) {
+  eeg_pool2_kernel_body(u, co, p2, Tp, T2, P1, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_pool2_kernel)
 
 // a3[b,g,w] = sum_k Wd[g,k] p2pad[b,g,w+k];  a4[b,h,w] = sum_g Wp[h,g] a3[b,g,w];  BN3 sums.
 // One thread per (b, w); optionally stores a3.  grid (ceil(T2p/256), B)
-__global__ __launch_bounds__(256) void eeg_sep_kernel(const float* __restrict__ p2, const float* __restrict__ Wd,
+__device__ __forceinline__ void eeg_sep_kernel_body(const float* __restrict__ p2, const float* __restrict__ Wd,
                                                       const float* __restrict__ Wp, float* __restrict__ a3out,
                                                       float* __restrict__ a4, EegStats* __restrict__ st, int T2,
-                                                      int T2p, int want_stats, int B) {
+                                                      int T2p, int want_stats, int B, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float red[4];
-  // a workgroup walks every gridDim.y-th trial and keeps its 32 per-channel sums in registers: one round of block
+  // a workgroup walks every zgy-th trial and keeps its 32 per-channel sums in registers: one round of block
   // sums and atomics per workgroup instead of one per trial (short windows: 63 live threads, 32 block sums each)
   const int w = blockIdx.x * 256 + threadIdx.x;
   const bool live = w < T2p;
   float s1[kF2], s2[kF2];
 #pragma unroll
   for (int h = 0; h < kF2; ++h) s1[h] = s2[h] = 0.f;
-  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+  for (int b = blockIdx.y; b < B; b += zgy) {
     float a3[kF2];
 #pragma unroll
     for (int g = 0; g < kF2; ++g) {
@@ -746,10 +835,18 @@ __global__ __launch_bounds__(256) void eeg_sep_kernel(const float* __restrict__ 
     }
   }
 }
+ISD_ZONE_FN(eeg_sep_kernel, 256)
+__global__ __launch_bounds__(256) void eeg_sep_kernel(const float* __restrict__ p2, const float* __restrict__ Wd,
+                                                      const float* __restrict__ Wp, float* __restrict__ a3out,
+                                                      float* __restrict__ a4, EegStats* __restrict__ st, int T2,
+                                                      int T2p, int want_stats, int B) {
+  eeg_sep_kernel_body(p2, Wd, Wp, a3out, a4, st, T2, T2p, want_stats, B, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_sep_kernel)
 
-__global__ void eeg_finalize3_kernel(const float* __restrict__ params, float* __restrict__ bufs,
+__device__ __forceinline__ void eeg_finalize3_kernel_body(const float* __restrict__ params, float* __restrict__ bufs,
                                      const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N3,
-                                     int training, float momentum, float eps) {
+                                     int training, float momentum, float eps, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int h = threadIdx.x;
   if (h >= kF2) return;
   double mu, var;
@@ -770,11 +867,18 @@ __global__ void eeg_finalize3_kernel(const float* __restrict__ params, float* __
   co->A3[h] = (float)(g3 / sig);
   co->B3[h] = (float)(b3 - g3 * mu / sig);
 }
+ISD_ZONE_FN(eeg_finalize3_kernel, 1024)
+__global__ void eeg_finalize3_kernel(const float* __restrict__ params, float* __restrict__ bufs,
+                                     const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N3,
+                                     int training, float momentum, float eps) {
+  eeg_finalize3_kernel_body(params, bufs, st, co, off, N3, training, momentum, eps, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_finalize3_kernel)
 
 // pooled[b,h] = mean_{w < 8*T3} ELU(A3 a4 + B3)   (AvgPool(1,8) floor + AdaptiveAvgPool); one wave per row
-__global__ __launch_bounds__(256) void eeg_pool3_kernel(const float* __restrict__ a4, const EegCoef* __restrict__ co,
+__device__ __forceinline__ void eeg_pool3_kernel_body(const float* __restrict__ a4, const EegCoef* __restrict__ co,
                                                         float* __restrict__ pooled, int64_t rows, int T2p, int T3,
-                                                        float dp, uint64_t seed) {
+                                                        float dp, uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -787,21 +891,28 @@ __global__ __launch_bounds__(256) void eeg_pool3_kernel(const float* __restrict_
   s = wave_sum(s);
   if (lane == 0) pooled[row] = T3 > 0 ? s / (float)(8 * T3) : 0.f;
 }
+ISD_ZONE_FN(eeg_pool3_kernel, 256)
+__global__ __launch_bounds__(256) void eeg_pool3_kernel(const float* __restrict__ a4, const EegCoef* __restrict__ co,
+                                                        float* __restrict__ pooled, int64_t rows, int T2p, int T3,
+                                                        float dp, uint64_t seed) {
+  eeg_pool3_kernel_body(a4, co, pooled, rows, T2p, T3, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_pool3_kernel)
 
 // ---------------------------------------------------------------- backward
 // dy3 = de3 * ELU'(y3); sums of dy3 and dy3*xhat3 per h.  One wave per (b,h) row.
-__global__ __launch_bounds__(256) void eeg_bwd3_sums_kernel(const float* __restrict__ a4,
+__device__ __forceinline__ void eeg_bwd3_sums_kernel_body(const float* __restrict__ a4,
                                                             const float* __restrict__ dpooled,
                                                             const EegCoef* __restrict__ co, EegStats* __restrict__ st,
-                                                            int64_t rows, int T2p, int T3, float dp, uint64_t seed) {
-  // gridDim.x is a multiple of 4: a wave's rows (every 4 gridDim.x-th) share h, and it sends ONE atomic pair
+                                                            int64_t rows, int T2p, int T3, float dp, uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+  // zgx is a multiple of 4: a wave's rows (every 4 zgx-th) share h, and it sends ONE atomic pair
   const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row0 >= rows) return;
   const int h = (int)(row0 & (kF2 - 1));
   const float A = co->A3[h], Bc = co->B3[h], mu = co->mu3[h], isg = 1.f / co->sig3[h];
   float s1 = 0.f, s2 = 0.f;
-  for (int64_t row = row0; row < rows; row += (int64_t)gridDim.x * 4) {
+  for (int64_t row = row0; row < rows; row += (int64_t)zgx * 4) {
     const float de = T3 > 0 ? dpooled[row] / (float)(8 * T3) : 0.f;
     const float* ar = a4 + row * T2p;
     for (int w = lane; w < 8 * T3; w += 64) {
@@ -819,13 +930,21 @@ __global__ __launch_bounds__(256) void eeg_bwd3_sums_kernel(const float* __restr
     atomicAdd(&st->dy3x[h], (double)s2);
   }
 }
+ISD_ZONE_FN(eeg_bwd3_sums_kernel, 256)
+__global__ __launch_bounds__(256) void eeg_bwd3_sums_kernel(const float* __restrict__ a4,
+                                                            const float* __restrict__ dpooled,
+                                                            const EegCoef* __restrict__ co, EegStats* __restrict__ st,
+                                                            int64_t rows, int T2p, int T3, float dp, uint64_t seed) {
+  eeg_bwd3_sums_kernel_body(a4, dpooled, co, st, rows, T2p, T3, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_bwd3_sums_kernel)
 
 // BN backward coefficients for stage `which` (3 or 2) and the gamma/beta gradients
 // gs: 1 / world size under synchronised BatchNorm -- the sums are then global on every rank and the gradient
 // all-reduce that follows adds the ranks' copies
-__global__ void eeg_bwd_bn_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
+__device__ __forceinline__ void eeg_bwd_bn_coef_kernel_body(const float* __restrict__ params, float* __restrict__ dparams,
                                        const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N,
-                                       int which, double gs, int bn_train) {
+                                       int which, double gs, int bn_train, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int h = threadIdx.x;
   if (h >= kF2) return;
   const double inv = bn_train ? 1.0 / N : 0.0;           // running statistics do not depend on the batch: no mean terms
@@ -843,13 +962,20 @@ __global__ void eeg_bwd_bn_coef_kernel(const float* __restrict__ params, float* 
     co->cC2[h] = (float)(st->dy2x[h] * inv);
   }
 }
+ISD_ZONE_FN(eeg_bwd_bn_coef_kernel, 1024)
+__global__ void eeg_bwd_bn_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
+                                       const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N,
+                                       int which, double gs, int bn_train) {
+  eeg_bwd_bn_coef_kernel_body(params, dparams, st, co, off, N, which, gs, bn_train, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_bwd_bn_coef_kernel)
 
 // da4 = cA3 (dy3 - cB3 - xhat3 cC3);  da3[b,g,w] = sum_h Wp[h,g] da4[b,h,w].  One thread per (b,w).
-__global__ __launch_bounds__(256) void eeg_bwd_sep_kernel(const float* __restrict__ a4,
+__device__ __forceinline__ void eeg_bwd_sep_kernel_body(const float* __restrict__ a4,
                                                           const float* __restrict__ dpooled,
                                                           const float* __restrict__ Wp, const EegCoef* __restrict__ co,
                                                           float* __restrict__ da4, float* __restrict__ da3, int T2p,
-                                                          int T3, float dp, uint64_t seed) {
+                                                          int T3, float dp, uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int b = blockIdx.y;
   const int w = blockIdx.x * 256 + threadIdx.x;
   if (w >= T2p) return;
@@ -874,12 +1000,21 @@ __global__ __launch_bounds__(256) void eeg_bwd_sep_kernel(const float* __restric
     da3[((int64_t)b * kF2 + g) * T2p + w] = acc;
   }
 }
+ISD_ZONE_FN(eeg_bwd_sep_kernel, 256)
+__global__ __launch_bounds__(256) void eeg_bwd_sep_kernel(const float* __restrict__ a4,
+                                                          const float* __restrict__ dpooled,
+                                                          const float* __restrict__ Wp, const EegCoef* __restrict__ co,
+                                                          float* __restrict__ da4, float* __restrict__ da3, int T2p,
+                                                          int T3, float dp, uint64_t seed) {
+  eeg_bwd_sep_kernel_body(a4, dpooled, Wp, co, da4, da3, T2p, T3, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_bwd_sep_kernel)
 
 // dWp[h,g] = sum_{b,w} da4[b,h,w] a3[b,g,w];  dWd[g,k] = sum_{b,w} da3[b,g,w] p2pad[b,g,w+k].
 // One block per output element (512 blocks), fp64 block result.
-__global__ __launch_bounds__(256) void eeg_bwd_sepw_kernel(const float* __restrict__ da4, const float* __restrict__ a3,
+__device__ __forceinline__ void eeg_bwd_sepw_kernel_body(const float* __restrict__ da4, const float* __restrict__ a3,
                                                            const float* __restrict__ da3, const float* __restrict__ p2,
-                                                           EegStats* __restrict__ st, int B, int T2, int T2p) {
+                                                           EegStats* __restrict__ st, int B, int T2, int T2p, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float red[4];
   const int o = blockIdx.x;
   // thread = (trial b0 + 4 j, step w0 + 64 i): no 64-bit division per element, two independent accumulators
@@ -918,18 +1053,25 @@ __global__ __launch_bounds__(256) void eeg_bwd_sepw_kernel(const float* __restri
     else st->dWd[(o - kF2 * kF2) / kK2][(o - kF2 * kF2) % kK2] = (double)tot;
   }
 }
+ISD_ZONE_FN(eeg_bwd_sepw_kernel, 256)
+__global__ __launch_bounds__(256) void eeg_bwd_sepw_kernel(const float* __restrict__ da4, const float* __restrict__ a3,
+                                                           const float* __restrict__ da3, const float* __restrict__ p2,
+                                                           EegStats* __restrict__ st, int B, int T2, int T2p) {
+  eeg_bwd_sepw_kernel_body(da4, a3, da3, p2, st, B, T2, T2p, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_bwd_sepw_kernel)
 
 // dp2 -> de2 -> dy2 = de2 ELU'(y2), written to dy2[b,g,t'] (zero past 4*T2); BN2 backward sums.
-__global__ __launch_bounds__(256) void eeg_bwd_pool2_kernel(const float* __restrict__ da3, const float* __restrict__ Wd,
+__device__ __forceinline__ void eeg_bwd_pool2_kernel_body(const float* __restrict__ da3, const float* __restrict__ Wd,
                                                             const float* __restrict__ u, const EegCoef* __restrict__ co,
                                                             float* __restrict__ dy2, EegStats* __restrict__ st, int Tp,
                                                             int T2, int T2p, int P1, float dpr, uint64_t seed,
-                                                            int n_rows) {
+                                                            int n_rows, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float red[4];
-  const int g = blockIdx.y & (kF2 - 1);                 // gridDim.y is a multiple of 16: the rows of a workgroup share g
+  const int g = blockIdx.y & (kF2 - 1);                 // zgy is a multiple of 16: the rows of a workgroup share g
   float t1 = 0.f, t2 = 0.f;
-  for (int bg = blockIdx.y; bg < n_rows; bg += gridDim.y)
-  for (int tp = blockIdx.x * 256 + threadIdx.x; tp < Tp; tp += gridDim.x * 256) {   // one atomic pair per workgroup
+  for (int bg = blockIdx.y; bg < n_rows; bg += zgy)
+  for (int tp = blockIdx.x * 256 + threadIdx.x; tp < Tp; tp += zgx * 256) {   // one atomic pair per workgroup
     float dy = 0.f, xh = 0.f;
     const int v = tp / P1;
     if (v < T2) {
@@ -962,16 +1104,25 @@ __global__ __launch_bounds__(256) void eeg_bwd_pool2_kernel(const float* __restr
     atomicAdd(&st->dy2x[g], (double)s2);
   }
 }
+ISD_ZONE_FN(eeg_bwd_pool2_kernel, 256)
+__global__ __launch_bounds__(256) void eeg_bwd_pool2_kernel(const float* __restrict__ da3, const float* __restrict__ Wd,
+                                                            const float* __restrict__ u, const EegCoef* __restrict__ co,
+                                                            float* __restrict__ dy2, EegStats* __restrict__ st, int Tp,
+                                                            int T2, int T2p, int P1, float dpr, uint64_t seed,
+                                                            int n_rows) {
+  eeg_bwd_pool2_kernel_body(da3, Wd, u, co, dy2, st, Tp, T2, T2p, P1, dpr, seed, n_rows, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_bwd_pool2_kernel)
 
 // da2 = cA2 (dy2 - cB2 - xhat2 cC2) in place; Sd = sum da2, Su = sum da2*u
-__global__ __launch_bounds__(256) void eeg_bwd_bn2_kernel(float* __restrict__ dy2, const float* __restrict__ u,
+__device__ __forceinline__ void eeg_bwd_bn2_kernel_body(float* __restrict__ dy2, const float* __restrict__ u,
                                                           const EegCoef* __restrict__ co, EegStats* __restrict__ st,
-                                                          int Tp, int n_rows) {
+                                                          int Tp, int n_rows, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float red[4];
-  const int g = blockIdx.y & (kF2 - 1);                 // gridDim.y is a multiple of 16: the rows of a workgroup share g
+  const int g = blockIdx.y & (kF2 - 1);                 // zgy is a multiple of 16: the rows of a workgroup share g
   float t1 = 0.f, t2 = 0.f;
-  for (int bg = blockIdx.y; bg < n_rows; bg += gridDim.y)
-  for (int tp = blockIdx.x * 256 + threadIdx.x; tp < Tp; tp += gridDim.x * 256) {   // one atomic pair per workgroup
+  for (int bg = blockIdx.y; bg < n_rows; bg += zgy)
+  for (int tp = blockIdx.x * 256 + threadIdx.x; tp < Tp; tp += zgx * 256) {   // one atomic pair per workgroup
     const float uv = u[(int64_t)bg * Tp + tp];
     const float xh = (co->s1[g >> 1] * uv + co->o1[g >> 1] * co->wsum[g] - co->mu2[g]) / co->sig2[g];
     const float d = co->cA2[g] * (dy2[(int64_t)bg * Tp + tp] - co->cB2[g] - xh * co->cC2[g]);
@@ -986,6 +1137,13 @@ __global__ __launch_bounds__(256) void eeg_bwd_bn2_kernel(float* __restrict__ dy
     atomicAdd(&st->Su[g], (double)s2);
   }
 }
+ISD_ZONE_FN(eeg_bwd_bn2_kernel, 256)
+__global__ __launch_bounds__(256) void eeg_bwd_bn2_kernel(float* __restrict__ dy2, const float* __restrict__ u,
+                                                          const EegCoef* __restrict__ co, EegStats* __restrict__ st,
+                                                          int Tp, int n_rows) {
+  eeg_bwd_bn2_kernel_body(dy2, u, co, st, Tp, n_rows, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_bwd_bn2_kernel)
 
 // T1[g][k] = sum_{b,t'} da2[b,g,t'] zpad[b,g,t'+k]  (lane = t' inside a 64 block, K accumulators in registers)
 // and v[b,g,t] = sum_k Wt[f,k] da2[b,g,t-k+P].   grid (B*16), one wave per (b,g) row.
@@ -993,13 +1151,13 @@ __global__ __launch_bounds__(256) void eeg_bwd_bn2_kernel(float* __restrict__ dy
 // T = 4096 -- a CU held 4 of these one-wave workgroups and the kernel was the slowest of the raw stress head).
 constexpr int kCorrSeg = 1024;
 template <int KT>
-__global__ __launch_bounds__(64) void eeg_bwd_corr_kernel(const float* __restrict__ da2, const float* __restrict__ z,
+__device__ __forceinline__ void eeg_bwd_corr_kernel_body(const float* __restrict__ da2, const float* __restrict__ z,
                                                           const float* __restrict__ Wt, float* __restrict__ v,
-                                                          EegStats* __restrict__ st, int Krt, int T, int Tp, int n_rows) {
+                                                          EegStats* __restrict__ st, int Krt, int T, int Tp, int n_rows, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int K = KT ? KT : Krt;
   constexpr int KA = KT ? KT : kMaxK;                   // accumulators kept
   extern __shared__ float sm[];                         // z[s0 - P + j], j < L + K + 64;  da2[s0 - K + j], j < L + 2K + 64
-  // gridDim.x is a multiple of 16: the rows of a workgroup (every gridDim.x-th) share g, their K lag sums stay in
+  // zgx is a multiple of 16: the rows of a workgroup (every zgx-th) share g, their K lag sums stay in
   // registers and reach the fp64 accumulators once per workgroup (5 k rows x 64 lags on 1 k addresses were 0.15 ms)
   const int g = blockIdx.x & (kF2 - 1), f = g >> 1, P = K / 2, lane = threadIdx.x;
   const int s0 = blockIdx.y * kCorrSeg, L = kCorrSeg;
@@ -1010,7 +1168,7 @@ __global__ __launch_bounds__(64) void eeg_bwd_corr_kernel(const float* __restric
   float acc[KA];
 #pragma unroll
   for (int k = 0; k < KA; ++k) acc[k] = 0.f;
-  for (int bg = blockIdx.x; bg < n_rows; bg += gridDim.x) {
+  for (int bg = blockIdx.x; bg < n_rows; bg += zgx) {
     const float* zr = z + (int64_t)bg * T;
     const float* dr = da2 + (int64_t)bg * Tp;
     wave_lds_sync();                                    // the previous row's readers are done
@@ -1053,6 +1211,17 @@ __global__ __launch_bounds__(64) void eeg_bwd_corr_kernel(const float* __restric
     }
   }
 }
+ISD_ZONE_FN_T(eeg_bwd_corr_kernel, 64, int)
+template <int KT>
+__global__ __launch_bounds__(64) void eeg_bwd_corr_kernel(const float* __restrict__ da2, const float* __restrict__ z,
+                                                          const float* __restrict__ Wt, float* __restrict__ v,
+                                                          EegStats* __restrict__ st, int Krt, int T, int Tp, int n_rows) {
+  eeg_bwd_corr_kernel_body<KT>(da2, z, Wt, v, st, Krt, T, Tp, n_rows, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER_T(eeg_bwd_corr_kernel, 64)
+ISD_ZONE_REGISTER_T(eeg_bwd_corr_kernel, 32)
+ISD_ZONE_REGISTER_T(eeg_bwd_corr_kernel, 16)
+ISD_ZONE_REGISTER_T(eeg_bwd_corr_kernel, 0)
 
 // dWs_raw[g,c] = sum_{b,t} v[b,g,t] x[b,c,t] on the matrix cores; persistent waves, partial slabs.
 // A[g][t] = v, B[t][c] = x; K = 4 time steps per MFMA; a wave owns all C/16 channel tiles (<= 16) of its 256 channels.
@@ -1083,8 +1252,8 @@ __device__ __forceinline__ void dws_load_row(const float* __restrict__ row, int 
     }
   }
 }
-__global__ __launch_bounds__(64) void eeg_bwd_dws_kernel(const float* __restrict__ v, const float* __restrict__ x,
-                                                         float* __restrict__ part, int B, int C, int T) {
+__device__ __forceinline__ void eeg_bwd_dws_kernel_body(const float* __restrict__ v, const float* __restrict__ x,
+                                                         float* __restrict__ part, int B, int C, int T, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int lane = threadIdx.x, q = lane >> 4, jl = lane & 15;
   const int c_base = blockIdx.y * 256;                    // 16 channel tiles per wave
   const int n_ctile = (C - c_base + 15) / 16 < 16 ? (C - c_base + 15) / 16 : 16;
@@ -1094,7 +1263,7 @@ __global__ __launch_bounds__(64) void eeg_bwd_dws_kernel(const float* __restrict
   constexpr int CH = kDwsPasses * 16;
   const int chunks_per_b = (T + CH - 1) / CH;
   const int64_t n_chunks = (int64_t)B * chunks_per_b;
-  for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+  for (int64_t ch = blockIdx.x; ch < n_chunks; ch += zgx) {
     const int64_t b = ch / chunks_per_b;
     const int t_lo = (int)(ch - b * chunks_per_b) * CH;
     const int t_hi = t_lo + CH < T ? t_lo + CH : T;
@@ -1132,14 +1301,20 @@ __global__ __launch_bounds__(64) void eeg_bwd_dws_kernel(const float* __restrict
     }
   }
 }
+ISD_ZONE_FN(eeg_bwd_dws_kernel, 64)
+__global__ __launch_bounds__(64) void eeg_bwd_dws_kernel(const float* __restrict__ v, const float* __restrict__ x,
+                                                         float* __restrict__ part, int B, int C, int T) {
+  eeg_bwd_dws_kernel_body(v, x, part, B, C, T, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_bwd_dws_kernel)
 
 // dWs[g,c] = s1[f] * sum_slabs raw + o1[f] * Sd[g].  Block = 64 elements x 16 slab groups (coalesced 256-B rows, two
 // independent chains per group, LDS combine in a fixed order): one thread per element walking up to 1024 slabs on
 // its own was a 0.15 ms chain of dependent loads.
-__global__ __launch_bounds__(1024) void eeg_bwd_dws_reduce_kernel(const float* __restrict__ part, int n_slabs,
+__device__ __forceinline__ void eeg_bwd_dws_reduce_kernel_body(const float* __restrict__ part, int n_slabs,
                                                                   const EegStats* __restrict__ st,
                                                                   const EegCoef* __restrict__ co,
-                                                                  float* __restrict__ dWs, int C) {
+                                                                  float* __restrict__ dWs, int C, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
@@ -1163,13 +1338,21 @@ __global__ __launch_bounds__(1024) void eeg_bwd_dws_reduce_kernel(const float* _
     dWs[e] = co->s1[f] * t + co->o1[f] * (float)st->Sd[g];
   }
 }
+ISD_ZONE_FN(eeg_bwd_dws_reduce_kernel, 1024)
+__global__ __launch_bounds__(1024) void eeg_bwd_dws_reduce_kernel(const float* __restrict__ part, int n_slabs,
+                                                                  const EegStats* __restrict__ st,
+                                                                  const EegCoef* __restrict__ co,
+                                                                  float* __restrict__ dWs, int C) {
+  eeg_bwd_dws_reduce_kernel_body(part, n_slabs, st, co, dWs, C, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_bwd_dws_reduce_kernel)
 
 // Final assembly of the stage-1 gradients (dWt, dgamma1, dbeta1) and the separable weights.  One block.
-__global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restrict__ params,
+__device__ __forceinline__ void eeg_bwd_final_kernel_body(const float* __restrict__ params,
                                                             float* __restrict__ dparams,
                                                             const EegStats* __restrict__ st,
                                                             const EegCoef* __restrict__ co, EegOff off, int C, int K,
-                                                            double N1, int separable, double gs, int bn_train) {
+                                                            double N1, int separable, double gs, int bn_train, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const float* Wt = params + off.Wt;
   if (separable) {
     for (int e = threadIdx.x; e < kF2 * kF2; e += 256) dparams[off.Wp + e] = (float)st->dWp[e / kF2][e % kF2];
@@ -1200,6 +1383,15 @@ __global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restr
     dparams[off.Wt + e] = (float)(val * gs);
   }
 }
+ISD_ZONE_FN(eeg_bwd_final_kernel, 256)
+__global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restrict__ params,
+                                                            float* __restrict__ dparams,
+                                                            const EegStats* __restrict__ st,
+                                                            const EegCoef* __restrict__ co, EegOff off, int C, int K,
+                                                            double N1, int separable, double gs, int bn_train) {
+  eeg_bwd_final_kernel_body(params, dparams, st, co, off, C, K, N1, separable, gs, bn_train, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(eeg_bwd_final_kernel)
 
 // Gradient w.r.t. the input trials (what the attribution scripts differentiate).  With a1[f,c,t'] = (Wt_f * xpad_c)[t'],
 // BN1 and the depthwise spatial layer:
@@ -1209,11 +1401,11 @@ __global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restr
 //   meanD, meanDa as in eeg_bwd_final_kernel).  One workgroup per (row, 256-sample segment): the row segment with a
 //   64-sample halo in LDS, per filter the a1 values the segment's outputs touch, then the transposed filter.
 template <int KT>
-__global__ __launch_bounds__(256) void eeg_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ v,
+__device__ __forceinline__ void eeg_bwd_dx_kernel_body(const float* __restrict__ x, const float* __restrict__ v,
                                                          const float* __restrict__ params, float* __restrict__ dx,
                                                          const EegStats* __restrict__ st, const EegCoef* __restrict__ co,
                                                          EegOff off, int C, int Krt, int T, int Tp, double N1,
-                                                         int bn_train) {
+                                                         int bn_train, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int K = KT ? KT : Krt;
   constexpr int KA = KT ? KT : kMaxK;
   __shared__ float xs[256 + 2 * kMaxK];                  // x[s0 - K + j]
@@ -1277,6 +1469,19 @@ __global__ __launch_bounds__(256) void eeg_bwd_dx_kernel(const float* __restrict
   }
   if (t < T) dx[row * (int64_t)T + t] = acc;
 }
+ISD_ZONE_FN_T(eeg_bwd_dx_kernel, 256, int)
+template <int KT>
+__global__ __launch_bounds__(256) void eeg_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                                                         const float* __restrict__ params, float* __restrict__ dx,
+                                                         const EegStats* __restrict__ st, const EegCoef* __restrict__ co,
+                                                         EegOff off, int C, int Krt, int T, int Tp, double N1,
+                                                         int bn_train) {
+  eeg_bwd_dx_kernel_body<KT>(x, v, params, dx, st, co, off, C, Krt, T, Tp, N1, bn_train, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER_T(eeg_bwd_dx_kernel, 64)
+ISD_ZONE_REGISTER_T(eeg_bwd_dx_kernel, 32)
+ISD_ZONE_REGISTER_T(eeg_bwd_dx_kernel, 16)
+ISD_ZONE_REGISTER_T(eeg_bwd_dx_kernel, 0)
 
 // ------------------------------------------------------------------------------------------------
 // CVBlock (reference: src/fast/models/fast.py:32-100).  Stage 1 (temporal conv, BN1, depthwise spatial
@@ -1284,8 +1489,8 @@ __global__ __launch_bounds__(256) void eeg_bwd_dx_kernel(const float* __restrict
 // ELU, AvgPool 2, and the projector is Linear(16*T3 -> F) over the flattened [16, T3] map.
 // ------------------------------------------------------------------------------------------------
 // W3 [h][g][k] -> fwd layout [g][k][h] and data-gradient layout [h][k][g] (16 contiguous scalars per tap)
-__global__ __launch_bounds__(256) void cv_prep_kernel(const float* __restrict__ W3, float* __restrict__ Wf,
-                                                      float* __restrict__ Wb) {
+__device__ __forceinline__ void cv_prep_kernel_body(const float* __restrict__ W3, float* __restrict__ Wf,
+                                                      float* __restrict__ Wb, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= kF2 * kF2 * kK2) return;
   const int h = e >> 8, g = (e >> 4) & 15, k = e & 15;
@@ -1293,11 +1498,17 @@ __global__ __launch_bounds__(256) void cv_prep_kernel(const float* __restrict__ 
   Wf[(g * kK2 + k) * kF2 + h] = w;
   Wb[(h * kK2 + k) * kF2 + g] = w;
 }
+ISD_ZONE_FN(cv_prep_kernel, 256)
+__global__ __launch_bounds__(256) void cv_prep_kernel(const float* __restrict__ W3, float* __restrict__ Wf,
+                                                      float* __restrict__ Wb) {
+  cv_prep_kernel_body(W3, Wf, Wb, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(cv_prep_kernel)
 
 // a4[b,h,w] = sum_{g,k} W3[h,g,k] p2pad[b,g,w+k];  BN3 sums.  One thread per (b,w), 16 outputs in registers.
-__global__ __launch_bounds__(256) void cv_conv3_kernel(const float* __restrict__ p2, const float* __restrict__ Wf,
+__device__ __forceinline__ void cv_conv3_kernel_body(const float* __restrict__ p2, const float* __restrict__ Wf,
                                                        float* __restrict__ a4, EegStats* __restrict__ st, int64_t B,
-                                                       int T2, int T2p, int want_stats) {
+                                                       int T2, int T2p, int want_stats, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float red[4];
   __shared__ float tot[2 * kF2];
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1334,11 +1545,18 @@ __global__ __launch_bounds__(256) void cv_conv3_kernel(const float* __restrict__
     else if (threadIdx.x < 2 * kF2) atomicAdd(&st->a2[threadIdx.x - kF2], (double)tot[threadIdx.x]);
   }
 }
+ISD_ZONE_FN(cv_conv3_kernel, 256)
+__global__ __launch_bounds__(256) void cv_conv3_kernel(const float* __restrict__ p2, const float* __restrict__ Wf,
+                                                       float* __restrict__ a4, EegStats* __restrict__ st, int64_t B,
+                                                       int T2, int T2p, int want_stats) {
+  cv_conv3_kernel_body(p2, Wf, a4, st, B, T2, T2p, want_stats, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(cv_conv3_kernel)
 
 // p3[b,h,v] = mean_{r<P2} ELU(A3 a4[b,h,P2 v+r] + B3) * dropout      ([B,16,T3] == the flattened projector input)
-__global__ __launch_bounds__(256) void cv_pool3_kernel(const float* __restrict__ a4, const EegCoef* __restrict__ co,
+__device__ __forceinline__ void cv_pool3_kernel_body(const float* __restrict__ a4, const EegCoef* __restrict__ co,
                                                        float* __restrict__ p3, int64_t n, int T2p, int T3, int P2,
-                                                       float dp, uint64_t seed) {
+                                                       float dp, uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   const int64_t row = e / T3;
@@ -1349,6 +1567,13 @@ __global__ __launch_bounds__(256) void cv_pool3_kernel(const float* __restrict__
   for (int r = 0; r < P2; ++r) s += elu_f(fmaf(A, ar[r], Bc));
   p3[e] = s / (float)P2 * drop_scale((seed + co->seed_add) ^ 0x5bd1e995u, (uint64_t)e, dp);
 }
+ISD_ZONE_FN(cv_pool3_kernel, 256)
+__global__ __launch_bounds__(256) void cv_pool3_kernel(const float* __restrict__ a4, const EegCoef* __restrict__ co,
+                                                       float* __restrict__ p3, int64_t n, int T2p, int T3, int P2,
+                                                       float dp, uint64_t seed) {
+  cv_pool3_kernel_body(a4, co, p3, n, T2p, T3, P2, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(cv_pool3_kernel)
 
 __device__ __forceinline__ float cv_dy3(const float* __restrict__ dp3, const EegCoef* __restrict__ co, int64_t row,
                                         int h, int w, float av, int T3, int P2, float dp, uint64_t seed) {
@@ -1359,10 +1584,10 @@ __device__ __forceinline__ float cv_dy3(const float* __restrict__ dp3, const Eeg
 }
 
 // BN3 backward sums: one wave per (b,h) row
-__global__ __launch_bounds__(256) void cv_bwd3_sums_kernel(const float* __restrict__ a4, const float* __restrict__ dp3,
+__device__ __forceinline__ void cv_bwd3_sums_kernel_body(const float* __restrict__ a4, const float* __restrict__ dp3,
                                                            const EegCoef* __restrict__ co, EegStats* __restrict__ st,
                                                            int64_t rows, int T2p, int T3, int P2, float dp,
-                                                           uint64_t seed) {
+                                                           uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -1382,11 +1607,19 @@ __global__ __launch_bounds__(256) void cv_bwd3_sums_kernel(const float* __restri
     atomicAdd(&st->dy3x[h], (double)s2);
   }
 }
+ISD_ZONE_FN(cv_bwd3_sums_kernel, 256)
+__global__ __launch_bounds__(256) void cv_bwd3_sums_kernel(const float* __restrict__ a4, const float* __restrict__ dp3,
+                                                           const EegCoef* __restrict__ co, EegStats* __restrict__ st,
+                                                           int64_t rows, int T2p, int T3, int P2, float dp,
+                                                           uint64_t seed) {
+  cv_bwd3_sums_kernel_body(a4, dp3, co, st, rows, T2p, T3, P2, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(cv_bwd3_sums_kernel)
 
 // da4 = cA3 (dy3 - cB3 - xhat3 cC3), elementwise over [B,16,T2p]
-__global__ __launch_bounds__(256) void cv_bwd_da4_kernel(const float* __restrict__ a4, const float* __restrict__ dp3,
+__device__ __forceinline__ void cv_bwd_da4_kernel_body(const float* __restrict__ a4, const float* __restrict__ dp3,
                                                          const EegCoef* __restrict__ co, float* __restrict__ da4,
-                                                         int64_t n, int T2p, int T3, int P2, float dp, uint64_t seed) {
+                                                         int64_t n, int T2p, int T3, int P2, float dp, uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   const int64_t row = e / T2p;
@@ -1396,10 +1629,17 @@ __global__ __launch_bounds__(256) void cv_bwd_da4_kernel(const float* __restrict
   const float xh = (av - co->mu3[h]) / co->sig3[h];
   da4[e] = co->cA3[h] * (dy - co->cB3[h] - xh * co->cC3[h]);
 }
+ISD_ZONE_FN(cv_bwd_da4_kernel, 256)
+__global__ __launch_bounds__(256) void cv_bwd_da4_kernel(const float* __restrict__ a4, const float* __restrict__ dp3,
+                                                         const EegCoef* __restrict__ co, float* __restrict__ da4,
+                                                         int64_t n, int T2p, int T3, int P2, float dp, uint64_t seed) {
+  cv_bwd_da4_kernel_body(a4, dp3, co, da4, n, T2p, T3, P2, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(cv_bwd_da4_kernel)
 
 // dp2[b,g,v] = sum_{h,k} W3[h,g,k] da4[b,h,v-k+8].  One thread per (b,v), 16 outputs in registers.
-__global__ __launch_bounds__(256) void cv_bwd_dp2_kernel(const float* __restrict__ da4, const float* __restrict__ Wb,
-                                                         float* __restrict__ dp2, int64_t B, int T2, int T2p) {
+__device__ __forceinline__ void cv_bwd_dp2_kernel_body(const float* __restrict__ da4, const float* __restrict__ Wb,
+                                                         float* __restrict__ dp2, int64_t B, int T2, int T2p, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= B * T2) return;
   const int64_t b = e / T2;
@@ -1421,16 +1661,22 @@ __global__ __launch_bounds__(256) void cv_bwd_dp2_kernel(const float* __restrict
 #pragma unroll
   for (int g = 0; g < kF2; ++g) dp2[(b * kF2 + g) * T2 + v] = o[g];
 }
+ISD_ZONE_FN(cv_bwd_dp2_kernel, 256)
+__global__ __launch_bounds__(256) void cv_bwd_dp2_kernel(const float* __restrict__ da4, const float* __restrict__ Wb,
+                                                         float* __restrict__ dp2, int64_t B, int T2, int T2p) {
+  cv_bwd_dp2_kernel_body(da4, Wb, dp2, B, T2, T2p, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(cv_bwd_dp2_kernel)
 
 // dW3[h,g,k] = sum_{b,w} da4[b,h,w] p2pad[b,g,w+k] on the matrix cores: M = h, N = k (tap), K = w, one
 // 16x16 accumulator tile per input channel g.  Persistent waves over trials, partial slabs [h][g][k].
-__global__ __launch_bounds__(64) void cv_bwd_w3_kernel(const float* __restrict__ da4, const float* __restrict__ p2,
-                                                       float* __restrict__ part, int64_t B, int T2, int T2p) {
+__device__ __forceinline__ void cv_bwd_w3_kernel_body(const float* __restrict__ da4, const float* __restrict__ p2,
+                                                       float* __restrict__ part, int64_t B, int T2, int T2p, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int lane = threadIdx.x, q = lane >> 4, jl = lane & 15;
   f32x4 acc[kF2];
 #pragma unroll
   for (int g = 0; g < kF2; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+  for (int64_t b = blockIdx.x; b < B; b += zgx) {
     const float* dr = da4 + (b * kF2 + jl) * T2p;
     const float* pb = p2 + b * kF2 * T2;
     for (int w0 = 0; w0 < T2p; w0 += 4) {
@@ -1451,9 +1697,15 @@ __global__ __launch_bounds__(64) void cv_bwd_w3_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 4; ++r) slab[(4 * q + r) * (kF2 * kK2) + g * kK2 + jl] = acc[g][r];
 }
+ISD_ZONE_FN(cv_bwd_w3_kernel, 64)
+__global__ __launch_bounds__(64) void cv_bwd_w3_kernel(const float* __restrict__ da4, const float* __restrict__ p2,
+                                                       float* __restrict__ part, int64_t B, int T2, int T2p) {
+  cv_bwd_w3_kernel_body(da4, p2, part, B, T2, T2p, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(cv_bwd_w3_kernel)
 
-__global__ __launch_bounds__(256) void cv_w3_reduce_kernel(const float* __restrict__ part, int n_slabs,
-                                                           float* __restrict__ dW3) {
+__device__ __forceinline__ void cv_w3_reduce_kernel_body(const float* __restrict__ part, int n_slabs,
+                                                           float* __restrict__ dW3, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= kF2 * kF2 * kK2) return;
   float s0 = 0.f, s1 = 0.f;
@@ -1465,6 +1717,12 @@ __global__ __launch_bounds__(256) void cv_w3_reduce_kernel(const float* __restri
   if (k < n_slabs) s0 += part[(int64_t)k * (kF2 * kF2 * kK2) + e];
   dW3[e] = s0 + s1;
 }
+ISD_ZONE_FN(cv_w3_reduce_kernel, 256)
+__global__ __launch_bounds__(256) void cv_w3_reduce_kernel(const float* __restrict__ part, int n_slabs,
+                                                           float* __restrict__ dW3) {
+  cv_w3_reduce_kernel_body(part, n_slabs, dW3, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(cv_w3_reduce_kernel)
 
 }  // namespace isd
 
@@ -1628,50 +1886,50 @@ static int eeg_forward_stage(const isd_eegnet_plan* p, int stage, const float* x
   const int keep = training != 0;
   training &= 1;
   if (stage == 0) {
-    ISD_HIP_TRY(hipMemsetAsync(S, 0, sizeof(EegStats), st));
+    ISD_HIP_TRY(zone_clear(S, sizeof(EegStats), st));
     if (training) {
       if (T <= 79) {
         const int MT = (T + 16) / 16;                              // 16 MT >= T + 1: room for the column of ones
         const int64_t want_g = cdiv(cdiv(rows, 4), kStatWaves);
         const int grid_g = want_g < 1024 ? (int)want_g : 1024;
         switch (MT) {
-          case 1: hipLaunchKernelGGL(eeg_stats_gram_kernel<1>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
-          case 2: hipLaunchKernelGGL(eeg_stats_gram_kernel<2>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
-          case 3: hipLaunchKernelGGL(eeg_stats_gram_kernel<3>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
-          case 4: hipLaunchKernelGGL(eeg_stats_gram_kernel<4>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
-          default: hipLaunchKernelGGL(eeg_stats_gram_kernel<5>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+          case 1: ISD_ZLAUNCH(eeg_stats_gram_kernel<1>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+          case 2: ISD_ZLAUNCH(eeg_stats_gram_kernel<2>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+          case 3: ISD_ZLAUNCH(eeg_stats_gram_kernel<3>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+          case 4: ISD_ZLAUNCH(eeg_stats_gram_kernel<4>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
+          default: ISD_ZLAUNCH(eeg_stats_gram_kernel<5>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
         }
-        hipLaunchKernelGGL(eeg_stats_gram_derive_kernel, dim3(1), dim3(64), 0, st, S, T);
+        ISD_ZLAUNCH(eeg_stats_gram_derive_kernel, dim3(1), dim3(64), 0, st, S, T);
       } else {
         const int64_t want = cdiv(rows, kStatWaves);
         const int grid = want < 2048 ? (int)want : 2048;             // bulk: 32 waves per CU
-        hipLaunchKernelGGL(eeg_stats_kernel, dim3(grid), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
+        ISD_ZLAUNCH(eeg_stats_kernel, dim3(grid), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
         const int64_t want_e = cdiv(cdiv(rows, 4), kStatWaves);
         const int grid_e = want_e < 512 ? (int)want_e : 512;         // edge: 4 rows per MFMA step, head and tail blocks
-        hipLaunchKernelGGL(eeg_stats_edge_kernel, dim3(grid_e, 2), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
-        hipLaunchKernelGGL(eeg_stats_derive_kernel, dim3(1), dim3(64), 0, st, S);
+        ISD_ZLAUNCH(eeg_stats_edge_kernel, dim3(grid_e, 2), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
+        ISD_ZLAUNCH(eeg_stats_derive_kernel, dim3(1), dim3(64), 0, st, S);
       }
     }
     ISD_LAUNCH_CHECK();
     return ISD_OK;
   }
   if (stage == 1) {
-    hipLaunchKernelGGL(eeg_finalize1_kernel, dim3(1), dim3(256), 0, st, params, buffers, S, Cf, p->off, C, K, T,
+    ISD_ZLAUNCH(eeg_finalize1_kernel, dim3(1), dim3(256), 0, st, params, buffers, S, Cf, p->off, C, K, T,
                        rows * world, training, momentum, eps, p->seed_dev);
     if (C >= 128)                                               // wide inputs: whole rows per workgroup
-      hipLaunchKernelGGL(eeg_spatial_rows_kernel<5>, dim3((unsigned)cdiv(cdiv(T, 16), 5), (unsigned)B), dim3(256), 0, st,
+      ISD_ZLAUNCH(eeg_spatial_rows_kernel<5>, dim3((unsigned)cdiv(cdiv(T, 16), 5), (unsigned)B), dim3(256), 0, st,
                          x, params + p->off.Ws, ws + w.z, C, T);
     else
-      hipLaunchKernelGGL(eeg_spatial_kernel, dim3((unsigned)cdiv(T, 16), (unsigned)B), dim3(256), 0, st, x,
+      ISD_ZLAUNCH(eeg_spatial_kernel, dim3((unsigned)cdiv(T, 16), (unsigned)B), dim3(256), 0, st, x,
                          params + p->off.Ws, ws + w.z, C, T, (int)cdiv(T, 16));
     {
       const unsigned gx = row_blocks(Tp, B * kF2);
 #define ISD_EEG_K(KERNEL, ...)                          \
   do {                                                 \
-    if (K == 64) hipLaunchKernelGGL(KERNEL<64>, __VA_ARGS__);      \
-    else if (K == 32) hipLaunchKernelGGL(KERNEL<32>, __VA_ARGS__); \
-    else if (K == 16) hipLaunchKernelGGL(KERNEL<16>, __VA_ARGS__); \
-    else hipLaunchKernelGGL(KERNEL<0>, __VA_ARGS__);               \
+    if (K == 64) ISD_ZLAUNCH(KERNEL<64>, __VA_ARGS__);      \
+    else if (K == 32) ISD_ZLAUNCH(KERNEL<32>, __VA_ARGS__); \
+    else if (K == 16) ISD_ZLAUNCH(KERNEL<16>, __VA_ARGS__); \
+    else ISD_ZLAUNCH(KERNEL<0>, __VA_ARGS__);               \
   } while (0)
       ISD_EEG_K(eeg_tconv_kernel, dim3(gx, row_groups(B * kF2, gx)), dim3(256), 0, st, ws + w.z, params + p->off.Wt,
                 ws + w.u, S, K, T, Tp, training, (int)(B * kF2));
@@ -1680,36 +1938,36 @@ static int eeg_forward_stage(const isd_eegnet_plan* p, int stage, const float* x
     return ISD_OK;
   }
   if (stage == 2) {
-    hipLaunchKernelGGL(eeg_finalize2_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
+    ISD_ZLAUNCH(eeg_finalize2_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
                        (double)B * (double)Tp * wd, training, momentum, eps);
-    hipLaunchKernelGGL(eeg_pool2_kernel, dim3((unsigned)cdiv(T2, 256), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.u,
+    ISD_ZLAUNCH(eeg_pool2_kernel, dim3((unsigned)cdiv(T2, 256), (unsigned)(B * kF2)), dim3(256), 0, st, ws + w.u,
                        Cf, ws + w.p2, Tp, T2, p->P1, dp, seed);
     if (p->cv) {
-      hipLaunchKernelGGL(cv_prep_kernel, dim3(kF2 * kF2 * kK2 / 256), dim3(256), 0, st, params + p->off.Wd, ws + w.w3f,
+      ISD_ZLAUNCH(cv_prep_kernel, dim3(kF2 * kF2 * kK2 / 256), dim3(256), 0, st, params + p->off.Wd, ws + w.w3f,
                          ws + w.w3b);
-      hipLaunchKernelGGL(cv_conv3_kernel, dim3((unsigned)cdiv(B * T2p, 256)), dim3(256), 0, st, ws + w.p2, ws + w.w3f,
+      ISD_ZLAUNCH(cv_conv3_kernel, dim3((unsigned)cdiv(B * T2p, 256)), dim3(256), 0, st, ws + w.p2, ws + w.w3f,
                          ws + w.a4, S, B, T2, T2p, training);
     } else {
       const unsigned gxs = (unsigned)cdiv(T2p, 256);
       const int64_t gys = 2048 / gxs > 0 ? 2048 / gxs : 1;
-      hipLaunchKernelGGL(eeg_sep_kernel, dim3(gxs, (unsigned)(B < gys ? B : gys)), dim3(256), 0, st, ws + w.p2,
+      ISD_ZLAUNCH(eeg_sep_kernel, dim3(gxs, (unsigned)(B < gys ? B : gys)), dim3(256), 0, st, ws + w.p2,
                          params + p->off.Wd, params + p->off.Wp, keep ? ws + w.a3 : nullptr, ws + w.a4, S, T2, T2p,
                          training, (int)B);
     }
     ISD_LAUNCH_CHECK();
     return ISD_OK;
   }
-  hipLaunchKernelGGL(eeg_finalize3_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
+  ISD_ZLAUNCH(eeg_finalize3_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, p->off,
                      (double)B * (double)T2p * wd, training, momentum, eps);
   if (p->cv) {
     const int64_t n3 = B * kF2 * T3;
-    hipLaunchKernelGGL(cv_pool3_kernel, dim3((unsigned)cdiv(n3, 256)), dim3(256), 0, st, ws + w.a4, Cf, ws + w.pooled, n3,
+    ISD_ZLAUNCH(cv_pool3_kernel, dim3((unsigned)cdiv(n3, 256)), dim3(256), 0, st, ws + w.a4, Cf, ws + w.pooled, n3,
                        T2p, T3, p->P2, dp, seed);
     ISD_LAUNCH_CHECK();
     return isd_linear_forward(ws + w.pooled, params + p->off.Wl, params + p->off.bl, out, nullptr, B, kF2 * T3, p->F, 0,
                               stream);
   }
-  hipLaunchKernelGGL(eeg_pool3_kernel, dim3((unsigned)cdiv(B * kF2, 4)), dim3(256), 0, st, ws + w.a4, Cf,
+  ISD_ZLAUNCH(eeg_pool3_kernel, dim3((unsigned)cdiv(B * kF2, 4)), dim3(256), 0, st, ws + w.a4, Cf,
                      ws + w.pooled, B * kF2, T2p, T3, dp, seed);
   ISD_LAUNCH_CHECK();
   return isd_linear_forward(ws + w.pooled, params + p->off.Wl, params + p->off.bl, out, nullptr, B, kF2, p->F, 0,
@@ -1758,40 +2016,40 @@ static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* 
   const int64_t rows16 = B * kF2;
   const double wd = (double)world, gs = 1.0 / wd;
   if (stage == 0) {
-    ISD_HIP_TRY(hipMemsetAsync((char*)S + offsetof(EegStats, dy3s), 0, sizeof(EegStats) - offsetof(EegStats, dy3s), st));
+    ISD_HIP_TRY(zone_clear((char*)S + offsetof(EegStats, dy3s), sizeof(EegStats) - offsetof(EegStats, dy3s), st));
     int rc = isd_linear_backward(ws + w.pooled, params + p->off.Wl, dout, nullptr, ws + w.dpooled, dparams + p->off.Wl,
                                  dparams + p->off.bl, ws + w.lin, B, kF2 * (p->cv ? T3 : 1), p->F, 0, stream);
     if (rc) return rc;
     if (p->cv)
-      hipLaunchKernelGGL(cv_bwd3_sums_kernel, dim3((unsigned)cdiv(rows16, 4)), dim3(256), 0, st, ws + w.a4, ws + w.dpooled,
+      ISD_ZLAUNCH(cv_bwd3_sums_kernel, dim3((unsigned)cdiv(rows16, 4)), dim3(256), 0, st, ws + w.a4, ws + w.dpooled,
                          Cf, S, rows16, T2p, T3, p->P2, dropout_p, seed);
     else
-      hipLaunchKernelGGL(eeg_bwd3_sums_kernel, dim3((unsigned)(rows16 / 4 < 256 ? rows16 / 4 : 256)), dim3(256), 0, st,
+      ISD_ZLAUNCH(eeg_bwd3_sums_kernel, dim3((unsigned)(rows16 / 4 < 256 ? rows16 / 4 : 256)), dim3(256), 0, st,
                          ws + w.a4, ws + w.dpooled, Cf, S, rows16, T2p, T3, dropout_p, seed);
     ISD_LAUNCH_CHECK();
     return ISD_OK;
   }
   if (stage == 1) {
-    hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
+    ISD_ZLAUNCH(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
                        (double)B * (double)T2p * wd, 3, gs, bn_train);
     if (p->cv) {
-      hipLaunchKernelGGL(cv_bwd_da4_kernel, dim3((unsigned)cdiv(rows16 * T2p, 256)), dim3(256), 0, st, ws + w.a4,
+      ISD_ZLAUNCH(cv_bwd_da4_kernel, dim3((unsigned)cdiv(rows16 * T2p, 256)), dim3(256), 0, st, ws + w.a4,
                          ws + w.dpooled, Cf, ws + w.da4, rows16 * T2p, T2p, T3, p->P2, dropout_p, seed);
       const int slabs3 = B < w.n_slabs ? (int)B : w.n_slabs;
-      hipLaunchKernelGGL(cv_bwd_w3_kernel, dim3(slabs3), dim3(64), 0, st, ws + w.da4, ws + w.p2, ws + w.part, B, T2, T2p);
-      hipLaunchKernelGGL(cv_w3_reduce_kernel, dim3(kF2 * kF2 * kK2 / 256), dim3(256), 0, st, ws + w.part, slabs3,
+      ISD_ZLAUNCH(cv_bwd_w3_kernel, dim3(slabs3), dim3(64), 0, st, ws + w.da4, ws + w.p2, ws + w.part, B, T2, T2p);
+      ISD_ZLAUNCH(cv_w3_reduce_kernel, dim3(kF2 * kF2 * kK2 / 256), dim3(256), 0, st, ws + w.part, slabs3,
                          dparams + p->off.Wd);
-      hipLaunchKernelGGL(cv_bwd_dp2_kernel, dim3((unsigned)cdiv(B * T2, 256)), dim3(256), 0, st, ws + w.da4, ws + w.w3b,
+      ISD_ZLAUNCH(cv_bwd_dp2_kernel, dim3((unsigned)cdiv(B * T2, 256)), dim3(256), 0, st, ws + w.da4, ws + w.w3b,
                          ws + w.da3, B, T2, T2p);
-      hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), row_groups(rows16, row_blocks(Tp, rows16))),
+      ISD_ZLAUNCH(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), row_groups(rows16, row_blocks(Tp, rows16))),
                          dim3(256), 0, st, ws + w.da3, (const float*)nullptr, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p,
                          p->P1, dropout_p, seed, (int)rows16);
     } else {
-      hipLaunchKernelGGL(eeg_bwd_sep_kernel, dim3((unsigned)cdiv(T2p, 256), (unsigned)B), dim3(256), 0, st, ws + w.a4,
+      ISD_ZLAUNCH(eeg_bwd_sep_kernel, dim3((unsigned)cdiv(T2p, 256), (unsigned)B), dim3(256), 0, st, ws + w.a4,
                          ws + w.dpooled, params + p->off.Wp, Cf, ws + w.da4, ws + w.da3, T2p, T3, dropout_p, seed);
-      hipLaunchKernelGGL(eeg_bwd_sepw_kernel, dim3(kF2 * kF2 + kF2 * kK2), dim3(256), 0, st, ws + w.da4, ws + w.a3,
+      ISD_ZLAUNCH(eeg_bwd_sepw_kernel, dim3(kF2 * kF2 + kF2 * kK2), dim3(256), 0, st, ws + w.da4, ws + w.a3,
                          ws + w.da3, ws + w.p2, S, (int)B, T2, T2p);
-      hipLaunchKernelGGL(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), row_groups(rows16, row_blocks(Tp, rows16))),
+      ISD_ZLAUNCH(eeg_bwd_pool2_kernel, dim3(row_blocks(Tp, rows16), row_groups(rows16, row_blocks(Tp, rows16))),
                          dim3(256), 0, st, ws + w.da3, params + p->off.Wd, ws + w.u, Cf, ws + w.dy2, S, Tp, T2, T2p, p->P1,
                          dropout_p, seed, (int)rows16);
     }
@@ -1799,9 +2057,9 @@ static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* 
     return ISD_OK;
   }
   if (stage == 2) {
-    hipLaunchKernelGGL(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
+    ISD_ZLAUNCH(eeg_bwd_bn_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, p->off,
                        (double)B * (double)Tp * wd, 2, gs, bn_train);
-    hipLaunchKernelGGL(eeg_bwd_bn2_kernel, dim3(row_blocks(Tp, rows16), row_groups(rows16, row_blocks(Tp, rows16))),
+    ISD_ZLAUNCH(eeg_bwd_bn2_kernel, dim3(row_blocks(Tp, rows16), row_groups(rows16, row_blocks(Tp, rows16))),
                        dim3(256), 0, st, ws + w.dy2, ws + w.u, Cf, S, Tp, (int)rows16);
     {
       const size_t lds = sizeof(float) * (size_t)((kCorrSeg + K + 64) + (kCorrSeg + 2 * K + 64) + kMaxK);
@@ -1811,17 +2069,17 @@ static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* 
     }
     const int64_t n_chunks = B * ((T + kDwsPasses * 16 - 1) / (kDwsPasses * 16));
     const int slabs = n_chunks < w.n_slabs ? (int)n_chunks : w.n_slabs;
-    hipLaunchKernelGGL(eeg_bwd_dws_kernel, dim3(slabs, (unsigned)cdiv(C, 256)), dim3(64), 0, st, ws + w.v, x, ws + w.part,
+    ISD_ZLAUNCH(eeg_bwd_dws_kernel, dim3(slabs, (unsigned)cdiv(C, 256)), dim3(64), 0, st, ws + w.v, x, ws + w.part,
                        (int)B, C, T);
     // dWs takes the LOCAL sum of da2 (it is linear in the local batch): it runs in front of the all-reduce of B2
-    hipLaunchKernelGGL(eeg_bwd_dws_reduce_kernel, dim3((unsigned)cdiv((int64_t)kF2 * C, 64)), dim3(1024), 0, st,
+    ISD_ZLAUNCH(eeg_bwd_dws_reduce_kernel, dim3((unsigned)cdiv((int64_t)kF2 * C, 64)), dim3(1024), 0, st,
                        ws + w.part, slabs, S, Cf, dparams + p->off.Ws, C);
     ISD_LAUNCH_CHECK();
     return ISD_OK;
   }
   // the stage-1 gradients are assembled from GLOBAL sums (BatchNorm's backward couples the whole batch): every rank
   // computes the same global gradient, pre-divided by the world size; the separable weights are local sums
-  hipLaunchKernelGGL(eeg_bwd_final_kernel, dim3(1), dim3(256), 0, st, params, dparams, S, Cf, p->off, C, K,
+  ISD_ZLAUNCH(eeg_bwd_final_kernel, dim3(1), dim3(256), 0, st, params, dparams, S, Cf, p->off, C, K,
                      (double)(B * C) * (double)Tp * wd, !p->cv, gs, bn_train);
   ISD_LAUNCH_CHECK();
   return ISD_OK;

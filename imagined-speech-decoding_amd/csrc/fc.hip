@@ -6,9 +6,16 @@
 // N = 16 samples per wave (B = activation rows), K = input features in steps of 4, so the
 // accumulator of a lane is 4 consecutive output features of one sample -> float4 stores.
 #include "common.h"
+#include "zonebatch.h"
 #include <math.h>
 
 namespace isd {
+
+// every launch of this file goes through zone_launch: issued at once, or recorded for a zone-batched launch (zonebatch.h)
+#define ISD_ZLAUNCH(...)                                    \
+  do {                                                      \
+    if (!zone_launch(__VA_ARGS__)) return ISD_ERR_INVALID;  \
+  } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kKC = 64;      // K chunk staged in LDS
@@ -21,11 +28,11 @@ __device__ __forceinline__ float gelu1_grad(float x) {
 
 // y[m][o] = act( sum_i x[m][i] * W(o,i) + bias[o] ),  W(o,i) = w[o*so + i*si]
 // grid: (ceil(M/64), ceil(Nout/64)); block 256 = 4 waves x 16 samples; up to 4 output tiles per wave.
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__device__ __forceinline__ void linear_fwd_kernel_body(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y,
                                                          float* __restrict__ pre, int64_t M, int K, int Nout,
                                                          int64_t so, int64_t si, int act,
-                                                         const float* __restrict__ res) {
+                                                         const float* __restrict__ res, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float xs[64 * kRS];
   __shared__ float wsm[64 * kRS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -78,24 +85,39 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     }
   }
 }
+ISD_ZONE_FN(linear_fwd_kernel, 256)
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         float* __restrict__ pre, int64_t M, int K, int Nout,
+                                                         int64_t so, int64_t si, int act,
+                                                         const float* __restrict__ res) {
+  linear_fwd_kernel_body(x, w, bias, y, pre, M, K, Nout, so, si, act, res, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(linear_fwd_kernel)
 
 // dpre = dy * gelu'(pre)   (act) or a plain copy
-__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dpre,
-                               int64_t n, int act) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+__device__ __forceinline__ void act_bwd_kernel_body(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dpre,
+                               int64_t n, int act, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)zgx * blockDim.x)
     dpre[e] = act ? dy[e] * gelu1_grad(pre[e]) : dy[e];
 }
+ISD_ZONE_FN(act_bwd_kernel, 1024)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dpre,
+                               int64_t n, int act) {
+  act_bwd_kernel_body(dy, pre, dpre, n, act, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(act_bwd_kernel)
 
 // dW[o][i] = sum_m dpre[m][o] * x[m][i];  column i == K is the bias gradient (x == 1).
 // M = o (A = dpre^T), N = i (16 per wave), K = samples.  grid: (slabs, ceil((K+1)/64)); partial slabs.
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ x,
+__device__ __forceinline__ void linear_wgrad_kernel_body(const float* __restrict__ dpre, const float* __restrict__ x,
                                                            float* __restrict__ part, int64_t M, int K, int Nout,
-                                                           int m_per_wg) {
+                                                           int m_per_wg, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float ds[64 * 80];   // [64 samples][Nout<=64], stride 80 == 16 (mod 32)
   __shared__ float xs[64 * 80];   // [64 samples][64 inputs]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i0 = blockIdx.y * 64;
-  const int n0 = blockIdx.z * 64;                       // output-feature chunk
+  const int n0 = zbz * 64;                       // output-feature chunk
   const int nn = (Nout - n0) < 64 ? (Nout - n0) : 64;
   const int64_t m_lo = (int64_t)blockIdx.x * m_per_wg;
   const int64_t m_hi = (m_lo + m_per_wg) < M ? (m_lo + m_per_wg) : M;
@@ -138,15 +160,22 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
       if (o < nn) slab[(int64_t)(n0 + o) * (K + 1) + i] = acc[t][r];
     }
 }
+ISD_ZONE_FN(linear_wgrad_kernel, 256)
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ x,
+                                                           float* __restrict__ part, int64_t M, int K, int Nout,
+                                                           int m_per_wg) {
+  linear_wgrad_kernel_body(dpre, x, part, M, K, Nout, m_per_wg, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(linear_wgrad_kernel)
 
 // Slab sums in a fixed order.  blockIdx.y selects a run of L slabs (index k * stride); with gridDim.y > 1 the
 // run's sum replaces its first slab and a second launch (stride = L) adds the run sums and scatters to dw / db.
-__global__ void linear_wgrad_reduce_kernel(float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
-                                           int K, int Nout, int n_slabs, int L, int stride) {
+__device__ __forceinline__ void linear_wgrad_reduce_kernel_body(float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                           int K, int Nout, int n_slabs, int L, int stride, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int n = Nout * (K + 1);
   const int k0 = blockIdx.y * L;
   const int k1 = k0 + L < n_slabs ? k0 + L : n_slabs;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += zgx * blockDim.x) {
     float s0 = 0.f, s1 = 0.f;
     int k = k0;
     for (; k + 1 < k1; k += 2) {
@@ -155,7 +184,7 @@ __global__ void linear_wgrad_reduce_kernel(float* __restrict__ part, float* __re
     }
     if (k < k1) s0 += part[(int64_t)k * stride * n + e];
     const float s = s0 + s1;
-    if (gridDim.y > 1) {
+    if (zgy > 1) {
       part[(int64_t)k0 * stride * n + e] = s;
       continue;
     }
@@ -164,16 +193,22 @@ __global__ void linear_wgrad_reduce_kernel(float* __restrict__ part, float* __re
     else if (db) db[o] = s;
   }
 }
+ISD_ZONE_FN(linear_wgrad_reduce_kernel, 1024)
+__global__ void linear_wgrad_reduce_kernel(float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                           int K, int Nout, int n_slabs, int L, int stride) {
+  linear_wgrad_reduce_kernel_body(part, dw, db, K, Nout, n_slabs, L, stride, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(linear_wgrad_reduce_kernel)
 
 // Mean over tokens, softmax cross-entropy (mean over the global batch), gradient and argmax.
 // One thread per trial; per-block partial loss sums go to `part` and the LAST block (agent-scope
 // ticket) adds them in block order, so the loss is deterministic without a second launch.
-__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ lt, const void* __restrict__ labels,
+__device__ __forceinline__ void softmax_ce_kernel_body(const float* __restrict__ lt, const void* __restrict__ labels,
                                                          int label_bytes, float* __restrict__ lmean,
                                                          float* __restrict__ loss, float* __restrict__ dlt,
                                                          int64_t* __restrict__ pred, int64_t B, int n_tok, int n_cls,
                                                          float grad_scale, float* __restrict__ part,
-                                                         unsigned int* __restrict__ ticket) {
+                                                         unsigned int* __restrict__ ticket, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float red[256];
   __shared__ bool last;
   float lsum = 0.f;
@@ -218,17 +253,27 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last = (t == gridDim.x - 1);
+    last = (t == zgx - 1);
     if (last) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       float tot = 0.f;
-      for (unsigned int k = 0; k < gridDim.x; ++k)
+      for (unsigned int k = 0; k < zgx; ++k)
         tot += __hip_atomic_load(&part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *loss = tot * grad_scale;
     }
   }
 }
+ISD_ZONE_FN(softmax_ce_kernel, 256)
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ lt, const void* __restrict__ labels,
+                                                         int label_bytes, float* __restrict__ lmean,
+                                                         float* __restrict__ loss, float* __restrict__ dlt,
+                                                         int64_t* __restrict__ pred, int64_t B, int n_tok, int n_cls,
+                                                         float grad_scale, float* __restrict__ part,
+                                                         unsigned int* __restrict__ ticket) {
+  softmax_ce_kernel_body(lt, labels, label_bytes, lmean, loss, dlt, pred, B, n_tok, n_cls, grad_scale, part, ticket, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(softmax_ce_kernel)
 
 }  // namespace isd
 
@@ -238,7 +283,7 @@ static int launch_linear(const float* x, const float* w, const float* bias, floa
                          int Nout, int64_t so, int64_t si, int act, hipStream_t st, const float* res = nullptr) {
   const int64_t gx = cdiv(M, 64);
   ISD_CHECK_ARG(gx <= 0x7fffffffLL, "linear: M too large");
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)gx, (unsigned)cdiv(Nout, 64)), dim3(256), 0, st, x, w, bias, y,
+  ISD_ZLAUNCH(linear_fwd_kernel, dim3((unsigned)gx, (unsigned)cdiv(Nout, 64)), dim3(256), 0, st, x, w, bias, y,
                      pre, M, K, Nout, so, si, act, res);
   ISD_LAUNCH_CHECK();
   return ISD_OK;
@@ -285,8 +330,8 @@ extern "C" int isd_linear_backward(const float* x, const float* w, const float* 
   ISD_CHECK_ARG(dw, "isd_linear_backward: null dw");
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
-    ISD_HIP_TRY(hipMemsetAsync(dw, 0, sizeof(float) * N * K, st));
-    if (db) ISD_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * N, st));
+    ISD_HIP_TRY(zone_clear(dw, sizeof(float) * N * K, st));
+    if (db) ISD_HIP_TRY(zone_clear(db, sizeof(float) * N, st));
     return ISD_OK;
   }
   ISD_CHECK_ARG(x && w && dy && workspace, "isd_linear_backward: null argument");
@@ -294,7 +339,7 @@ extern "C" int isd_linear_backward(const float* x, const float* w, const float* 
   float* part = dpre + ((M * N + 63) / 64) * 64;
   const float* dsrc = dy;
   if (act) {
-    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(cdiv(M * N, 256) < 4096 ? cdiv(M * N, 256) : 4096)), dim3(256), 0,
+    ISD_ZLAUNCH(act_bwd_kernel, dim3((unsigned)(cdiv(M * N, 256) < 4096 ? cdiv(M * N, 256) : 4096)), dim3(256), 0,
                        st, dy, pre, dpre, M * N, act);
     ISD_LAUNCH_CHECK();
     dsrc = dpre;
@@ -305,7 +350,7 @@ extern "C" int isd_linear_backward(const float* x, const float* w, const float* 
   }
   int mp;
   const int slabs = wgrad_slabs(M, &mp);
-  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(slabs, (unsigned)cdiv(K + 1, 64), (unsigned)cdiv(N, 64)), dim3(256), 0,
+  ISD_ZLAUNCH(linear_wgrad_kernel, dim3(slabs, (unsigned)cdiv(K + 1, 64), (unsigned)cdiv(N, 64)), dim3(256), 0,
                      st, dsrc, x, part, M, K, N, mp);
   {
     const unsigned bx = (unsigned)cdiv((int64_t)N * (K + 1), 256);
@@ -313,10 +358,10 @@ extern "C" int isd_linear_backward(const float* x, const float* w, const float* 
       int L = 8;
       while (L * L < slabs) L *= 2;
       const int S = (int)cdiv(slabs, L);
-      hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3(bx, S), dim3(256), 0, st, part, dw, db, K, N, slabs, L, 1);
-      hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, part, dw, db, K, N, S, S, L);
+      ISD_ZLAUNCH(linear_wgrad_reduce_kernel, dim3(bx, S), dim3(256), 0, st, part, dw, db, K, N, slabs, L, 1);
+      ISD_ZLAUNCH(linear_wgrad_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, part, dw, db, K, N, S, S, L);
     } else {
-      hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, part, dw, db, K, N, slabs, slabs, 1);
+      ISD_ZLAUNCH(linear_wgrad_reduce_kernel, dim3(bx, 1), dim3(256), 0, st, part, dw, db, K, N, slabs, slabs, 1);
     }
   }
   ISD_LAUNCH_CHECK();
@@ -340,12 +385,12 @@ extern "C" int isd_softmax_ce(const float* logits_tok, const void* labels, int l
   const bool want_loss = labels && loss;
   ISD_CHECK_ARG(!want_loss || workspace, "isd_softmax_ce: the loss reduction needs isd_softmax_ce_workspace_bytes(B) bytes");
   if (B == 0) {
-    if (want_loss) ISD_HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
+    if (want_loss) ISD_HIP_TRY(zone_clear(loss, sizeof(float), st));
     return ISD_OK;
   }
   float* scratch = want_loss ? (float*)workspace : nullptr;
-  if (scratch) ISD_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(unsigned int), st));   // arrival ticket
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, logits_tok, labels, label_bytes,
+  if (scratch) ISD_HIP_TRY(zone_clear(scratch, sizeof(unsigned int), st));   // arrival ticket
+  ISD_ZLAUNCH(softmax_ce_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, logits_tok, labels, label_bytes,
                      logits_mean, want_loss ? loss : nullptr, labels ? dlogits_tok : nullptr, pred, B, n_tok, n_cls,
                      grad_scale, scratch ? scratch + 64 : nullptr, reinterpret_cast<unsigned int*>(scratch));
   ISD_LAUNCH_CHECK();

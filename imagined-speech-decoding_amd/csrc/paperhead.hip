@@ -14,10 +14,17 @@
 // accumulator per tap, persistent waves and per-wave partial slabs reduced in a fixed order.
 // Statistics and cross-batch sums accumulate in fp64.
 #include "common.h"
+#include "zonebatch.h"
 #include <math.h>
 #include <stddef.h>
 
 namespace isd {
+
+// every launch of this file goes through zone_launch: issued at once, or recorded for a zone-batched launch (zonebatch.h)
+#define ISD_ZLAUNCH(...)                                    \
+  do {                                                      \
+    if (!zone_launch(__VA_ARGS__)) return ISD_ERR_INVALID;  \
+  } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kPhMaxF = 64;      // widest layer supported (feature_dim <= 64)
@@ -65,9 +72,9 @@ __device__ __forceinline__ float ph_block_sum(float v, float* red) {
 // Weff / beff, and the two scalar-load layouts of every layer's weight:
 //   Wf[l][c][k][Fp]  (forward: 16 consecutive output channels per tap)
 //   Wb[l][o][k][Cp]  (data gradient: 16 consecutive input channels per tap)
-__global__ __launch_bounds__(256) void ph_prep_kernel(const float* __restrict__ params, float* __restrict__ Wf,
+__device__ __forceinline__ void ph_prep_kernel_body(const float* __restrict__ params, float* __restrict__ Wf,
                                                       float* __restrict__ Wb, float* __restrict__ beff, PhGeo g,
-                                                      int l, int64_t wf_off, int64_t wb_off) {
+                                                      int l, int64_t wf_off, int64_t wb_off, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int Fo = g.Fo[l], Ci = g.Ci[l], Fp = g.Fp[l], Cp = g.Cp[l];
   const int e = blockIdx.x * 256 + threadIdx.x;
   const int n = (Fp > Fo ? Fp : Fo) * (Cp > Ci ? Cp : Ci) * 3;
@@ -94,13 +101,20 @@ __global__ __launch_bounds__(256) void ph_prep_kernel(const float* __restrict__ 
   if (c < Ci && o < Fp) Wf[wf_off + ((int64_t)c * 3 + k) * Fp + o] = w;
   if (o < Fo && c < Cp) Wb[wb_off + ((int64_t)o * 3 + k) * Cp + c] = w;
 }
+ISD_ZONE_FN(ph_prep_kernel, 256)
+__global__ __launch_bounds__(256) void ph_prep_kernel(const float* __restrict__ params, float* __restrict__ Wf,
+                                                      float* __restrict__ Wb, float* __restrict__ beff, PhGeo g,
+                                                      int l, int64_t wf_off, int64_t wb_off) {
+  ph_prep_kernel_body(params, Wf, Wb, beff, g, l, wf_off, wb_off, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(ph_prep_kernel)
 
 // y[b,o,t] = bias[o] + sum_{c,k} W[o,c,k] in[b,c,t+k];  per-channel sums of y and y^2.
 // Persistent blocks over (b,t); blockIdx.y selects a tile of 16 output channels.
-__global__ __launch_bounds__(256) void ph_conv_kernel(const float* __restrict__ in, const float* __restrict__ Wf,
+__device__ __forceinline__ void ph_conv_kernel_body(const float* __restrict__ in, const float* __restrict__ Wf,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       double* __restrict__ s1, double* __restrict__ s2, int64_t B,
-                                                      int Ci, int Ti, int To, int Fo, int Fp, int want_stats) {
+                                                      int Ci, int Ti, int To, int Fo, int Fp, int want_stats, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float red[4];
   __shared__ float tot[32];
   const int o0 = blockIdx.y * 16;
@@ -108,7 +122,7 @@ __global__ __launch_bounds__(256) void ph_conv_kernel(const float* __restrict__ 
 #pragma unroll
   for (int i = 0; i < 16; ++i) a1[i] = a2[i] = 0.f;
   const int64_t n = B * To;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)zgx * 256) {
     const int64_t b = e / To;
     const int t = (int)(e - b * To);
     float acc[16];
@@ -141,11 +155,19 @@ __global__ __launch_bounds__(256) void ph_conv_kernel(const float* __restrict__ 
     else if (threadIdx.x >= 16 && threadIdx.x < 32 && o0 + i < Fo) atomicAdd(&s2[o0 + i], (double)tot[16 + i]);
   }
 }
+ISD_ZONE_FN(ph_conv_kernel, 256)
+__global__ __launch_bounds__(256) void ph_conv_kernel(const float* __restrict__ in, const float* __restrict__ Wf,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      double* __restrict__ s1, double* __restrict__ s2, int64_t B,
+                                                      int Ci, int Ti, int To, int Fo, int Fp, int want_stats) {
+  ph_conv_kernel_body(in, Wf, bias, y, s1, s2, B, Ci, Ti, To, Fo, Fp, want_stats, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(ph_conv_kernel)
 
 // BN coefficients of layer l: bn(y) = A y + Bc.  training: batch statistics (+ running update); eval: running buffers.
-__global__ void ph_finalize_kernel(const float* __restrict__ params, float* __restrict__ bufs,
+__device__ __forceinline__ void ph_finalize_kernel_body(const float* __restrict__ params, float* __restrict__ bufs,
                                    const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N,
-                                   int training, float momentum, float eps) {
+                                   int training, float momentum, float eps, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int o = threadIdx.x;
   if (o >= g.Fo[l]) return;
   double mu, var;
@@ -166,10 +188,17 @@ __global__ void ph_finalize_kernel(const float* __restrict__ params, float* __re
   co->mu[l][o] = (float)mu;
   co->isg[l][o] = (float)isg;
 }
+ISD_ZONE_FN(ph_finalize_kernel, 1024)
+__global__ void ph_finalize_kernel(const float* __restrict__ params, float* __restrict__ bufs,
+                                   const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N,
+                                   int training, float momentum, float eps) {
+  ph_finalize_kernel_body(params, bufs, st, co, g, l, N, training, momentum, eps, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(ph_finalize_kernel)
 
 // a[b,o,p] = max(GELU(bn(y[2p])), GELU(bn(y[2p+1])))
-__global__ __launch_bounds__(256) void ph_pool_kernel(const float* __restrict__ y, const PhCoef* __restrict__ co,
-                                                      float* __restrict__ a, int64_t n, int l, int Fo, int To, int Tp) {
+__device__ __forceinline__ void ph_pool_kernel_body(const float* __restrict__ y, const PhCoef* __restrict__ co,
+                                                      float* __restrict__ a, int64_t n, int l, int Fo, int To, int Tp, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   const int64_t row = e / Tp;
@@ -178,31 +207,43 @@ __global__ __launch_bounds__(256) void ph_pool_kernel(const float* __restrict__ 
   const float* yr = y + row * To + 2 * p;
   a[e] = fmaxf(ph_gelu(fmaf(A, yr[0], Bc)), ph_gelu(fmaf(A, yr[1], Bc)));
 }
+ISD_ZONE_FN(ph_pool_kernel, 256)
+__global__ __launch_bounds__(256) void ph_pool_kernel(const float* __restrict__ y, const PhCoef* __restrict__ co,
+                                                      float* __restrict__ a, int64_t n, int l, int Fo, int To, int Tp) {
+  ph_pool_kernel_body(y, co, a, n, l, Fo, To, Tp, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(ph_pool_kernel)
 
 // out[b,o] = mean_p a4[b,o,p]
-__global__ __launch_bounds__(256) void ph_mean_kernel(const float* __restrict__ a, float* __restrict__ out, int64_t rows,
-                                                      int Tp) {
+__device__ __forceinline__ void ph_mean_kernel_body(const float* __restrict__ a, float* __restrict__ out, int64_t rows,
+                                                      int Tp, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
   float s = 0.f;
   for (int p = 0; p < Tp; ++p) s += a[r * Tp + p];
   out[r] = s / (float)Tp;
 }
+ISD_ZONE_FN(ph_mean_kernel, 256)
+__global__ __launch_bounds__(256) void ph_mean_kernel(const float* __restrict__ a, float* __restrict__ out, int64_t rows,
+                                                      int Tp) {
+  ph_mean_kernel_body(a, out, rows, Tp, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(ph_mean_kernel)
 
 // ------------------------------------------------------------------------------------------------ backward
 // Max-pool routing + GELU':  dyh[b,o,t] (gradient w.r.t. the BN output) from da[b,o,p] (or dout[b,o]/Tp for the
 // last layer), and the BN backward sums.  blockIdx.y = channel; persistent over (b,p).
-__global__ __launch_bounds__(256) void ph_bwd_pool_kernel(const float* __restrict__ y, const float* __restrict__ da,
+__device__ __forceinline__ void ph_bwd_pool_kernel_body(const float* __restrict__ y, const float* __restrict__ da,
                                                           const float* __restrict__ dout,
                                                           const PhCoef* __restrict__ co, float* __restrict__ dyh,
                                                           PhStats* __restrict__ st, int64_t B, int l, int Fo, int To,
-                                                          int Tp) {
+                                                          int Tp, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   __shared__ float red[4];
   const int o = blockIdx.y;
   const float A = co->A[l][o], Bc = co->Bc[l][o], mu = co->mu[l][o], isg = co->isg[l][o];
   float s1 = 0.f, s2 = 0.f;
   const int64_t n = B * Tp;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)zgx * 256) {
     const int64_t b = e / Tp;
     const int p = (int)(e - b * Tp);
     const int64_t row = b * Fo + o;
@@ -224,10 +265,19 @@ __global__ __launch_bounds__(256) void ph_bwd_pool_kernel(const float* __restric
     atomicAdd(&st->d[l][1][o], (double)r2);
   }
 }
+ISD_ZONE_FN(ph_bwd_pool_kernel, 256)
+__global__ __launch_bounds__(256) void ph_bwd_pool_kernel(const float* __restrict__ y, const float* __restrict__ da,
+                                                          const float* __restrict__ dout,
+                                                          const PhCoef* __restrict__ co, float* __restrict__ dyh,
+                                                          PhStats* __restrict__ st, int64_t B, int l, int Fo, int To,
+                                                          int Tp) {
+  ph_bwd_pool_kernel_body(y, da, dout, co, dyh, st, B, l, Fo, To, Tp, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(ph_bwd_pool_kernel)
 
-__global__ void ph_bwd_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
+__device__ __forceinline__ void ph_bwd_coef_kernel_body(const float* __restrict__ params, float* __restrict__ dparams,
                                    const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N,
-                                   int bn_train, double gs) {
+                                   int bn_train, double gs, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int o = threadIdx.x;
   if (o >= g.Fo[l]) return;
   const double inv = bn_train ? 1.0 / N : 0.0;           // running statistics do not depend on the batch: no mean terms
@@ -237,22 +287,36 @@ __global__ void ph_bwd_coef_kernel(const float* __restrict__ params, float* __re
   co->cB[l][o] = (float)(st->d[l][0][o] * inv);
   co->cC[l][o] = (float)(st->d[l][1][o] * inv);
 }
+ISD_ZONE_FN(ph_bwd_coef_kernel, 1024)
+__global__ void ph_bwd_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
+                                   const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N,
+                                   int bn_train, double gs) {
+  ph_bwd_coef_kernel_body(params, dparams, st, co, g, l, N, bn_train, gs, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(ph_bwd_coef_kernel)
 
 // dy = cA (dyh - cB - xhat cC) in place
-__global__ __launch_bounds__(256) void ph_bwd_bn_kernel(float* __restrict__ dyh, const float* __restrict__ y,
+__device__ __forceinline__ void ph_bwd_bn_kernel_body(float* __restrict__ dyh, const float* __restrict__ y,
                                                         const PhCoef* __restrict__ co, int64_t n, int l, int Fo,
-                                                        int To) {
+                                                        int To, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   const int o = (int)((e / To) % Fo);
   const float xh = (y[e] - co->mu[l][o]) * co->isg[l][o];
   dyh[e] = co->cA[l][o] * (dyh[e] - co->cB[l][o] - xh * co->cC[l][o]);
 }
+ISD_ZONE_FN(ph_bwd_bn_kernel, 256)
+__global__ __launch_bounds__(256) void ph_bwd_bn_kernel(float* __restrict__ dyh, const float* __restrict__ y,
+                                                        const PhCoef* __restrict__ co, int64_t n, int l, int Fo,
+                                                        int To) {
+  ph_bwd_bn_kernel_body(dyh, y, co, n, l, Fo, To, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(ph_bwd_bn_kernel)
 
 // da[b,c,s] = sum_{o,k} W[o,c,k] dy[b,o,s-k]   (gradient w.r.t. the layer input = the previous pooled activation)
-__global__ __launch_bounds__(256) void ph_bwd_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ Wb,
+__device__ __forceinline__ void ph_bwd_dgrad_kernel_body(const float* __restrict__ dy, const float* __restrict__ Wb,
                                                            float* __restrict__ da, int64_t B, int Ci, int Cp, int Ti,
-                                                           int To, int Fo) {
+                                                           int To, int Fo, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int c0 = blockIdx.y * 16;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= B * Ti) return;
@@ -276,20 +340,27 @@ __global__ __launch_bounds__(256) void ph_bwd_dgrad_kernel(const float* __restri
   for (int i = 0; i < 16; ++i)
     if (c0 + i < Ci) da[(b * Ci + c0 + i) * Ti + s] = acc[i];
 }
+ISD_ZONE_FN(ph_bwd_dgrad_kernel, 256)
+__global__ __launch_bounds__(256) void ph_bwd_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ Wb,
+                                                           float* __restrict__ da, int64_t B, int Ci, int Cp, int Ti,
+                                                           int To, int Fo) {
+  ph_bwd_dgrad_kernel_body(dy, Wb, da, B, Ci, Cp, Ti, To, Fo, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(ph_bwd_dgrad_kernel)
 
 // dW[o,c,k] = sum_{b,t} dy[b,o,t] in[b,c,t+k] on the matrix cores (A = dy tile [16 o][4 t], B = in tile [4 t][16 c],
 // one accumulator per tap) + the bias column sum_{b,t} dy[b,o,t].  blockIdx.y = (o tile, c tile); persistent over b.
 // Partial slabs: part[block][o][c][k] and pbias[block][o].
-__global__ __launch_bounds__(64) void ph_bwd_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ in,
+__device__ __forceinline__ void ph_bwd_wgrad_kernel_body(const float* __restrict__ dy, const float* __restrict__ in,
                                                           float* __restrict__ part, float* __restrict__ pbias,
-                                                          int64_t B, int Ci, int Ti, int To, int Fo, int n_ctile) {
+                                                          int64_t B, int Ci, int Ti, int To, int Fo, int n_ctile, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int lane = threadIdx.x, q = lane >> 4, jl = lane & 15;
   const int ot = blockIdx.y / n_ctile, ct = blockIdx.y - ot * n_ctile;
   const int o = ot * 16 + jl, c = ct * 16 + jl;
   f32x4 acc[3], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 3; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+  for (int64_t b = blockIdx.x; b < B; b += zgx) {
     const float* dr = dy + (b * Fo + (o < Fo ? o : 0)) * To;
     const float* ir = in + (b * Ci + (c < Ci ? c : 0)) * Ti;
     for (int t0 = 0; t0 < To; t0 += 4) {
@@ -315,9 +386,16 @@ __global__ __launch_bounds__(64) void ph_bwd_wgrad_kernel(const float* __restric
     if (pbias && ct == 0 && jl == 0 && oo < Fo) pbias[(int64_t)blockIdx.x * Fo + oo] = accb[r];
   }
 }
+ISD_ZONE_FN(ph_bwd_wgrad_kernel, 64)
+__global__ __launch_bounds__(64) void ph_bwd_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ in,
+                                                          float* __restrict__ part, float* __restrict__ pbias,
+                                                          int64_t B, int Ci, int Ti, int To, int Fo, int n_ctile) {
+  ph_bwd_wgrad_kernel_body(dy, in, part, pbias, B, Ci, Ti, To, Fo, n_ctile, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(ph_bwd_wgrad_kernel)
 
-__global__ __launch_bounds__(256) void ph_reduce_kernel(const float* __restrict__ part, int n_slabs, int64_t n,
-                                                        float* __restrict__ dst) {
+__device__ __forceinline__ void ph_reduce_kernel_body(const float* __restrict__ part, int n_slabs, int64_t n,
+                                                        float* __restrict__ dst, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   float s0 = 0.f, s1 = 0.f;
@@ -329,11 +407,17 @@ __global__ __launch_bounds__(256) void ph_reduce_kernel(const float* __restrict_
   if (k < n_slabs) s0 += part[(int64_t)k * n + e];
   dst[e] = s0 + s1;
 }
+ISD_ZONE_FN(ph_reduce_kernel, 256)
+__global__ __launch_bounds__(256) void ph_reduce_kernel(const float* __restrict__ part, int n_slabs, int64_t n,
+                                                        float* __restrict__ dst) {
+  ph_reduce_kernel_body(part, n_slabs, n, dst, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(ph_reduce_kernel)
 
 // dWeff [F1][C][3], dbeff [F1] -> gradients of cnn1_t.weight, cnn1_t.bias, cnn1_s.weight.  One block.
-__global__ __launch_bounds__(256) void ph_bwd_l1_kernel(const float* __restrict__ params, float* __restrict__ dparams,
+__device__ __forceinline__ void ph_bwd_l1_kernel_body(const float* __restrict__ params, float* __restrict__ dparams,
                                                         const float* __restrict__ dWeff, const float* __restrict__ dbeff,
-                                                        PhGeo g) {
+                                                        PhGeo g, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
   const int F1 = g.Fo[0], C = g.C;
   const float* Wt = params + g.wt;
   const float* bt = params + g.bt;
@@ -362,6 +446,13 @@ __global__ __launch_bounds__(256) void ph_bwd_l1_kernel(const float* __restrict_
     dparams[g.bt + f] = s;
   }
 }
+ISD_ZONE_FN(ph_bwd_l1_kernel, 256)
+__global__ __launch_bounds__(256) void ph_bwd_l1_kernel(const float* __restrict__ params, float* __restrict__ dparams,
+                                                        const float* __restrict__ dWeff, const float* __restrict__ dbeff,
+                                                        PhGeo g) {
+  ph_bwd_l1_kernel_body(params, dparams, dWeff, dbeff, g, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+}
+ISD_ZONE_REGISTER(ph_bwd_l1_kernel)
 
 }  // namespace isd
 
@@ -480,19 +571,19 @@ static int ph_forward_stage(const isd_paperhead_plan* p, int stage, const float*
   PhStats* S = (PhStats*)(ws + w.stats);
   PhCoef* Cf = (PhCoef*)(ws + w.coef);
   if (stage == 0) {
-    ISD_HIP_TRY(hipMemsetAsync(S, 0, sizeof(PhStats), st));
+    ISD_HIP_TRY(zone_clear(S, sizeof(PhStats), st));
     for (int l = 0; l < 4; ++l) {
       const int nmax = (g.Fp[l] > g.Fo[l] ? g.Fp[l] : g.Fo[l]) * g.Cp[l] * 3;
-      hipLaunchKernelGGL(ph_prep_kernel, dim3((unsigned)cdiv(nmax, 256)), dim3(256), 0, st, params, ws, ws, ws + w.beff,
+      ISD_ZLAUNCH(ph_prep_kernel, dim3((unsigned)cdiv(nmax, 256)), dim3(256), 0, st, params, ws, ws, ws + w.beff,
                          g, l, w.wf[l], w.wb[l]);
     }
   }
   if (stage > 0) {
     const int l = stage - 1;
-    hipLaunchKernelGGL(ph_finalize_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, g, l,
+    ISD_ZLAUNCH(ph_finalize_kernel, dim3(1), dim3(64), 0, st, params, buffers, S, Cf, g, l,
                        (double)B * (double)g.To[l] * (double)world, training, momentum, eps);
     const int64_t np = B * g.Fo[l] * g.Tp[l];
-    hipLaunchKernelGGL(ph_pool_kernel, dim3((unsigned)cdiv(np, 256)), dim3(256), 0, st, ws + w.y[l], Cf, ws + w.a[l], np,
+    ISD_ZLAUNCH(ph_pool_kernel, dim3((unsigned)cdiv(np, 256)), dim3(256), 0, st, ws + w.y[l], Cf, ws + w.a[l], np,
                        l, g.Fo[l], g.To[l], g.Tp[l]);
   }
   if (stage < 4) {
@@ -500,11 +591,11 @@ static int ph_forward_stage(const isd_paperhead_plan* p, int stage, const float*
     const float* in = l == 0 ? x : ws + w.a[l - 1];
     const int64_t n = B * g.To[l];
     const unsigned gx = (unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
-    hipLaunchKernelGGL(ph_conv_kernel, dim3(gx, (unsigned)(g.Fp[l] / 16)), dim3(256), 0, st, in, ws + w.wf[l],
+    ISD_ZLAUNCH(ph_conv_kernel, dim3(gx, (unsigned)(g.Fp[l] / 16)), dim3(256), 0, st, in, ws + w.wf[l],
                        l == 0 ? ws + w.beff : (const float*)nullptr, ws + w.y[l], S->s[l][0], S->s[l][1], B, g.Ci[l],
                        g.Ti[l], g.To[l], g.Fo[l], g.Fp[l], training);
   } else {
-    hipLaunchKernelGGL(ph_mean_kernel, dim3((unsigned)cdiv(B * g.F, 256)), dim3(256), 0, st, ws + w.a[3], out, B * g.F,
+    ISD_ZLAUNCH(ph_mean_kernel, dim3((unsigned)cdiv(B * g.F, 256)), dim3(256), 0, st, ws + w.a[3], out, B * g.F,
                        g.Tp[3]);
   }
   ISD_LAUNCH_CHECK();
@@ -564,32 +655,32 @@ static int ph_backward_stage(const isd_paperhead_plan* p, int stage, const float
   PhCoef* Cf = (PhCoef*)(ws + w.coef);
   const int slabs = B < kPhSlabs ? (int)B : kPhSlabs;
   if (stage == 0)
-    ISD_HIP_TRY(hipMemsetAsync((char*)S + offsetof(PhStats, d), 0, sizeof(PhStats) - offsetof(PhStats, d), st));
+    ISD_HIP_TRY(zone_clear((char*)S + offsetof(PhStats, d), sizeof(PhStats) - offsetof(PhStats, d), st));
   if (stage > 0) {
     // the layer whose BatchNorm sums are complete: BN backward, weight gradient, data gradient
     const int l = 4 - stage;
-    hipLaunchKernelGGL(ph_bwd_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, g, l,
+    ISD_ZLAUNCH(ph_bwd_coef_kernel, dim3(1), dim3(64), 0, st, params, dparams, S, Cf, g, l,
                        (double)B * (double)g.To[l] * (double)world, bn_train, 1.0 / (double)world);
     const int64_t ny = B * g.Fo[l] * g.To[l];
-    hipLaunchKernelGGL(ph_bwd_bn_kernel, dim3((unsigned)cdiv(ny, 256)), dim3(256), 0, st, ws + w.dy[l], ws + w.y[l], Cf,
+    ISD_ZLAUNCH(ph_bwd_bn_kernel, dim3((unsigned)cdiv(ny, 256)), dim3(256), 0, st, ws + w.dy[l], ws + w.y[l], Cf,
                        ny, l, g.Fo[l], g.To[l]);
     const float* in = l == 0 ? x : ws + w.a[l - 1];
     const int n_ctile = g.Cp[l] / 16, n_otile = g.Fp[l] / 16;
     const int64_t nw = (int64_t)g.Fo[l] * g.Ci[l] * 3;
-    hipLaunchKernelGGL(ph_bwd_wgrad_kernel, dim3(slabs, (unsigned)(n_ctile * n_otile)), dim3(64), 0, st, ws + w.dy[l], in,
+    ISD_ZLAUNCH(ph_bwd_wgrad_kernel, dim3(slabs, (unsigned)(n_ctile * n_otile)), dim3(64), 0, st, ws + w.dy[l], in,
                        ws + w.part, l == 0 ? ws + w.pbias : (float*)nullptr, B, g.Ci[l], g.Ti[l], g.To[l], g.Fo[l],
                        n_ctile);
-    hipLaunchKernelGGL(ph_reduce_kernel, dim3((unsigned)cdiv(nw, 256)), dim3(256), 0, st, ws + w.part, slabs, nw,
+    ISD_ZLAUNCH(ph_reduce_kernel, dim3((unsigned)cdiv(nw, 256)), dim3(256), 0, st, ws + w.part, slabs, nw,
                        l == 0 ? ws + w.dweff : dparams + g.w[l]);
     if (l == 0) {
-      hipLaunchKernelGGL(ph_reduce_kernel, dim3(1), dim3(256), 0, st, ws + w.pbias, slabs, (int64_t)g.Fo[0],
+      ISD_ZLAUNCH(ph_reduce_kernel, dim3(1), dim3(256), 0, st, ws + w.pbias, slabs, (int64_t)g.Fo[0],
                          ws + w.dbeff);
-      hipLaunchKernelGGL(ph_bwd_l1_kernel, dim3(1), dim3(256), 0, st, params, dparams, ws + w.dweff, ws + w.dbeff, g);
+      ISD_ZLAUNCH(ph_bwd_l1_kernel, dim3(1), dim3(256), 0, st, params, dparams, ws + w.dweff, ws + w.dbeff, g);
       if (dx)   // the fused first layer is one C -> F1 three-tap convolution: its data gradient is the input gradient
-        hipLaunchKernelGGL(ph_bwd_dgrad_kernel, dim3((unsigned)cdiv(B * g.Ti[0], 256), (unsigned)n_ctile), dim3(256), 0,
+        ISD_ZLAUNCH(ph_bwd_dgrad_kernel, dim3((unsigned)cdiv(B * g.Ti[0], 256), (unsigned)n_ctile), dim3(256), 0,
                            st, ws + w.dy[0], ws + w.wb[0], dx, B, g.Ci[0], g.Cp[0], g.Ti[0], g.To[0], g.Fo[0]);
     } else {
-      hipLaunchKernelGGL(ph_bwd_dgrad_kernel, dim3((unsigned)cdiv(B * g.Ti[l], 256), (unsigned)n_ctile), dim3(256), 0, st,
+      ISD_ZLAUNCH(ph_bwd_dgrad_kernel, dim3((unsigned)cdiv(B * g.Ti[l], 256), (unsigned)n_ctile), dim3(256), 0, st,
                          ws + w.dy[l], ws + w.wb[l], ws + w.da[l - 1], B, g.Ci[l], g.Cp[l], g.Ti[l], g.To[l], g.Fo[l]);
     }
   }
@@ -598,7 +689,7 @@ static int ph_backward_stage(const isd_paperhead_plan* p, int stage, const float
     const int l = 3 - stage;
     const int64_t np = B * g.Tp[l];
     const unsigned gx = (unsigned)(cdiv(np, 256) < 256 ? cdiv(np, 256) : 256);
-    hipLaunchKernelGGL(ph_bwd_pool_kernel, dim3(gx, (unsigned)g.Fo[l]), dim3(256), 0, st, ws + w.y[l],
+    ISD_ZLAUNCH(ph_bwd_pool_kernel, dim3(gx, (unsigned)g.Fo[l]), dim3(256), 0, st, ws + w.y[l],
                        l == 3 ? (const float*)nullptr : ws + w.da[l], l == 3 ? dout : (const float*)nullptr, Cf,
                        ws + w.dy[l], S, B, l, g.Fo[l], g.To[l], g.Tp[l]);
   }

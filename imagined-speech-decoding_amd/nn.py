@@ -13,6 +13,7 @@ optimizer.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -394,6 +395,76 @@ class _PaperHeadFn(torch.autograd.Function):
         return dx, dflat, None, None, None, None, None, None
 
 
+class _BNZonesFn(torch.autograd.Function):
+    """All zones of a BatchNorm head (EEGNet_Encoder / CVBlock / HeadConv_Paper_Version instances, fast.py:203-210) in
+    zone-batched launches: the per-zone C-ABI calls are recorded and launch i of every zone goes out as ONE kernel
+    (include/isd_hip.h, ``isd_zone_batch_*``).  Eight chains of ~20 short kernels per direction are launch-bound
+    however they are queued.  Parameter gradients only, single device; ``Head`` keeps the per-zone path for the rest
+    (input gradients, eval-mode gradients, synchronised BatchNorm across ranks)."""
+
+    @staticmethod
+    def forward(ctx, xw, idxs, calls, *thetas):
+        L, B, dev = _lib.lib(), xw.shape[0], xw.device
+        xs = [_f32c(xw.index_select(1, idx), "x") for idx in idxs]
+        thetas = [_f32c(t, "params") for t in thetas]
+        kind = calls[0][0]
+        ws_bytes = L.isd_eegnet_workspace_bytes if kind == "eeg" else L.isd_paperhead_workspace_bytes
+        outs = [torch.empty((B, c[2].F), dtype=torch.float32, device=dev) for c in calls]
+        wss = [torch.empty(max(int(ws_bytes(c[2]._h, B)) // 4, 1), dtype=torch.float32, device=dev) for c in calls]
+        with torch.cuda.device(dev):
+            st = _stream()
+            _lib.check(L.isd_zone_batch_begin())
+            try:
+                for z, (c, x, th, out, ws) in enumerate(zip(calls, xs, thetas, outs, wss)):
+                    if z:
+                        _lib.check(L.isd_zone_batch_next())
+                    if kind == "eeg":
+                        _, bufs, plan, training, momentum, eps, p, seed = c
+                        _lib.check(L.isd_eegnet_forward(plan._h, x.data_ptr(), th.data_ptr(), bufs.data_ptr(),
+                                                        out.data_ptr(), ws.data_ptr(), B, int(bool(training)),
+                                                        float(momentum), float(eps), float(p), int(seed), st))
+                    else:
+                        _, bufs, plan, training, momentum, eps = c
+                        _lib.check(L.isd_paperhead_forward(plan._h, x.data_ptr(), th.data_ptr(), bufs.data_ptr(),
+                                                           out.data_ptr(), ws.data_ptr(), B, int(bool(training)),
+                                                           float(momentum), float(eps), st))
+                _lib.check(L.isd_zone_batch_launch(st))
+            except Exception:
+                L.isd_zone_batch_abort()
+                raise
+        ctx.calls, ctx.wss, ctx.n = calls, wss, len(calls)
+        ctx.save_for_backward(*xs, *thetas)
+        return torch.stack(outs, dim=1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        L, n = _lib.lib(), ctx.n
+        xs, thetas = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        B = xs[0].shape[0]
+        dz = _f32c(dout.permute(1, 0, 2), "dout")                  # [Z][B'][F]: one contiguous block per zone
+        dflats = [torch.empty_like(t) for t in thetas]
+        kind = ctx.calls[0][0]
+        with torch.cuda.device(dz.device):
+            st = _stream()
+            _lib.check(L.isd_zone_batch_begin())
+            try:
+                for z, (c, x, th, dfl, ws) in enumerate(zip(ctx.calls, xs, thetas, dflats, ctx.wss)):
+                    if z:
+                        _lib.check(L.isd_zone_batch_next())
+                    if kind == "eeg":
+                        _lib.check(L.isd_eegnet_backward(c[2]._h, x.data_ptr(), th.data_ptr(), dz[z].data_ptr(),
+                                                         dfl.data_ptr(), ws.data_ptr(), B, float(c[6]), int(c[7]), st))
+                    else:
+                        _lib.check(L.isd_paperhead_backward(c[2]._h, x.data_ptr(), th.data_ptr(), dz[z].data_ptr(),
+                                                            dfl.data_ptr(), ws.data_ptr(), B, st))
+                _lib.check(L.isd_zone_batch_launch(st))
+            except Exception:
+                L.isd_zone_batch_abort()
+                raise
+        ctx.wss = None
+        return (None, None, None) + tuple(dflats)
+
+
 class _LinearResFn(torch.autograd.Function):
     """y = x @ w.T + b + res (residual fused in the epilogue)."""
 
@@ -765,8 +836,10 @@ class _BNStackMixin(_FlatParamMixin):
         for plan in self._plans.values():
             plan.set_seed_counter(counter)
 
-    def _run(self, x):
-        plan = self._plan_for(x.shape[-1])
+    def _zone_call(self, T):
+        """One forward's bookkeeping (call counter, ``num_batches_tracked``) and the arguments of ``_EEGNetFn`` after
+        ``x`` -- also what ``Head`` hands to the zone-batched ``_BNZonesFn``."""
+        plan = self._plan_for(T)
         flat = self.flat_params()
         theta = torch.cat([p.reshape(-1) for p in self._ordered_params()]) if torch.is_grad_enabled() else flat
         bn = self._bns()[0]
@@ -774,9 +847,12 @@ class _BNStackMixin(_FlatParamMixin):
         if self.training:
             for b in self._bns():
                 b.num_batches_tracked += 1
-        return _EEGNetFn.apply(x, theta, self.flat_buffers(), plan, self.training,
-                               0.1 if bn.momentum is None else bn.momentum, bn.eps, self.p if self.training else 0.0,
-                               _dropout_seed(self._stream_id, self._calls), getattr(self, "sync_bn", True))
+        return ("eeg", theta, self.flat_buffers(), plan, self.training, 0.1 if bn.momentum is None else bn.momentum,
+                bn.eps, self.p if self.training else 0.0, _dropout_seed(self._stream_id, self._calls),
+                getattr(self, "sync_bn", True))
+
+    def _run(self, x):
+        return _EEGNetFn.apply(x, *self._zone_call(x.shape[-1])[1:])
 
 
 class EEGNet_Encoder(nn.Module, _BNStackMixin):
@@ -889,10 +965,7 @@ class HeadConv_Paper_Version(nn.Module, _BNStackMixin):
                 self.cnn2.weight, self.norm2.weight, self.norm2.bias, self.cnn3.weight, self.norm3.weight,
                 self.norm3.bias, self.cnn4.weight, self.norm4.weight, self.norm4.bias]
 
-    def forward(self, x):
-        if x.dim() != 3:
-            raise ValueError("expected [batch, channels, time]")
-        T = x.shape[-1]
+    def _zone_call(self, T):
         plan = self._plans.get(T)
         if plan is None:
             plan = self._plans[T] = PaperHeadPlan(self.in_channels, self.feature_dim, T)
@@ -902,8 +975,13 @@ class HeadConv_Paper_Version(nn.Module, _BNStackMixin):
             for b in self._bns():
                 b.num_batches_tracked += 1
         bn = self.norm1
-        return _PaperHeadFn.apply(x, theta, self.flat_buffers(), plan, self.training,
-                                  0.1 if bn.momentum is None else bn.momentum, bn.eps, getattr(self, "sync_bn", True))
+        return ("paper", theta, self.flat_buffers(), plan, self.training, 0.1 if bn.momentum is None else bn.momentum,
+                bn.eps, getattr(self, "sync_bn", True))
+
+    def forward(self, x):
+        if x.dim() != 3:
+            raise ValueError("expected [batch, channels, time]")
+        return _PaperHeadFn.apply(x, *self._zone_call(x.shape[-1])[1:])
 
 
 class Head(nn.Module, _FlatParamMixin):
@@ -952,8 +1030,31 @@ class Head(nn.Module, _FlatParamMixin):
             return torch.cat([p.reshape(-1) for p in self._ordered_params()])
         return flat
 
+    @staticmethod
+    def _zone_batchable(encs, xw):
+        """The BatchNorm heads' zones go out in zone-batched launches (``_BNZonesFn``) when only parameter gradients
+        of a train-mode pass, or no gradients, are asked for on a single device."""
+        if os.environ.get("ISD_ZONE_BATCH_OFF") or not 1 <= len(encs) <= 8 or xw.dim() != 3 or xw.requires_grad:
+            return False
+        kind = type(encs[0])
+        if kind not in (EEGNet_Encoder, CVBlock, HeadConv_Paper_Version) or any(type(e) is not kind for e in encs):
+            return False
+        if any(e.training != encs[0].training for e in encs) or encs[0].feature_dim > 64:
+            return False                                           # (wider projectors spread their weight gradient over grid.z)
+        if not encs[0].training and torch.is_grad_enabled() and any(p.requires_grad for e in encs for p in e.parameters()):
+            return False                                           # eval-mode gradients: the per-zone backward_x path
+        return _bn_sync_world(getattr(encs[0], "sync_bn", True), encs[0].training)[1] == 1
+
     def _per_zone(self, xw):
         """Registry heads other than Conv4Layers: one encoder call per zone on its gathered channels (fast.py:210)."""
+        encs = list(self.encoders.values())
+        for area in self.encoders:
+            if self.index_dict[area].device != xw.device:
+                self.index_dict[area] = self.index_dict[area].to(xw.device)
+        if self._zone_batchable(encs, xw):
+            calls = [enc._zone_call(xw.shape[-1]) for enc in encs]
+            return _BNZonesFn.apply(xw, [self.index_dict[a] for a in self.encoders],
+                                    [(c[0],) + tuple(c[2:-1]) for c in calls], *[c[1] for c in calls])
         # The zones are independent until the stack: each runs on its own HIP stream (forked from / joined to the
         # caller's), so their short kernels overlap on the GPU and, in a captured graph, form parallel branches.
         main = torch.cuda.current_stream(xw.device)

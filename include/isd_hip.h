@@ -376,6 +376,21 @@ int isd_paperhead_backward_stage(const isd_paperhead_plan* plan, int stage, cons
 int isd_paperhead_sync_block(const isd_paperhead_plan* plan, int64_t B, int backward, int stage, int64_t* byte_offset,
                              int64_t* n_doubles);
 
+/* ------------------------------------------------------------------------
+ * Zone-batched launches for the one-encoder-per-zone heads (Head.encoders, fast.py:203-210: eight EEGNet_Encoder /
+ * CVBlock / HeadConv_Paper_Version instances on eight channel subsets).  Between isd_zone_batch_begin() and
+ * isd_zone_batch_launch() the calls
+ *   isd_eegnet_forward / isd_eegnet_backward / isd_paperhead_forward / isd_paperhead_backward
+ * made by THIS thread record their kernel launches instead of issuing them; isd_zone_batch_next() separates the
+ * zones (at most 8).  isd_zone_batch_launch() then issues launch i of all zones as ONE kernel (blockIdx.z = zone).
+ * The zones must make the same calls on plans of the same kind, batch and length (channel counts may differ); a
+ * call that cannot be recorded fails and poisons the batch (isd_zone_batch_launch then returns ISD_ERR_INVALID).
+ * Nothing is read on the host in between: the recorded calls only have to use the stream given to the launch. */
+int isd_zone_batch_begin(void);
+int isd_zone_batch_next(void);
+int isd_zone_batch_launch(void* stream);
+int isd_zone_batch_abort(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -165,3 +165,77 @@ def test_fast_with_registry_heads_vs_oracle(inn, head, enc):
     assert rel_err(xg.grad.cpu(), xr.grad) < 2e-4
     with pytest.raises(KeyError):
         inn.FAST(inn.fast_config(electrodes, zones, head="NoSuchHead"))
+
+
+@pytest.mark.parametrize("head", ["EEGNet_Encoder", "CVBlock", "HeadConv_Paper_Version"])
+def test_zone_batched_launches_equal_per_zone_calls(inn, head, monkeypatch):
+    """Head(...) with one BatchNorm encoder per zone (fast.py:203-210): the zone-batched launches (isd_zone_batch_*:
+    launch i of all eight zones as one kernel) give the per-zone calls' outputs bit for bit, their running statistics
+    and -- up to the order of the fp32 / fp64 atomic sums -- their parameter gradients, in train mode (with dropout:
+    the masks are counter-based per zone) and in eval mode; an input that needs a gradient keeps the per-zone path."""
+    import isd_amd._lib as L
+
+    def run(off, train, p=None):
+        if off:
+            monkeypatch.setenv("ISD_ZONE_BATCH_OFF", "1")
+        else:
+            monkeypatch.delenv("ISD_ZONE_BATCH_OFF", raising=False)
+        torch.manual_seed(5)
+        h = inn.Head(head, ocnn.ELECTRODES, ocnn.ZONES, 32).cuda().train(train)
+        ids = []
+        for e in h.encoders.values():
+            if p is not None and hasattr(e, "p"):
+                e.p = p
+            if hasattr(e, "_stream_id"):
+                ids.append(e._stream_id)
+        x = torch.randn(21, 64, 250, device="cuda")
+        w = torch.randn(21, 8, 32, device="cuda")
+        if train:
+            f = h(x)
+            (f * w).sum().backward()
+            g = torch.cat([q.grad.reshape(-1) for q in h.parameters()])
+        else:
+            with torch.no_grad():
+                f = h(x)
+            g = None
+        return h, ids, f.detach(), g, torch.cat([b.reshape(-1).float() for b in h.buffers()])
+
+    h0, ids0, f0, g0, b0 = run(True, True, p=0.0)
+    h1, ids1, f1, g1, b1 = run(False, True, p=0.0)
+    assert torch.equal(f0, f1)
+    assert float((g0 - g1).abs().max() / g0.abs().max()) < 1e-5
+    assert float((b0 - b1).abs().max()) < 1e-6
+    # dropout on: same masks when the encoders' dropout streams are the same
+    if ids0:
+        def with_streams(off):
+            if off:
+                monkeypatch.setenv("ISD_ZONE_BATCH_OFF", "1")
+            else:
+                monkeypatch.delenv("ISD_ZONE_BATCH_OFF", raising=False)
+            torch.manual_seed(6)
+            h = inn.Head(head, ocnn.ELECTRODES, ocnn.ZONES, 32).cuda().train()
+            for e, sid in zip(h.encoders.values(), ids0):
+                e._stream_id = sid
+            x = torch.randn(9, 64, 250, device="cuda")
+            return h(x).detach()
+        assert torch.equal(with_streams(True), with_streams(False))
+    # eval mode, no gradients
+    _, _, e0, _, _ = run(True, False)
+    _, _, e1, _, _ = run(False, False)
+    assert torch.equal(e0, e1)
+    # an input gradient: per-zone path, still correct
+    monkeypatch.delenv("ISD_ZONE_BATCH_OFF", raising=False)
+    x = torch.randn(5, 64, 250, device="cuda", requires_grad=True)
+    assert not h1._zone_batchable(list(h1.encoders.values()), x)
+    h1(x).sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    # the recorder's own errors
+    lib = L.lib()
+    with pytest.raises(L.IsdError):
+        L.check(lib.isd_zone_batch_launch(0))                          # nothing open
+    L.check(lib.isd_zone_batch_begin())
+    with pytest.raises(L.IsdError):
+        L.check(lib.isd_zone_batch_begin())                            # already open
+    L.check(lib.isd_zone_batch_abort())
+    L.check(lib.isd_zone_batch_begin())
+    L.check(lib.isd_zone_batch_launch(0))                              # an empty batch launches nothing
