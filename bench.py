@@ -126,19 +126,21 @@ def cpu_baseline(cfg_name, cfg):
 
 
 def hip_event_ms(fn, stream, n):
-    """Mean duration of ``fn`` over n launches, HIP events recorded on the launch stream."""
-    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
-    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    """Mean duration of ``fn`` over n back-to-back launches between ONE pair of HIP events recorded on the launch
+    stream (an event pair around every single ~1 ms launch added up to 0.15 ms of marker handling to it on some
+    boxes: 1.21 ms where rocprofv3 saw 1.06 ms kernels)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fn()
-    for a, b in zip(e0, e1):
-        a.record(stream)
+    fn()
+    e0.record(stream)
+    for _ in range(n):
         fn()
-        b.record(stream)
+    e1.record(stream)
     torch.cuda.synchronize()
-    return float(np.mean([a.elapsed_time(b) for a, b in zip(e0, e1)]))
+    return float(e0.elapsed_time(e1)) / n
 
 
-def filterbank_hbm_roofline(fx, x, nb, n=4):
+def filterbank_hbm_roofline(fx, x, nb, n=8):
     """North-star evidence: achieved HBM rate of the MATERIALISING filterbank stage (read x once, write nb filtered
     copies -- what the scipy path does), measured after the timed region on (a slice of) the resident batch."""
     B, C, T = x.shape
