@@ -137,7 +137,8 @@ constexpr int kStatWaves = 4;                          // waves per workgroup
 // The waves of a workgroup meet in LDS (fp32) before ONE set of fp64 global atomics per workgroup: 2048 waves
 // sending 85 atomics per lane to the same ~5 k addresses took 0.15 ms on their own.
 __device__ __forceinline__ void eeg_stats_kernel_body(const float* __restrict__ x,
-                                                                    EegStats* __restrict__ st, int64_t rows, int T, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                                    EegStats* __restrict__ st, int64_t rows, int T,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float tot[21][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int e = threadIdx.x; e < 21 * 64; e += 64 * kStatWaves) (&tot[0][0])[e] = 0.f;
@@ -192,7 +193,8 @@ __device__ __forceinline__ void eeg_stats_kernel_body(const float* __restrict__ 
 ISD_ZONE_FN(eeg_stats_kernel, 64 * kStatWaves)
 __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_kernel(const float* __restrict__ x,
                                                                     EegStats* __restrict__ st, int64_t rows, int T) {
-  eeg_stats_kernel_body(x, st, rows, T, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_stats_kernel_body(x, st, rows, T,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_stats_kernel)
 
@@ -205,7 +207,8 @@ ISD_ZONE_REGISTER(eeg_stats_kernel)
 // 62 lag products per lane and row behind an LDS window -- held 200+ VGPRs and paid a memory latency per row.)
 __device__ __forceinline__ void eeg_stats_edge_kernel_body(const float* __restrict__ x,
                                                                          EegStats* __restrict__ st, int64_t rows,
-                                                                         int T, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                                         int T,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float tot[32][96];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
   const int which = blockIdx.y;
@@ -258,7 +261,8 @@ ISD_ZONE_FN(eeg_stats_edge_kernel, 64 * kStatWaves)
 __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_edge_kernel(const float* __restrict__ x,
                                                                          EegStats* __restrict__ st, int64_t rows,
                                                                          int T) {
-  eeg_stats_edge_kernel_body(x, st, rows, T, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_stats_edge_kernel_body(x, st, rows, T,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_stats_edge_kernel)
 
@@ -270,7 +274,8 @@ ISD_ZONE_REGISTER(eeg_stats_edge_kernel)
 template <int MT>
 __device__ __forceinline__ void eeg_stats_gram_kernel_body(const float* __restrict__ x,
                                                                          EegStats* __restrict__ st, int64_t rows,
-                                                                         int T, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                                         int T,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float tot[16 * MT][16 * MT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
   for (int e = threadIdx.x; e < 256 * MT * MT; e += 64 * kStatWaves) (&tot[0][0])[e] = 0.f;
@@ -325,7 +330,8 @@ template <int MT>
 __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_gram_kernel(const float* __restrict__ x,
                                                                          EegStats* __restrict__ st, int64_t rows,
                                                                          int T) {
-  eeg_stats_gram_kernel_body<MT>(x, st, rows, T, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_stats_gram_kernel_body<MT>(x, st, rows, T,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER_T(eeg_stats_gram_kernel, 1)
 ISD_ZONE_REGISTER_T(eeg_stats_gram_kernel, 2)
@@ -335,7 +341,8 @@ ISD_ZONE_REGISTER_T(eeg_stats_gram_kernel, 5)
 
 // Gs -> the quantities eeg_finalize1_kernel consumes (same definitions as eeg_stats_derive_kernel: samples outside
 // the row are zero).  One block of 64 threads (thread = lag d).
-__device__ __forceinline__ void eeg_stats_gram_derive_kernel_body(EegStats* __restrict__ st, int T, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+__device__ __forceinline__ void eeg_stats_gram_derive_kernel_body(EegStats* __restrict__ st, int T,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int d = threadIdx.x;
   double a = 0.0;
   for (int s = 0; s + d < T; ++s) a += st->Gs[s][s + d];
@@ -363,12 +370,14 @@ __device__ __forceinline__ void eeg_stats_gram_derive_kernel_body(EegStats* __re
 }
 ISD_ZONE_FN(eeg_stats_gram_derive_kernel, 64)
 __global__ __launch_bounds__(64) void eeg_stats_gram_derive_kernel(EegStats* __restrict__ st, int T) {
-  eeg_stats_gram_derive_kernel_body(st, T, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_stats_gram_derive_kernel_body(st, T,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_stats_gram_derive_kernel)
 
 // raw accumulators -> the quantities eeg_finalize1_kernel consumes.  One block of 64 threads (thread = lag d).
-__device__ __forceinline__ void eeg_stats_derive_kernel_body(EegStats* __restrict__ st, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+__device__ __forceinline__ void eeg_stats_derive_kernel_body(EegStats* __restrict__ st,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int d = threadIdx.x;
   double a = 0.0;
   for (int i = 0; i < 16; ++i) a += st->D[(i + d) >> 4][i * 16 + ((i + d) & 15)];
@@ -392,7 +401,8 @@ __device__ __forceinline__ void eeg_stats_derive_kernel_body(EegStats* __restric
 }
 ISD_ZONE_FN(eeg_stats_derive_kernel, 64)
 __global__ __launch_bounds__(64) void eeg_stats_derive_kernel(EegStats* __restrict__ st) {
-  eeg_stats_derive_kernel_body(st, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_stats_derive_kernel_body(st,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_stats_derive_kernel)
 
@@ -401,7 +411,8 @@ __device__ __forceinline__ void eeg_finalize1_kernel_body(const float* __restric
                                                             const EegStats* __restrict__ st, EegCoef* __restrict__ co,
                                                             EegOff off, int C, int K, int T, int64_t rows,
                                                             int training, float momentum, float eps,
-                                                            const unsigned long long* __restrict__ seed_dev, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                            const unsigned long long* __restrict__ seed_dev,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int P = K / 2;
   if (threadIdx.x == 0) co->seed_add = seed_dev ? 0xD1342543DE82EF95ull * *seed_dev : 0ull;
   const double N1 = (double)rows * (double)(T + 2 * P - K + 1);
@@ -492,7 +503,8 @@ __global__ __launch_bounds__(256) void eeg_finalize1_kernel(const float* __restr
                                                             EegOff off, int C, int K, int T, int64_t rows,
                                                             int training, float momentum, float eps,
                                                             const unsigned long long* __restrict__ seed_dev) {
-  eeg_finalize1_kernel_body(params, bufs, st, co, off, C, K, T, rows, training, momentum, eps, seed_dev, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_finalize1_kernel_body(params, bufs, st, co, off, C, K, T, rows, training, momentum, eps, seed_dev,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_finalize1_kernel)
 
@@ -501,7 +513,8 @@ ISD_ZONE_REGISTER(eeg_finalize1_kernel)
 // 8 loads and 4 independent MFMA chains per step) and meet in LDS in a fixed order.  (One wave per tile walking
 // all channels left 640 waves on the chip at C = 5120, T = 65: 0.29 ms; the scalar version before it 2.3 ms.)
 __device__ __forceinline__ void eeg_spatial_kernel_body(const float* __restrict__ x, const float* __restrict__ Ws,
-                                                          float* __restrict__ z, int C, int T, int n_tiles, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                          float* __restrict__ z, int C, int T, int n_tiles,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float red[3][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
   const int tile = blockIdx.x;
@@ -566,7 +579,8 @@ __device__ __forceinline__ void eeg_spatial_kernel_body(const float* __restrict_
 ISD_ZONE_FN(eeg_spatial_kernel, 256)
 __global__ __launch_bounds__(256) void eeg_spatial_kernel(const float* __restrict__ x, const float* __restrict__ Ws,
                                                           float* __restrict__ z, int C, int T, int n_tiles) {
-  eeg_spatial_kernel_body(x, Ws, z, C, T, n_tiles, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_spatial_kernel_body(x, Ws, z, C, T, n_tiles,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_spatial_kernel)
 
@@ -576,7 +590,8 @@ ISD_ZONE_REGISTER(eeg_spatial_kernel)
 // row's cache lines into its own L2) and a Ws fragment serves NTG MFMAs instead of one.
 template <int NTG>
 __device__ __forceinline__ void eeg_spatial_rows_kernel_body(const float* __restrict__ x, const float* __restrict__ Ws,
-                                                               float* __restrict__ z, int C, int T, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                               float* __restrict__ z, int C, int T,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float red[3][NTG][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
   const int b = blockIdx.y;
@@ -645,7 +660,8 @@ ISD_ZONE_FN_T(eeg_spatial_rows_kernel, 256, int)
 template <int NTG>
 __global__ __launch_bounds__(256) void eeg_spatial_rows_kernel(const float* __restrict__ x, const float* __restrict__ Ws,
                                                                float* __restrict__ z, int C, int T) {
-  eeg_spatial_rows_kernel_body<NTG>(x, Ws, z, C, T, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_spatial_rows_kernel_body<NTG>(x, Ws, z, C, T,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER_T(eeg_spatial_rows_kernel, 5)
 
@@ -655,7 +671,8 @@ ISD_ZONE_REGISTER_T(eeg_spatial_rows_kernel, 5)
 template <int KT>
 __device__ __forceinline__ void eeg_tconv_kernel_body(const float* __restrict__ z, const float* __restrict__ Wt,
                                                         float* __restrict__ u, EegStats* __restrict__ st, int Krt, int T,
-                                                        int Tp, int want_stats, int n_rows, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                        int Tp, int want_stats, int n_rows,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int K = KT ? KT : Krt;
   __shared__ float red[4];
   __shared__ float zs[256 + kMaxK];                    // zpad[tp0 .. tp0 + 256 + K): the tile's inputs, staged once
@@ -707,7 +724,8 @@ template <int KT>
 __global__ __launch_bounds__(256) void eeg_tconv_kernel(const float* __restrict__ z, const float* __restrict__ Wt,
                                                         float* __restrict__ u, EegStats* __restrict__ st, int Krt, int T,
                                                         int Tp, int want_stats, int n_rows) {
-  eeg_tconv_kernel_body<KT>(z, Wt, u, st, Krt, T, Tp, want_stats, n_rows, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_tconv_kernel_body<KT>(z, Wt, u, st, Krt, T, Tp, want_stats, n_rows,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER_T(eeg_tconv_kernel, 64)
 ISD_ZONE_REGISTER_T(eeg_tconv_kernel, 32)
@@ -716,7 +734,8 @@ ISD_ZONE_REGISTER_T(eeg_tconv_kernel, 0)
 
 __device__ __forceinline__ void eeg_finalize2_kernel_body(const float* __restrict__ params, float* __restrict__ bufs,
                                      const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N2,
-                                     int training, float momentum, float eps, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                     int training, float momentum, float eps,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int g = threadIdx.x;
   if (g >= kF2) return;
   const int f = g >> 1;
@@ -747,14 +766,16 @@ ISD_ZONE_FN(eeg_finalize2_kernel, 1024)
 __global__ void eeg_finalize2_kernel(const float* __restrict__ params, float* __restrict__ bufs,
                                      const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N2,
                                      int training, float momentum, float eps) {
-  eeg_finalize2_kernel_body(params, bufs, st, co, off, N2, training, momentum, eps, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_finalize2_kernel_body(params, bufs, st, co, off, N2, training, momentum, eps,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_finalize2_kernel)
 
 // p2[b,g,v] = mean_{r<P1} ELU(A2 u[b,g,P1 v+r] + B2)   (P1 = 4 EEGNet, 8 CVBlock)
 __device__ __forceinline__ void eeg_pool2_kernel_body(const float* __restrict__ u, const EegCoef* __restrict__ co,
                                                         float* __restrict__ p2, int Tp, int T2, int P1, float dp,
-                                                        uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                        uint64_t seed,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int bg = blockIdx.y, g = bg & (kF2 - 1);
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v >= T2) return;
@@ -768,7 +789,8 @@ ISD_ZONE_FN(eeg_pool2_kernel, 256)
 __global__ __launch_bounds__(256) void eeg_pool2_kernel(const float* __restrict__ u, const EegCoef* __restrict__ co,
                                                         float* __restrict__ p2, int Tp, int T2, int P1, float dp,
                                                         uint64_t seed) {
-  eeg_pool2_kernel_body(u, co, p2, Tp, T2, P1, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_pool2_kernel_body(u, co, p2, Tp, T2, P1, dp, seed,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_pool2_kernel)
 
@@ -777,7 +799,8 @@ ISD_ZONE_REGISTER(eeg_pool2_kernel)
 __device__ __forceinline__ void eeg_sep_kernel_body(const float* __restrict__ p2, const float* __restrict__ Wd,
                                                       const float* __restrict__ Wp, float* __restrict__ a3out,
                                                       float* __restrict__ a4, EegStats* __restrict__ st, int T2,
-                                                      int T2p, int want_stats, int B, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                      int T2p, int want_stats, int B,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float red[4];
   // a workgroup walks every zgy-th trial and keeps its 32 per-channel sums in registers: one round of block
   // sums and atomics per workgroup instead of one per trial (short windows: 63 live threads, 32 block sums each)
@@ -840,13 +863,15 @@ __global__ __launch_bounds__(256) void eeg_sep_kernel(const float* __restrict__ 
                                                       const float* __restrict__ Wp, float* __restrict__ a3out,
                                                       float* __restrict__ a4, EegStats* __restrict__ st, int T2,
                                                       int T2p, int want_stats, int B) {
-  eeg_sep_kernel_body(p2, Wd, Wp, a3out, a4, st, T2, T2p, want_stats, B, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_sep_kernel_body(p2, Wd, Wp, a3out, a4, st, T2, T2p, want_stats, B,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_sep_kernel)
 
 __device__ __forceinline__ void eeg_finalize3_kernel_body(const float* __restrict__ params, float* __restrict__ bufs,
                                      const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N3,
-                                     int training, float momentum, float eps, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                     int training, float momentum, float eps,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int h = threadIdx.x;
   if (h >= kF2) return;
   double mu, var;
@@ -871,14 +896,16 @@ ISD_ZONE_FN(eeg_finalize3_kernel, 1024)
 __global__ void eeg_finalize3_kernel(const float* __restrict__ params, float* __restrict__ bufs,
                                      const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N3,
                                      int training, float momentum, float eps) {
-  eeg_finalize3_kernel_body(params, bufs, st, co, off, N3, training, momentum, eps, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_finalize3_kernel_body(params, bufs, st, co, off, N3, training, momentum, eps,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_finalize3_kernel)
 
 // pooled[b,h] = mean_{w < 8*T3} ELU(A3 a4 + B3)   (AvgPool(1,8) floor + AdaptiveAvgPool); one wave per row
 __device__ __forceinline__ void eeg_pool3_kernel_body(const float* __restrict__ a4, const EegCoef* __restrict__ co,
                                                         float* __restrict__ pooled, int64_t rows, int T2p, int T3,
-                                                        float dp, uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                        float dp, uint64_t seed,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -895,7 +922,8 @@ ISD_ZONE_FN(eeg_pool3_kernel, 256)
 __global__ __launch_bounds__(256) void eeg_pool3_kernel(const float* __restrict__ a4, const EegCoef* __restrict__ co,
                                                         float* __restrict__ pooled, int64_t rows, int T2p, int T3,
                                                         float dp, uint64_t seed) {
-  eeg_pool3_kernel_body(a4, co, pooled, rows, T2p, T3, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_pool3_kernel_body(a4, co, pooled, rows, T2p, T3, dp, seed,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_pool3_kernel)
 
@@ -904,7 +932,8 @@ ISD_ZONE_REGISTER(eeg_pool3_kernel)
 __device__ __forceinline__ void eeg_bwd3_sums_kernel_body(const float* __restrict__ a4,
                                                             const float* __restrict__ dpooled,
                                                             const EegCoef* __restrict__ co, EegStats* __restrict__ st,
-                                                            int64_t rows, int T2p, int T3, float dp, uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                            int64_t rows, int T2p, int T3, float dp, uint64_t seed,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   // zgx is a multiple of 4: a wave's rows (every 4 zgx-th) share h, and it sends ONE atomic pair
   const int64_t row0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -935,7 +964,8 @@ __global__ __launch_bounds__(256) void eeg_bwd3_sums_kernel(const float* __restr
                                                             const float* __restrict__ dpooled,
                                                             const EegCoef* __restrict__ co, EegStats* __restrict__ st,
                                                             int64_t rows, int T2p, int T3, float dp, uint64_t seed) {
-  eeg_bwd3_sums_kernel_body(a4, dpooled, co, st, rows, T2p, T3, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_bwd3_sums_kernel_body(a4, dpooled, co, st, rows, T2p, T3, dp, seed,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_bwd3_sums_kernel)
 
@@ -944,7 +974,8 @@ ISD_ZONE_REGISTER(eeg_bwd3_sums_kernel)
 // all-reduce that follows adds the ranks' copies
 __device__ __forceinline__ void eeg_bwd_bn_coef_kernel_body(const float* __restrict__ params, float* __restrict__ dparams,
                                        const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N,
-                                       int which, double gs, int bn_train, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                       int which, double gs, int bn_train,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int h = threadIdx.x;
   if (h >= kF2) return;
   const double inv = bn_train ? 1.0 / N : 0.0;           // running statistics do not depend on the batch: no mean terms
@@ -966,7 +997,8 @@ ISD_ZONE_FN(eeg_bwd_bn_coef_kernel, 1024)
 __global__ void eeg_bwd_bn_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
                                        const EegStats* __restrict__ st, EegCoef* __restrict__ co, EegOff off, double N,
                                        int which, double gs, int bn_train) {
-  eeg_bwd_bn_coef_kernel_body(params, dparams, st, co, off, N, which, gs, bn_train, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_bwd_bn_coef_kernel_body(params, dparams, st, co, off, N, which, gs, bn_train,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_bwd_bn_coef_kernel)
 
@@ -975,7 +1007,8 @@ __device__ __forceinline__ void eeg_bwd_sep_kernel_body(const float* __restrict_
                                                           const float* __restrict__ dpooled,
                                                           const float* __restrict__ Wp, const EegCoef* __restrict__ co,
                                                           float* __restrict__ da4, float* __restrict__ da3, int T2p,
-                                                          int T3, float dp, uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                          int T3, float dp, uint64_t seed,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int b = blockIdx.y;
   const int w = blockIdx.x * 256 + threadIdx.x;
   if (w >= T2p) return;
@@ -1006,7 +1039,8 @@ __global__ __launch_bounds__(256) void eeg_bwd_sep_kernel(const float* __restric
                                                           const float* __restrict__ Wp, const EegCoef* __restrict__ co,
                                                           float* __restrict__ da4, float* __restrict__ da3, int T2p,
                                                           int T3, float dp, uint64_t seed) {
-  eeg_bwd_sep_kernel_body(a4, dpooled, Wp, co, da4, da3, T2p, T3, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_bwd_sep_kernel_body(a4, dpooled, Wp, co, da4, da3, T2p, T3, dp, seed,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_bwd_sep_kernel)
 
@@ -1014,7 +1048,8 @@ ISD_ZONE_REGISTER(eeg_bwd_sep_kernel)
 // One block per output element (512 blocks), fp64 block result.
 __device__ __forceinline__ void eeg_bwd_sepw_kernel_body(const float* __restrict__ da4, const float* __restrict__ a3,
                                                            const float* __restrict__ da3, const float* __restrict__ p2,
-                                                           EegStats* __restrict__ st, int B, int T2, int T2p, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                           EegStats* __restrict__ st, int B, int T2, int T2p,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float red[4];
   const int o = blockIdx.x;
   // thread = (trial b0 + 4 j, step w0 + 64 i): no 64-bit division per element, two independent accumulators
@@ -1057,7 +1092,8 @@ ISD_ZONE_FN(eeg_bwd_sepw_kernel, 256)
 __global__ __launch_bounds__(256) void eeg_bwd_sepw_kernel(const float* __restrict__ da4, const float* __restrict__ a3,
                                                            const float* __restrict__ da3, const float* __restrict__ p2,
                                                            EegStats* __restrict__ st, int B, int T2, int T2p) {
-  eeg_bwd_sepw_kernel_body(da4, a3, da3, p2, st, B, T2, T2p, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_bwd_sepw_kernel_body(da4, a3, da3, p2, st, B, T2, T2p,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_bwd_sepw_kernel)
 
@@ -1066,7 +1102,8 @@ __device__ __forceinline__ void eeg_bwd_pool2_kernel_body(const float* __restric
                                                             const float* __restrict__ u, const EegCoef* __restrict__ co,
                                                             float* __restrict__ dy2, EegStats* __restrict__ st, int Tp,
                                                             int T2, int T2p, int P1, float dpr, uint64_t seed,
-                                                            int n_rows, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                            int n_rows,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float red[4];
   const int g = blockIdx.y & (kF2 - 1);                 // zgy is a multiple of 16: the rows of a workgroup share g
   float t1 = 0.f, t2 = 0.f;
@@ -1110,14 +1147,16 @@ __global__ __launch_bounds__(256) void eeg_bwd_pool2_kernel(const float* __restr
                                                             float* __restrict__ dy2, EegStats* __restrict__ st, int Tp,
                                                             int T2, int T2p, int P1, float dpr, uint64_t seed,
                                                             int n_rows) {
-  eeg_bwd_pool2_kernel_body(da3, Wd, u, co, dy2, st, Tp, T2, T2p, P1, dpr, seed, n_rows, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_bwd_pool2_kernel_body(da3, Wd, u, co, dy2, st, Tp, T2, T2p, P1, dpr, seed, n_rows,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_bwd_pool2_kernel)
 
 // da2 = cA2 (dy2 - cB2 - xhat2 cC2) in place; Sd = sum da2, Su = sum da2*u
 __device__ __forceinline__ void eeg_bwd_bn2_kernel_body(float* __restrict__ dy2, const float* __restrict__ u,
                                                           const EegCoef* __restrict__ co, EegStats* __restrict__ st,
-                                                          int Tp, int n_rows, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                          int Tp, int n_rows,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float red[4];
   const int g = blockIdx.y & (kF2 - 1);                 // zgy is a multiple of 16: the rows of a workgroup share g
   float t1 = 0.f, t2 = 0.f;
@@ -1141,7 +1180,8 @@ ISD_ZONE_FN(eeg_bwd_bn2_kernel, 256)
 __global__ __launch_bounds__(256) void eeg_bwd_bn2_kernel(float* __restrict__ dy2, const float* __restrict__ u,
                                                           const EegCoef* __restrict__ co, EegStats* __restrict__ st,
                                                           int Tp, int n_rows) {
-  eeg_bwd_bn2_kernel_body(dy2, u, co, st, Tp, n_rows, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_bwd_bn2_kernel_body(dy2, u, co, st, Tp, n_rows,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_bwd_bn2_kernel)
 
@@ -1153,7 +1193,8 @@ constexpr int kCorrSeg = 1024;
 template <int KT>
 __device__ __forceinline__ void eeg_bwd_corr_kernel_body(const float* __restrict__ da2, const float* __restrict__ z,
                                                           const float* __restrict__ Wt, float* __restrict__ v,
-                                                          EegStats* __restrict__ st, int Krt, int T, int Tp, int n_rows, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                          EegStats* __restrict__ st, int Krt, int T, int Tp, int n_rows,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int K = KT ? KT : Krt;
   constexpr int KA = KT ? KT : kMaxK;                   // accumulators kept
   extern __shared__ float sm[];                         // z[s0 - P + j], j < L + K + 64;  da2[s0 - K + j], j < L + 2K + 64
@@ -1216,7 +1257,8 @@ template <int KT>
 __global__ __launch_bounds__(64) void eeg_bwd_corr_kernel(const float* __restrict__ da2, const float* __restrict__ z,
                                                           const float* __restrict__ Wt, float* __restrict__ v,
                                                           EegStats* __restrict__ st, int Krt, int T, int Tp, int n_rows) {
-  eeg_bwd_corr_kernel_body<KT>(da2, z, Wt, v, st, Krt, T, Tp, n_rows, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_bwd_corr_kernel_body<KT>(da2, z, Wt, v, st, Krt, T, Tp, n_rows,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER_T(eeg_bwd_corr_kernel, 64)
 ISD_ZONE_REGISTER_T(eeg_bwd_corr_kernel, 32)
@@ -1253,7 +1295,8 @@ __device__ __forceinline__ void dws_load_row(const float* __restrict__ row, int 
   }
 }
 __device__ __forceinline__ void eeg_bwd_dws_kernel_body(const float* __restrict__ v, const float* __restrict__ x,
-                                                         float* __restrict__ part, int B, int C, int T, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                         float* __restrict__ part, int B, int C, int T,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int lane = threadIdx.x, q = lane >> 4, jl = lane & 15;
   const int c_base = blockIdx.y * 256;                    // 16 channel tiles per wave
   const int n_ctile = (C - c_base + 15) / 16 < 16 ? (C - c_base + 15) / 16 : 16;
@@ -1304,7 +1347,8 @@ __device__ __forceinline__ void eeg_bwd_dws_kernel_body(const float* __restrict_
 ISD_ZONE_FN(eeg_bwd_dws_kernel, 64)
 __global__ __launch_bounds__(64) void eeg_bwd_dws_kernel(const float* __restrict__ v, const float* __restrict__ x,
                                                          float* __restrict__ part, int B, int C, int T) {
-  eeg_bwd_dws_kernel_body(v, x, part, B, C, T, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_bwd_dws_kernel_body(v, x, part, B, C, T,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_bwd_dws_kernel)
 
@@ -1314,7 +1358,8 @@ ISD_ZONE_REGISTER(eeg_bwd_dws_kernel)
 __device__ __forceinline__ void eeg_bwd_dws_reduce_kernel_body(const float* __restrict__ part, int n_slabs,
                                                                   const EegStats* __restrict__ st,
                                                                   const EegCoef* __restrict__ co,
-                                                                  float* __restrict__ dWs, int C, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                                  float* __restrict__ dWs, int C,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
@@ -1343,7 +1388,8 @@ __global__ __launch_bounds__(1024) void eeg_bwd_dws_reduce_kernel(const float* _
                                                                   const EegStats* __restrict__ st,
                                                                   const EegCoef* __restrict__ co,
                                                                   float* __restrict__ dWs, int C) {
-  eeg_bwd_dws_reduce_kernel_body(part, n_slabs, st, co, dWs, C, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_bwd_dws_reduce_kernel_body(part, n_slabs, st, co, dWs, C,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_bwd_dws_reduce_kernel)
 
@@ -1352,7 +1398,8 @@ __device__ __forceinline__ void eeg_bwd_final_kernel_body(const float* __restric
                                                             float* __restrict__ dparams,
                                                             const EegStats* __restrict__ st,
                                                             const EegCoef* __restrict__ co, EegOff off, int C, int K,
-                                                            double N1, int separable, double gs, int bn_train, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                            double N1, int separable, double gs, int bn_train,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const float* Wt = params + off.Wt;
   if (separable) {
     for (int e = threadIdx.x; e < kF2 * kF2; e += 256) dparams[off.Wp + e] = (float)st->dWp[e / kF2][e % kF2];
@@ -1389,7 +1436,8 @@ __global__ __launch_bounds__(256) void eeg_bwd_final_kernel(const float* __restr
                                                             const EegStats* __restrict__ st,
                                                             const EegCoef* __restrict__ co, EegOff off, int C, int K,
                                                             double N1, int separable, double gs, int bn_train) {
-  eeg_bwd_final_kernel_body(params, dparams, st, co, off, C, K, N1, separable, gs, bn_train, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_bwd_final_kernel_body(params, dparams, st, co, off, C, K, N1, separable, gs, bn_train,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(eeg_bwd_final_kernel)
 
@@ -1405,7 +1453,8 @@ __device__ __forceinline__ void eeg_bwd_dx_kernel_body(const float* __restrict__
                                                          const float* __restrict__ params, float* __restrict__ dx,
                                                          const EegStats* __restrict__ st, const EegCoef* __restrict__ co,
                                                          EegOff off, int C, int Krt, int T, int Tp, double N1,
-                                                         int bn_train, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                         int bn_train,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int K = KT ? KT : Krt;
   constexpr int KA = KT ? KT : kMaxK;
   __shared__ float xs[256 + 2 * kMaxK];                  // x[s0 - K + j]
@@ -1476,7 +1525,8 @@ __global__ __launch_bounds__(256) void eeg_bwd_dx_kernel(const float* __restrict
                                                          const EegStats* __restrict__ st, const EegCoef* __restrict__ co,
                                                          EegOff off, int C, int Krt, int T, int Tp, double N1,
                                                          int bn_train) {
-  eeg_bwd_dx_kernel_body<KT>(x, v, params, dx, st, co, off, C, Krt, T, Tp, N1, bn_train, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  eeg_bwd_dx_kernel_body<KT>(x, v, params, dx, st, co, off, C, Krt, T, Tp, N1, bn_train,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER_T(eeg_bwd_dx_kernel, 64)
 ISD_ZONE_REGISTER_T(eeg_bwd_dx_kernel, 32)
@@ -1490,7 +1540,8 @@ ISD_ZONE_REGISTER_T(eeg_bwd_dx_kernel, 0)
 // ------------------------------------------------------------------------------------------------
 // W3 [h][g][k] -> fwd layout [g][k][h] and data-gradient layout [h][k][g] (16 contiguous scalars per tap)
 __device__ __forceinline__ void cv_prep_kernel_body(const float* __restrict__ W3, float* __restrict__ Wf,
-                                                      float* __restrict__ Wb, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                      float* __restrict__ Wb,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= kF2 * kF2 * kK2) return;
   const int h = e >> 8, g = (e >> 4) & 15, k = e & 15;
@@ -1501,14 +1552,16 @@ __device__ __forceinline__ void cv_prep_kernel_body(const float* __restrict__ W3
 ISD_ZONE_FN(cv_prep_kernel, 256)
 __global__ __launch_bounds__(256) void cv_prep_kernel(const float* __restrict__ W3, float* __restrict__ Wf,
                                                       float* __restrict__ Wb) {
-  cv_prep_kernel_body(W3, Wf, Wb, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  cv_prep_kernel_body(W3, Wf, Wb,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(cv_prep_kernel)
 
 // a4[b,h,w] = sum_{g,k} W3[h,g,k] p2pad[b,g,w+k];  BN3 sums.  One thread per (b,w), 16 outputs in registers.
 __device__ __forceinline__ void cv_conv3_kernel_body(const float* __restrict__ p2, const float* __restrict__ Wf,
                                                        float* __restrict__ a4, EegStats* __restrict__ st, int64_t B,
-                                                       int T2, int T2p, int want_stats, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                       int T2, int T2p, int want_stats,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float red[4];
   __shared__ float tot[2 * kF2];
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1549,14 +1602,16 @@ ISD_ZONE_FN(cv_conv3_kernel, 256)
 __global__ __launch_bounds__(256) void cv_conv3_kernel(const float* __restrict__ p2, const float* __restrict__ Wf,
                                                        float* __restrict__ a4, EegStats* __restrict__ st, int64_t B,
                                                        int T2, int T2p, int want_stats) {
-  cv_conv3_kernel_body(p2, Wf, a4, st, B, T2, T2p, want_stats, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  cv_conv3_kernel_body(p2, Wf, a4, st, B, T2, T2p, want_stats,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(cv_conv3_kernel)
 
 // p3[b,h,v] = mean_{r<P2} ELU(A3 a4[b,h,P2 v+r] + B3) * dropout      ([B,16,T3] == the flattened projector input)
 __device__ __forceinline__ void cv_pool3_kernel_body(const float* __restrict__ a4, const EegCoef* __restrict__ co,
                                                        float* __restrict__ p3, int64_t n, int T2p, int T3, int P2,
-                                                       float dp, uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                       float dp, uint64_t seed,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   const int64_t row = e / T3;
@@ -1571,7 +1626,8 @@ ISD_ZONE_FN(cv_pool3_kernel, 256)
 __global__ __launch_bounds__(256) void cv_pool3_kernel(const float* __restrict__ a4, const EegCoef* __restrict__ co,
                                                        float* __restrict__ p3, int64_t n, int T2p, int T3, int P2,
                                                        float dp, uint64_t seed) {
-  cv_pool3_kernel_body(a4, co, p3, n, T2p, T3, P2, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  cv_pool3_kernel_body(a4, co, p3, n, T2p, T3, P2, dp, seed,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(cv_pool3_kernel)
 
@@ -1587,7 +1643,8 @@ __device__ __forceinline__ float cv_dy3(const float* __restrict__ dp3, const Eeg
 __device__ __forceinline__ void cv_bwd3_sums_kernel_body(const float* __restrict__ a4, const float* __restrict__ dp3,
                                                            const EegCoef* __restrict__ co, EegStats* __restrict__ st,
                                                            int64_t rows, int T2p, int T3, int P2, float dp,
-                                                           uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                           uint64_t seed,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -1612,14 +1669,16 @@ __global__ __launch_bounds__(256) void cv_bwd3_sums_kernel(const float* __restri
                                                            const EegCoef* __restrict__ co, EegStats* __restrict__ st,
                                                            int64_t rows, int T2p, int T3, int P2, float dp,
                                                            uint64_t seed) {
-  cv_bwd3_sums_kernel_body(a4, dp3, co, st, rows, T2p, T3, P2, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  cv_bwd3_sums_kernel_body(a4, dp3, co, st, rows, T2p, T3, P2, dp, seed,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(cv_bwd3_sums_kernel)
 
 // da4 = cA3 (dy3 - cB3 - xhat3 cC3), elementwise over [B,16,T2p]
 __device__ __forceinline__ void cv_bwd_da4_kernel_body(const float* __restrict__ a4, const float* __restrict__ dp3,
                                                          const EegCoef* __restrict__ co, float* __restrict__ da4,
-                                                         int64_t n, int T2p, int T3, int P2, float dp, uint64_t seed, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                         int64_t n, int T2p, int T3, int P2, float dp, uint64_t seed,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   const int64_t row = e / T2p;
@@ -1633,13 +1692,15 @@ ISD_ZONE_FN(cv_bwd_da4_kernel, 256)
 __global__ __launch_bounds__(256) void cv_bwd_da4_kernel(const float* __restrict__ a4, const float* __restrict__ dp3,
                                                          const EegCoef* __restrict__ co, float* __restrict__ da4,
                                                          int64_t n, int T2p, int T3, int P2, float dp, uint64_t seed) {
-  cv_bwd_da4_kernel_body(a4, dp3, co, da4, n, T2p, T3, P2, dp, seed, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  cv_bwd_da4_kernel_body(a4, dp3, co, da4, n, T2p, T3, P2, dp, seed,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(cv_bwd_da4_kernel)
 
 // dp2[b,g,v] = sum_{h,k} W3[h,g,k] da4[b,h,v-k+8].  One thread per (b,v), 16 outputs in registers.
 __device__ __forceinline__ void cv_bwd_dp2_kernel_body(const float* __restrict__ da4, const float* __restrict__ Wb,
-                                                         float* __restrict__ dp2, int64_t B, int T2, int T2p, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                         float* __restrict__ dp2, int64_t B, int T2, int T2p,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= B * T2) return;
   const int64_t b = e / T2;
@@ -1664,14 +1725,16 @@ __device__ __forceinline__ void cv_bwd_dp2_kernel_body(const float* __restrict__
 ISD_ZONE_FN(cv_bwd_dp2_kernel, 256)
 __global__ __launch_bounds__(256) void cv_bwd_dp2_kernel(const float* __restrict__ da4, const float* __restrict__ Wb,
                                                          float* __restrict__ dp2, int64_t B, int T2, int T2p) {
-  cv_bwd_dp2_kernel_body(da4, Wb, dp2, B, T2, T2p, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  cv_bwd_dp2_kernel_body(da4, Wb, dp2, B, T2, T2p,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(cv_bwd_dp2_kernel)
 
 // dW3[h,g,k] = sum_{b,w} da4[b,h,w] p2pad[b,g,w+k] on the matrix cores: M = h, N = k (tap), K = w, one
 // 16x16 accumulator tile per input channel g.  Persistent waves over trials, partial slabs [h][g][k].
 __device__ __forceinline__ void cv_bwd_w3_kernel_body(const float* __restrict__ da4, const float* __restrict__ p2,
-                                                       float* __restrict__ part, int64_t B, int T2, int T2p, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                       float* __restrict__ part, int64_t B, int T2, int T2p,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int lane = threadIdx.x, q = lane >> 4, jl = lane & 15;
   f32x4 acc[kF2];
 #pragma unroll
@@ -1700,12 +1763,14 @@ __device__ __forceinline__ void cv_bwd_w3_kernel_body(const float* __restrict__ 
 ISD_ZONE_FN(cv_bwd_w3_kernel, 64)
 __global__ __launch_bounds__(64) void cv_bwd_w3_kernel(const float* __restrict__ da4, const float* __restrict__ p2,
                                                        float* __restrict__ part, int64_t B, int T2, int T2p) {
-  cv_bwd_w3_kernel_body(da4, p2, part, B, T2, T2p, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  cv_bwd_w3_kernel_body(da4, p2, part, B, T2, T2p,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(cv_bwd_w3_kernel)
 
 __device__ __forceinline__ void cv_w3_reduce_kernel_body(const float* __restrict__ part, int n_slabs,
-                                                           float* __restrict__ dW3, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                           float* __restrict__ dW3,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= kF2 * kF2 * kK2) return;
   float s0 = 0.f, s1 = 0.f;
@@ -1720,7 +1785,8 @@ __device__ __forceinline__ void cv_w3_reduce_kernel_body(const float* __restrict
 ISD_ZONE_FN(cv_w3_reduce_kernel, 256)
 __global__ __launch_bounds__(256) void cv_w3_reduce_kernel(const float* __restrict__ part, int n_slabs,
                                                            float* __restrict__ dW3) {
-  cv_w3_reduce_kernel_body(part, n_slabs, dW3, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  cv_w3_reduce_kernel_body(part, n_slabs, dW3,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(cv_w3_reduce_kernel)
 

@@ -32,7 +32,8 @@ __device__ __forceinline__ void linear_fwd_kernel_body(const float* __restrict__
                                                          const float* __restrict__ bias, float* __restrict__ y,
                                                          float* __restrict__ pre, int64_t M, int K, int Nout,
                                                          int64_t so, int64_t si, int act,
-                                                         const float* __restrict__ res, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                         const float* __restrict__ res,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float xs[64 * kRS];
   __shared__ float wsm[64 * kRS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -91,20 +92,23 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
                                                          float* __restrict__ pre, int64_t M, int K, int Nout,
                                                          int64_t so, int64_t si, int act,
                                                          const float* __restrict__ res) {
-  linear_fwd_kernel_body(x, w, bias, y, pre, M, K, Nout, so, si, act, res, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  linear_fwd_kernel_body(x, w, bias, y, pre, M, K, Nout, so, si, act, res,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(linear_fwd_kernel)
 
 // dpre = dy * gelu'(pre)   (act) or a plain copy
 __device__ __forceinline__ void act_bwd_kernel_body(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dpre,
-                               int64_t n, int act, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                               int64_t n, int act,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)zgx * blockDim.x)
     dpre[e] = act ? dy[e] * gelu1_grad(pre[e]) : dy[e];
 }
 ISD_ZONE_FN(act_bwd_kernel, 1024)
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dpre,
                                int64_t n, int act) {
-  act_bwd_kernel_body(dy, pre, dpre, n, act, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  act_bwd_kernel_body(dy, pre, dpre, n, act,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(act_bwd_kernel)
 
@@ -112,7 +116,8 @@ ISD_ZONE_REGISTER(act_bwd_kernel)
 // M = o (A = dpre^T), N = i (16 per wave), K = samples.  grid: (slabs, ceil((K+1)/64)); partial slabs.
 __device__ __forceinline__ void linear_wgrad_kernel_body(const float* __restrict__ dpre, const float* __restrict__ x,
                                                            float* __restrict__ part, int64_t M, int K, int Nout,
-                                                           int m_per_wg, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                           int m_per_wg,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float ds[64 * 80];   // [64 samples][Nout<=64], stride 80 == 16 (mod 32)
   __shared__ float xs[64 * 80];   // [64 samples][64 inputs]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -164,14 +169,16 @@ ISD_ZONE_FN(linear_wgrad_kernel, 256)
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ x,
                                                            float* __restrict__ part, int64_t M, int K, int Nout,
                                                            int m_per_wg) {
-  linear_wgrad_kernel_body(dpre, x, part, M, K, Nout, m_per_wg, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  linear_wgrad_kernel_body(dpre, x, part, M, K, Nout, m_per_wg,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(linear_wgrad_kernel)
 
 // Slab sums in a fixed order.  blockIdx.y selects a run of L slabs (index k * stride); with gridDim.y > 1 the
 // run's sum replaces its first slab and a second launch (stride = L) adds the run sums and scatters to dw / db.
 __device__ __forceinline__ void linear_wgrad_reduce_kernel_body(float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
-                                           int K, int Nout, int n_slabs, int L, int stride, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                           int K, int Nout, int n_slabs, int L, int stride,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int n = Nout * (K + 1);
   const int k0 = blockIdx.y * L;
   const int k1 = k0 + L < n_slabs ? k0 + L : n_slabs;
@@ -196,7 +203,8 @@ __device__ __forceinline__ void linear_wgrad_reduce_kernel_body(float* __restric
 ISD_ZONE_FN(linear_wgrad_reduce_kernel, 1024)
 __global__ void linear_wgrad_reduce_kernel(float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
                                            int K, int Nout, int n_slabs, int L, int stride) {
-  linear_wgrad_reduce_kernel_body(part, dw, db, K, Nout, n_slabs, L, stride, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  linear_wgrad_reduce_kernel_body(part, dw, db, K, Nout, n_slabs, L, stride,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(linear_wgrad_reduce_kernel)
 
@@ -208,7 +216,8 @@ __device__ __forceinline__ void softmax_ce_kernel_body(const float* __restrict__
                                                          float* __restrict__ loss, float* __restrict__ dlt,
                                                          int64_t* __restrict__ pred, int64_t B, int n_tok, int n_cls,
                                                          float grad_scale, float* __restrict__ part,
-                                                         unsigned int* __restrict__ ticket, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                         unsigned int* __restrict__ ticket,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float red[256];
   __shared__ bool last;
   float lsum = 0.f;
@@ -271,7 +280,8 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
                                                          int64_t* __restrict__ pred, int64_t B, int n_tok, int n_cls,
                                                          float grad_scale, float* __restrict__ part,
                                                          unsigned int* __restrict__ ticket) {
-  softmax_ce_kernel_body(lt, labels, label_bytes, lmean, loss, dlt, pred, B, n_tok, n_cls, grad_scale, part, ticket, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  softmax_ce_kernel_body(lt, labels, label_bytes, lmean, loss, dlt, pred, B, n_tok, n_cls, grad_scale, part, ticket,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(softmax_ce_kernel)
 

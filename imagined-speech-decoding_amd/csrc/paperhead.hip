@@ -74,7 +74,8 @@ __device__ __forceinline__ float ph_block_sum(float v, float* red) {
 //   Wb[l][o][k][Cp]  (data gradient: 16 consecutive input channels per tap)
 __device__ __forceinline__ void ph_prep_kernel_body(const float* __restrict__ params, float* __restrict__ Wf,
                                                       float* __restrict__ Wb, float* __restrict__ beff, PhGeo g,
-                                                      int l, int64_t wf_off, int64_t wb_off, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                      int l, int64_t wf_off, int64_t wb_off,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int Fo = g.Fo[l], Ci = g.Ci[l], Fp = g.Fp[l], Cp = g.Cp[l];
   const int e = blockIdx.x * 256 + threadIdx.x;
   const int n = (Fp > Fo ? Fp : Fo) * (Cp > Ci ? Cp : Ci) * 3;
@@ -105,7 +106,8 @@ ISD_ZONE_FN(ph_prep_kernel, 256)
 __global__ __launch_bounds__(256) void ph_prep_kernel(const float* __restrict__ params, float* __restrict__ Wf,
                                                       float* __restrict__ Wb, float* __restrict__ beff, PhGeo g,
                                                       int l, int64_t wf_off, int64_t wb_off) {
-  ph_prep_kernel_body(params, Wf, Wb, beff, g, l, wf_off, wb_off, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  ph_prep_kernel_body(params, Wf, Wb, beff, g, l, wf_off, wb_off,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(ph_prep_kernel)
 
@@ -114,7 +116,8 @@ ISD_ZONE_REGISTER(ph_prep_kernel)
 __device__ __forceinline__ void ph_conv_kernel_body(const float* __restrict__ in, const float* __restrict__ Wf,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       double* __restrict__ s1, double* __restrict__ s2, int64_t B,
-                                                      int Ci, int Ti, int To, int Fo, int Fp, int want_stats, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                      int Ci, int Ti, int To, int Fo, int Fp, int want_stats,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float red[4];
   __shared__ float tot[32];
   const int o0 = blockIdx.y * 16;
@@ -160,14 +163,16 @@ __global__ __launch_bounds__(256) void ph_conv_kernel(const float* __restrict__ 
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       double* __restrict__ s1, double* __restrict__ s2, int64_t B,
                                                       int Ci, int Ti, int To, int Fo, int Fp, int want_stats) {
-  ph_conv_kernel_body(in, Wf, bias, y, s1, s2, B, Ci, Ti, To, Fo, Fp, want_stats, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  ph_conv_kernel_body(in, Wf, bias, y, s1, s2, B, Ci, Ti, To, Fo, Fp, want_stats,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(ph_conv_kernel)
 
 // BN coefficients of layer l: bn(y) = A y + Bc.  training: batch statistics (+ running update); eval: running buffers.
 __device__ __forceinline__ void ph_finalize_kernel_body(const float* __restrict__ params, float* __restrict__ bufs,
                                    const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N,
-                                   int training, float momentum, float eps, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                   int training, float momentum, float eps,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int o = threadIdx.x;
   if (o >= g.Fo[l]) return;
   double mu, var;
@@ -192,13 +197,15 @@ ISD_ZONE_FN(ph_finalize_kernel, 1024)
 __global__ void ph_finalize_kernel(const float* __restrict__ params, float* __restrict__ bufs,
                                    const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N,
                                    int training, float momentum, float eps) {
-  ph_finalize_kernel_body(params, bufs, st, co, g, l, N, training, momentum, eps, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  ph_finalize_kernel_body(params, bufs, st, co, g, l, N, training, momentum, eps,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(ph_finalize_kernel)
 
 // a[b,o,p] = max(GELU(bn(y[2p])), GELU(bn(y[2p+1])))
 __device__ __forceinline__ void ph_pool_kernel_body(const float* __restrict__ y, const PhCoef* __restrict__ co,
-                                                      float* __restrict__ a, int64_t n, int l, int Fo, int To, int Tp, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                      float* __restrict__ a, int64_t n, int l, int Fo, int To, int Tp,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   const int64_t row = e / Tp;
@@ -210,13 +217,15 @@ __device__ __forceinline__ void ph_pool_kernel_body(const float* __restrict__ y,
 ISD_ZONE_FN(ph_pool_kernel, 256)
 __global__ __launch_bounds__(256) void ph_pool_kernel(const float* __restrict__ y, const PhCoef* __restrict__ co,
                                                       float* __restrict__ a, int64_t n, int l, int Fo, int To, int Tp) {
-  ph_pool_kernel_body(y, co, a, n, l, Fo, To, Tp, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  ph_pool_kernel_body(y, co, a, n, l, Fo, To, Tp,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(ph_pool_kernel)
 
 // out[b,o] = mean_p a4[b,o,p]
 __device__ __forceinline__ void ph_mean_kernel_body(const float* __restrict__ a, float* __restrict__ out, int64_t rows,
-                                                      int Tp, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                      int Tp,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
   float s = 0.f;
@@ -226,7 +235,8 @@ __device__ __forceinline__ void ph_mean_kernel_body(const float* __restrict__ a,
 ISD_ZONE_FN(ph_mean_kernel, 256)
 __global__ __launch_bounds__(256) void ph_mean_kernel(const float* __restrict__ a, float* __restrict__ out, int64_t rows,
                                                       int Tp) {
-  ph_mean_kernel_body(a, out, rows, Tp, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  ph_mean_kernel_body(a, out, rows, Tp,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(ph_mean_kernel)
 
@@ -237,7 +247,8 @@ __device__ __forceinline__ void ph_bwd_pool_kernel_body(const float* __restrict_
                                                           const float* __restrict__ dout,
                                                           const PhCoef* __restrict__ co, float* __restrict__ dyh,
                                                           PhStats* __restrict__ st, int64_t B, int l, int Fo, int To,
-                                                          int Tp, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                          int Tp,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float red[4];
   const int o = blockIdx.y;
   const float A = co->A[l][o], Bc = co->Bc[l][o], mu = co->mu[l][o], isg = co->isg[l][o];
@@ -271,13 +282,15 @@ __global__ __launch_bounds__(256) void ph_bwd_pool_kernel(const float* __restric
                                                           const PhCoef* __restrict__ co, float* __restrict__ dyh,
                                                           PhStats* __restrict__ st, int64_t B, int l, int Fo, int To,
                                                           int Tp) {
-  ph_bwd_pool_kernel_body(y, da, dout, co, dyh, st, B, l, Fo, To, Tp, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  ph_bwd_pool_kernel_body(y, da, dout, co, dyh, st, B, l, Fo, To, Tp,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(ph_bwd_pool_kernel)
 
 __device__ __forceinline__ void ph_bwd_coef_kernel_body(const float* __restrict__ params, float* __restrict__ dparams,
                                    const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N,
-                                   int bn_train, double gs, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                   int bn_train, double gs,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int o = threadIdx.x;
   if (o >= g.Fo[l]) return;
   const double inv = bn_train ? 1.0 / N : 0.0;           // running statistics do not depend on the batch: no mean terms
@@ -291,14 +304,16 @@ ISD_ZONE_FN(ph_bwd_coef_kernel, 1024)
 __global__ void ph_bwd_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
                                    const PhStats* __restrict__ st, PhCoef* __restrict__ co, PhGeo g, int l, double N,
                                    int bn_train, double gs) {
-  ph_bwd_coef_kernel_body(params, dparams, st, co, g, l, N, bn_train, gs, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  ph_bwd_coef_kernel_body(params, dparams, st, co, g, l, N, bn_train, gs,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(ph_bwd_coef_kernel)
 
 // dy = cA (dyh - cB - xhat cC) in place
 __device__ __forceinline__ void ph_bwd_bn_kernel_body(float* __restrict__ dyh, const float* __restrict__ y,
                                                         const PhCoef* __restrict__ co, int64_t n, int l, int Fo,
-                                                        int To, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                        int To,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   const int o = (int)((e / To) % Fo);
@@ -309,14 +324,16 @@ ISD_ZONE_FN(ph_bwd_bn_kernel, 256)
 __global__ __launch_bounds__(256) void ph_bwd_bn_kernel(float* __restrict__ dyh, const float* __restrict__ y,
                                                         const PhCoef* __restrict__ co, int64_t n, int l, int Fo,
                                                         int To) {
-  ph_bwd_bn_kernel_body(dyh, y, co, n, l, Fo, To, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  ph_bwd_bn_kernel_body(dyh, y, co, n, l, Fo, To,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(ph_bwd_bn_kernel)
 
 // da[b,c,s] = sum_{o,k} W[o,c,k] dy[b,o,s-k]   (gradient w.r.t. the layer input = the previous pooled activation)
 __device__ __forceinline__ void ph_bwd_dgrad_kernel_body(const float* __restrict__ dy, const float* __restrict__ Wb,
                                                            float* __restrict__ da, int64_t B, int Ci, int Cp, int Ti,
-                                                           int To, int Fo, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                           int To, int Fo,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int c0 = blockIdx.y * 16;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= B * Ti) return;
@@ -344,7 +361,8 @@ ISD_ZONE_FN(ph_bwd_dgrad_kernel, 256)
 __global__ __launch_bounds__(256) void ph_bwd_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ Wb,
                                                            float* __restrict__ da, int64_t B, int Ci, int Cp, int Ti,
                                                            int To, int Fo) {
-  ph_bwd_dgrad_kernel_body(dy, Wb, da, B, Ci, Cp, Ti, To, Fo, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  ph_bwd_dgrad_kernel_body(dy, Wb, da, B, Ci, Cp, Ti, To, Fo,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(ph_bwd_dgrad_kernel)
 
@@ -353,7 +371,8 @@ ISD_ZONE_REGISTER(ph_bwd_dgrad_kernel)
 // Partial slabs: part[block][o][c][k] and pbias[block][o].
 __device__ __forceinline__ void ph_bwd_wgrad_kernel_body(const float* __restrict__ dy, const float* __restrict__ in,
                                                           float* __restrict__ part, float* __restrict__ pbias,
-                                                          int64_t B, int Ci, int Ti, int To, int Fo, int n_ctile, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                          int64_t B, int Ci, int Ti, int To, int Fo, int n_ctile,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int lane = threadIdx.x, q = lane >> 4, jl = lane & 15;
   const int ot = blockIdx.y / n_ctile, ct = blockIdx.y - ot * n_ctile;
   const int o = ot * 16 + jl, c = ct * 16 + jl;
@@ -390,12 +409,14 @@ ISD_ZONE_FN(ph_bwd_wgrad_kernel, 64)
 __global__ __launch_bounds__(64) void ph_bwd_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ in,
                                                           float* __restrict__ part, float* __restrict__ pbias,
                                                           int64_t B, int Ci, int Ti, int To, int Fo, int n_ctile) {
-  ph_bwd_wgrad_kernel_body(dy, in, part, pbias, B, Ci, Ti, To, Fo, n_ctile, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  ph_bwd_wgrad_kernel_body(dy, in, part, pbias, B, Ci, Ti, To, Fo, n_ctile,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(ph_bwd_wgrad_kernel)
 
 __device__ __forceinline__ void ph_reduce_kernel_body(const float* __restrict__ part, int n_slabs, int64_t n,
-                                                        float* __restrict__ dst, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                        float* __restrict__ dst,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   float s0 = 0.f, s1 = 0.f;
@@ -410,14 +431,16 @@ __device__ __forceinline__ void ph_reduce_kernel_body(const float* __restrict__ 
 ISD_ZONE_FN(ph_reduce_kernel, 256)
 __global__ __launch_bounds__(256) void ph_reduce_kernel(const float* __restrict__ part, int n_slabs, int64_t n,
                                                         float* __restrict__ dst) {
-  ph_reduce_kernel_body(part, n_slabs, n, dst, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  ph_reduce_kernel_body(part, n_slabs, n, dst,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(ph_reduce_kernel)
 
 // dWeff [F1][C][3], dbeff [F1] -> gradients of cnn1_t.weight, cnn1_t.bias, cnn1_s.weight.  One block.
 __device__ __forceinline__ void ph_bwd_l1_kernel_body(const float* __restrict__ params, float* __restrict__ dparams,
                                                         const float* __restrict__ dWeff, const float* __restrict__ dbeff,
-                                                        PhGeo g, unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {
+                                                        PhGeo g,
+    unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int F1 = g.Fo[0], C = g.C;
   const float* Wt = params + g.wt;
   const float* bt = params + g.bt;
@@ -450,7 +473,8 @@ ISD_ZONE_FN(ph_bwd_l1_kernel, 256)
 __global__ __launch_bounds__(256) void ph_bwd_l1_kernel(const float* __restrict__ params, float* __restrict__ dparams,
                                                         const float* __restrict__ dWeff, const float* __restrict__ dbeff,
                                                         PhGeo g) {
-  ph_bwd_l1_kernel_body(params, dparams, dWeff, dbeff, g, gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
+  ph_bwd_l1_kernel_body(params, dparams, dWeff, dbeff, g,
+      gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
 }
 ISD_ZONE_REGISTER(ph_bwd_l1_kernel)
 

@@ -6,7 +6,7 @@
 // isd_zone_batch_launch() every kernel launch of this thread is RECORDED instead of issued (kernel, grid, block,
 // arguments); isd_zone_batch_next() closes a zone.  The launch then zips the zones' chains: launch i of every zone
 // is the same kernel, so it goes out ONCE with blockIdx.z = zone and the zones' argument tuples side by side in the
-// kernel argument block.  A kernel takes part through ISD_ZONE_KERNEL (its body is a __device__ function that gets
+// kernel argument block.  A kernel takes part through ISD_ZONE_FN + ISD_ZONE_REGISTER (its body is a __device__ function that gets
 // its own zone's grid size -- and blockIdx.z / gridDim.z -- as trailing arguments: grid-stride loops must not see the
 // other zones', and blockIdx.z is the zone in the multi-zone launch).
 #pragma once
@@ -72,7 +72,7 @@ struct ZoneRecorder {
   bool active = false;
   std::vector<std::vector<ZoneOp>> zones;
 };
-ZoneRecorder& zone_recorder();                                      // thread-local (api.cpp)
+ZoneRecorder& zone_recorder();                                      // thread-local (zonebatch.hip)
 
 #if defined(__HIPCC__)
 template <typename Fn, typename... P>
@@ -101,7 +101,7 @@ hipError_t zone_zip(int n, const ZoneOp* const* ops, hipStream_t st) {
   return hipGetLastError();
 }
 
-// registry: kernel stub -> zip function (filled by ISD_ZONE_KERNEL's static registrars)
+// registry: kernel stub -> zip function (filled by the static registrars of ISD_ZONE_REGISTER)
 std::unordered_map<const void*, hipError_t (*)(int, const ZoneOp* const*, hipStream_t)>& zone_registry();
 struct ZoneRegistrar {
   ZoneRegistrar(const void* k, hipError_t (*zip)(int, const ZoneOp* const*, hipStream_t)) { zone_registry()[k] = zip; }
@@ -148,9 +148,9 @@ inline hipError_t zone_clear(void* ptr, size_t bytes, hipStream_t st) {
 }
 
 // A zone-batchable kernel NAME: `NAME_body(params..., zgx, zgy, zbz, zgz)` is the __device__ body (zgx / zgy / zgz
-// stand for gridDim.x / .y / .z of the zone's own launch, zbz for its blockIdx.z); ISD_ZONE_KERNEL defines the functor the multi-zone kernel
-// calls and registers the pair.  TPL / TARGS carry the template header and arguments of kernel templates
-// (ISD_ZONE_KERNEL_T, then one ISD_ZONE_REGISTER_T per instantiation that is launched).
+// stand for gridDim.x / .y / .z of the zone's own launch, zbz for its blockIdx.z).  ISD_ZONE_FN defines the functor the
+// multi-zone kernel calls, ISD_ZONE_REGISTER ties it to the plain __global__ entry point (kernel templates:
+// ISD_ZONE_FN_T, then one ISD_ZONE_REGISTER_T per instantiation that is launched).
 #define ISD_ZONE_FN(NAME, BOUNDS)                                                        \
   struct NAME##_zfn {                                                                    \
     static constexpr int kBounds = BOUNDS;                                               \
