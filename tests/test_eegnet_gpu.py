@@ -57,7 +57,10 @@ def test_eegnet_matches_reference_golden(inn, tag, C, T):
                                      # rows of at most 79 samples take the one-Gram-matrix statistics path
                                      (5, 65, 64, 6), (3, 79, 64, 5), (7, 30, 16, 9), (6, 80, 64, 5), (130, 47, 32, 3),
                                      # long rows: several segments of the backward correlation kernel
-                                     (3, 2100, 64, 2), (2, 1024, 64, 2)])
+                                     (3, 2100, 64, 2), (2, 1024, 64, 2),
+                                     # wide inputs: whole-row spatial product (5-tile groups), spatial weight gradient
+                                     # in 80-step chunks with dword-aligned 16-byte loads and a one-step last chunk
+                                     (200, 81, 32, 2), (515, 100, 16, 2), (129, 161, 64, 2)])
 def test_eegnet_vs_oracle_shapes(inn, C, T, K, B):
     torch.manual_seed(C + T)
     m = inn.EEGNet_Encoder(C, 16, kernel_length=K, dropout=0.0).cuda()
