@@ -1197,7 +1197,8 @@ __device__ __forceinline__ void eeg_bwd_corr_kernel_body(const float* __restrict
     unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int K = KT ? KT : Krt;
   constexpr int KA = KT ? KT : kMaxK;                   // accumulators kept
-  extern __shared__ float sm[];                         // z[s0 - P + j], j < L + K + 64;  da2[s0 - K + j], j < L + 2K + 64
+  // z[s0 - P + j], j < L + K + 64;  da2[s0 - K + j], j < L + 2K + 64
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   // zgx is a multiple of 16: the rows of a workgroup (every zgx-th) share g, their K lag sums stay in
   // registers and reach the fp64 accumulators once per workgroup (5 k rows x 64 lags on 1 k addresses were 0.15 ms)
   const int g = blockIdx.x & (kF2 - 1), f = g >> 1, P = K / 2, lane = threadIdx.x;
@@ -1214,7 +1215,8 @@ __device__ __forceinline__ void eeg_bwd_corr_kernel_body(const float* __restrict
     const float* dr = da2 + (int64_t)bg * Tp;
     wave_lds_sync();                                    // the previous row's readers are done
     const int n1 = Tp - s0 < L ? Tp - s0 : L;           // t' = s0 + u, u < n1
-    const int Lr = (n1 + 63) & ~63;                     // what this segment touches (short rows: a fraction of L)
+    // what this segment touches (short rows: a fraction of L); the register-window loops below walk 256 steps a round
+    const int Lr = KT ? (n1 + 255) & ~255 : (n1 + 63) & ~63;
     // clamped addresses + selects: a branch around each load would serialise them (one L2 round trip per iteration)
 #pragma unroll 4
     for (int j = lane; j < Lr + K + 64; j += 64) {
@@ -1229,19 +1231,64 @@ __device__ __forceinline__ void eeg_bwd_corr_kernel_body(const float* __restrict
       dp[j] = (t >= 0 && t < Tp) ? dv : 0.f;
     }
     wave_lds_sync();
-    for (int u0 = 0; u0 < n1; u0 += 64) {
-      const float dv = dp[K + u0 + lane];               // da2[s0 + u0 + lane], 0 beyond Tp
-#pragma unroll
-      for (int k = 0; k < KA; ++k)
-        if (KT || k < K) acc[k] = fmaf(dv, zp[u0 + lane + k], acc[k]);    // z[t' + k - P]
-    }
     const int n2 = T - s0 < L ? T - s0 : L;             // t = s0 + u, u < n2
-    for (int u = lane; u < n2; u += 64) {
-      float a = 0.f;
+    if constexpr (KT != 0) {
+      // A lane owns FOUR consecutive steps and holds the K + 4 inputs they touch in registers (aligned 16-byte LDS
+      // reads): 2 x 4 K FMAs on (K + 4) / 4 + 1 LDS reads each.  With one step per lane every FMA had its own LDS
+      // read and the LDS pipe, not the vector ALU, set the pace (0.52 ms at the zone shape of the FAST heads).
+      constexpr int NW4 = (KT + 4) / 4;
+      for (int u0 = 0; u0 < n1; u0 += 256) {
+        const int ub = u0 + 4 * lane;
+        float zw[KT + 4];
 #pragma unroll
-      for (int k = 0; k < KA; ++k)
-        if (KT || k < K) a = fmaf(w[k], dp[K + u - k + P], a);            // da2[t - k + P]
-      v[(int64_t)bg * T + s0 + u] = a;
+        for (int m = 0; m < NW4; ++m) {
+          const float4 qv = *reinterpret_cast<const float4*>(zp + ub + 4 * m);
+          zw[4 * m] = qv.x; zw[4 * m + 1] = qv.y; zw[4 * m + 2] = qv.z; zw[4 * m + 3] = qv.w;
+        }
+        const float4 dq = *reinterpret_cast<const float4*>(dp + K + ub);      // da2[s0 + ub ..], 0 beyond Tp
+        const float dv[4] = {dq.x, dq.y, dq.z, dq.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < KT; ++k) acc[k] = fmaf(dv[j], zw[j + k], acc[k]);   // z[t' + k - P]
+      }
+      for (int u0 = 0; u0 < n2; u0 += 256) {
+        const int ub = u0 + 4 * lane;
+        float dw[KT + 4];                                // dw[m] = da2[s0 + ub - K + P + m]
+#pragma unroll
+        for (int m = 0; m < NW4; ++m) {
+          const float4 qv = *reinterpret_cast<const float4*>(dp + ub + P + 4 * m);
+          dw[4 * m] = qv.x; dw[4 * m + 1] = qv.y; dw[4 * m + 2] = qv.z; dw[4 * m + 3] = qv.w;
+        }
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k4 = 0; k4 < KT / 4; ++k4) {
+          const float4 wq = *reinterpret_cast<const float4*>(w + 4 * k4);      // same address in every lane
+          const float wv[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = fmaf(wv[e], dw[KT + j - (4 * k4 + e)], a[j]);   // da2[t - k + P]
+        }
+        float* vo = v + (int64_t)bg * T + s0 + ub;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ub + j < n2) vo[j] = a[j];
+      }
+    } else {
+      for (int u0 = 0; u0 < n1; u0 += 64) {
+        const float dv = dp[K + u0 + lane];               // da2[s0 + u0 + lane], 0 beyond Tp
+#pragma unroll
+        for (int k = 0; k < KA; ++k)
+          if (k < K) acc[k] = fmaf(dv, zp[u0 + lane + k], acc[k]);          // z[t' + k - P]
+      }
+      for (int u = lane; u < n2; u += 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < KA; ++k)
+          if (k < K) a = fmaf(w[k], dp[K + u - k + P], a);                  // da2[t - k + P]
+        v[(int64_t)bg * T + s0 + u] = a;
+      }
     }
   }
 #pragma unroll
