@@ -685,6 +685,53 @@ __device__ __forceinline__ void eeg_tconv_kernel_body(const float* __restrict__ 
   const int g = blockIdx.y & (kF2 - 1), f = g >> 1, P = K / 2;
   const float* w = Wt + f * K;
   float t1 = 0.f, t2 = 0.f;
+  if constexpr (KT != 0) {
+    // Compile-time filter length: a WAVE takes a tile of 256 outputs of its own row (the workgroup's four waves walk
+    // four rows that share the filter) and a lane FOUR consecutive outputs, with the K + 4 inputs they touch in
+    // registers (aligned 16-byte LDS reads): 4 K FMAs on (K + 4) / 4 LDS reads, where one output per lane paid an LDS
+    // read per FMA.
+    __shared__ __attribute__((aligned(16))) float zw4[4][256 + KT + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* zt = zw4[wave];
+    float wk[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) wk[k] = w[k];           // wave-uniform: scalar registers
+    for (int bg0 = blockIdx.y; bg0 < n_rows; bg0 += 4 * (int)zgy) {
+      const int bg = bg0 + wave * (int)zgy;
+      if (bg >= n_rows) continue;                         // (no workgroup barrier below)
+      const float* zr = z + (int64_t)bg * T;
+      for (int tp0 = blockIdx.x * 256; tp0 < Tp; tp0 += zgx * 256) {
+        wave_lds_sync();                                  // the previous tile's readers are done
+#pragma unroll
+        for (int j = lane; j < 256 + KT + 4; j += 64) {
+          const int t = tp0 + j - P;
+          const float zv = zr[t < 0 ? 0 : (t < T ? t : T - 1)];
+          zt[j] = (t >= 0 && t < T) ? zv : 0.f;
+        }
+        wave_lds_sync();
+        float win[KT + 4];
+#pragma unroll
+        for (int m = 0; m < (KT + 4) / 4; ++m) {
+          const float4 qv = *reinterpret_cast<const float4*>(zt + 4 * lane + 4 * m);
+          win[4 * m] = qv.x; win[4 * m + 1] = qv.y; win[4 * m + 2] = qv.z; win[4 * m + 3] = qv.w;
+        }
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] = fmaf(wk[k], win[j + k], a[j]);
+        const int tp = tp0 + 4 * lane;
+        float* uo = u + (int64_t)bg * Tp + tp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (tp + j < Tp) {
+            uo[j] = a[j];
+            t1 += a[j];
+            t2 = fmaf(a[j], a[j], t2);
+          }
+      }
+    }
+  } else
   for (int bg = blockIdx.y; bg < n_rows; bg += zgy) {
     const float* zr = z + (int64_t)bg * T;
     for (int tp0 = blockIdx.x * 256; tp0 < Tp; tp0 += zgx * 256) {
