@@ -157,10 +157,17 @@ __device__ __forceinline__ void eeg_stats_kernel_body(const float* __restrict__ 
     for (int s0 = 0; s0 < T; s0 += 256) {
       float vA[17], vB[17];
 #pragma unroll
-      for (int j = 0; j < 17; ++j) {
+      for (int j = 0; j < 17; ++j) {                                // clamped addresses: no test around a load ...
         const int idx = s0 + lane + 16 * j;
-        vA[j] = idx < T ? srcA[idx] : 0.f;
-        vB[j] = (two && idx < T) ? srcB[idx] : 0.f;
+        const int ic = idx < T ? idx : T - 1;
+        vA[j] = srcA[ic];
+        vB[j] = srcB[ic];
+      }
+#pragma unroll
+      for (int j = 0; j < 17; ++j) {                                // ... the 34 loads are in flight together, then selects
+        const bool in = s0 + lane + 16 * j < T;
+        vA[j] = in ? vA[j] : 0.f;
+        vB[j] = (two && in) ? vB[j] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -230,11 +237,18 @@ __device__ __forceinline__ void eeg_stats_edge_kernel_body(const float* __restri
       live[h] = g + h * stride < n_grp && r < rows;
       const float* src = x + (live[h] ? r : 0) * (int64_t)T;
 #pragma unroll
-      for (int nt = 0; nt < 6; ++nt) {
+      for (int nt = 0; nt < 6; ++nt) {                              // clamped addresses, selects below: no test around a load
         const int t = base + 16 * nt + i;
-        b[h][nt] = (live[h] && t >= 0 && t < T) ? src[t] : 0.f;
+        b[h][nt] = src[t < 0 ? 0 : (t < T ? t : T - 1)];
       }
     }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int nt = 0; nt < 6; ++nt) {
+        const int t = base + 16 * nt + i;
+        b[h][nt] = (live[h] && t >= 0 && t < T) ? b[h][nt] : 0.f;
+      }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const float a0 = b[h][0];
@@ -2050,7 +2064,7 @@ static int eeg_forward_stage(const isd_eegnet_plan* p, int stage, const float* x
     if (training) {
       if (T <= 79) {
         const int MT = (T + 16) / 16;                              // 16 MT >= T + 1: room for the column of ones
-        const int64_t want_g = cdiv(cdiv(rows, 4), kStatWaves);
+        const int64_t want_g = cdiv(cdiv(rows, 4), (int64_t)kStatWaves * 8);   // >= 8 row groups per wave (see below)
         const int grid_g = want_g < 1024 ? (int)want_g : 1024;
         switch (MT) {
           case 1: ISD_ZLAUNCH(eeg_stats_gram_kernel<1>, dim3(grid_g), dim3(64 * kStatWaves), 0, st, x, S, rows, T); break;
@@ -2061,10 +2075,13 @@ static int eeg_forward_stage(const isd_eegnet_plan* p, int stage, const float* x
         }
         ISD_ZLAUNCH(eeg_stats_gram_derive_kernel, dim3(1), dim3(64), 0, st, S, T);
       } else {
-        const int64_t want = cdiv(rows, kStatWaves);
+        // every workgroup ends with 1280 (bulk) / 3072 (edge) fp64 atomics on the plan's accumulators: give a wave at
+        // least 16 rows (8 groups of 4) before that, or the atomics are the kernel (a workgroup per 4 rows of the FAST
+        // heads' zone shape sent 6.5 M of them per launch: 0.2 ms for 20 MB of input)
+        const int64_t want = cdiv(rows, (int64_t)kStatWaves * 16);
         const int grid = want < 2048 ? (int)want : 2048;             // bulk: 32 waves per CU
         ISD_ZLAUNCH(eeg_stats_kernel, dim3(grid), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
-        const int64_t want_e = cdiv(cdiv(rows, 4), kStatWaves);
+        const int64_t want_e = cdiv(cdiv(rows, 4), (int64_t)kStatWaves * 8);
         const int grid_e = want_e < 512 ? (int)want_e : 512;         // edge: 4 rows per MFMA step, head and tail blocks
         ISD_ZLAUNCH(eeg_stats_edge_kernel, dim3(grid_e, 2), dim3(64 * kStatWaves), 0, st, x, S, rows, T);
         ISD_ZLAUNCH(eeg_stats_derive_kernel, dim3(1), dim3(64), 0, st, S);
