@@ -417,16 +417,27 @@ ISD_ZONE_REGISTER(ph_bwd_wgrad_kernel)
 __device__ __forceinline__ void ph_reduce_kernel_body(const float* __restrict__ part, int n_slabs, int64_t n,
                                                         float* __restrict__ dst,
     unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
-  float s0 = 0.f, s1 = 0.f;
-  int k = 0;
-  for (; k + 1 < n_slabs; k += 2) {
-    s0 += part[(int64_t)k * n + e];
-    s1 += part[(int64_t)(k + 1) * n + e];
+  // block = 64 elements x 4 slab groups (contiguous quarters of the slabs, four loads in flight each, combined in LDS in
+  // a fixed order): one thread per element walking all the slabs was a chain of ~160 dependent load pairs, 42 us a launch
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + l;
+  const int per = (n_slabs + 3) / 4;
+  const int k_lo = gq * per, k_hi = k_lo + per < n_slabs ? k_lo + per : n_slabs;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < n) {
+    int k = k_lo;
+    for (; k + 3 < k_hi; k += 4) {
+      s0 += part[(int64_t)k * n + e];
+      s1 += part[(int64_t)(k + 1) * n + e];
+      s2 += part[(int64_t)(k + 2) * n + e];
+      s3 += part[(int64_t)(k + 3) * n + e];
+    }
+    for (; k < k_hi; ++k) s0 += part[(int64_t)k * n + e];
   }
-  if (k < n_slabs) s0 += part[(int64_t)k * n + e];
-  dst[e] = s0 + s1;
+  red[gq][l] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (gq == 0 && e < n) dst[e] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
 }
 ISD_ZONE_FN(ph_reduce_kernel, 256)
 __global__ __launch_bounds__(256) void ph_reduce_kernel(const float* __restrict__ part, int n_slabs, int64_t n,
@@ -694,7 +705,7 @@ static int ph_backward_stage(const isd_paperhead_plan* p, int stage, const float
     ISD_ZLAUNCH(ph_bwd_wgrad_kernel, dim3(slabs, (unsigned)(n_ctile * n_otile)), dim3(64), 0, st, ws + w.dy[l], in,
                        ws + w.part, l == 0 ? ws + w.pbias : (float*)nullptr, B, g.Ci[l], g.Ti[l], g.To[l], g.Fo[l],
                        n_ctile);
-    ISD_ZLAUNCH(ph_reduce_kernel, dim3((unsigned)cdiv(nw, 256)), dim3(256), 0, st, ws + w.part, slabs, nw,
+    ISD_ZLAUNCH(ph_reduce_kernel, dim3((unsigned)cdiv(nw, 64)), dim3(256), 0, st, ws + w.part, slabs, nw,
                        l == 0 ? ws + w.dweff : dparams + g.w[l]);
     if (l == 0) {
       ISD_ZLAUNCH(ph_reduce_kernel, dim3(1), dim3(256), 0, st, ws + w.pbias, slabs, (int64_t)g.Fo[0],
