@@ -1879,16 +1879,26 @@ ISD_ZONE_REGISTER(cv_bwd_w3_kernel)
 __device__ __forceinline__ void cv_w3_reduce_kernel_body(const float* __restrict__ part, int n_slabs,
                                                            float* __restrict__ dW3,
     unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= kF2 * kF2 * kK2) return;
-  float s0 = 0.f, s1 = 0.f;
-  int k = 0;
-  for (; k + 1 < n_slabs; k += 2) {
-    s0 += part[(int64_t)k * (kF2 * kF2 * kK2) + e];
-    s1 += part[(int64_t)(k + 1) * (kF2 * kF2 * kK2) + e];
+  // block = 64 elements x 4 slab groups (contiguous quarters of the slabs, combined in LDS in a fixed order): one
+  // thread per element walking up to 1024 slabs was a chain of dependent loads
+  __shared__ float red[4][64];
+  constexpr int N = kF2 * kF2 * kK2;
+  const int l = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + l;                      // N is a multiple of 64
+  const int per = (n_slabs + 3) / 4;
+  const int k_lo = gq * per, k_hi = k_lo + per < n_slabs ? k_lo + per : n_slabs;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = k_lo;
+  for (; k + 3 < k_hi; k += 4) {
+    s0 += part[(int64_t)k * N + e];
+    s1 += part[(int64_t)(k + 1) * N + e];
+    s2 += part[(int64_t)(k + 2) * N + e];
+    s3 += part[(int64_t)(k + 3) * N + e];
   }
-  if (k < n_slabs) s0 += part[(int64_t)k * (kF2 * kF2 * kK2) + e];
-  dW3[e] = s0 + s1;
+  for (; k < k_hi; ++k) s0 += part[(int64_t)k * N + e];
+  red[gq][l] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (gq == 0) dW3[e] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
 }
 ISD_ZONE_FN(cv_w3_reduce_kernel, 256)
 __global__ __launch_bounds__(256) void cv_w3_reduce_kernel(const float* __restrict__ part, int n_slabs,
@@ -2214,7 +2224,7 @@ static int eeg_backward_stage(const isd_eegnet_plan* p, int stage, const float* 
                          ws + w.dpooled, Cf, ws + w.da4, rows16 * T2p, T2p, T3, p->P2, dropout_p, seed);
       const int slabs3 = B < w.n_slabs ? (int)B : w.n_slabs;
       ISD_ZLAUNCH(cv_bwd_w3_kernel, dim3(slabs3), dim3(64), 0, st, ws + w.da4, ws + w.p2, ws + w.part, B, T2, T2p);
-      ISD_ZLAUNCH(cv_w3_reduce_kernel, dim3(kF2 * kF2 * kK2 / 256), dim3(256), 0, st, ws + w.part, slabs3,
+      ISD_ZLAUNCH(cv_w3_reduce_kernel, dim3(kF2 * kF2 * kK2 / 64), dim3(256), 0, st, ws + w.part, slabs3,
                          dparams + p->off.Wd);
       ISD_ZLAUNCH(cv_bwd_dp2_kernel, dim3((unsigned)cdiv(B * T2, 256)), dim3(256), 0, st, ws + w.da4, ws + w.w3b,
                          ws + w.da3, B, T2, T2p);
