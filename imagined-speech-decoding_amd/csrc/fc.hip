@@ -42,23 +42,37 @@ __device__ __forceinline__ void linear_fwd_kernel_body(const float* __restrict__
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += kKC) {
-    __syncthreads();
-    // clamped addresses + selects instead of a branch around each load: the 32 loads of a thread go out together
-    // (behind their bounds tests they were serial round trips: 34 us for a [320 x 256] x [256 x 32] product)
-#pragma unroll 8
-    for (int e = threadIdx.x; e < 64 * kKC; e += 256) {
+  // The next K chunk is fetched into registers while the matrix cores work on the current one (and every load of a
+  // chunk goes out behind clamped addresses, not bounds tests): with the fetch at the top of each chunk a
+  // [320 x 256] x [256 x 32] product was four exposed memory latencies long, 34 us on 5 workgroups.
+  constexpr int NL = 64 * kKC / 256;
+  float xv[NL], wv[NL];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int e = threadIdx.x + 256 * i;
       const int r = e / kKC, c = e - r * kKC;
       const int64_t m = m0 + r;
       const int k = k0 + c;
       const int kc = k < K ? k : K - 1;
-      const float xv = x[(m < M ? m : M - 1) * K + kc];
-      xs[r * kRS + c] = (m < M && k < K) ? xv : 0.f;
       const int o = o0 + r;
-      const float wv = w[(int64_t)(o < Nout ? o : Nout - 1) * so + kc * si];
-      wsm[r * kRS + c] = (o < Nout && k < K) ? wv : 0.f;
+      xv[i] = x[(m < M ? m : M - 1) * K + kc];
+      wv[i] = w[(int64_t)(o < Nout ? o : Nout - 1) * so + kc * si];
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += kKC) {
+    __syncthreads();                                    // the previous chunk's readers are done
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      const int r = e / kKC, c = e - r * kKC;
+      const bool kin = k0 + c < K;
+      xs[r * kRS + c] = (m0 + r < M && kin) ? xv[i] : 0.f;
+      wsm[r * kRS + c] = (o0 + r < Nout && kin) ? wv[i] : 0.f;
     }
     __syncthreads();
+    if (k0 + kKC < K) fetch(k0 + kKC);
     const float* xr = xs + (wave * 16 + (lane & 15)) * kRS + (lane >> 4);
     const float* wr = wsm + (lane & 15) * kRS + (lane >> 4);
 #pragma unroll 4
