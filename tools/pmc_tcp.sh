@@ -1,3 +1,4 @@
+# PMC pass over tools/prof_cfg5.py cfg5: L1 (TCP) / L2 (TCC) request counters per kernel
 set -e
 R=$PWD
 O=$R/gpurun_out/pmc_tcp

@@ -1,3 +1,4 @@
+# end-of-round refresh: tools/profile_r2.sh + the FAST head table + the EEGNet-head kernel table at B = 64
 set -e
 R=$PWD
 mkdir -p $R/gpurun_out/prof_r2 $R/gpurun_out/prof_r2b

@@ -1,3 +1,6 @@
+"""A/B check of the zone-batched launches (isd_zone_batch_*) against the per-zone calls for the three BatchNorm heads:
+outputs, parameter gradients and running statistics of one training step (ISD_ZONE_BATCH_OFF=1 selects the per-zone path).
+The test suite holds the same comparison: tests/test_bnheads_gpu.py::test_zone_batched_launches_equal_per_zone_calls."""
 import os, sys, time
 sys.path.insert(0, '/root/repo')
 import torch
