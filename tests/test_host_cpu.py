@@ -199,3 +199,19 @@ def test_dropout_streams_differ_per_module_instance_and_call():
     head = inn.Head("EEGNet_Encoder", ["a", "b", "c", "d"], {"z0": ["a", "b"], "z1": ["c", "d"]}, 16)
     ids = [enc._stream_id for enc in head.encoders.values()]
     assert len(set(ids)) == len(ids)
+
+
+def test_zone_batch_recorder_states_without_a_gpu():
+    """isd_zone_batch_* (include/isd_hip.h): the recorder's own state machine needs no device -- a launch with nothing
+    open fails, a second begin fails, abort closes, an empty batch launches nothing."""
+    import isd_amd._lib as L
+    lib = L.lib()
+    assert lib.isd_zone_batch_launch(None) != 0
+    assert b"no zone batch is open" in lib.isd_last_error()
+    assert lib.isd_zone_batch_begin() == 0
+    assert lib.isd_zone_batch_begin() != 0
+    assert lib.isd_zone_batch_abort() == 0
+    assert lib.isd_zone_batch_next() != 0
+    assert lib.isd_zone_batch_begin() == 0
+    assert lib.isd_zone_batch_next() == 0
+    assert lib.isd_zone_batch_launch(None) == 0
