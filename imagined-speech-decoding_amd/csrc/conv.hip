@@ -1543,7 +1543,7 @@ __device__ __forceinline__ void fused_wgrad_x_bf16(unsigned g_base, unsigned xt_
 // __builtin_amdgcn_s_waitcnt (vmcnt 0) + a workgroup barrier.  `lds_base` must be wave-uniform.
 __device__ __forceinline__ void dma16_async(const void* src_lane, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-               :: "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(src_lane) : "memory");
+               :: "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(src_lane) : "memory", "m0");
 }
 
 // One item ahead: GELU'(A4), A3 and A2 of the next item stream into the other tile set by LDS-DMA and its x channels

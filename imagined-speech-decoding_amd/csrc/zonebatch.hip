@@ -62,13 +62,15 @@ extern "C" int isd_zone_batch_launch(void* stream) {
     ISD_CHECK_ARG(zones[z].size() == len, "isd_zone_batch_launch: zone %d recorded %zu launches, zone 0 %zu", z,
                   zones[z].size(), len);
   const ZoneOp* ops[kMaxBatchZones];
-  for (size_t i = 0; i < len; ++i) {
-    for (int z = 0; z < n; ++z) {
-      ops[z] = &zones[z][i];
-      ISD_CHECK_ARG(ops[z]->kind == ops[0]->kind && ops[z]->kernel == ops[0]->kernel &&
-                        ops[z]->block.x == ops[0]->block.x && ops[z]->block.y == ops[0]->block.y,
+  // every chain is validated before the first launch goes out: a mismatch must not leave half a stage issued
+  for (size_t i = 0; i < len; ++i)
+    for (int z = 1; z < n; ++z) {
+      const ZoneOp &o = zones[z][i], &o0 = zones[0][i];
+      ISD_CHECK_ARG(o.kind == o0.kind && o.kernel == o0.kernel && o.block.x == o0.block.x && o.block.y == o0.block.y,
                     "isd_zone_batch_launch: launch %zu differs between zone 0 and zone %d", i, z);
     }
+  for (size_t i = 0; i < len; ++i) {
+    for (int z = 0; z < n; ++z) ops[z] = &zones[z][i];
     if (ops[0]->kind == 0) {
       ISD_HIP_TRY(ops[0]->zip(n, ops, st));
     } else {

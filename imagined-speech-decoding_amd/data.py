@@ -222,6 +222,8 @@ class DeviceStager:
         self.stream = torch.cuda.Stream(self.device)
         self._queue = []
         self._pinned = {}                                  # (slot, shape, dtype) -> reusable pinned buffer
+        self._puts = 0                                     # monotonic: the slot alternates whatever the queue holds
+        self._slot_done = [None, None]                     # the event behind the last upload out of each slot
 
     def _pin(self, slot, arr):
         torch = self.torch
@@ -236,7 +238,10 @@ class DeviceStager:
     def put(self, *arrays):
         """Start the upload of one item (any number of arrays: trials, labels)."""
         torch = self.torch
-        slot = len(self._queue) % 2                        # two pinned buffers per array position: double buffering
+        slot = self._puts % 2                              # two pinned buffers per array position: double buffering
+        self._puts += 1
+        if self._slot_done[slot] is not None:
+            self._slot_done[slot].synchronize()            # the DMA out of this slot's pinned buffers has finished
         outs = []
         with torch.cuda.stream(self.stream):
             for i, a in enumerate(arrays):
@@ -244,6 +249,7 @@ class DeviceStager:
                 outs.append(host.to(self.device, non_blocking=True))
             done = torch.cuda.Event()
             done.record(self.stream)
+        self._slot_done[slot] = done
         self._queue.append((outs, done))
 
     def get(self):

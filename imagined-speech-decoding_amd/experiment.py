@@ -159,9 +159,14 @@ def _fold_worker(device, tasks, results):
         task = tasks.get()
         if task is None:
             return
-        key, cfg, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, mode = task
-        acc, sd, _ = train_one_fold(cfg, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, mode)
-        results.put((key, acc, {k: v.cpu().numpy() for k, v in sd.items()}))
+        key = task[0]
+        try:
+            _, cfg, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, mode = task
+            acc, sd, _ = train_one_fold(cfg, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, mode)
+            results.put((key, acc, {k: v.cpu().numpy() for k, v in sd.items()}))
+        except Exception as e:                           # the parent re-raises; a silent worker would hang it
+            import traceback
+            results.put((key, None, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
 
 
 def run_folds(fold_tasks, workers=0, devices=None):
@@ -183,9 +188,28 @@ def run_folds(fold_tasks, workers=0, devices=None):
         tasks.put((k,) + tuple(t))
     for _ in procs:
         tasks.put(None)
+    import queue as _queue
     out = {}
-    for _ in fold_tasks:
-        k, acc, sd = results.get()
+
+    def _abort(msg):
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join()
+        raise RuntimeError(msg)
+    while len(out) < len(fold_tasks):
+        try:
+            k, acc, sd = results.get(timeout=1.0)
+        except _queue.Empty:
+            dead = [p for p in procs if p.exitcode not in (None, 0)]
+            if dead:                                     # killed (OOM, signal): it will never post its result
+                _abort(f"fold worker exited with code {dead[0].exitcode}")
+            if not any(p.is_alive() for p in procs) and results.empty():
+                _abort("fold workers ended without returning every fold")
+            continue
+        if acc is None:
+            _abort(f"fold {k} failed in its worker:\n{sd}")
         out[k] = (acc, {n: torch.from_numpy(v) for n, v in sd.items()})
     for p in procs:
         p.join()

@@ -53,9 +53,13 @@ class GraphedTrainStep:
         for enc in getattr(model.head, "encoders", {}).values():
             if hasattr(enc, "set_seed_counter"):
                 enc.set_seed_counter(model.seed_dev)
-        # warm-up steps build plans, workspaces and optimizer state; the training itself must not see them
+        # warm-up steps build plans, workspaces and optimizer state; the training itself must not see them:
+        # parameters, optimizer state AND module buffers (BatchNorm running statistics / num_batches_tracked of the
+        # EEGNet_Encoder / CVBlock / HeadConv_Paper_Version heads) are put back after the capture
         params = [p for g in opt.param_groups for p in g["params"]]
         keep = [p.detach().clone() for p in params]
+        keep_buf = {n: b.detach().clone() for n, b in model.named_buffers()}     # by NAME: the first forward of a
+        # BatchNorm head re-registers its running statistics as views of one packed block (nn._BNStackMixin)
         self.lr.zero_()                                        # lr 0 + restored parameters: the warm-up is a no-op
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
@@ -70,6 +74,8 @@ class GraphedTrainStep:
         with torch.no_grad():
             for p, k in zip(params, keep):
                 p.copy_(k)
+            for n, b in model.named_buffers():
+                b.copy_(keep_buf[n])
             for st in opt.state.values():                      # fresh optimizer state, as before the warm-up
                 for v in st.values():
                     if isinstance(v, torch.Tensor):

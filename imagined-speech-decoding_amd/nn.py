@@ -1041,6 +1041,9 @@ class Head(nn.Module, _FlatParamMixin):
             return False
         if any(e.training != encs[0].training for e in encs) or encs[0].feature_dim > 64:
             return False                                           # (wider projectors spread their weight gradient over grid.z)
+        if kind is not HeadConv_Paper_Version and len({e.in_channels >= 128 for e in encs}) > 1:
+            return False                # launch i must be the same kernel in every zone: the spatial projection takes
+                                        # whole rows per workgroup from 128 channels on (csrc/eegnet.hip, stage 1)
         if not encs[0].training and torch.is_grad_enabled() and any(p.requires_grad for e in encs for p in e.parameters()):
             return False                                           # eval-mode gradients: the per-zone backward_x path
         return _bn_sync_world(getattr(encs[0], "sync_bn", True), encs[0].training)[1] == 1

@@ -239,3 +239,23 @@ def test_zone_batched_launches_equal_per_zone_calls(inn, head, monkeypatch):
     L.check(lib.isd_zone_batch_abort())
     L.check(lib.isd_zone_batch_begin())
     L.check(lib.isd_zone_batch_launch(0))                              # an empty batch launches nothing
+
+
+def test_zones_on_both_sides_of_128_channels_take_the_per_zone_path(inn):
+    """a head whose zones straddle 128 channels records different kernel chains (the spatial projection
+    takes whole rows per workgroup from 128 channels on), so it must not be zone-batched -- it falls back to the
+    per-zone streams and matches the oracle zone by zone."""
+    electrodes = [f"E{i}" for i in range(140)]
+    zones = {"Wide": electrodes[:130], "Narrow": electrodes[130:]}
+    torch.manual_seed(2)
+    h = inn.Head("EEGNet_Encoder", electrodes, zones, 16).cuda().eval()
+    x = torch.randn(3, 140, 250, device="cuda")
+    assert not h._zone_batchable(list(h.encoders.values()), x)
+    with torch.no_grad():
+        f = h(x)
+    assert f.shape == (3, 2, 16)
+    for zi, (area, enc) in enumerate(h.encoders.items()):
+        p = {k: v.detach().cpu().double() for k, v in enc.state_dict().items()}
+        idx = torch.tensor([electrodes.index(e) for e in zones[area]])
+        ref = ocnn.eegnet_encoder(x.cpu().double()[:, idx], p, training=False)
+        assert rel_err(f[:, zi].cpu(), ref) < 1e-4, area

@@ -215,6 +215,30 @@ def test_device_stager_uploads_asynchronously_and_in_order(isd):
         assert abs(float(s) - float((xh.astype(np.float64) ** 2).sum())) < 1e-2 * float((xh ** 2).sum())
 
 
+def test_device_stager_never_overwrites_a_pinned_buffer_in_flight(isd):
+    """in the put(k+1) / get(k) loop the queue length is 1 at every put, so the pinned slot must come from a
+    put counter (not the queue length) and a slot is refilled only after the DMA out of it has completed.  Large items
+    (64 MB: the copy is still in flight when the next put arrives) over six batches."""
+    from isd_amd.data import DeviceStager
+    n_items, shape = 6, (64, 64, 4096)
+    items = [np.full(shape, float(k + 1), dtype=np.float32) for k in range(n_items)]
+    for it in items:
+        it[:, :, ::97] += np.arange(it[:, :, ::97].shape[-1], dtype=np.float32)
+    st = DeviceStager()
+    st.put(items[0])
+    slots, sums = [], []
+    for k in range(n_items):
+        if k + 1 < n_items:
+            st.put(items[k + 1])
+        xd = st.get()
+        sums.append((xd.double().sum(), xd[:, :, 1].clone()))
+    torch.cuda.synchronize()
+    assert st._puts == n_items and len({key[0][0] for key in st._pinned}) == 2       # both slots in use, alternating
+    for (s, col), it in zip(sums, items):
+        assert float(s) == float(it.astype(np.float64).sum())
+        assert np.array_equal(col.cpu().numpy(), it[:, :, 1])
+
+
 def test_fold_packing_over_worker_processes_equals_serial_run(isd, tmp_path):
     """The subject x fold trainings packed over two worker processes (scripts/train_fast.py:86-111 runs them one after
     another) give the results of the serial run: same fold accuracies, same best checkpoints."""
@@ -298,11 +322,23 @@ def test_graphed_step_with_batchnorm_heads(isd, head):
     X = rng.standard_normal((30, 64, 800)).astype(np.float32)
     y = rng.integers(0, 5, 30).astype(np.uint8)
     cfg = inn.fast_config(dropout=0.0, head=head)
-    hist = {}
+    hist, sds, accs = {}, {}, {}
     for graph in (False, True):
-        hist[graph] = E.train_one_fold(_no_head_dropout(cfg), X[:24], y[:24], X[24:], y[24:], 2, 12, seed=7, graph=graph)[2]
+        accs[graph], sds[graph], hist[graph] = E.train_one_fold(_no_head_dropout(cfg), X[:24], y[:24], X[24:], y[24:], 2,
+                                                                12, seed=7, graph=graph)
     for he, hg in zip(hist[False], hist[True]):
         assert abs(he["loss"] - hg["loss"]) < 5e-3 * max(1.0, abs(he["loss"])), (head, he, hg)
+    # the capture's warm-up steps must not leak into the BatchNorm buffers -- the graphed fold ends with
+    # the eager fold's running statistics, step count and validation accuracy
+    n_buf = 0
+    for k, v in sds[False].items():
+        if "num_batches_tracked" in k:
+            assert int(v) == int(sds[True][k]), k
+            n_buf += 1
+        elif "running_" in k:
+            assert float((v - sds[True][k]).abs().max()) < 5e-3 * max(1.0, float(v.abs().max())), k
+            n_buf += 1
+    assert n_buf > 0 and accs[False] == accs[True]
     # masks: EEGNet zones draw dropout (0.25) -- replays at learning rate 0 differ, the counter advances
     if head == "EEGNet_Encoder":
         torch.manual_seed(0)
@@ -319,7 +355,7 @@ def test_graphed_step_with_batchnorm_heads(isd, head):
             losses.append(float(g.loss_sum) / 16)
         assert len(set(losses)) == 3 and all(np.isfinite(losses)) and int(m.seed_dev) == 3
         nbt = next(iter(m.head.encoders.values())).temporal_conv[1].num_batches_tracked
-        assert int(nbt) >= 3                                      # BatchNorm bookkeeping advanced inside the replays
+        assert int(nbt) == 3                # BatchNorm bookkeeping advanced inside the replays, and only there
 
 
 def _no_head_dropout(cfg):

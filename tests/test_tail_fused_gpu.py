@@ -105,10 +105,119 @@ def test_fused_tail_full_batch_properties(inn):
     assert rel_err(lg[1000:1003].cpu(), want.detach()) < 1e-4
 
 
+def _host_masks(seed, B, S, D, H, L, p_blk, p_cls):
+    """The counter-based dropout masks of csrc/tailfused.hip (tf_drop / tf_keep) recomputed on the host: per layer the
+    attention-probability mask [B, H, S, S], the two MLP masks [B, S, 2D] / [B, S, D], and the cls mask [B, D]; every
+    entry is 0 or 1 / (1 - p) in fp32, exactly what the kernels multiply by."""
+    M64 = (1 << 64) - 1
+
+    def key(layer, site):
+        v = (seed + 0x9E3779B97F4A7C15 * (layer * 8 + site + 1)) & M64
+        v ^= v >> 30
+        v = (v * 0xBF58476D1CE4E5B9) & M64
+        v ^= v >> 27
+        v = (v * 0x94D049BB133111EB) & M64
+        v ^= v >> 31
+        return (v ^ (v >> 32)) & 0xFFFFFFFF
+
+    def keep(k, e, p):
+        e = e.astype(np.uint64)
+        lo, hi = (e & np.uint64(0xFFFFFFFF)).astype(np.uint32), (e >> np.uint64(32)).astype(np.uint32)
+        h = ((lo ^ (hi * np.uint32(0x27D4EB2F))) * np.uint32(0x9E3779B1)) ^ np.uint32(k)
+        h ^= h >> np.uint32(16)
+        h = h * np.uint32(0x85EBCA6B)
+        h ^= h >> np.uint32(13)
+        h = h * np.uint32(0xC2B2AE35)
+        h ^= h >> np.uint32(16)
+        u = (h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        inv = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+        return np.where(u >= np.float32(p), inv, np.float32(0.0)).astype(np.float64)
+
+    tok = (np.arange(B)[:, None] * S + np.arange(S)[None, :]).astype(np.int64)          # [B, S]
+    out = []
+    with np.errstate(over="ignore"):
+        for l in range(L):
+            e = (tok[:, None, :, None] * H + np.arange(H)[None, :, None, None]) * 8 + np.arange(S)[None, None, None, :]
+            out.append((keep(key(l, 0), e, p_blk),
+                        keep(key(l, 1), tok[:, :, None] * (2 * D) + np.arange(2 * D)[None, None, :], p_blk),
+                        keep(key(l, 2), tok[:, :, None] * D + np.arange(D)[None, None, :], p_blk)))
+        cls = keep(key(8, 0), np.arange(B)[:, None] * D + np.arange(D)[None, :], p_cls)
+    return out, cls
+
+
+def _torch_tail_masked(m, feature, masks, cls_mask):
+    """fast.py:10-29, 260-268 written out in fp64 torch with the dropout masks given: attention probabilities,
+    MLP hidden, MLP output, cls token (the four nn.Dropout / MultiheadAttention(dropout=) sites of the reference)."""
+    import torch.nn.functional as F
+    p = {k: v.detach().cpu().double().clone().requires_grad_() for k, v in m.state_dict().items()}
+    B, N, Z, Fd = feature.shape
+    x = feature.detach().cpu().double().reshape(B, N, Z * Fd).requires_grad_()
+    tok = F.gelu(F.linear(x, p["input_layer.0.weight"], p["input_layer.0.bias"]))
+    tok = torch.cat([p["cls_token"].expand(B, -1, -1), tok], dim=1) + p["pos_embedding"][:, :N + 1]
+    D, H = m.config.dim_token, m.config.num_heads
+    S, dh = N + 1, D // H
+    for l, (ma, m1, m2) in enumerate(masks):
+        q = f"transformer.{l}."
+        h = F.layer_norm(tok, (D,), p[q + "layer_norm_1.weight"], p[q + "layer_norm_1.bias"])
+        qkv = F.linear(h, p[q + "attn.in_proj_weight"], p[q + "attn.in_proj_bias"]).view(B, S, 3, H, dh)
+        qq, kk, vv = (qkv[:, :, t].transpose(1, 2) for t in range(3))                    # [B, H, S, dh]
+        pr = torch.softmax(qq @ kk.transpose(-1, -2) / dh ** 0.5, dim=-1) * torch.from_numpy(ma)
+        ctx = (pr @ vv).transpose(1, 2).reshape(B, S, D)
+        tok = tok + F.linear(ctx, p[q + "attn.out_proj.weight"], p[q + "attn.out_proj.bias"])
+        h = F.layer_norm(tok, (D,), p[q + "layer_norm_2.weight"], p[q + "layer_norm_2.bias"])
+        h = F.gelu(F.linear(h, p[q + "linear.0.weight"], p[q + "linear.0.bias"])) * torch.from_numpy(m1)
+        tok = tok + F.linear(h, p[q + "linear.3.weight"], p[q + "linear.3.bias"]) * torch.from_numpy(m2)
+    cls = tok[:, 0] * torch.from_numpy(cls_mask)
+    return F.linear(cls, p["last_layer.weight"], p["last_layer.bias"]), p, x
+
+
+@pytest.mark.parametrize("B,N,kw", [
+    (64, 5, {}),                                                         # production shape, 10 trials per workgroup
+    (23, 7, dict(seq_len=1000)),                                         # 8 tokens, ragged last workgroup
+    (9, 2, dict(dim_token=16, num_heads=2, num_layers=2, n_classes=3)),  # head width 8, D = 16
+])
+def test_fused_tail_under_dropout_matches_torch_autograd_with_the_same_masks(inn, B, N, kw):
+    """Training mode, dropout 0.3: the kernels' counter-based masks are recomputed on the host
+    from the launch's seed, the reference network is evaluated in fp64 torch with exactly those masks, and the logits,
+    EVERY parameter gradient of the tail (52 tensors at 4 blocks), the token-projection gradients and the gradient
+    w.r.t. the zone features must agree per tensor -- the same bound as the dropout-free comparison above."""
+    from isd_amd.nn import _dropout_seed
+    torch.manual_seed(20 + B)
+    m = inn.FAST(inn.fast_config(dropout=0.3, **kw)).cuda().train()
+    feature = torch.randn(B, N, 8, 32, device="cuda")
+    y = torch.randint(0, m.config.n_classes, (B,), device="cuda")
+    m.zero_grad(set_to_none=True)
+    m._tail_calls = 40
+    f = feature.clone().requires_grad_()
+    logits = m.forward_transformer(f)
+    torch.nn.functional.cross_entropy(logits, y).backward()
+    seed = _dropout_seed(m._tail_stream, m._tail_calls)
+    c = m.config
+    masks, cls_mask = _host_masks(seed, B, N + 1, c.dim_token, c.num_heads, len(m.transformer), 0.3, 0.3)
+    frac = float(np.mean([float((a == 0).mean()) for ms in masks for a in ms]))
+    assert 0.25 < frac < 0.35                                           # the masks do drop ~30 %
+    want, p, xr = _torch_tail_masked(m, feature, masks, cls_mask)
+    torch.nn.functional.cross_entropy(want, y.cpu()).backward()
+    assert rel_err(logits.detach().cpu(), want.detach()) < 1e-4
+    named = dict(m.named_parameters())
+    tail = [k for k in named if not k.startswith("head.")]
+    assert len(tail) == 2 + 2 + 2 + 12 * len(m.transformer)
+    for k in tail:
+        assert rel_err(named[k].grad.cpu(), p[k].grad) < 2e-4, k
+    assert rel_err(f.grad.cpu().reshape(B, N, -1), xr.grad) < 2e-4
+    # eval mode draws nothing
+    m.eval()
+    with torch.no_grad():
+        le = m.forward_transformer(feature)
+    ones = [tuple(np.ones_like(a) for a in ms) for ms in masks]
+    we, _, _ = _torch_tail_masked(m, feature, ones, np.ones_like(cls_mask))
+    assert rel_err(le.cpu(), we.detach()) < 1e-4
+
+
 def test_fused_tail_dropout_masks_and_directional_derivative(inn):
     """Training mode, dropout 0.3: masks are counter-based -- the same call index reproduces the logits, the next one
-    does not -- and the analytic gradient equals the central
-    difference of the loss along the gradient direction (same masks on both sides)."""
+    does not -- and the analytic gradient equals the central difference of the loss along RANDOM directions (same masks
+    on both sides; fp64 loss, a step small enough that the cubic term is below the bound)."""
     torch.manual_seed(2)
     m = inn.FAST(inn.fast_config(dropout=0.3)).cuda().train()
     B = 64
@@ -129,20 +238,25 @@ def test_fused_tail_dropout_masks_and_directional_derivative(inn):
         le = float(loss_at(7))
         m.train()
         assert le != float(l0)
-        gnorm = float(torch.sqrt(sum((a.double() ** 2).sum() for a in g)))
-        v = [a / gnorm for a in g]                       # unit step along the gradient: the derivative there is |g|
-        eps = 1e-2
-        for q, d in zip(ps, v):
-            q.add_(eps * d)
-        lp = float(loss_at(7))
-        for q, d in zip(ps, v):
-            q.sub_(2 * eps * d)
-        lm = float(loss_at(7))
-        for q, d in zip(ps, v):
-            q.add_(eps * d)
-    fd = (lp - lm) / (2 * eps)
-    an = float(sum((a.double() * d.double()).sum() for a, d in zip(g, v)))
-    assert abs(fd - an) < 2e-2 * abs(an) + 1e-5, (fd, an)
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        for trial in range(3):
+            # random direction, each tensor's step relative to its own scale (a uniform absolute step on every
+            # parameter is dominated by the curvature of the smallest tensors)
+            v = [torch.randn(q.shape, device="cuda", generator=gen) * q.abs().mean().clamp_min(1e-3) for q in ps]
+            errs = []
+            for eps in (4e-3, 2e-3):
+                for q, d in zip(ps, v):
+                    q.add_(eps * d)
+                lp = float(loss_at(7))
+                for q, d in zip(ps, v):
+                    q.sub_(2 * eps * d)
+                lm = float(loss_at(7))
+                for q, d in zip(ps, v):
+                    q.add_(eps * d)
+                errs.append((lp - lm) / (2 * eps))
+            an = float(sum((a.double() * d.double()).sum() for a, d in zip(g, v)))
+            fd = (4 * errs[1] - errs[0]) / 3                               # Richardson: removes the eps^2 term
+            assert abs(fd - an) < 2e-2 * abs(an) + 2e-5, (trial, errs, fd, an)
 
 
 def test_fused_tail_rejects_bad_arguments(inn):
