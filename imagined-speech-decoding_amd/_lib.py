@@ -91,6 +91,8 @@ SIGNATURES = {
     "isd_paperhead_forward_stage": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _i, _p]),
     "isd_paperhead_backward_stage": (_i, [_p, _i, _p, _p, _p, _p, _p, _i64, _i, _p]),
     "isd_paperhead_sync_block": (_i, [_p, _i64, _i, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "isd_paperhead_sync_block_kind": (_i, [_i, _i]),
+    "isd_eegnet_sync_block_kind": (_i, [_i, _i]),
     "isd_zone_batch_begin": (_i, []),
     "isd_zone_batch_next": (_i, []),
     "isd_zone_batch_launch": (_i, [_p]),

@@ -20,6 +20,7 @@
 // break parity with any reference RNG stream).
 #include "common.h"
 #include "zonebatch.h"
+#include "exact.h"
 #include <math.h>
 #include <stddef.h>
 #include <string.h>
@@ -43,7 +44,8 @@ struct EegOff {
 // offsets inside the buffer block: rm1 rv1 rm2 rv2 rm3 rv3
 constexpr int kRm1 = 0, kRv1 = 8, kRm2 = 16, kRv2 = 32, kRm3 = 48, kRv3 = 64, kBufTotal = 80;
 
-// fp64 statistics block (doubles) in the workspace
+// Statistics block in the workspace.  Sums that many workgroups add to are ExactAcc (exact.h: integer atomics, the same
+// bits whatever the arrival order); what single workgroups derive from them is fp64.
 struct EegStats {
   double A[kMaxK];              // sum_rows sum_s x[s] x[s+d]
   double H[32][kMaxK];          // head prefix:  H[a][d] = sum_rows sum_{s<a} x[s] x[s+d]
@@ -52,18 +54,19 @@ struct EegStats {
   double Hs[32];                // Hs[a] = sum_rows sum_{s<a} x[s]
   double Ts[33];                // Ts[e] = sum_rows sum_{s>T-e} x[s]
   // raw accumulators of eeg_stats_kernel (eeg_stats_derive_kernel turns them into A, H, Tl, Hs, Ts above)
-  double D[5][256];             // D[q][i][j] = sum_rows sum_k x[16k+i] x[16k+j+16q]   (matrix cores)
-  double Gs[80][80];            // short rows (T <= 79): upper triangle of the full Gram matrix sum_rows y[a] y[j], with
+  ExactAcc Sx;                  // sum of all samples (eeg_stats_kernel; S above is its fp64 reading)
+  ExactAcc D[5][256];           // D[q][i][j] = sum_rows sum_k x[16k+i] x[16k+j+16q]   (matrix cores)
+  ExactAcc Gs[80][80];          // short rows (T <= 79): upper triangle of the full Gram matrix sum_rows y[a] y[j], with
                                 //   y = (x[0..T), 1, 0, ...) (eeg_stats_gram_kernel); everything below is derived from it
-  double Pe[2][32][96];         // Gram blocks of the head / tail windows (eeg_stats_edge_kernel):
+  ExactAcc Pe[2][32][96];       // Gram blocks of the head / tail windows (eeg_stats_edge_kernel):
                                 //   sum_rows x[s] x[s+d] = Pe[0][s][s+d],  sum_rows x[T-i] x[T-i+d] = Pe[1][31-i][31-i+d],
                                 //   sum_rows x[s] = Pe[0][31][s],          sum_rows x[T-i]        = Pe[1][31][31-i]
-  double u1[kF2], u2[kF2];      // sum u, sum u^2 per g
-  double a1[kF2], a2[kF2];      // sum a4, sum a4^2 per h
-  double dy3s[kF2], dy3x[kF2];  // BN3 backward sums
-  double dy2s[kF2], dy2x[kF2];  // BN2 backward sums
-  double Sd[kF2], Su[kF2];      // sum da2, sum da2*u
-  double T1[kF2][kMaxK];        // sum da2[t'] zpad[t'+k]
+  ExactAcc u1[kF2], u2[kF2];      // sum u, sum u^2 per g
+  ExactAcc a1[kF2], a2[kF2];      // sum a4, sum a4^2 per h
+  ExactAcc dy3s[kF2], dy3x[kF2];  // BN3 backward sums
+  ExactAcc dy2s[kF2], dy2x[kF2];  // BN2 backward sums
+  ExactAcc Sd[kF2], Su[kF2];      // sum da2, sum da2*u
+  ExactAcc T1[kF2][kMaxK];        // sum da2[t'] zpad[t'+k]
   double dWp[kF2][kF2], dWd[kF2][kK2];
 };
 
@@ -183,19 +186,23 @@ __device__ __forceinline__ void eeg_stats_kernel_body(const float* __restrict__ 
       }
     }
   }
-  __syncthreads();                                              // tot[] is zero
-#pragma unroll
-  for (int q = 0; q < 5; ++q)
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) atomicAdd(&tot[q * 4 + rr][lane], Dq[q][rr]);
   const float rtot = wave_sum(rs);
-  if (lane == 0) atomicAdd(&tot[20][0], rtot);
+  for (int w = 0; w < kStatWaves; ++w) {                        // the waves add in wave order: the same fp32 sum every run
+    __syncthreads();                                            // (first pass: tot[] is zero)
+    if (wave == w) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) tot[q * 4 + rr][lane] += Dq[q][rr];
+      if (lane == 0) tot[20][0] += rtot;
+    }
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < 20 * 64; e += 64 * kStatWaves) {
     const int slot = e >> 6, l = e & 63;
-    atomicAdd(&st->D[slot >> 2][(4 * (l >> 4) + (slot & 3)) * 16 + (l & 15)], (double)tot[slot][l]);
+    exact_add(&st->D[slot >> 2][(4 * (l >> 4) + (slot & 3)) * 16 + (l & 15)], tot[slot][l]);
   }
-  if (threadIdx.x == 0) atomicAdd(&st->S, (double)tot[20][0]);
+  if (threadIdx.x == 0) exact_add(&st->Sx, tot[20][0]);
 }
 ISD_ZONE_FN(eeg_stats_kernel, 64 * kStatWaves)
 __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_kernel(const float* __restrict__ x,
@@ -260,16 +267,20 @@ __device__ __forceinline__ void eeg_stats_edge_kernel_body(const float* __restri
       }
     }
   }
-  __syncthreads();                                              // tot[] is zero
+  for (int w = 0; w < kStatWaves; ++w) {                        // wave order (see eeg_stats_kernel)
+    __syncthreads();
+    if (wave == w) {
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 6; ++nt)
+        for (int nt = 0; nt < 6; ++nt)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) atomicAdd(&tot[16 * mt + 4 * q + rr][16 * nt + i], acc[mt][nt][rr]);
+          for (int rr = 0; rr < 4; ++rr) tot[16 * mt + 4 * q + rr][16 * nt + i] += acc[mt][nt][rr];
+    }
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < 32 * 96; e += 64 * kStatWaves)
-    atomicAdd(&st->Pe[which][e / 96][e % 96], (double)tot[e / 96][e % 96]);
+    exact_add(&st->Pe[which][e / 96][e % 96], tot[e / 96][e % 96]);
 }
 ISD_ZONE_FN(eeg_stats_edge_kernel, 64 * kStatWaves)
 __global__ __launch_bounds__(64 * kStatWaves) void eeg_stats_edge_kernel(const float* __restrict__ x,
@@ -326,17 +337,21 @@ __device__ __forceinline__ void eeg_stats_gram_kernel_body(const float* __restri
         for (int nt = mt; nt < MT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[h][mt], y[h][nt], acc[mt][nt], 0, 0, 0);
   }
-  __syncthreads();                                              // tot[] is zero
+  for (int w = 0; w < kStatWaves; ++w) {                        // wave order (see eeg_stats_kernel)
+    __syncthreads();
+    if (wave == w) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = mt; nt < MT; ++nt)
+        for (int nt = mt; nt < MT; ++nt)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) atomicAdd(&tot[16 * mt + 4 * q + rr][16 * nt + i], acc[mt][nt][rr]);
+          for (int rr = 0; rr < 4; ++rr) tot[16 * mt + 4 * q + rr][16 * nt + i] += acc[mt][nt][rr];
+    }
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < 256 * MT * MT; e += 64 * kStatWaves) {
     const int a = e / (16 * MT), j = e - a * (16 * MT);
-    if (j >= a && a <= T && j <= T) atomicAdd(&st->Gs[a][j], (double)tot[a][j]);
+    if (j >= a && a <= T && j <= T) exact_add(&st->Gs[a][j], tot[a][j]);
   }
 }
 ISD_ZONE_FN_T(eeg_stats_gram_kernel, 64 * kStatWaves, int)
@@ -359,27 +374,27 @@ __device__ __forceinline__ void eeg_stats_gram_derive_kernel_body(EegStats* __re
     unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int d = threadIdx.x;
   double a = 0.0;
-  for (int s = 0; s + d < T; ++s) a += st->Gs[s][s + d];
+  for (int s = 0; s + d < T; ++s) a += exact_get(&st->Gs[s][s + d]);
   st->A[d] = a;
   double h = 0.0, t = 0.0;
   for (int k = 1; k < 32; ++k) {
     const int s = k - 1;
-    if (s + d < T) h += st->Gs[s][s + d];                // H[k][d] = sum_{s<k} x[s] x[s+d]
+    if (s + d < T) h += exact_get(&st->Gs[s][s + d]);                // H[k][d] = sum_{s<k} x[s] x[s+d]
     st->H[k][d] = h;
   }
   for (int e = 2; e < 33; ++e) {
     const int s = T - (e - 1);
-    if (s >= 0 && s + d < T) t += st->Gs[s][s + d];      // Tl[e][d] = sum_{i<e} x[T-i] x[T-i+d]
+    if (s >= 0 && s + d < T) t += exact_get(&st->Gs[s][s + d]);      // Tl[e][d] = sum_{i<e} x[T-i] x[T-i+d]
     st->Tl[e][d] = t;
   }
   if (d == 0) {
     double tot = 0.0, hs = 0.0, ts = 0.0;
-    for (int j = 0; j < T; ++j) tot += st->Gs[j][T];
+    for (int j = 0; j < T; ++j) tot += exact_get(&st->Gs[j][T]);
     st->S = tot;
     st->Hs[0] = 0.0;
-    for (int k = 1; k < 32; ++k) { if (k - 1 < T) hs += st->Gs[k - 1][T]; st->Hs[k] = hs; }
+    for (int k = 1; k < 32; ++k) { if (k - 1 < T) hs += exact_get(&st->Gs[k - 1][T]); st->Hs[k] = hs; }
     st->Ts[0] = st->Ts[1] = 0.0;
-    for (int e = 2; e < 33; ++e) { if (T - (e - 1) >= 0) ts += st->Gs[T - (e - 1)][T]; st->Ts[e] = ts; }
+    for (int e = 2; e < 33; ++e) { if (T - (e - 1) >= 0) ts += exact_get(&st->Gs[T - (e - 1)][T]); st->Ts[e] = ts; }
   }
 }
 ISD_ZONE_FN(eeg_stats_gram_derive_kernel, 64)
@@ -394,23 +409,24 @@ __device__ __forceinline__ void eeg_stats_derive_kernel_body(EegStats* __restric
     unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   const int d = threadIdx.x;
   double a = 0.0;
-  for (int i = 0; i < 16; ++i) a += st->D[(i + d) >> 4][i * 16 + ((i + d) & 15)];
+  for (int i = 0; i < 16; ++i) a += exact_get(&st->D[(i + d) >> 4][i * 16 + ((i + d) & 15)]);
   st->A[d] = a;
   double h = 0.0, t = 0.0;
   for (int k = 1; k < 32; ++k) {
-    h += st->Pe[0][k - 1][k - 1 + d];                    // H[k][d] = sum_{s<k} x[s] x[s+d]
+    h += exact_get(&st->Pe[0][k - 1][k - 1 + d]);                    // H[k][d] = sum_{s<k} x[s] x[s+d]
     st->H[k][d] = h;
   }
   for (int e = 2; e < 33; ++e) {
-    t += st->Pe[1][32 - e][32 - e + d];                  // Tl[e][d] = sum_{i<e} x[T-i] x[T-i+d],  i = e - 1
+    t += exact_get(&st->Pe[1][32 - e][32 - e + d]);                  // Tl[e][d] = sum_{i<e} x[T-i] x[T-i+d],  i = e - 1
     st->Tl[e][d] = t;
   }
   if (d == 0) {
     double hs = 0.0, ts = 0.0;
+    st->S = exact_get(&st->Sx);
     st->Hs[0] = 0.0;
-    for (int k = 1; k < 32; ++k) { hs += st->Pe[0][31][k - 1]; st->Hs[k] = hs; }
+    for (int k = 1; k < 32; ++k) { hs += exact_get(&st->Pe[0][31][k - 1]); st->Hs[k] = hs; }
     st->Ts[0] = st->Ts[1] = 0.0;
-    for (int e = 2; e < 33; ++e) { ts += st->Pe[1][31][32 - e]; st->Ts[e] = ts; }
+    for (int e = 2; e < 33; ++e) { ts += exact_get(&st->Pe[1][31][32 - e]); st->Ts[e] = ts; }
   }
 }
 ISD_ZONE_FN(eeg_stats_derive_kernel, 64)
@@ -775,8 +791,8 @@ __device__ __forceinline__ void eeg_tconv_kernel_body(const float* __restrict__ 
     const float s1 = block_sum(t1, red);
     const float s2 = block_sum(t2, red);
     if (threadIdx.x == 0) {
-      atomicAdd(&st->u1[g], (double)s1);
-      atomicAdd(&st->u2[g], (double)s2);
+      exact_add(&st->u1[g], s1);
+      exact_add(&st->u2[g], s2);
     }
   }
 }
@@ -803,8 +819,8 @@ __device__ __forceinline__ void eeg_finalize2_kernel_body(const float* __restric
   const float s1 = co->s1[f], c1 = co->o1[f] * co->wsum[g];
   double mu2, var2;
   if (training) {
-    const double muu = st->u1[g] / N2;
-    double varu = st->u2[g] / N2 - muu * muu;
+    const double muu = exact_get(&st->u1[g]) / N2;
+    double varu = exact_get(&st->u2[g]) / N2 - muu * muu;
     if (varu < 0.0) varu = 0.0;
     co->muu[g] = muu;
     co->varu[g] = varu;
@@ -914,8 +930,8 @@ __device__ __forceinline__ void eeg_sep_kernel_body(const float* __restrict__ p2
     __syncthreads();
     if (threadIdx.x < 2 * kF2) {
       const float tot = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-      if (threadIdx.x < kF2) atomicAdd(&st->a1[threadIdx.x], (double)tot);
-      else atomicAdd(&st->a2[threadIdx.x - kF2], (double)tot);
+      if (threadIdx.x < kF2) exact_add(&st->a1[threadIdx.x], tot);
+      else exact_add(&st->a2[threadIdx.x - kF2], tot);
     }
   }
 }
@@ -937,8 +953,8 @@ __device__ __forceinline__ void eeg_finalize3_kernel_body(const float* __restric
   if (h >= kF2) return;
   double mu, var;
   if (training) {
-    mu = st->a1[h] / N3;
-    var = st->a2[h] / N3 - mu * mu;
+    mu = exact_get(&st->a1[h]) / N3;
+    var = exact_get(&st->a2[h]) / N3 - mu * mu;
     if (var < 0.0) var = 0.0;
     bufs[kRm3 + h] = (1.f - momentum) * bufs[kRm3 + h] + momentum * (float)mu;
     bufs[kRv3 + h] = (1.f - momentum) * bufs[kRv3 + h] + momentum * (float)(var * N3 / (N3 > 1.0 ? N3 - 1.0 : 1.0));
@@ -1016,8 +1032,8 @@ __device__ __forceinline__ void eeg_bwd3_sums_kernel_body(const float* __restric
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   if (lane == 0) {
-    atomicAdd(&st->dy3s[h], (double)s1);
-    atomicAdd(&st->dy3x[h], (double)s2);
+    exact_add(&st->dy3s[h], s1);
+    exact_add(&st->dy3x[h], s2);
   }
 }
 ISD_ZONE_FN(eeg_bwd3_sums_kernel, 256)
@@ -1041,17 +1057,17 @@ __device__ __forceinline__ void eeg_bwd_bn_coef_kernel_body(const float* __restr
   if (h >= kF2) return;
   const double inv = bn_train ? 1.0 / N : 0.0;           // running statistics do not depend on the batch: no mean terms
   if (which == 3) {
-    dparams[off.g3 + h] = (float)(st->dy3x[h] * gs);
-    dparams[off.b3 + h] = (float)(st->dy3s[h] * gs);
+    dparams[off.g3 + h] = (float)(exact_get(&st->dy3x[h]) * gs);
+    dparams[off.b3 + h] = (float)(exact_get(&st->dy3s[h]) * gs);
     co->cA3[h] = params[off.g3 + h] / co->sig3[h];
-    co->cB3[h] = (float)(st->dy3s[h] * inv);
-    co->cC3[h] = (float)(st->dy3x[h] * inv);
+    co->cB3[h] = (float)(exact_get(&st->dy3s[h]) * inv);
+    co->cC3[h] = (float)(exact_get(&st->dy3x[h]) * inv);
   } else {
-    dparams[off.g2 + h] = (float)(st->dy2x[h] * gs);
-    dparams[off.b2 + h] = (float)(st->dy2s[h] * gs);
+    dparams[off.g2 + h] = (float)(exact_get(&st->dy2x[h]) * gs);
+    dparams[off.b2 + h] = (float)(exact_get(&st->dy2s[h]) * gs);
     co->cA2[h] = params[off.g2 + h] / co->sig2[h];
-    co->cB2[h] = (float)(st->dy2s[h] * inv);
-    co->cC2[h] = (float)(st->dy2x[h] * inv);
+    co->cB2[h] = (float)(exact_get(&st->dy2s[h]) * inv);
+    co->cC2[h] = (float)(exact_get(&st->dy2x[h]) * inv);
   }
 }
 ISD_ZONE_FN(eeg_bwd_bn_coef_kernel, 1024)
@@ -1198,8 +1214,8 @@ __device__ __forceinline__ void eeg_bwd_pool2_kernel_body(const float* __restric
   const float s1 = block_sum(t1, red);
   const float s2 = block_sum(t2, red);
   if (threadIdx.x == 0) {
-    atomicAdd(&st->dy2s[g], (double)s1);
-    atomicAdd(&st->dy2x[g], (double)s2);
+    exact_add(&st->dy2s[g], s1);
+    exact_add(&st->dy2x[g], s2);
   }
 }
 ISD_ZONE_FN(eeg_bwd_pool2_kernel, 256)
@@ -1233,8 +1249,8 @@ __device__ __forceinline__ void eeg_bwd_bn2_kernel_body(float* __restrict__ dy2,
   const float s1 = block_sum(t1, red);
   const float s2 = block_sum(t2, red);
   if (threadIdx.x == 0) {
-    atomicAdd(&st->Sd[g], (double)s1);
-    atomicAdd(&st->Su[g], (double)s2);
+    exact_add(&st->Sd[g], s1);
+    exact_add(&st->Su[g], s2);
   }
 }
 ISD_ZONE_FN(eeg_bwd_bn2_kernel, 256)
@@ -1356,7 +1372,7 @@ __device__ __forceinline__ void eeg_bwd_corr_kernel_body(const float* __restrict
   for (int k = 0; k < KA; ++k) {
     if (KT || k < K) {
       const float tot = wave_sum(acc[k]);
-      if (lane == 0) atomicAdd(&st->T1[g][k], (double)tot);
+      if (lane == 0) exact_add(&st->T1[g][k], tot);
     }
   }
 }
@@ -1488,7 +1504,7 @@ __device__ __forceinline__ void eeg_bwd_dws_reduce_kernel_body(const float* __re
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += red[i][lane];
     const int g = e / C, f = g >> 1;
-    dWs[e] = co->s1[f] * t + co->o1[f] * (float)st->Sd[g];
+    dWs[e] = co->s1[f] * t + co->o1[f] * (float)exact_get(&st->Sd[g]);
   }
 }
 ISD_ZONE_FN(eeg_bwd_dws_reduce_kernel, 1024)
@@ -1516,8 +1532,8 @@ __device__ __forceinline__ void eeg_bwd_final_kernel_body(const float* __restric
   __shared__ double SD[kF1], SU[kF1];
   if (threadIdx.x < kF1) {
     const int f = threadIdx.x;
-    const double sd = (double)co->wsum[2 * f] * st->Sd[2 * f] + (double)co->wsum[2 * f + 1] * st->Sd[2 * f + 1];
-    const double su = st->Su[2 * f] + st->Su[2 * f + 1];
+    const double sd = (double)co->wsum[2 * f] * exact_get(&st->Sd[2 * f]) + (double)co->wsum[2 * f + 1] * exact_get(&st->Sd[2 * f + 1]);
+    const double su = exact_get(&st->Su[2 * f]) + exact_get(&st->Su[2 * f + 1]);
     SD[f] = sd;
     SU[f] = su;
     dparams[off.b1 + f] = (float)(sd * gs);
@@ -1528,7 +1544,7 @@ __device__ __forceinline__ void eeg_bwd_final_kernel_body(const float* __restric
   for (int e = threadIdx.x; e < kF1 * K; e += 256) {
     const int f = e / K, k = e - f * K;
     const double sig = co->sig1[f], mu = co->mu1[f];
-    const double t1 = st->T1[2 * f][k] + st->T1[2 * f + 1][k];
+    const double t1 = exact_get(&st->T1[2 * f][k]) + exact_get(&st->T1[2 * f + 1][k]);
     const double meanD = bn_train ? SD[f] / N1 : 0.0;
     const double meanDa = bn_train ? (SU[f] - mu * SD[f]) / (sig * N1) : 0.0;
     double wg = 0.0;
@@ -1584,8 +1600,8 @@ __device__ __forceinline__ void eeg_bwd_dx_kernel_body(const float* __restrict__
   if (bn_train) {
     if (tid < kF1) {
       const int f = tid;
-      const double sd = (double)co->wsum[2 * f] * st->Sd[2 * f] + (double)co->wsum[2 * f + 1] * st->Sd[2 * f + 1];
-      const double su = st->Su[2 * f] + st->Su[2 * f + 1];
+      const double sd = (double)co->wsum[2 * f] * exact_get(&st->Sd[2 * f]) + (double)co->wsum[2 * f + 1] * exact_get(&st->Sd[2 * f + 1]);
+      const double su = exact_get(&st->Su[2 * f]) + exact_get(&st->Su[2 * f + 1]);
       const double sig = co->sig1[f], mu = co->mu1[f], g1 = params[off.g1 + f];
       const double meanD = sd / N1, meanDa = (su - mu * sd) / (sig * N1);
       const double c3 = g1 * meanDa / (sig * sig);
@@ -1702,8 +1718,8 @@ __device__ __forceinline__ void cv_conv3_kernel_body(const float* __restrict__ p
       if (threadIdx.x == 0) { tot[h] = s1; tot[kF2 + h] = s2; }
     }
     __syncthreads();
-    if (threadIdx.x < kF2) atomicAdd(&st->a1[threadIdx.x], (double)tot[threadIdx.x]);
-    else if (threadIdx.x < 2 * kF2) atomicAdd(&st->a2[threadIdx.x - kF2], (double)tot[threadIdx.x]);
+    if (threadIdx.x < kF2) exact_add(&st->a1[threadIdx.x], tot[threadIdx.x]);
+    else if (threadIdx.x < 2 * kF2) exact_add(&st->a2[threadIdx.x - kF2], tot[threadIdx.x]);
   }
 }
 ISD_ZONE_FN(cv_conv3_kernel, 256)
@@ -1768,8 +1784,8 @@ __device__ __forceinline__ void cv_bwd3_sums_kernel_body(const float* __restrict
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   if (lane == 0) {
-    atomicAdd(&st->dy3s[h], (double)s1);
-    atomicAdd(&st->dy3x[h], (double)s2);
+    exact_add(&st->dy3s[h], s1);
+    exact_add(&st->dy3x[h], s2);
   }
 }
 ISD_ZONE_FN(cv_bwd3_sums_kernel, 256)
@@ -2351,3 +2367,6 @@ extern "C" int isd_eegnet_sync_block(const isd_eegnet_plan* p, int64_t B, int ba
   *n_doubles = (int64_t)((hi - lo) / sizeof(double));
   return ISD_OK;
 }
+
+// 0: the block holds fp64 sums; 1: 64-bit integer words of exact accumulators (csrc/exact.h) -- all-reduce as int64
+extern "C" int isd_eegnet_sync_block_kind(int backward, int stage) { return (backward || stage > 0) ? 1 : 0; }

@@ -15,6 +15,7 @@
 // Statistics and cross-batch sums accumulate in fp64.
 #include "common.h"
 #include "zonebatch.h"
+#include "exact.h"
 #include <math.h>
 #include <stddef.h>
 
@@ -40,8 +41,9 @@ struct PhGeo {
 struct PhStats {
   // per layer one contiguous block of batch sums (under data parallelism it is all-reduced before the layer's
   // normalisation / BatchNorm backward: synchronised BatchNorm)
-  double s[4][2][kPhMaxF];                  // [layer][sum y | sum y^2]
-  double d[4][2][kPhMaxF];                  // [layer][sum dyhat | sum dyhat*xhat]
+  // (ExactAcc, csrc/exact.h: integer atomics -- the same bits whatever the order the workgroups arrive in)
+  ExactAcc s[4][2][kPhMaxF];                // [layer][sum y | sum y^2]
+  ExactAcc d[4][2][kPhMaxF];                // [layer][sum dyhat | sum dyhat*xhat]
 };
 struct PhCoef {
   float A[4][kPhMaxF], Bc[4][kPhMaxF], mu[4][kPhMaxF], isg[4][kPhMaxF];
@@ -115,7 +117,7 @@ ISD_ZONE_REGISTER(ph_prep_kernel)
 // Persistent blocks over (b,t); blockIdx.y selects a tile of 16 output channels.
 __device__ __forceinline__ void ph_conv_kernel_body(const float* __restrict__ in, const float* __restrict__ Wf,
                                                       const float* __restrict__ bias, float* __restrict__ y,
-                                                      double* __restrict__ s1, double* __restrict__ s2, int64_t B,
+                                                      ExactAcc* __restrict__ s1, ExactAcc* __restrict__ s2, int64_t B,
                                                       int Ci, int Ti, int To, int Fo, int Fp, int want_stats,
     unsigned zgx, unsigned zgy, unsigned zbz, unsigned zgz) {   // this zone's own gridDim.x/.y, blockIdx.z, gridDim.z
   __shared__ float red[4];
@@ -154,14 +156,14 @@ __device__ __forceinline__ void ph_conv_kernel_body(const float* __restrict__ in
     }
     __syncthreads();
     const int i = threadIdx.x & 15;
-    if (threadIdx.x < 16 && o0 + i < Fo) atomicAdd(&s1[o0 + i], (double)tot[i]);
-    else if (threadIdx.x >= 16 && threadIdx.x < 32 && o0 + i < Fo) atomicAdd(&s2[o0 + i], (double)tot[16 + i]);
+    if (threadIdx.x < 16 && o0 + i < Fo) exact_add(&s1[o0 + i], tot[i]);
+    else if (threadIdx.x >= 16 && threadIdx.x < 32 && o0 + i < Fo) exact_add(&s2[o0 + i], tot[16 + i]);
   }
 }
 ISD_ZONE_FN(ph_conv_kernel, 256)
 __global__ __launch_bounds__(256) void ph_conv_kernel(const float* __restrict__ in, const float* __restrict__ Wf,
                                                       const float* __restrict__ bias, float* __restrict__ y,
-                                                      double* __restrict__ s1, double* __restrict__ s2, int64_t B,
+                                                      ExactAcc* __restrict__ s1, ExactAcc* __restrict__ s2, int64_t B,
                                                       int Ci, int Ti, int To, int Fo, int Fp, int want_stats) {
   ph_conv_kernel_body(in, Wf, bias, y, s1, s2, B, Ci, Ti, To, Fo, Fp, want_stats,
       gridDim.x, gridDim.y, blockIdx.z, gridDim.z);
@@ -177,8 +179,8 @@ __device__ __forceinline__ void ph_finalize_kernel_body(const float* __restrict_
   if (o >= g.Fo[l]) return;
   double mu, var;
   if (training) {
-    mu = st->s[l][0][o] / N;
-    var = st->s[l][1][o] / N - mu * mu;
+    mu = exact_get(&st->s[l][0][o]) / N;
+    var = exact_get(&st->s[l][1][o]) / N - mu * mu;
     if (var < 0.0) var = 0.0;
     bufs[g.rm[l] + o] = (1.f - momentum) * bufs[g.rm[l] + o] + momentum * (float)mu;
     bufs[g.rv[l] + o] = (1.f - momentum) * bufs[g.rv[l] + o] + momentum * (float)(var * N / (N > 1.0 ? N - 1.0 : 1.0));
@@ -272,8 +274,8 @@ __device__ __forceinline__ void ph_bwd_pool_kernel_body(const float* __restrict_
   const float r1 = ph_block_sum(s1, red);
   const float r2 = ph_block_sum(s2, red);
   if (threadIdx.x == 0) {
-    atomicAdd(&st->d[l][0][o], (double)r1);
-    atomicAdd(&st->d[l][1][o], (double)r2);
+    exact_add(&st->d[l][0][o], r1);
+    exact_add(&st->d[l][1][o], r2);
   }
 }
 ISD_ZONE_FN(ph_bwd_pool_kernel, 256)
@@ -294,11 +296,11 @@ __device__ __forceinline__ void ph_bwd_coef_kernel_body(const float* __restrict_
   const int o = threadIdx.x;
   if (o >= g.Fo[l]) return;
   const double inv = bn_train ? 1.0 / N : 0.0;           // running statistics do not depend on the batch: no mean terms
-  dparams[g.g[l] + o] = (float)(st->d[l][1][o] * gs);    // global sums on every rank: pre-divided by the world size
-  dparams[g.b[l] + o] = (float)(st->d[l][0][o] * gs);
+  dparams[g.g[l] + o] = (float)(exact_get(&st->d[l][1][o]) * gs);    // global sums on every rank: pre-divided by the world size
+  dparams[g.b[l] + o] = (float)(exact_get(&st->d[l][0][o]) * gs);
   co->cA[l][o] = params[g.g[l] + o] * co->isg[l][o];
-  co->cB[l][o] = (float)(st->d[l][0][o] * inv);
-  co->cC[l][o] = (float)(st->d[l][1][o] * inv);
+  co->cB[l][o] = (float)(exact_get(&st->d[l][0][o]) * inv);
+  co->cC[l][o] = (float)(exact_get(&st->d[l][1][o]) * inv);
 }
 ISD_ZONE_FN(ph_bwd_coef_kernel, 1024)
 __global__ void ph_bwd_coef_kernel(const float* __restrict__ params, float* __restrict__ dparams,
@@ -667,19 +669,22 @@ extern "C" int isd_paperhead_forward_stage(const isd_paperhead_plan* p, int stag
                           (hipStream_t)stream);
 }
 
-// The fp64 sums that are complete after `stage` (0..3) of the forward (backward = 0: sums of layer stage + 1) or of the
+// The batch sums that are complete after `stage` (0..3) of the forward (backward = 0: sums of layer stage + 1) or of the
 // backward (backward = 1: sums of layer 4 - stage): byte offset from the workspace base and number of doubles.
 extern "C" int isd_paperhead_sync_block(const isd_paperhead_plan* p, int64_t B, int backward, int stage,
                                         int64_t* byte_offset, int64_t* n_doubles) {
   ISD_CHECK_ARG(p && byte_offset && n_doubles, "isd_paperhead_sync_block: null argument");
   ISD_CHECK_ARG(stage >= 0 && stage < 4 && B >= 0, "isd_paperhead_sync_block: stage=%d not in [0,4)", stage);
   const PhWs w = ph_layout(p->g, B);
-  const size_t lo = backward ? offsetof(PhStats, d) + sizeof(double) * 2 * kPhMaxF * (3 - stage)
-                             : offsetof(PhStats, s) + sizeof(double) * 2 * kPhMaxF * stage;
+  const size_t lo = backward ? offsetof(PhStats, d) + sizeof(ExactAcc) * 2 * kPhMaxF * (3 - stage)
+                             : offsetof(PhStats, s) + sizeof(ExactAcc) * 2 * kPhMaxF * stage;
   *byte_offset = w.stats * 4 + (int64_t)lo;
-  *n_doubles = 2 * kPhMaxF;
+  *n_doubles = (int64_t)(sizeof(ExactAcc) / 8) * 2 * kPhMaxF;       // 8-byte words (int64: isd_paperhead_sync_block_kind)
   return ISD_OK;
 }
+
+// 1: every block holds 64-bit integer words of exact accumulators (csrc/exact.h) -- all-reduce as int64
+extern "C" int isd_paperhead_sync_block_kind(int backward, int stage) { (void)backward; (void)stage; return 1; }
 
 static int ph_backward_stage(const isd_paperhead_plan* p, int stage, const float* x, const float* params,
                              const float* dout, float* dparams, float* dx, float* ws, int64_t B, int bn_train, int world,

@@ -220,10 +220,11 @@ def _bn_sync_world(sync, training):
     return None, 1
 
 
-def _all_reduce_block(dist, ws, byte_off, n_doubles):
-    """SUM over ranks of a block of fp64 batch sums inside the workspace (RCCL on the current stream; gloo, used by
-    rehearsals with ranks sharing a card, stages through the host)."""
-    blk = ws.view(torch.uint8)[byte_off:byte_off + 8 * n_doubles].view(torch.float64)
+def _all_reduce_block(dist, ws, byte_off, n_words, integer=False):
+    """SUM over ranks of a block of batch sums inside the workspace -- fp64 values, or (``integer``) the int64 words of
+    exact accumulators, which add exactly (RCCL on the current stream; gloo, used by rehearsals with ranks sharing a
+    card, stages through the host)."""
+    blk = ws.view(torch.uint8)[byte_off:byte_off + 8 * n_words].view(torch.int64 if integer else torch.float64)
     if blk.is_cuda and dist.get_backend() == "gloo":
         h = blk.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -249,7 +250,7 @@ def eegnet_forward(plan, x, flat, bufs, out, ws, training, momentum, eps, dropou
         _lib.check(L.isd_eegnet_forward_stage(plan._h, stage, *args, world, st))
         if stage < 3:
             _lib.check(L.isd_eegnet_sync_block(plan._h, B, 0, stage, C.byref(off), C.byref(n)))
-            _all_reduce_block(dist, ws, off.value, n.value)
+            _all_reduce_block(dist, ws, off.value, n.value, bool(L.isd_eegnet_sync_block_kind(0, stage)))
     return world
 
 
@@ -269,7 +270,7 @@ def eegnet_backward(plan, x, flat, dout, dflat, ws, dropout_p, seed, world=1):
         _lib.check(L.isd_eegnet_backward_stage(plan._h, stage, *args, world, st))
         if stage < 3:
             _lib.check(L.isd_eegnet_sync_block(plan._h, B, 1, stage, C.byref(off), C.byref(n)))
-            _all_reduce_block(dist, ws, off.value, n.value)
+            _all_reduce_block(dist, ws, off.value, n.value, bool(L.isd_eegnet_sync_block_kind(1, stage)))
 
 
 class _EEGNetFn(torch.autograd.Function):
@@ -356,7 +357,7 @@ class _PaperHeadFn(torch.autograd.Function):
                     _lib.check(L.isd_paperhead_forward_stage(plan._h, stage, *args, world, _stream()))
                     if stage < 4:
                         _lib.check(L.isd_paperhead_sync_block(plan._h, B, 0, stage, C.byref(off), C.byref(n)))
-                        _all_reduce_block(dist, ws, off.value, n.value)
+                        _all_reduce_block(dist, ws, off.value, n.value, bool(L.isd_paperhead_sync_block_kind(0, stage)))
         ctx.plan, ctx.ws, ctx.training, ctx.world = plan, ws, training, world
         ctx.save_for_backward(x, flat)
         return out
@@ -390,7 +391,7 @@ class _PaperHeadFn(torch.autograd.Function):
                                                               ctx.world, _stream()))
                     if stage < 4:
                         _lib.check(L.isd_paperhead_sync_block(ctx.plan._h, B, 1, stage, C.byref(off), C.byref(n)))
-                        _all_reduce_block(dist, ctx.ws, off.value, n.value)
+                        _all_reduce_block(dist, ctx.ws, off.value, n.value, bool(L.isd_paperhead_sync_block_kind(1, stage)))
         ctx.ws = None
         return dx, dflat, None, None, None, None, None, None
 

