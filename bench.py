@@ -125,30 +125,50 @@ def cpu_baseline(cfg_name, cfg):
                       f"{threads} threads: {t_cnn / steps:.2f} s/step)"}
 
 
-def hip_event_ms(fn, stream, n):
-    """Mean duration of ``fn`` over n back-to-back launches between ONE pair of HIP events recorded on the launch
-    stream (an event pair around every single ~1 ms launch added up to 0.15 ms of marker handling to it on some
-    boxes: 1.21 ms where rocprofv3 saw 1.06 ms kernels)."""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+def hip_event_groups_ms(fn, stream, groups, per_group):
+    """Per-launch duration of ``fn``: ``groups`` means over ``per_group`` back-to-back launches, each group between ONE
+    pair of HIP events recorded on the launch stream (an event pair around every single ~1 ms launch added up to
+    0.15 ms of marker handling to it on some boxes: 1.21 ms where rocprofv3 saw 1.06 ms kernels)."""
     fn()
     fn()
-    e0.record(stream)
-    for _ in range(n):
-        fn()
-    e1.record(stream)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(groups)]
+    for e0, e1 in evs:
+        e0.record(stream)
+        for _ in range(per_group):
+            fn()
+        e1.record(stream)
+    clk = shader_clock_mhz()                                     # sampled while the passes are still running
     torch.cuda.synchronize()
-    return float(e0.elapsed_time(e1)) / n
+    return [float(e0.elapsed_time(e1)) / per_group for e0, e1 in evs], clk
 
 
-def filterbank_hbm_roofline(fx, x, nb, n=8):
+def shader_clock_mhz():
+    """Current shader clock of the first amdgpu card (sysfs pp_dpm_sclk, the starred level), or None."""
+    import glob
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for ln in open(f):
+                if "*" in ln:
+                    return int(ln.split(":")[1].strip().split("M")[0])
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
+def filterbank_hbm_roofline(fx, x, nb, groups=8, per_group=4):
     """North-star evidence: achieved HBM rate of the MATERIALISING filterbank stage (read x once, write nb filtered
-    copies -- what the scipy path does), measured after the timed region on (a slice of) the resident batch."""
+    copies -- what the scipy path does), measured after the timed region on (a slice of) the resident batch.
+    ``achieved`` / ``frac`` come from the MEDIAN group (the number of record); the best group and the shader clock
+    while the passes ran are given beside it."""
     B, C, T = x.shape
     per_trial = (1 + nb) * C * T * 4
     Bs = int(min(B, max(1, (24 << 30) // per_trial)))                # keep the filtered tensor under 24 GiB
     xs = x[:Bs].contiguous()
     y = torch.empty((Bs, nb, C, T), dtype=torch.float32, device=x.device)
-    ms = hip_event_ms(lambda: fx.fb.forward(xs, out=y), torch.cuda.current_stream(), n)
+    if per_trial * Bs > (4 << 30):
+        groups, per_group = 4, 2                                     # long passes (cfg5: 7 ms each)
+    times, clk = hip_event_groups_ms(lambda: fx.fb.forward(xs, out=y), torch.cuda.current_stream(), groups, per_group)
+    ms, ms_min = float(np.median(times)), float(min(times))
     by = per_trial * Bs
     if T <= 1024:
         launches = {"f32": "fb_kernel<float,%d>", "f64": "fb_kernel<double,%d>",
@@ -161,10 +181,13 @@ def filterbank_hbm_roofline(fx, x, nb, n=8):
     del y
     return {"bound": "hbm", "kernel": launches, "achieved": round(by / (ms * 1e-3) / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic": None, "ms_per_pass": round(ms, 4), "trials_per_pass": Bs, "algorithmic_bytes_per_pass": by}
+            "traffic": None, "ms_per_pass": round(ms, 4), "ms_per_pass_min": round(ms_min, 4),
+            "frac_best": round(by / (ms_min * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "passes": f"{len(times)} groups x {per_group} back-to-back passes, one HIP event pair per group; median group",
+            "shader_clock_mhz": clk, "trials_per_pass": Bs, "algorithmic_bytes_per_pass": by}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
@@ -175,6 +198,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-roofline", action="store_true", help="skip the filterbank-stage HBM measurement")
     ap.add_argument("--bf16", action="store_true", help="config 3: bf16 activations/grads in the CNN, fp32 accumulate")
+    ap.add_argument("--no-also", action="store_true",
+                    help="default invocation only: skip the BASELINE config 3 (bf16) and config 5 (stress) runs that are "
+                         "reported under \"also\" beside the cfg2 fp32 line")
     ap.add_argument("--overlap", action="store_true",
                     help="extract the features of the next batch on a second HIP stream while the CNN trains on the "
                          "current one (measured: no gain on MI355X -- the fused extractor already fills every wave "
@@ -182,37 +208,18 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N > 1 only: wait for the gradient all-reduce before extracting the next batch's features "
                          "(default: the all-reduce of step k runs under the feature extraction of batch k+1)")
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
-    args.steps = cfg["steps"] if args.steps is None else args.steps
-    args.warmup = cfg["warmup"] if args.warmup is None else args.warmup
-    args.batch = cfg["batch"] if args.batch is None else args.batch
-    if args.config == "cfg5" and (args.bf16 or args.two_kernel):
-        raise SystemExit("--bf16 / --two-kernel apply to cfg2")
+    return ap.parse_args()
 
+
+def run_workload(config, steps, warmup, batch, bf16, two_kernel, overlap_flag, no_pipeline, hbm_roofline, env):
+    """One workload: W untimed warm-up steps, exactly K timed steps between barrier + synchronize pairs, the MAX of the
+    ranks' wall times.  Returns the JSON line's fields on rank 0 (None elsewhere)."""
     import torch.distributed as dist
     import isd_amd
     from isd_amd.classifier import _EEGNetFeatureModel, _FeatureModel
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
-    # ISD_DIST_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (ranks share a card)
-    backend = os.environ.get("ISD_DIST_BACKEND", "nccl")
-    if backend != "nccl":
-        local %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    B, C, T, fs = args.batch, cfg["C"], cfg["T"], cfg["fs"]
+    rank, world, dev, backend = env["rank"], env["world"], env["dev"], env["backend"]
+    cfg = CONFIGS[config]
+    B, C, T, fs = batch, cfg["C"], cfg["T"], cfg["fs"]
     bands = getattr(isd_amd, cfg["bands"])
     nb = len(bands)
     Xh, yh = synth_trials(B, C, T, fs, seed=rank)               # rank r uses default_rng(r)
@@ -222,18 +229,18 @@ def main():
 
     torch.manual_seed(42)                                        # reference default seed (train_fast.py:275)
     fx = isd_amd.FeatureExtractor(T, fs, bands, nperseg=cfg["nperseg"], noverlap=cfg["noverlap"])
-    if args.config == "cfg2":
-        model = _FeatureModel(nb * C, 32, 5, 4, "bf16" if args.bf16 else "f32").to(dev)
+    if config == "cfg2":
+        model = _FeatureModel(nb * C, 32, 5, 4, "bf16" if bf16 else "f32").to(dev)
     else:
         model = _EEGNetFeatureModel(nb * C, 32, 5, kernel_length=64, dropout=0.25).to(dev)
     trainer = isd_amd.Trainer(model, lr=5e-4, weight_decay=1e-2, schedule=None)
     feats = torch.empty((B, nb, C, fx.n_frames), dtype=torch.float32, device=dev)
-    yfilt = torch.empty((B, nb, C, T), dtype=torch.float32, device=dev) if args.two_kernel else None
+    yfilt = torch.empty((B, nb, C, T), dtype=torch.float32, device=dev) if two_kernel else None
     global_batch = B * world
-    fused = not args.two_kernel
+    fused = not two_kernel
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    overlap = fused and args.overlap
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    overlap = fused and overlap_flag
     main_stream = torch.cuda.current_stream()
     feat_stream = torch.cuda.Stream() if overlap else main_stream
     fbuf = [feats, torch.empty_like(feats)] if overlap else [feats, feats]
@@ -270,7 +277,7 @@ def main():
     # N > 1: the features do not depend on the parameters, so the one exchange step of the iteration (the flat
     # gradient all-reduce, RCCL's own stream) is started right after the backward pass and waited for only after
     # the next batch's features are queued: forward/backward(k) -> all-reduce(k) || extract(k+1) -> AdamW(k).
-    pipelined = world > 1 and not overlap and not args.no_pipeline
+    pipelined = world > 1 and not overlap and not no_pipeline
 
     def pipelined_step(e=None):
         out = trainer.step_begin(feats.view(B, nb * C, fx.n_frames), y, global_batch=global_batch)
@@ -286,7 +293,7 @@ def main():
     freed[0].record(main_stream); freed[1].record(main_stream)
     if overlap or pipelined:
         extract(0)
-    for i in range(args.warmup):
+    for i in range(warmup):
         if pipelined:
             pipelined_step()
         elif overlap:
@@ -299,8 +306,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    base = args.warmup
-    for i in range(args.steps):
+    base = warmup
+    for i in range(steps):
         if pipelined:
             out = pipelined_step(ev[i])
         elif overlap:
@@ -318,81 +325,137 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss = float(out["loss"])
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        ms = dt / args.steps * 1e3
-        t_feat = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-        t_train = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if not (overlap or pipelined) else float("nan")
-        n_sec, bins = 4, [hi - lo + 1 for lo, hi in fx.bins]
-        roof_hbm = None
-        if fused and args.config == "cfg2":
-            # dominant kernel: the fused filterbank+STFT extractor, fp32-VALU-bound on its algorithmic traffic, so the
-            # compute roofline is the honest one.  Algorithmic flops per (trial, channel): cascade = nb bands x T
-            # samples x (4 sections x 9 flop [3-op recursion + two state fix-up FMAs] + 1 gain multiply); band DFT =
-            # 64 windowed samples per (frame, in-band bin), one complex MAC by a real sample each (4 flop).
-            flops = B * C * (nb * T * (n_sec * 9 + 1) + sum(bins) * fx.n_frames * 64 * 4)
-            roof = {"bound": "valu", "kernel": "fused_kernel<float> (fp32 vector ALU; no MFMA in this kernel)",
-                    "achieved": round(flops / (t_feat * 1e-3) / 1e12, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(flops / (t_feat * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": None,
-                    "ms_per_launch": round(t_feat, 4),
-                    "algorithmic_bytes_per_launch": B * C * 4 * (T + nb * fx.n_frames)}
-        elif fused:
-            # cfg5: fused_rows4_kernel<float,5> (24 bands) + fused_rows4_kernel<double,5> (16 bands), one launch each per
-            # extraction; the pair is VALU-bound.  Algorithmic flops per (trial, channel, band): cascade T x (4 x 9 + 1)
-            # + half-block DFT sums of the band's bins and their two Hann neighbours: (bins + 2) x T complex MACs x 4.
-            flops = B * C * sum(T * (n_sec * 9 + 1) + (nbin + 2) * T * 4 for nbin in bins)
-            roof = {"bound": "valu", "kernel": "fused_rows4_kernel<float,5> + fused_rows4_kernel<double,5> (one launch "
-                                               "each per extraction; priced against the fp32 vector peak)",
-                    "achieved": round(flops / (t_feat * 1e-3) / 1e12, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(flops / (t_feat * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": None,
-                    "ms_per_launch": round(t_feat, 4),
-                    "algorithmic_bytes_per_launch": B * C * 4 * (T + nb * fx.n_frames)}
+    ms = dt / steps * 1e3
+    t_feat = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    t_train = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if not (overlap or pipelined) else float("nan")
+    n_sec, bins = 4, [hi - lo + 1 for lo, hi in fx.bins]
+    roof_hbm = None
+    if fused and config == "cfg2":
+        # dominant kernel: the fused filterbank+STFT extractor, fp32-VALU-bound on its algorithmic traffic, so the
+        # compute roofline is the honest one.  Algorithmic flops per (trial, channel): cascade = nb bands x T
+        # samples x (4 sections x 9 flop [3-op recursion + two state fix-up FMAs] + 1 gain multiply); band DFT =
+        # 64 windowed samples per (frame, in-band bin), one complex MAC by a real sample each (4 flop).
+        flops = B * C * (nb * T * (n_sec * 9 + 1) + sum(bins) * fx.n_frames * 64 * 4)
+        roof = {"bound": "valu", "kernel": "fused_kernel<float> (fp32 vector ALU; no MFMA in this kernel)",
+                "achieved": round(flops / (t_feat * 1e-3) / 1e12, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / (t_feat * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                "ms_per_launch": round(t_feat, 4),
+                "algorithmic_bytes_per_launch": B * C * 4 * (T + nb * fx.n_frames)}
+    elif fused:
+        # cfg5: fused_rows4_kernel<float,5> (24 bands) + fused_rows4_kernel<double,5> (16 bands), one launch each per
+        # extraction; the pair is VALU-bound.  Algorithmic flops per (trial, channel, band): cascade T x (4 x 9 + 1)
+        # + half-block DFT sums of the band's bins and their two Hann neighbours: (bins + 2) x T complex MACs x 4.
+        flops = B * C * sum(T * (n_sec * 9 + 1) + (nbin + 2) * T * 4 for nbin in bins)
+        roof = {"bound": "valu", "kernel": "fused_rows4_kernel<float,5> + fused_rows4_kernel<double,5> (one launch "
+                                           "each per extraction; priced against the fp32 vector peak)",
+                "achieved": round(flops / (t_feat * 1e-3) / 1e12, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / (t_feat * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                "ms_per_launch": round(t_feat, 4),
+                "algorithmic_bytes_per_launch": B * C * 4 * (T + nb * fx.n_frames)}
+    else:
+        t_fb = float(np.mean([e[0].elapsed_time(e[3]) for e in ev]))
+        by = (1 + nb) * C * T * 4 * B                         # read x once + write nb filtered copies
+        roof = {"bound": "hbm", "kernel": "fb_kernel<float,1>", "achieved": round(by / (t_fb * 1e-3) / 1e9, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (t_fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "traffic": None, "ms_per_launch": round(t_fb, 4), "algorithmic_bytes_per_launch": by}
+    if fused and world == 1 and hbm_roofline:
+        del feats, fbuf                                       # room for the filtered tensor
+        roof_hbm = filterbank_hbm_roofline(fx, x, nb)
+    tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tf):
+        try:
+            table = json.load(open(tf))
+            def measured(ent, trials):
+                # PMC bytes of the pass the table was measured on; every trial is independent, so an entry may give
+                # bytes per trial instead (measured on a smaller batch of the same shape)
+                if not ent:
+                    return None
+                if "bytes_per_trial" in ent:
+                    return int(round(ent["bytes_per_trial"] * trials))
+                return ent["bytes_per_launch"] if trials == ent.get("trials_per_launch", 4096) else None
+            roof["traffic"] = measured(table.get(roof["kernel"].split(" ")[0]), B)
+            if roof_hbm:
+                roof_hbm["traffic"] = measured(table.get(roof_hbm["kernel"].split(" ")[0]), roof_hbm["trials_per_pass"])
+        except Exception:
+            pass
+    line = {
+        "metric": "trials/sec end-to-end (filterbank+CNN fwd+bwd)", "value": round(global_batch * steps / dt, 1),
+        "unit": "trials/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 activations/grads in the CNN, f32 features + accumulate" if bf16 else "f32",
+        "data": "synthetic",
+        "config": {"workload": cfg["workload"],
+                   "trials_per_gpu": B, "global_batch": global_batch, "parallelism": f"dp{world}",
+                   "feature_path": "fused" if fused else "filterbank+bandpower kernels",
+                   "streams": "features of batch k+1 overlap the CNN step of batch k" if overlap else
+                              "one stream; gradient all-reduce of step k (RCCL stream) under the feature "
+                              "extraction of batch k+1" if pipelined else "one stream"},
+        "stages_ms": {"extract_features": round(t_feat, 4),
+                      "cnn_fwd_bwd_allreduce_adamw": None if (overlap or pipelined) else round(t_train, 4)},
+        "final_loss": round(loss, 5),
+        "roofline": roof,
+    }
+    if roof_hbm:
+        line["roofline_hbm"] = roof_hbm
+    return line
+
+
+def main():
+    args = parse_args()
+    cfg = CONFIGS[args.config]
+    # the headline invocation (any --steps / --warmup): cfg2 fp32, fused, one stream, the configuration's own batch
+    default_call = args.config == "cfg2" and args.batch is None and not (args.bf16 or args.two_kernel or args.overlap)
+    args.steps = cfg["steps"] if args.steps is None else args.steps
+    args.warmup = cfg["warmup"] if args.warmup is None else args.warmup
+    args.batch = cfg["batch"] if args.batch is None else args.batch
+    if args.config == "cfg5" and (args.bf16 or args.two_kernel):
+        raise SystemExit("--bf16 / --two-kernel apply to cfg2")
+
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    # ISD_DIST_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (ranks share a card)
+    backend = os.environ.get("ISD_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
-            t_fb = float(np.mean([e[0].elapsed_time(e[3]) for e in ev]))
-            by = (1 + nb) * C * T * 4 * B                         # read x once + write nb filtered copies
-            roof = {"bound": "hbm", "kernel": "fb_kernel<float,1>", "achieved": round(by / (t_fb * 1e-3) / 1e9, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (t_fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "traffic": None, "ms_per_launch": round(t_fb, 4), "algorithmic_bytes_per_launch": by}
-        if fused and world == 1 and not args.no_hbm_roofline:
-            roof_hbm = filterbank_hbm_roofline(fx, x, nb)
-        tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tf):
-            try:
-                table = json.load(open(tf))
-                def measured(ent, trials):
-                    # PMC bytes of the pass the table was measured on; every trial is independent, so an entry may give
-                    # bytes per trial instead (measured on a smaller batch of the same shape)
-                    if not ent:
-                        return None
-                    if "bytes_per_trial" in ent:
-                        return int(round(ent["bytes_per_trial"] * trials))
-                    return ent["bytes_per_launch"] if trials == ent.get("trials_per_launch", 4096) else None
-                roof["traffic"] = measured(table.get(roof["kernel"].split(" ")[0]), B)
-                if roof_hbm:
-                    roof_hbm["traffic"] = measured(table.get(roof_hbm["kernel"].split(" ")[0]), roof_hbm["trials_per_pass"])
-            except Exception:
-                pass
-        line = {
-            "metric": "trials/sec end-to-end (filterbank+CNN fwd+bwd)", "value": round(global_batch * args.steps / dt, 1),
-            "unit": "trials/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 activations/grads in the CNN, f32 features + accumulate" if args.bf16 else "f32",
-            "data": "synthetic",
-            "config": {"workload": cfg["workload"],
-                       "trials_per_gpu": B, "global_batch": global_batch, "parallelism": f"dp{world}",
-                       "feature_path": "fused" if fused else "filterbank+bandpower kernels",
-                       "streams": "features of batch k+1 overlap the CNN step of batch k" if overlap else
-                                  "one stream; gradient all-reduce of step k (RCCL stream) under the feature "
-                                  "extraction of batch k+1" if pipelined else "one stream"},
-            "stages_ms": {"extract_features": round(t_feat, 4),
-                          "cnn_fwd_bwd_allreduce_adamw": None if (overlap or pipelined) else round(t_train, 4)},
-            "final_loss": round(loss, 5),
-            "roofline": roof,
-        }
-        if roof_hbm:
-            line["roofline_hbm"] = roof_hbm
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.config, cfg)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    env = dict(rank=rank, world=world, dev=dev, backend=backend)
+
+    line = run_workload(args.config, args.steps, args.warmup, args.batch, args.bf16, args.two_kernel, args.overlap,
+                        args.no_pipeline, not args.no_hbm_roofline, env)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.config, cfg)
+    # The driver's plain `python bench.py` also times BASELINE config 3 (the same workload with bf16 activations and
+    # gradients) and config 5 (the stress configuration at its own batch of 2048) after the cfg2 fp32 region: `value`
+    # stays the cfg2 fp32 number, the other two ride along under "also" (VERDICT r2, item 3).
+    if world == 1 and (default_call or os.environ.get("ISD_BENCH_ALSO")) and not args.no_also:
+        also = {}
+        torch.cuda.empty_cache()
+        l3 = run_workload("cfg2", 10, 3, CONFIGS["cfg2"]["batch"], True, False, False, False, False, env)
+        also["cfg3"] = {k: l3[k] for k in ("value", "ms_per_step", "stages_ms", "dtype", "steps", "warmup", "final_loss")}
+        also["cfg3"]["workload"] = "cfg2's workload with bf16 activations / activation gradients in the CNN (bf16 MFMA), " \
+                                   "f32 features, parameters and accumulation"
+        torch.cuda.empty_cache()
+        l5 = run_workload("cfg5", 3, 1, CONFIGS["cfg5"]["batch"], False, False, False, False, True, env)
+        also["cfg5"] = {k: l5[k] for k in ("value", "ms_per_step", "stages_ms", "dtype", "steps", "warmup", "final_loss",
+                                           "roofline", "roofline_hbm") if k in l5}
+        also["cfg5"]["workload"] = CONFIGS["cfg5"]["workload"]
+        line["also"] = also
+    if rank == 0:
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes rather than seconds (still part of -m gpu)")
 
 
 def load_golden(name):
