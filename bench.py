@@ -137,22 +137,28 @@ def hip_event_groups_ms(fn, stream, groups, per_group):
         for _ in range(per_group):
             fn()
         e1.record(stream)
-    clk = shader_clock_mhz()                                     # sampled while the passes are still running
+    clk = shader_clock_mhz()                                     # probed while the passes are still running
     torch.cuda.synchronize()
     return [float(e0.elapsed_time(e1)) / per_group for e0, e1 in evs], clk
 
 
-def shader_clock_mhz():
-    """Current shader clock of the first amdgpu card (sysfs pp_dpm_sclk, the starred level), or None."""
-    import glob
-    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
-        try:
-            for ln in open(f):
-                if "*" in ln:
-                    return int(ln.split(":")[1].strip().split("M")[0])
-        except (OSError, ValueError, IndexError):
-            continue
-    return None
+_clock_stream = None
+
+
+def shader_clock_mhz(spin_us=300):
+    """Shader clock right now, under whatever is queued on the device: a one-wave probe kernel on a second stream
+    (isd_shader_clock_probe: shader-clock counter against the constant-rate counter over ~spin_us)."""
+    global _clock_stream
+    from isd_amd import _lib
+    L = _lib.lib()
+    if _clock_stream is None:
+        _clock_stream = torch.cuda.Stream()
+    with torch.cuda.stream(_clock_stream):                       # allocated and filled on the probe's own stream
+        out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    _lib.check(L.isd_shader_clock_probe(out.data_ptr(), int(spin_us), _clock_stream.cuda_stream))
+    _clock_stream.synchronize()
+    t, r = (int(v) for v in out.tolist())
+    return round(t / r * L.isd_wall_clock_khz() / 1000.0, 1) if r > 0 else None
 
 
 def filterbank_hbm_roofline(fx, x, nb, groups=8, per_group=4):

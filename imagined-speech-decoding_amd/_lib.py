@@ -32,6 +32,8 @@ _pi, _pd = C.POINTER(C.c_int), C.POINTER(C.c_double)
 SIGNATURES = {
     "isd_abi_version": (_i, []),
     "isd_last_error": (C.c_char_p, []),
+    "isd_shader_clock_probe": (_i, [_p, _i, _p]),
+    "isd_wall_clock_khz": (_i, []),
     "isd_device_count": (_i, []),
     "isd_fb_plan_create": (_i, [C.POINTER(_p), _i, _i, _pd, _pd, _i]),
     "isd_fb_plan_destroy": (_i, [_p]),

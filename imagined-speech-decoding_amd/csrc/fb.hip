@@ -1046,6 +1046,23 @@ void fused_long_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict_
   }
 }
 
+// Real sample x complex twiddle into a (re, im) accumulator, the sample taken from the LOW / HIGH half of a register
+// pair and the twiddle from an SGPR pair.  Written as (f2){s, s} * t the compiler materialises the duplicated pairs
+// (a v_mov per sample and 64 more live registers); the packed FMA's operand selects do the broadcast for nothing.
+__device__ __forceinline__ void cmac_lo(f2& acc, const f2& pr, const f2& t) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(pr), "s"(t));
+}
+__device__ __forceinline__ void cmac_hi(f2& acc, const f2& pr, const f2& t) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(pr), "s"(t));
+}
+// x * g on the plain (unpacked) multiplier, opaque to the SLP vectoriser: written into one half of a register pair it
+// needs no copy, where packing two loaded dwords for a v_pk_mul costs a v_mov each
+__device__ __forceinline__ float mul_unpacked(float x, float g) {
+  float r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(g));
+  return r;
+}
+
 // The same extraction with FOUR ROWS PER WAVE (rows of a multiple of 512 samples, at most 16 blocks per frame): every
 // 16-lane group walks its own row in 512-sample passes and carries its section states from pass to pass.  In
 // fused_long_kernel the wave's four groups hold consecutive quarters of one 2048-sample pass and their end states are
@@ -1053,10 +1070,23 @@ void fused_long_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict_
 // section body of a kernel that is VALU-issue bound (PMC: 1 447 vector instructions per band and pass, 100 % of the
 // launch at 4 cycles each).  Groups that own their rows need none of it: the carry is two doubles per (section,
 // group) in LDS.  The frames are finished as the row streams by: a frame is the sum of nblk consecutive block sums,
-// so after every pass the eight frames whose last block just arrived are formed from a 32-block ring per (row, bin)
-// -- keeping all 64 blocks of four rows until the end of the band cost 10 KiB of LDS and two waves per SIMD.
+// so after every SECOND pass the sixteen frames whose last block has arrived are formed from a 32-block ring per
+// (row, bin), one frame per lane of the row's group -- keeping all 64 blocks of four rows until the end of the band
+// cost 10 KiB of LDS and two waves per SIMD.
+//
+// Round 3 (the kernel is VALU-issue bound: 1 228 vector instructions per band and pass, 95 useful flops each):
+//  * the lane's 128 bytes of a pass come as eight float4 loads off ONE address with immediate offsets, and the gain
+//    multiply writes the register pairs directly (mul_unpacked): 42 v_mov + 32 address instructions + 16 v_pk_mul
+//    became 32 v_mul + 4;
+//  * the half-block DFT sums take the sample from a pair half by operand select (cmac_lo / cmac_hi) instead of from a
+//    duplicated pair: -49 v_mov per pass and 32 fewer live registers; the table comes through SMEM in opaque-offset
+//    batches (later()) like fused_kernel's;
+//  * the odd lane's half-block rotation e^{-2 pi i k 32 / n} and the block's absolute phase e^{-2 pi i k m / nblk} are
+//    ONE per-lane factor per bin, looked up once per band (it changes sign from pass to pass for odd bins at 16 blocks
+//    per frame: one v_xor per component): a complex multiply instead of two plus an index computation per bin and pass;
+//  * frames are finished every second pass, sixteen at a time (one per lane, no half-window join).
 template <typename VT, int KB>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(std::is_same<VT, float>::value ? 4 : 3)))
 void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                         const double* __restrict__ Qtab, const float2* __restrict__ blk,
                         const float* __restrict__ x, float* __restrict__ feat, int C,
@@ -1067,20 +1097,19 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane0 = threadIdx.x;
   const int n_iter = T / kSeg;                                             // 512-sample passes
-  const int n_blocks = T >> 6;                                             // 64-sample blocks of a row
   float2* ring = reinterpret_cast<float2*>(smem_raw);                      // [4 rows][KB][32]: block m at m & 31
-  float2* tw = ring + 4 * KB * 32;                                         // [64]  e^{-2 pi i u / nblk}
-  double* carry = reinterpret_cast<double*>(tw + 64);                      // [kMaxSec][4 groups][2]
-  double* Qlds = carry + kMaxSec * 8;                                      // [kMaxSec][16][4] the band's per-lane M^i
+  float2* tw = ring + 4 * KB * 32;                                         // [64]  e^{-2 pi i u / (2 nblk)}, u < 2 nblk
+  double* carry = reinterpret_cast<double*>(tw + 64);                      // [ns][4 groups][2]
+  double* Qlds = carry + ns * 8;                                           // [ns][16][4] the band's per-lane M^i
   // id = 8 kLongShare q + 8 w + c  <->  row quad = 8 q + c, band subset w (the sharers of a quad run on one XCD)
   const int id = blockIdx.x;
   const int quad = (id / (8 * kLongShare)) * 8 + (id & 7);
   const int share = (id >> 3) % kLongShare;
   if (quad * 4 >= n_rows) return;
-  const int nblk = 1 << log2_nblk, half = nblk >> 1;
-  if (lane0 < nblk) {
+  const int nblk = 1 << log2_nblk, nblk2 = 2 * nblk;
+  if (lane0 < nblk2) {
     float sn, cs;
-    sincospif(2.f * (float)lane0 / (float)nblk, &sn, &cs);
+    sincospif(2.f * (float)lane0 / (float)nblk2, &sn, &cs);
     tw[lane0] = make_float2(cs, -sn);
   }
   wave_lds_sync();
@@ -1090,7 +1119,7 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
     const int q = lane >> 4, li = lane & 15;
     const bool row_ok = quad * 4 + q < n_rows;
     const int row = row_ok ? quad * 4 + q : n_rows - 1;                    // a missing row recomputes the last one
-    const float* src = x + row * (int64_t)T;
+    const float4* src4 = reinterpret_cast<const float4*>(x + row * (int64_t)T + li * kL);
     const int bt = row / C, ch = row - bt * C;
     float* out = feat + (((int64_t)bt * nb_out + bmap[b]) * C + ch) * (int64_t)J;
     const int klo = fbnd.klo[b], khi = fbnd.khi[b];
@@ -1099,6 +1128,22 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
 #pragma unroll
     for (int e = 0; e < 2 * KB; ++e) ring[e * 64 + lane] = make_float2(0.f, 0.f);      // 4 x KB x 32 slots
     stage_q(Qlds, Qtab, b, ns, lane);
+    // this lane's factor per bin: block phase e^{-2 pi i k m / nblk} of its block m = 8 it + (li >> 1) at it = 0, times
+    // the half-block offset e^{-2 pi i k 32 / n} on odd lanes; pass it multiplies by e^{-2 pi i k 8 it / nblk} = +-1
+    // (2 k (li >> 1) + k (li & 1) = k li.)  The fp32 instance keeps the KB factors in registers; the fp64 instance,
+    // which is at its register cap, looks them up per pass.
+    constexpr bool kFacRegs = std::is_same<VT, float>::value;
+    f2 fac[kFacRegs ? KB : 1];
+    unsigned flip[kFacRegs ? KB : 1];                    // wave-uniform: sign bit when the factor alternates
+    if constexpr (kFacRegs) {
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) {
+        const int kq = k0 + kk;
+        const float2 w = tw[(kq * li) & (nblk2 - 1)];
+        fac[kk] = (f2){w.x, w.y};
+        flip[kk] = ((16 * kq) & (nblk2 - 1)) ? 0x80000000u : 0u;          // 16 k / (2 nblk) turns per pass: 0 or 1/2
+      }
+    }
     wave_lds_sync();
     const auto gain = O::g(bands[b]);
     for (int it = 0; it <= n_iter; ++it) {
@@ -1111,11 +1156,20 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
         typename O::Arr v;
         {
           float4 xf[kL / 4];
-          chunk_issue<true>(xf, src, 0, it * 16 + li, T);
-          XArr xs;
+          const float4* p4 = src4 + it * (kSeg / 4);     // one address, eight immediate offsets
 #pragma unroll
-          for (int j = 0; j < kL / 2; ++j) xs[j] = (f2){f4_get(xf[j >> 2], j & 3), f4_get(xf[(j >> 2) + 4], j & 3)};
-          O::from_x(v, xs, gain);
+          for (int e = 0; e < kL / 4; ++e) xf[e] = p4[e];
+          if constexpr (std::is_same<VT, float>::value) {
+#pragma unroll
+            for (int j = 0; j < kL / 2; ++j)
+              v[j] = (f2){mul_unpacked(f4_get(xf[j >> 2], j & 3), gain), mul_unpacked(f4_get(xf[(j >> 2) + 4], j & 3), gain)};
+          } else {
+#pragma unroll
+            for (int j = 0; j < kL / 2; ++j) {
+              v[j] = (double)f4_get(xf[j >> 2], j & 3) * gain;
+              v[j + 16] = (double)f4_get(xf[(j >> 2) + 4], j & 3) * gain;
+            }
+          }
         }
         for (int sct = 0; sct < ns; ++sct) {
           double c1 = carry[(sct * 4 + q) * 2], c2 = carry[(sct * 4 + q) * 2 + 1];
@@ -1126,77 +1180,80 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
             carry[(sct * 4 + q) * 2 + 1] = c2;
           }
         }
-        float vf[kL];
-#pragma unroll
-        for (int n = 0; n < kL; ++n) vf[n] = (float)O::at(v, n);
-        // half-block DFT sums with block-local phase (this lane's 32 samples start at offset 32*(lane&1) in the block)
-        const int m = it * 8 + (li >> 1);
+        XArr vf;                                        // fp32 pairs {sample j, sample j + 16} (the chunk itself in fp32)
+        O::to_f32(v, vf);
+        // half-block DFT sums with block-local phase (this lane's 32 samples start at offset 32 (lane & 1) in the block)
+        const int sl = (it * 8 + (li >> 1)) & 31;
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
-          __builtin_amdgcn_sched_barrier(0);            // one bin's 64 table scalars at a time in the SGPR file
           const int k = k0 + kk < n_bins_max ? k0 + kk : n_bins_max;
-          const float2* tb = blk + (int64_t)k * 64;
-          f2 acc = {0.f, 0.f}, acc_b = {0.f, 0.f};
+          const f2* __restrict__ tb = reinterpret_cast<const f2*>(blk + (int64_t)k * 64);
+          f2 acc_a = {0.f, 0.f}, acc_b = {0.f, 0.f};     // two chains: samples 0..15 and 16..31
 #pragma unroll
-          for (int n = 0; n < kL; n += 2) {             // two chains: a dependent v_pk_fma costs a wait state each
-            acc = __builtin_elementwise_fma((f2){vf[n], vf[n]}, (f2){tb[n].x, tb[n].y}, acc);
-            acc_b = __builtin_elementwise_fma((f2){vf[n + 1], vf[n + 1]}, (f2){tb[n + 1].x, tb[n + 1].y}, acc_b);
+          for (int j0 = 0; j0 < kL / 2; j0 += 8) {
+            const f2* __restrict__ tq = later(tb);       // 32 table scalars per batch in the SGPR file
+#pragma unroll
+            for (int j = j0; j < j0 + 8; ++j) {
+              cmac_lo(acc_a, vf[j], tq[j]);
+              cmac_hi(acc_b, vf[j], tq[16 + j]);
+            }
           }
-          acc += acc_b;
-          const float2 ph = tb[kL];                     // e^{-2 pi i k 32 / n}: the odd lane's offset in the block
-          const float px = (lane & 1) ? acc.x * ph.x - acc.y * ph.y : acc.x;
-          const float py = (lane & 1) ? acc.x * ph.y + acc.y * ph.x : acc.y;
-          const float sx = px + row_shl<1>(px), sy = py + row_shl<1>(py);
-          // absolute block phase e^{-2 pi i k m / nblk}, then into the ring
-          const float2 w = tw[((k0 + kk) * m) & (nblk - 1)];
-          if (!(lane & 1)) ring[(q * KB + kk) * 32 + (m & 31)] = make_float2(sx * w.x - sy * w.y, sx * w.y + sy * w.x);
+          const f2 sum = acc_a + acc_b;
+          f2 fk;
+          if constexpr (kFacRegs) {
+            fk = fac[kk];
+            fac[kk] = (f2){__uint_as_float(__float_as_uint(fk.x) ^ flip[kk]), __uint_as_float(__float_as_uint(fk.y) ^ flip[kk])};
+          } else {
+            const float2 w = tw[((k0 + kk) * (li + 16 * it)) & (nblk2 - 1)];
+            fk = (f2){w.x, w.y};
+          }
+          float px = sum.x * fk.x - sum.y * fk.y, py = sum.x * fk.y + sum.y * fk.x;
+          px += row_shl<1>(px);
+          py += row_shl<1>(py);
+          if (!(lane & 1)) ring[(q * KB + kk) * 32 + sl] = make_float2(px, py);
         }
       }
+      if (!(it & 1) && it != n_iter) continue;           // frames are finished after every second pass (and the last)
       wave_lds_sync();
-      // frames j = 8 it - 7 .. 8 it: their last block (j + half - 1 <= 8 it + 7) has arrived, or lies past the row.
-      // Lane = (frame j0 + (li & 7), half of the window li >> 3); the two halves meet through one DPP rotation.
+      // frames j = 8 it - 15 .. 8 it, one per lane of the group: their last block (j + half - 1 <= 8 it + 7) has arrived
+      // or lies past the row, their first (j - half >= 8 it - 23) is still in the 32-block ring.  (After the last
+      // pass of a row with an even number of passes the first eight of them are formed a second time.)
       {
-        const int j = 8 * it - 7 + (li & 7);
-        const int m0 = j - half + (li >> 3) * half;      // this lane's `half` blocks: m0 .. m0 + half - 1
+        const int half = nblk >> 1;
+        const int j = 8 * it - 15 + li;
+        const int m0 = j - half;                         // this frame's nblk blocks: m0 .. m0 + nblk - 1
         // blocks before the row and past its end read as zero because their ring slots ARE zero (cleared at the start
         // of the band and, for the slots past the end, before the last round): no test per read
         const float2* rq = ring + q * KB * 32;
-        float2 R[KB];
+        f2 R[KB];
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) R[kk] = make_float2(0.f, 0.f);
-        if (half == 8) {
+        for (int kk = 0; kk < KB; ++kk) R[kk] = (f2){0.f, 0.f};
+        if (nblk == 16) {
 #pragma unroll
-          for (int d = 0; d < 8; ++d) {
+          for (int d = 0; d < 16; ++d) {
             const int sl = (m0 + d) & 31;
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
               const float2 sv = rq[kk * 32 + sl];
-              R[kk].x += sv.x;
-              R[kk].y += sv.y;
+              R[kk] += (f2){sv.x, sv.y};
             }
           }
         } else {
-          for (int d = 0; d < half; ++d) {
+          for (int d = 0; d < nblk; ++d) {
             const int sl = (m0 + d) & 31;
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
               const float2 sv = rq[kk * 32 + sl];
-              R[kk].x += sv.x;
-              R[kk].y += sv.y;
+              R[kk] += (f2){sv.x, sv.y};
             }
           }
         }
-#pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
-          R[kk].x += row_ror<8>(R[kk].x);
-          R[kk].y += row_ror<8>(R[kk].y);
-        }
-        const float2 wn = tw[j & (nblk - 1)];                        // e^{-2 pi i j/nblk};  w^j = conj(wn)
+        const float2 wn = tw[(2 * j) & (nblk2 - 1)];                   // e^{-2 pi i j/nblk};  w^j = conj(wn)
         float acc = 0.f;
 #pragma unroll
         for (int bq = 0; bq < KB - 2; ++bq) {
           if (bq < nbin) {
-            const float2 lo = R[bq], mid = R[bq + 1], hi = R[bq + 2];
+            const f2 lo = R[bq], mid = R[bq + 1], hi = R[bq + 2];
             const float sx = hi.x * wn.x + hi.y * wn.y + lo.x * wn.x - lo.y * wn.y;
             const float sy = hi.y * wn.x - hi.x * wn.y + lo.y * wn.x + lo.x * wn.y;
             const float vx = 0.5f * mid.x + 0.25f * sx, vy = 0.5f * mid.y + 0.25f * sy;
@@ -1206,7 +1263,7 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
         }
         float r = nbin > 0 ? acc / (float)nbin : 0.f;
         if (mode == ISD_BP_LOGPOWER) r = logf(r + eps);
-        if (row_ok && li < 8 && j >= 0 && j < J) out[j] = r;
+        if (row_ok && j >= 0 && j < J) out[j] = r;
       }
       wave_lds_sync();                                   // the ring slots this round read may be overwritten next pass
     }
@@ -1500,7 +1557,7 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
                      log2_nblk, st->n / 2, st->scale * st->scale, fbnd, mode, eps, fs.d_map, fb->n_bands, (int)rows)
       // rows of whole 512-sample passes covering all 64 blocks: four rows per wave, no cross-group chain
       const bool rows4 = vec && st->T % kSeg == 0 && log2_nblk <= 4 && log2_nblk >= 1 && rows4_enabled();
-      const size_t lds4 = sizeof(float2) * ((size_t)4 * KB * 32 + 64) + sizeof(double) * (8 * kMaxSec + 64 * kMaxSec);
+      const size_t lds4 = sizeof(float2) * ((size_t)4 * KB * 32 + 64) + sizeof(double) * (8 + 64) * (size_t)fb->n_sections;
 #define ISD_FL_LAUNCH4(VT, K)                                                                                         \
   do {                                                                                                                \
     ISD_HIP_TRY(hipFuncSetAttribute((const void*)fused_rows4_kernel<VT, K>, hipFuncAttributeMaxDynamicSharedMemorySize, \

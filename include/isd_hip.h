@@ -36,6 +36,12 @@ enum {
 
 int isd_abi_version(void);
 const char* isd_last_error(void);
+/* Measurement aid (bench.py): one wave reads the shader-clock counter and the constant-rate counter around a spin of
+ * about `spin_us` microseconds and stores {shader ticks, constant-rate ticks} as two uint64 at `out` (device memory);
+ * shader MHz = ticks[0] / ticks[1] * isd_wall_clock_khz() / 1000.  Launch it on a second stream beside the kernels
+ * being timed. */
+int isd_shader_clock_probe(uint64_t* out, int spin_us, void* stream);
+int isd_wall_clock_khz(void);
 /* number of visible HIP devices (0 on a CPU-only host; never fails) */
 int isd_device_count(void);
 
