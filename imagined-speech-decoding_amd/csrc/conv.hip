@@ -958,15 +958,19 @@ struct FusedBwdArgs {
   int Ctot, Tx, N, S;
 };
 
-// acc[gt][k] += sum over this wave's time steps of G[gt*16 + row][t] * In[col][t + k - pad]   (MFMA: M = filter,
-// N = channel, K = 4 time steps).  Steps first, first + stride, ... < nks; fragments of the next step are fetched
-// from LDS while the MFMAs of the current one run.  `accb` (optional) takes an all-ones B operand: sum_t G.
+// acc[k] += sum over this wave's time steps of G[row][t] * In[col][t + k - pad]   (MFMA: M = the 16 filters of ONE
+// filter tile -- G points at its first row --, N = channel, K = 4 time steps).  Steps first, first + stride, ... < nks;
+// fragments of the next step are fetched from LDS while the MFMAs of the current one run.  `accb` (BIAS) takes an
+// all-ones B operand: sum_t G.
+// (Round 2 gave a wave BOTH filter tiles: 30 accumulator tiles = 120 registers across the three layers, 256 VGPRs,
+// 132 bytes of scratch and 176 v_readlane / v_writelane.  A wave now owns one filter tile and twice the time steps:
+// the same MFMAs, 15 accumulator tiles.)
 template <bool BIAS>
 __device__ __forceinline__ void fused_wgrad_mma(const float* __restrict__ G, const float* __restrict__ In, int T1,
                                                 int RSi, int Tin, int pad, int first, int stride, int nks, int q,
-                                                int jl, f32x4 (&acc)[2][kTaps], f32x4 (&accb)[2]) {
+                                                int jl, f32x4 (&acc)[kTaps], f32x4& accb) {
   struct Frag {
-    float a[2];
+    float a;
     float b[kTaps];
     float one;
   };
@@ -980,8 +984,7 @@ __device__ __forceinline__ void fused_wgrad_mma(const float* __restrict__ G, con
   auto load = [&](int s, Frag& f) {
     const int t0 = s * 4;
     if (s >= s_lo && s < s_hi) {
-      f.a[0] = gr[t0];
-      f.a[1] = gr[16 * T1 + t0];
+      f.a = gr[t0];
 #pragma unroll
       for (int k = 0; k < kTaps; ++k) f.b[k] = ir[t0 + k];
       f.one = 1.f;
@@ -989,9 +992,8 @@ __device__ __forceinline__ void fused_wgrad_mma(const float* __restrict__ G, con
     }
     const int t = t0 + q;
     const bool ok = t < T1;
-    const float v0 = gr[ok ? t0 : 0], v1 = gr[16 * T1 + (ok ? t0 : 0)];
-    f.a[0] = ok ? v0 : 0.f;
-    f.a[1] = ok ? v1 : 0.f;
+    const float v0 = gr[ok ? t0 : 0];
+    f.a = ok ? v0 : 0.f;
 #pragma unroll
     for (int k = 0; k < kTaps; ++k) {
       const int idx = t + k - pad;
@@ -1003,14 +1005,8 @@ __device__ __forceinline__ void fused_wgrad_mma(const float* __restrict__ G, con
   };
   auto mma = [&](const Frag& f) {
 #pragma unroll
-    for (int k = 0; k < kTaps; ++k) {
-      acc[0][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[0], f.b[k], acc[0][k], 0, 0, 0);
-      acc[1][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[1], f.b[k], acc[1][k], 0, 0, 0);
-    }
-    if (BIAS) {
-      accb[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[0], f.one, accb[0], 0, 0, 0);
-      accb[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[1], f.one, accb[1], 0, 0, 0);
-    }
+    for (int k = 0; k < kTaps; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a, f.b[k], acc[k], 0, 0, 0);
+    if (BIAS) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a, f.one, accb, 0, 0, 0);
   };
   Frag f0, f1;
   if (first < nks) load(first, f0);
@@ -1057,20 +1053,17 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a
 #pragma unroll
     for (int kk = 0; kk < kTaps; ++kk) ok2[j][kk] = off2[j] + kk >= 0 && off2[j] + kk < T1;
   }
-  // weight-gradient roles: cnn3/cnn4: channel tile = wave & 1, time share = wave >> 1 (of 4); Weff: time share = wave (of 8)
-  const int ct = wave & 1, ks = wave >> 1;
+  // weight-gradient roles: cnn3 / cnn4: channel tile = wave & 1, filter tile = (wave >> 1) & 1, time share = wave >> 2
+  // (of 2); Weff: filter tile = wave & 1, time share = wave >> 1 (of 4)
+  const int ct = wave & 1, gw = (wave >> 1) & 1, ks = wave >> 2;
+  const int g0w = wave & 1, ks0 = wave >> 1;
   const int nks = (T1 + 3) >> 2;
-  f32x4 acc4[2][kTaps], acc3[2][kTaps], acc0[2][kTaps], accb[2], nob[2];
+  f32x4 acc4[kTaps], acc3[kTaps], acc0[kTaps], accb = {0.f, 0.f, 0.f, 0.f}, nob = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    accb[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    nob[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < kTaps; ++k) {
-      acc4[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc3[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc0[g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+  for (int k = 0; k < kTaps; ++k) {
+    acc4[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc3[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc0[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const int n4 = (F * T1) >> 2;
   static_assert(NW == 8, "16 x rows = two per wave");
@@ -1109,7 +1102,7 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a
     }
     __syncthreads();                                   // G4, A3 and the x rows are in LDS
     // ---------------- cnn4: dW4 += G4 (*) A3 ; G3 = W4^T (*) G4 -> gb
-    fused_wgrad_mma<false>(ga, at + ct * 16 * T1, T1, T1, T1, 2, ks, 4, nks, q, jl, acc4, nob);
+    fused_wgrad_mma<false>(ga + gw * 16 * T1, at + ct * 16 * T1, T1, T1, T1, 2, ks, 2, nks, q, jl, acc4, nob);
     {
       f32x4 acc[NJ][2];
 #pragma unroll
@@ -1132,28 +1125,28 @@ __global__ __launch_bounds__(NW * 64) void conv4_fused_bwd_kernel(FusedBwdArgs a
       fused_layer_store<NW>(acc, nullptr, ga, T1, TT, wave, q, jl);
     }
     __syncthreads();                                   // G2 complete, A2 landed
-    fused_wgrad_mma<false>(gb, at + ct * 16 * T1, T1, T1, T1, 2, ks, 4, nks, q, jl, acc3, nob);
+    fused_wgrad_mma<false>(gb + gw * 16 * T1, at + ct * 16 * T1, T1, T1, T1, 2, ks, 2, nks, q, jl, acc3, nob);
     // ---------------- cnn1 o cnn2: dWeff += G2 (*) x (valid convolution), dbeff += sum_t G2
-    fused_wgrad_mma<true>(ga, xz, T1, W, W, 0, wave, NW, nks, q, jl, acc0, accb);
+    fused_wgrad_mma<true>(ga + g0w * 16 * T1, xz, T1, W, W, 0, ks0, 4, nks, q, jl, acc0, accb);
   }
   // ---------------- partial slabs
+  // (two time shares -> two slabs per workgroup for cnn3 / cnn4, four for Weff: the host sums exactly those)
   {
-    float* s4 = a.part4 + ((int64_t)blockIdx.x * 4 + ks) * a.slab1 + (int64_t)z * F * F * kTaps;
-    float* s3 = a.part3 + ((int64_t)blockIdx.x * 4 + ks) * a.slab1 + (int64_t)z * F * F * kTaps;
-    float* s0 = a.part0 + ((int64_t)blockIdx.x * NW + wave) * a.slab0 + zd.wg_off;
+    float* s4 = a.part4 + ((int64_t)blockIdx.x * 2 + ks) * a.slab1 + (int64_t)z * F * F * kTaps;
+    float* s3 = a.part3 + ((int64_t)blockIdx.x * 2 + ks) * a.slab1 + (int64_t)z * F * F * kTaps;
+    float* s0 = a.part0 + ((int64_t)blockIdx.x * 4 + ks0) * a.slab0 + zd.wg_off;
 #pragma unroll
-    for (int gt = 0; gt < 2; ++gt)
+    for (int r = 0; r < 4; ++r) {
+      const int g = gw * 16 + 4 * q + r, c = ct * 16 + jl;
+      const int g0 = g0w * 16 + 4 * q + r;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int g = gt * 16 + 4 * q + r, c = ct * 16 + jl;
-#pragma unroll
-        for (int k = 0; k < kTaps; ++k) {
-          s4[((int64_t)g * F + c) * kTaps + k] = acc4[gt][k][r];
-          s3[((int64_t)g * F + c) * kTaps + k] = acc3[gt][k][r];
-          if (jl < cz) s0[((int64_t)g * cin1 + jl) * kTaps + k] = acc0[gt][k][r];
-        }
-        if (jl < kTaps) s0[((int64_t)g * cin1 + cz) * kTaps + jl] = jl == 0 ? accb[gt][r] : 0.f;
+      for (int k = 0; k < kTaps; ++k) {
+        s4[((int64_t)g * F + c) * kTaps + k] = acc4[k][r];
+        s3[((int64_t)g * F + c) * kTaps + k] = acc3[k][r];
+        if (jl < cz) s0[((int64_t)g0 * cin1 + jl) * kTaps + k] = acc0[k][r];
       }
+      if (jl < kTaps) s0[((int64_t)g0 * cin1 + cz) * kTaps + jl] = jl == 0 ? accb[r] : 0.f;
+    }
   }
 }
 
@@ -1543,8 +1536,8 @@ __device__ __forceinline__ void fused_wgrad_x_bf16(unsigned g_base, unsigned xt_
 // __builtin_amdgcn_s_waitcnt (vmcnt 0) + a workgroup barrier.  `lds_base` must be wave-uniform.
 __device__ __forceinline__ void dma16_async(const void* src_lane, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-               :: "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(src_lane) : "memory", "m0");
-}
+               :: "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(src_lane) : "memory", "m0");   // (hipcc warns that m0 is reserved; the
+}                                                                                   // clobber still records that it changes)
 
 // One item ahead: GELU'(A4), A3 and A2 of the next item stream into the other tile set by LDS-DMA and its x channels
 // and dfeat row into registers while this item computes (one workgroup per CU: the 120 weight-gradient accumulators
@@ -3495,11 +3488,13 @@ static int conv4_backward_impl(const isd_conv4_plan* p, const float* x, const fl
                                       (int)lds));
       hipLaunchKernelGGL((conv4_fused_bwd_kernel<NW>), dim3(per_zone, p->Z), dim3(NW * 64), lds, st, fb);
       ISD_LAUNCH_CHECK();
-      launch_reduce_slabs(fb.part4, ws + g.o_wg34, g.slab1, per_zone * 4, st);
+      // the fp32 kernel leaves two slabs per workgroup for cnn3 / cnn4 and four for Weff (the buffers are sized for the
+      // bf16 twin's four and eight)
+      launch_reduce_slabs(fb.part4, ws + g.o_wg34, g.slab1, per_zone * 2, st);
       hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 1);
-      launch_reduce_slabs(fb.part3, ws + g.o_wg34, g.slab1, per_zone * 4, st);
+      launch_reduce_slabs(fb.part3, ws + g.o_wg34, g.slab1, per_zone * 2, st);
       hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 0);
-      launch_reduce_slabs(fb.part0, ws + g.o_wg, g.slab0, per_zone * NW, st);
+      launch_reduce_slabs(fb.part0, ws + g.o_wg, g.slab0, per_zone * 4, st);
       const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
       hipLaunchKernelGGL(fused_bwd_kernel, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,
                          ws + g.o_wg, dparams, F, nb2);
