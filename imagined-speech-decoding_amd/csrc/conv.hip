@@ -2098,6 +2098,205 @@ __global__ __launch_bounds__(NW * 64) void featcnn_tail_kernel(TailArgs a) {
   for (int e = threadIdx.x; e < a.slab; e += NW * 64) slab[e] = comb[e];
 }
 
+// BASELINE config 3, round 3: the same launch on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16).  The fp32-MFMA
+// instance above (featcnn_tail_kernel<., true>: bf16 I/O and bf16-rounded intermediates, 480 v_mfma_f32_16x16x4_f32
+// per item, 256 VGPRs + 172 AGPRs, one wave per SIMD) was the largest kernel of the bf16 classifier stage.  Here the
+// item's tiles are bf16 [time][32 channels] rows (64 bytes; two zero guard rows in front, zero rows behind T1 -- the
+// layout of the raw-EEG fused pair, whose fragment helpers it shares): K = 32 is all input channels of one tap, so
+// cnn3 / cnn4 and their data gradients are 5 taps x 2 filter tiles = 10 MFMAs each, the weight gradients (K = 32 time
+// steps, both operands through ds_read_b64_tr_b16) 20 each: 80 MFMAs per item.  A2 arrives and G2 leaves in exactly
+// the tile's row format ([item][t][32] bf16): no conversion on either side.  Eight waves per workgroup (two per SIMD).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void featcnn_tail_bf16_kernel(TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int F = 32, FR = kTaps * 2 * 64;                   // uint4 per K = 32 fragment set (10 KiB)
+  constexpr int R = 40, tile_b = R * 64;                       // fused16_rows(1) rows of 64 bytes
+  constexpr int priv_b = 4 * tile_b + 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, jl = lane & 15;
+  const int T1 = a.T1, n_cls = a.n_cls;
+  uint4* w3s = reinterpret_cast<uint4*>(smem);
+  uint4* w4s = w3s + FR;
+  uint4* w3ts = w4s + FR;
+  uint4* w4ts = w3ts + FR;
+  float* fcs = reinterpret_cast<float*>(w4ts + FR);            // [n_cls][F] then [n_cls]
+  char* priv = reinterpret_cast<char*>(fcs + kTailMaxCls * (F + 1)) + wave * priv_b;
+  char* tA2 = priv;
+  char* tA3 = priv + tile_b;
+  char* tG = priv + 2 * tile_b;                                // G4, later G2
+  char* tH = priv + 3 * tile_b;                                // G3
+  float* featL = reinterpret_cast<float*>(priv + 4 * tile_b);  // [32] pooled features
+  float* logL = featL + 32;                                    // [16] logits, [16] dlogits
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem;
+  const unsigned priv_base = smem_base + (unsigned)(4 * FR * 16 + kTailMaxCls * (F + 1) * 4 + wave * priv_b);
+  for (int e = threadIdx.x; e < FR; e += NW * 64) {
+    w3s[e] = reinterpret_cast<const uint4*>(a.w3)[e];
+    w4s[e] = reinterpret_cast<const uint4*>(a.w4)[e];
+    if (a.train) {
+      w3ts[e] = reinterpret_cast<const uint4*>(a.w3t)[e];
+      w4ts[e] = reinterpret_cast<const uint4*>(a.w4t)[e];
+    }
+  }
+  for (int e = threadIdx.x; e < n_cls * F; e += NW * 64) fcs[e] = a.fc_w[e];
+  for (int e = threadIdx.x; e < n_cls; e += NW * 64) fcs[n_cls * F + e] = a.fc_b[e];
+  for (int e = lane; e < priv_b / 16; e += 64) reinterpret_cast<uint4*>(priv)[e] = make_uint4(0u, 0u, 0u, 0u);   // guards, rows >= T1
+  __syncthreads();
+
+  f32x4 accW4[2][2][kTaps], accW3[2][2][kTaps];                // [channel tile][filter tile][tap]
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int k = 0; k < kTaps; ++k) {
+        accW4[c][g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        accW3[c][g][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+  float accfc[kTailMaxCls * F / 64], accb = 0.f, loss_acc = 0.f;   // lane l owns flat fc elements l, l+64, ...
+#pragma unroll
+  for (int i = 0; i < kTailMaxCls * F / 64; ++i) accfc[i] = 0.f;
+  const int tile = F * T1;                                     // bf16 elements of an item
+  const float inv_t = 1.f / (float)T1;
+  const int64_t stride = (int64_t)gridDim.x * NW;
+  const int tt0[1] = {0};
+  auto store_tile = [&](const f32x4 (&v)[2], char* dst) {      // 4 consecutive filters of step jl = 8 bytes per tile
+    if (jl < T1) {
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt)
+        *reinterpret_cast<uint2*>(dst + ((jl + 2) * 64 + (gt * 16 + 4 * q) * 2)) =
+            make_uint2(bf16_pack(v[gt][0], v[gt][1]), bf16_pack(v[gt][2], v[gt][3]));
+    }
+  };
+
+  // a wave past the end recomputes the last valid item (uniform control flow for the MFMAs) and contributes nothing
+  for (int64_t first = (int64_t)blockIdx.x * NW + wave; first - wave < a.items; first += stride) {
+    const bool live = first < a.items;
+    const int64_t item = live ? first : a.items - 1;
+    if (lane < 4 * T1)
+      *reinterpret_cast<uint4*>(tA2 + 128 + lane * 16) =
+          reinterpret_cast<const uint4*>((const unsigned short*)a.a2 + item * tile)[lane];
+    wave_lds_sync();
+    f32x4 acc[1][2];
+    auto clear = [&]() {
+      acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[0][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    clear();
+    fused_conv_bf16<1>(w3s, tA2, tt0, lane, acc);              // A3
+    store_tile(acc[0], tA3);
+    wave_lds_sync();
+    clear();
+    fused_conv_bf16<1>(w4s, tA3, tt0, lane, acc);              // A4 stays in registers (a bf16 tensor under autocast)
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[0][gt][r] = bf16_round(acc[0][gt][r]);
+    // GELU + mean over time: row sums inside each 16-lane row
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sacc = jl < T1 ? gelu_f(acc[0][gt][r]) : 0.f;
+        sacc += row_shr<8>(sacc);
+        sacc += row_shr<4>(sacc);
+        sacc += row_shr<2>(sacc);
+        sacc += row_shr<1>(sacc);
+        if (jl == 15) featL[gt * 16 + 4 * q + r] = sacc * inv_t;
+      }
+    wave_lds_sync();
+    if (lane < n_cls) {
+      float l = fcs[n_cls * F + lane];
+#pragma unroll
+      for (int g = 0; g < F; ++g) l = fmaf(fcs[lane * F + g], featL[g], l);
+      logL[lane] = l;
+      if (live) a.logits[item * n_cls + lane] = l;
+    }
+    wave_lds_sync();
+    float mx = -INFINITY, lse = 0.f;
+    int am = 0, yv = 0;
+    for (int c = 0; c < n_cls; ++c) {
+      const float v = logL[c];
+      if (v > mx) { mx = v; am = c; }                          // strict '>' keeps the lowest index on ties (torch.argmax)
+    }
+    if (lane == 0 && live) a.pred[item] = am;
+    if (a.labels) {
+      float se = 0.f;
+      for (int c = 0; c < n_cls; ++c) se += expf(logL[c] - mx);
+      yv = a.label_bytes == 1 ? (int)((const unsigned char*)a.labels)[item] : (int)((const long long*)a.labels)[item];
+      lse = mx + logf(se);
+      if (lane == 0 && live) loss_acc += (lse - logL[yv]) * a.grad_scale;
+    }
+    if (!a.labels || !a.train) continue;
+    // dlogits -> LDS (zero for a dead slot); G4 = dfeat/T1 * GELU'(A4)
+    if (lane < n_cls) logL[16 + lane] = live ? (expf(logL[lane] - lse) - (lane == yv ? 1.f : 0.f)) * a.grad_scale : 0.f;
+    wave_lds_sync();
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int g = gt * 16 + 4 * q + r;
+        float d = 0.f;
+        for (int c = 0; c < n_cls; ++c) d = fmaf(fcs[c * F + g], logL[16 + c], d);
+        acc[0][gt][r] = d * inv_t * gelu_grad_f(acc[0][gt][r]);
+      }
+    store_tile(acc[0], tG);
+    // FC gradients: flat element e = lane + 64 j of [n_cls][F]
+#pragma unroll
+    for (int j = 0; j < kTailMaxCls * F / 64; ++j) {
+      const int e = lane + 64 * j;
+      if (e < n_cls * F) accfc[j] = fmaf(logL[16 + (e >> 5)], featL[e & 31], accfc[j]);
+    }
+    if (lane < n_cls) accb += logL[16 + lane];
+    wave_lds_sync();
+    fused_wgrad_bf16(priv_base + 2 * tile_b, priv_base + tile_b, 0, 0, 1, 1, q, jl, accW4[0]);   // dW4 += G4 (*) A3
+    fused_wgrad_bf16(priv_base + 2 * tile_b, priv_base + tile_b, 1, 0, 1, 1, q, jl, accW4[1]);
+    clear();
+    fused_conv_bf16<1>(w4ts, tG, tt0, lane, acc);              // G3
+    store_tile(acc[0], tH);
+    wave_lds_sync();
+    fused_wgrad_bf16(priv_base + 3 * tile_b, priv_base, 0, 0, 1, 1, q, jl, accW3[0]);            // dW3 += G3 (*) A2
+    fused_wgrad_bf16(priv_base + 3 * tile_b, priv_base, 1, 0, 1, 1, q, jl, accW3[1]);
+    clear();
+    fused_conv_bf16<1>(w3ts, tH, tt0, lane, acc);              // G2
+    wave_lds_sync();                                           // every read of tG (wgrad4, cnn4 data gradient) is done
+    store_tile(acc[0], tG);
+    wave_lds_sync();
+    if (live && lane < 4 * T1)
+      reinterpret_cast<uint4*>((unsigned short*)a.g2 + item * tile)[lane] = *reinterpret_cast<const uint4*>(tG + 128 + lane * 16);
+    wave_lds_sync();                                           // tiles are reused by the next item
+  }
+  if (!a.labels) return;
+  // combine the waves in wave order through LDS (the fragment sets are dead), then one slab per workgroup
+  __syncthreads();
+  float* comb = smem;                                          // [2*F*F*5 + n_cls*(F+1) + 1]
+  const int o_fc = 2 * F * F * kTaps, o_b = o_fc + n_cls * F, o_loss = o_b + n_cls;
+  for (int w = 0; w < NW; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int k = 0; k < kTaps; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int idx = ((gt * 16 + 4 * q + r) * F + ct * 16 + jl) * kTaps + k;
+              comb[idx] = (w == 0 ? 0.f : comb[idx]) + accW3[ct][gt][k][r];
+              comb[F * F * kTaps + idx] = (w == 0 ? 0.f : comb[F * F * kTaps + idx]) + accW4[ct][gt][k][r];
+            }
+#pragma unroll
+      for (int i = 0; i < kTailMaxCls * F / 64; ++i) {
+        const int e = lane + 64 * i;
+        if (e < n_cls * F) comb[o_fc + e] = (w == 0 ? 0.f : comb[o_fc + e]) + accfc[i];
+      }
+      if (lane < n_cls) comb[o_b + lane] = (w == 0 ? 0.f : comb[o_b + lane]) + accb;
+      if (lane == 0) comb[o_loss] = (w == 0 ? 0.f : comb[o_loss]) + loss_acc;
+    }
+    __syncthreads();
+  }
+  float* slab = a.part + (int64_t)blockIdx.x * a.slab;
+  for (int e = threadIdx.x; e < a.slab; e += NW * 64) slab[e] = comb[e];
+}
+
 // ---------------------------------------------------------------------------------------
 // GELU + mean over time (fast.py:117-118) and its backward (in place on the activation).
 // one 16-lane row per (item, zone, filter) row of length T
@@ -3030,8 +3229,9 @@ static int launch_prep(const isd_conv4_plan* p, const Geo& g, const float* param
                        bool tap16 = false) {
   const int F = p->F;
   const int nbw = (int)cdiv(((int64_t)(p->max_cz + 3) / 4) * 4 * F, 256);
+  // K = 32 bf16 fragments of cnn3 / cnn4: the raw-EEG fused pair and (tap16) the feature classifier's bf16 tail
   PrepConvArgs pc{ws + g.o_w3, ws + g.o_w3t, ws + g.o_w4, ws + g.o_w4t, p->conv_zstride, p->n_layers,
-                  fused16_ok(p, g) && fused16_lds(p, g, true) <= 160 * 1024 ? 1 : 0};
+                  (tap16 && F == 32) || (fused16_ok(p, g) && fused16_lds(p, g, true) <= 160 * 1024) ? 1 : 0};
   const int extra = p->n_layers == 4 ? 8 : 0;
   hipLaunchKernelGGL(prep_fused_kernel, dim3(nbw + F + extra, p->Z), dim3(256), 0, st, params, p->d_zones,
                      ws + g.o_eff, ws + g.o_beff, F, nbw, p->act_bf16, pc,
@@ -3388,8 +3588,15 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
   const size_t lds = sizeof(float) * (size_t)(4 * 8 * kTaps * 2 * 64 + kTailMaxCls * (F + 1) + TNW * kTailNI * (4 * tile + 64) + 16);
   ISD_CHECK_ARG(lds <= 160 * 1024 && (int64_t)blocks * t.slab <= g.total - g.o_part, "isd_featcnn_step: workspace");
   if (tap16) {
-    ISD_HIP_TRY(hipFuncSetAttribute((const void*)featcnn_tail_kernel<TNW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((featcnn_tail_kernel<TNW, true>), dim3(blocks), dim3(TNW * 64), lds, st, t);
+    // bf16 matrix cores: eight waves per workgroup, an item per wave and round
+    constexpr int BNW = 8;
+    blocks = (int)cdiv(g.items, BNW * 2);
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    const size_t lds16 = (size_t)4 * kTaps * 2 * 64 * 16 + sizeof(float) * kTailMaxCls * (F + 1) + (size_t)BNW * (4 * 40 * 64 + 256) + 64;
+    ISD_CHECK_ARG(lds16 <= 160 * 1024 && (int64_t)blocks * t.slab <= g.total - g.o_part, "isd_featcnn_step: workspace");
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)featcnn_tail_bf16_kernel<BNW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+    hipLaunchKernelGGL((featcnn_tail_bf16_kernel<BNW>), dim3(blocks), dim3(BNW * 64), lds16, st, t);
   } else {
     ISD_HIP_TRY(hipFuncSetAttribute((const void*)featcnn_tail_kernel<TNW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((featcnn_tail_kernel<TNW, false>), dim3(blocks), dim3(TNW * 64), lds, st, t);

@@ -902,6 +902,10 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
   const bool st0 = row_ok && i < J, st16 = row_ok && i == LPR - 1 && J == LPR + 1;
   XArr xs;
   load_chunks<FULL>(xs, tile, x, lane, xbase, gt0, T, vec != 0);
+#ifdef ISD_MFMA_PROBE
+  typedef float f32x4p __attribute__((ext_vector_type(4)));
+  f32x4p probe[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#endif
   for (int b = 0; b < nb; ++b) {
     typename O::Arr v;
     O::from_x(v, xs, O::g(bands[b]));
@@ -912,6 +916,15 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
     XArr vf;                                          // fp32 copy for the DFT (the chunk itself when VT is fp32)
     O::to_f32(v, vf);
     if (!FULL && T < LPR * kL) zero_past_end(vf, i, T);   // FULL: T == LPR * kL
+#ifdef ISD_MFMA_PROBE
+    // Measurement build (ISD_HIPCC_FLAGS=-DISD_MFMA_PROBE=32, tools/mfma_probe.sh): the matrix-pipe load a
+    // band DFT on the matrix cores would add -- ISD_MFMA_PROBE v_mfma_f32_16x16x4_f32 per band and wave on live
+    // registers, four independent accumulators -- issued BESIDE the unchanged vector code: what co-issue costs the
+    // VALU-bound kernel, before anything is saved.
+#pragma unroll
+    for (int pi = 0; pi < ISD_MFMA_PROBE; ++pi)
+      probe[pi & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[pi & 15].x, vf[(pi + 5) & 15].y, probe[pi & 3], 0, 0, 0);
+#endif
     float o0, o16;
     band_reduce_pairs<MAG, GPR>(vf, dft, fbnd.klo[b], fbnd.khi[b], false, 0, 0, scale2, o0, o16, i == 0);
     const float inv = fbnd.inv[b];
@@ -922,6 +935,12 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
     if (st0) o[0] = o0;
     if (st16) o[1] = o16;
   }
+#ifdef ISD_MFMA_PROBE
+  {                                                   // keeps the probe's accumulators alive; never true
+    const float ps = probe[0][0] + probe[1][1] + probe[2][2] + probe[3][3];
+    if (ps == 1.2345678e30f && row_ok) feat[0] = ps;
+  }
+#endif
 }
 
 // Fused spec-S extractor for long rows with heavily overlapped frames (stress configuration: 4096 samples,

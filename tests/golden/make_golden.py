@@ -6,8 +6,8 @@
 Imports the *reference itself* (``/root/reference/src/fast/models/fast.py``,
 read-only) and scipy.signal, runs them on seeded inputs and stores inputs +
 outputs as small ``.npz`` files.  The reference never travels to the GPU box;
-these vectors do.  IDs follow SURVEY.md 8c (G1..G9); G10..G14 were added by the build (BN heads, FIR,
-the stress configuration's shapes).
+these vectors do.  IDs follow SURVEY.md 8c (G1..G9); G10..G16 were added by the build (BN heads, FIR,
+the stress configuration's shapes, the bf16-autocast runs).
 """
 import os
 import sys
@@ -400,8 +400,34 @@ def g15():
     save("g15_bf16_autocast.npz", **out)
 
 
+def g16():
+    """BASELINE config 3 for the reference-native modes: G5's FAST(small_config) (same seed, same parameters -- they are
+    in g5_fast_small.npz --, same x and labels) under torch.autocast(bfloat16), the precision scripts/train_fast.py:277
+    trains with: forward_head features, and logits / loss / every gradient of 'train_head' and 'default'."""
+    cfg = small_config()
+    torch.manual_seed(0)
+    m = FAST(cfg)
+    m.train()
+    x = torch.randn(2, 8, 500)
+    labels = torch.tensor([0, 2])
+    out = {}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        out["features"] = m.forward_head(x).detach().float().numpy()
+    for mode in ("train_head", "default"):
+        m.zero_grad()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            logits = m(x, forward_mode=mode)
+            loss = torch.nn.CrossEntropyLoss()(logits.float(), labels)
+        loss.backward()
+        out[f"{mode}.logits"], out[f"{mode}.loss"] = logits.detach().float().numpy(), loss.detach().numpy()
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                out[f"{mode}.grad.{k}"] = p.grad.detach().float().numpy().copy()
+    save("g16_fast_small_autocast.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5_g9, g6, g7, g8, g10, g11, g12, g13, g14, g15):
+    for fn in (g1, g2, g3, g4, g5_g9, g6, g7, g8, g10, g11, g12, g13, g14, g15, g16):
         if not only or fn.__name__ in only:
             fn()

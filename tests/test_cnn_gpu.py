@@ -137,6 +137,49 @@ def test_fast_small_train_head_matches_reference_golden(inn):
     assert m.transformer[0].attn.in_proj_weight.grad is not None
 
 
+def _bf16_small_run(inn, g):
+    """FAST(small_config, act_dtype='bf16') on G5's parameters and input: forward_head features, and logits / loss /
+    gradients of both trained modes."""
+    cfg = _small_cfg(inn)
+    cfg.act_dtype = "bf16"
+    m = inn.FAST(cfg).cuda()
+    m.load_state_dict(_sd(g, "sd."))
+    x = torch.from_numpy(g["x"]).cuda()
+    y = torch.from_numpy(g["labels"]).long().cuda()
+    out = {"features": m.forward_head(x).detach().cpu().numpy()}
+    for mode in ("train_head", "default"):
+        m.zero_grad(set_to_none=True)
+        logits = m(x, forward_mode=mode)
+        loss = torch.nn.functional.cross_entropy(logits, y)
+        loss.backward()
+        out[f"{mode}.logits"], out[f"{mode}.loss"] = logits.detach().cpu().numpy(), float(loss.detach())
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                out[f"{mode}.grad.{k}"] = p.grad.detach().cpu().numpy()
+    return out
+
+
+def test_fast_small_bf16_vs_reference_autocast_golden(inn):
+    """BASELINE config 3 for the modes the reference trains: FAST(small_config) with bf16 zone-CNN
+    activations against G16 = the reference under torch.autocast(bfloat16) (scripts/train_fast.py:277) and against its
+    fp32 run G5.  The reference's own autocast run deviates from its fp32 run by 5.7e-3 (features), 2.0e-3 (logits) and
+    up to 1.3e-2 (gradients, of each tensor's largest magnitude); the stated tolerance here is twice that, against
+    either reference.  (The HIP path keeps the transformer tail, the token projection and every parameter in fp32:
+    it is closer to the fp32 run than autocast, which also rounds those to bf16.)"""
+    g5, g16 = load_golden("g5_fast_small.npz"), load_golden("g16_fast_small_autocast.npz")
+    got = _bf16_small_run(inn, g5)
+    for name, ref in (("autocast", g16), ("fp32", g5)):
+        assert 0 < rel_err(got["features"], ref["features"]) < 1.2e-2, name
+        for mode in ("train_head", "default"):
+            assert rel_err(got[f"{mode}.logits"], ref[f"{mode}.logits"]) < 4e-3, (name, mode)
+            assert abs(got[f"{mode}.loss"] - float(ref[f"{mode}.loss"])) < 3e-3, (name, mode)
+            keys = [k for k in ref.files if k.startswith(f"{mode}.grad.")]
+            assert len(keys) >= 19 and all(k in got for k in keys)
+            for k in keys:
+                assert rel_err(got[k], ref[k]) < 2.6e-2, (name, k)
+            assert np.array_equal(got[f"{mode}.logits"].argmax(1), ref[f"{mode}.logits"].argmax(1))
+
+
 def test_fast_prod_eval_logits_bitexact_argmax(inn):
     g = load_golden("g6_fast_prod.npz")
     m = inn.FAST(inn.fast_config()).cuda().eval()
@@ -305,8 +348,10 @@ def test_bf16_matrix_core_step_vs_reference_autocast_at_576_channels(inn):
     """BASELINE config 3 at the cfg2 width: the classifier step on the bf16 matrix cores (conv5_fwd_bf16_kernel,
     featcnn_tail_kernel<.., true>, conv5_wgrad_wide_bf16_kernel behind isd_featcnn_step) against G15 = the reference's
     Conv4Layers(576, 32) + Linear under torch.autocast(bfloat16) on CPU (scripts/train_fast.py:277), and against its
-    fp32 run.  Stated tolerance: logits 2e-2 and parameter gradients 5e-2 of the tensor's largest magnitude, against
-    either -- the reference's own autocast run deviates from its fp32 run by 4e-3 / 8e-3 here."""
+    fp32 run.  The reference's own autocast run deviates from its fp32 run by 4.0e-3 (logits) / 7.6e-3 (gradients) of
+    the tensor's largest magnitude here; the stated tolerance is TWICE that against either run: logits 8e-3, parameter
+    gradients 1.6e-2 (measured, tools/bf16_deviation.py: 4.0e-3 / 7.9e-3 against the autocast run, 2.3e-3 / 3.7e-3
+    against the fp32 run -- the bf16 tail of round 3 on v_mfma_f32_16x16x32_bf16)."""
     from test_oracle import g15_params
     import isd_amd
     from isd_amd.classifier import _FeatureModel
@@ -327,12 +372,12 @@ def test_bf16_matrix_core_step_vs_reference_autocast_at_576_channels(inn):
     lg16, loss16, g16 = outs["bf16"]
     assert rel_err(lg32, g["fp32.logits"]) < 1e-4 and abs(loss32 - float(g["fp32.loss"])) < 1e-5
     for ref in ("bf16", "fp32"):
-        assert 0 < rel_err(lg16, g[f"{ref}.logits"]) < 2e-2, ref
-        assert abs(loss16 - float(g[f"{ref}.loss"])) < 5e-3, ref
+        assert 0 < rel_err(lg16, g[f"{ref}.logits"]) < 8e-3, ref
+        assert abs(loss16 - float(g[f"{ref}.loss"])) < 1e-3, ref
         for k, got in g16.items():
             want = g[f"{ref}." + ("fc.grad." + k[3:] if k.startswith("fc.") else "cnn.grad." + k[4:])]
             got = got[:, :, ::9] if k == "cnn.cnn2.weight" else got
-            assert rel_err(got, want) < 5e-2, (ref, k)
+            assert rel_err(got, want) < 1.6e-2, (ref, k)
     assert np.array_equal(lg16.argmax(1), g["bf16.logits"].argmax(1))
 
 
@@ -352,8 +397,8 @@ def test_bf16_matrix_core_step_shapes_vs_fp32_path(inn, B, C, T):
     o32 = isd_amd.HotPath(m32).forward(x, y, want_grad=True)
     hp16 = isd_amd.HotPath(m16)
     o16 = hp16.forward(x, y, want_grad=True)
-    assert 0 < rel_err(o16["logits"].cpu(), o32["logits"].cpu()) < 2e-2
-    assert rel_err(m16.flat_grads().cpu(), m32.flat_grads().cpu()) < 5e-2
+    assert 0 < rel_err(o16["logits"].cpu(), o32["logits"].cpu()) < 8e-3
+    assert rel_err(m16.flat_grads().cpu(), m32.flat_grads().cpu()) < 1.6e-2
     inf = hp16.forward(x)
     ev = hp16.forward(x, y)
     assert torch.equal(inf["logits"], o16["logits"]) and torch.equal(inf["pred"], o16["pred"])
@@ -364,8 +409,9 @@ def test_bf16_fused_raw_eeg_head_vs_fp32(inn):
     """The reference-native shape (8 zones, windows of 250 samples) with bf16 activations runs the fused forward /
     backward on the bf16 matrix cores (conv4_fused_fwd_bf16_kernel / conv4_fused_bwd_bf16_kernel: [time][channel] bf16
     tiles, v_mfma_f32_16x16x32_bf16, transposed LDS reads for the weight gradients).  Stated tolerance against the
-    fp32 kernels on the same parameters: features 2e-2, parameter gradients 5e-2 of the tensor's largest magnitude
-    (scripts/train_fast.py:277 trains under bf16-mixed autocast)."""
+    fp32 kernels on the same parameters: features 8e-3, parameter gradients 2e-2 of the tensor's largest magnitude --
+    about twice what the reference's own autocast run deviates from its fp32 run (G16: 5.7e-3 / 1.3e-2; measured here:
+    2.4e-3 / 7.4e-3, tools/bf16_deviation.py; scripts/train_fast.py:277 trains under bf16-mixed autocast)."""
     torch.manual_seed(3)
     h32 = inn.Head("Conv4Layers", ocnn.ELECTRODES, ocnn.ZONES, 32).cuda()
     h16 = inn.Head("Conv4Layers", ocnn.ELECTRODES, ocnn.ZONES, 32, act_dtype="bf16").cuda()
@@ -382,9 +428,9 @@ def test_bf16_fused_raw_eeg_head_vs_fp32(inn):
             (f * w).sum().backward()
             outs.append((f.detach().cpu(), {k: p.grad.detach().cpu().clone() for k, p in h.named_parameters()}))
         (f32, g32), (f16, g16) = outs
-        assert 0 < rel_err(f16, f32) < 2e-2, (B, T)
+        assert 0 < rel_err(f16, f32) < 8e-3, (B, T)
         for k in g32:
-            assert rel_err(g16[k], g32[k]) < 5e-2, (B, T, k)
+            assert rel_err(g16[k], g32[k]) < 2e-2, (B, T, k)
     # other window lengths: 260 samples (T1 = 256: the x fetch takes its fifth 64-step chunk, 16 full column tiles),
     # 100 samples (6 column tiles, 3 blocks of 32 steps in the weight gradients), many more items than workgroups
     for B, T, wl, st in ((5, 520, 260, 130), (9, 300, 100, 50), (700, 250, 250, 125)):
@@ -398,9 +444,9 @@ def test_bf16_fused_raw_eeg_head_vs_fp32(inn):
             (f * w).sum().backward()
             outs.append((f.detach().cpu(), {k: p.grad.detach().cpu().clone() for k, p in h.named_parameters()}))
         (f32, g32), (f16, g16) = outs
-        assert 0 < rel_err(f16, f32) < 2e-2, (B, T, wl)
+        assert 0 < rel_err(f16, f32) < 8e-3, (B, T, wl)
         for k in g32:
-            assert rel_err(g16[k], g32[k]) < 5e-2, (B, T, wl, k)
+            assert rel_err(g16[k], g32[k]) < 2e-2, (B, T, wl, k)
         with torch.no_grad():                                # inference keeps no activations: same features
             assert torch.equal(h16.forward_windows(x, wl, st).cpu(), f16)
     # the oracle (fp64) agrees with the bf16 features within the same tolerance
@@ -408,4 +454,4 @@ def test_bf16_fused_raw_eeg_head_vs_fp32(inn):
     p = {"head." + k: v.detach().cpu().double() for k, v in h32.state_dict().items()}
     ref = ocnn.forward_head(x.double(), p, list(ocnn.ZONES), ocnn.zone_index_lists(), 250, 125)
     got = h16.forward_windows(x.cuda(), 250, 125).detach().cpu()
-    assert rel_err(got, ref.reshape(got.shape)) < 2e-2
+    assert rel_err(got, ref.reshape(got.shape)) < 8e-3
