@@ -34,6 +34,8 @@ SIGNATURES = {
     "isd_last_error": (C.c_char_p, []),
     "isd_shader_clock_probe": (_i, [_p, _i, _p]),
     "isd_wall_clock_khz": (_i, []),
+    "isd_exact_sum_workspace_bytes": (_i64, []),
+    "isd_exact_sum": (_i, [_p, _i64, _p, _p, _p]),
     "isd_device_count": (_i, []),
     "isd_fb_plan_create": (_i, [C.POINTER(_p), _i, _i, _pd, _pd, _i]),
     "isd_fb_plan_destroy": (_i, [_p]),
@@ -46,6 +48,7 @@ SIGNATURES = {
     "isd_stft_forward": (_i, [_p, _p, _p, _i64, _p]),
     "isd_stft_bandpower": (_i, [_p, _p, _p, _i64, _i64, _i, _i, _pi, _pi, _i, _f, _p]),
     "isd_features_fused": (_i, [_p, _p, _p, _p, _i64, _i64, _pi, _pi, _i, _f, _p]),
+    "isd_features_fused_bf16": (_i, [_p, _p, _p, _p, _i64, _i64, _pi, _pi, _i, _f, _p]),
     "isd_fir_plan_create": (_i, [C.POINTER(_p), _i, _pd]),
     "isd_fir_plan_destroy": (_i, [_p]),
     "isd_fir_plan_taps": (_i, [_p]),
@@ -82,6 +85,7 @@ SIGNATURES = {
     "isd_eegnet_plan_create": (_i, [C.POINTER(_p), _i, _i, _i, _i]),
     "isd_featcnn_supported": (_i, [_p, _i64, _i64, _i]),
     "isd_featcnn_step": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _f, _p]),
+    "isd_featcnn_step_bf16": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _f, _p]),
     "isd_paperhead_plan_create": (_i, [C.POINTER(_p), _i, _i, _i]),
     "isd_paperhead_plan_destroy": (_i, [_p]),
     "isd_paperhead_param_count": (_i64, [_p]),

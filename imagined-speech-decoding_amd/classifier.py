@@ -132,8 +132,11 @@ class HotPath:
         """The kernels take raw pointers: everything they assume about the operands is checked here."""
         if not isinstance(x, torch.Tensor):
             raise TypeError("x must be a torch tensor")
-        if x.dtype != torch.float32:
-            raise TypeError(f"x must be float32, got {x.dtype}")
+        if x.dtype == torch.bfloat16:
+            if getattr(self.model._conv(), "act_dtype", "f32") != "bf16":
+                raise TypeError("a bfloat16 feature map needs a model with act_dtype='bf16' (BASELINE config 3)")
+        elif x.dtype != torch.float32:
+            raise TypeError(f"x must be float32 (or bfloat16 for a bf16 model), got {x.dtype}")
         if x.dim() != 3:
             raise ValueError("x must be [batch, channels, time]")
         if not x.is_contiguous():
@@ -169,7 +172,8 @@ class HotPath:
             pred = torch.empty((B,), dtype=torch.int64, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev) if labels is not None else None
             gp = gflat.data_ptr() if (want_grad and labels is not None) else 0
-            _lib.check(L.isd_featcnn_step(plan._h, x.data_ptr(), fp, fp + wo * f4, fp + bo * f4,
+            step = L.isd_featcnn_step_bf16 if x.dtype == torch.bfloat16 else L.isd_featcnn_step
+            _lib.check(step(plan._h, x.data_ptr(), fp, fp + wo * f4, fp + bo * f4,
                                           0 if labels is None else labels.data_ptr(),
                                           0 if labels is None else labels.element_size(), gp, gp + wo * f4 if gp else 0,
                                           logits.data_ptr(), pred.data_ptr(), 0 if loss is None else loss.data_ptr(),
@@ -178,6 +182,8 @@ class HotPath:
             if loss is not None:
                 out["loss"] = loss
             return out
+        if x.dtype != torch.float32:
+            raise TypeError("a bfloat16 input is taken by the one-call classifier step only (isd_featcnn_step_bf16)")
         feat = self._buf("feat", B * N * plan.n_zones * plan.F, dev)
         _lib.check(L.isd_conv4_forward(plan._h, x.data_ptr(), fp, feat.data_ptr(), ws.data_ptr(), B, T, st))
         # dense layers
@@ -638,8 +644,15 @@ class FilterbankCNNClassifier(_Estimator):
         return self.extractor_
 
     def extract_features(self, trials):
-        """trials f32 CUDA [B, C, T] -> [B, nb, C, J] (same as the module-level ``extract_features``)."""
-        return self._extractor(trials.shape[-1])(trials, fused=self.fused)
+        """trials f32 CUDA [B, C, T] -> [B, nb, C, J] (same as the module-level ``extract_features``).  With
+        ``precision='bf16'`` the short-row fused extractor writes the map as bf16 -- the rounding the bf16 first layer
+        applies to an fp32 map anyway (bit-identical results), half the bytes for the classifier to read."""
+        fx = self._extractor(trials.shape[-1])
+        st = fx.stft
+        if (self.precision == "bf16" and self.fused is not False and fx.can_fuse and st.nperseg == 64 and st.noverlap == 32
+                and trials.shape[-1] <= 1024 and (fx.n_bands * trials.shape[1]) % 8 == 0 and fx.n_frames <= 17):
+            return fx(trials, fused=True, out_dtype=torch.bfloat16)
+        return fx(trials, fused=self.fused)
 
     def _n_classes(self):
         return int(self.n_classes)

@@ -559,7 +559,11 @@ __global__ __launch_bounds__(256) void conv5_fwd_glds_kernel(ConvArgs a) {
 // Preconditions (host): one column tile (Tout <= 13 so that only sample 16 lies beyond the DPP row), Tin <= 17,
 // contiguous zone channels, whole-row windows, cin % 4 == 0, 16-byte aligned row blocks.
 // ---------------------------------------------------------------------------------------
-template <int GT, int NT>
+// IN16 (round 3): the input itself is bf16 (the extractor's isd_features_fused_bf16 map: the same RNE rounding, done
+// once by the producer) -- half the bytes to stream, the window is built from 16-bit LDS reads and packed with one
+// v_lshl_or_b32 per pair instead of a rounding sequence.  Rows are then 2 Tin bytes: the chunk copies stay whole
+// 16-byte pieces when the zone has a multiple of 8 channels (host check).
+template <int GT, int NT, bool IN16 = false>
 __global__ __launch_bounds__(256) void conv5_fwd_bf16_kernel(ConvArgs a, const uint4* __restrict__ wfrag16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int z = blockIdx.y;
@@ -581,10 +585,14 @@ __global__ __launch_bounds__(256) void conv5_fwd_bf16_kernel(ConvArgs a, const u
     float* w_tile = in_tile + in_len;
     const int c_lo = ch * kCK;
     const int ckc = (cin - c_lo) < kCK ? (cin - c_lo) : kCK;
-    const int cnt4 = (ckc * a.Tin) >> 2;
+    const int cnt4 = IN16 ? (ckc * a.Tin) >> 3 : (ckc * a.Tin) >> 2;
     for (int ii = wave; ii < n_items; ii += 4) {
       const int64_t soff = ((item0 + ii) * a.Ctot + chan0 + c_lo) * (int64_t)a.Tx;
-      glds_copy16((const float*)a.in + soff, in_tile + ii * kCK * a.RS, cnt4, lane);
+      if (IN16)
+        glds_copy16(reinterpret_cast<const float*>((const unsigned short*)a.in + soff), in_tile + ((ii * kCK * a.RS) >> 1),
+                    cnt4, lane);
+      else
+        glds_copy16((const float*)a.in + soff, in_tile + ii * kCK * a.RS, cnt4, lane);
     }
     const int wlen4 = (ckc / 4) * GT * 64;                  // 16-byte pieces of the weight chunk
     glds_copy16_strided(reinterpret_cast<const float*>(wbase + (int64_t)ch * (kCK / 4) * GT * 64), w_tile, wlen4,
@@ -623,17 +631,32 @@ __global__ __launch_bounds__(256) void conv5_fwd_bf16_kernel(ConvArgs a, const u
       const float* rowp = in_tile + cg * 4 * a.RS;
 #pragma unroll
       for (int jj = 0; jj < NT; ++jj) {
+        uint4 bw;
+        if constexpr (IN16) {
+          const unsigned short* r = reinterpret_cast<const unsigned short*>(in_tile) + cg * 4 * a.RS + boff[jj];
+          unsigned u0 = r[j0];
+          u0 = own_ok ? u0 : 0u;
+          unsigned u16 = has16 ? (unsigned)r[16] : 0u;
+          u16 = jl == 12 ? u16 : 0u;
+          const float f0 = __uint_as_float(u0);             // bit patterns ride the DPP row shifts unchanged
+          const unsigned u1 = __float_as_uint(row_shl<1>(f0)), u2 = __float_as_uint(row_shl<2>(f0)),
+                         u3 = __float_as_uint(row_shl<3>(f0)), u4 = __float_as_uint(row_shl<4>(f0)) | u16;
+          bw.x = u0 | (u1 << 16);
+          bw.y = u2 | (u3 << 16);
+          bw.z = u4;
+          bw.w = 0u;
+        } else {
         const float* r = rowp + boff[jj];
         float e0 = r[j0];
         e0 = own_ok ? e0 : 0.f;
         float s16 = has16 ? r[16] : 0.f;                    // the one sample beyond the DPP row that a stored output needs
         s16 = jl == 12 ? s16 : 0.f;
         const float e1 = row_shl<1>(e0), e2 = row_shl<2>(e0), e3 = row_shl<3>(e0), e4 = row_shl<4>(e0) + s16;
-        uint4 bw;
         bw.x = bf16_pack(e0, e1);
         bw.y = bf16_pack(e2, e3);
         bw.z = bf16_pack(e4, 0.f);
         bw.w = 0u;
+        }
         const bf16x8 bfr = __builtin_bit_cast(bf16x8, bw);
 #pragma unroll
         for (int g = 0; g < GT; ++g)
@@ -2731,7 +2754,7 @@ __global__ __launch_bounds__(256) void conv5_wgrad_wide_kernel(WgradArgs a) {
 // Same workgroup roles, LDS-DMA double buffering, slab layout and dbias column as conv5_wgrad_wide_kernel.
 // Preconditions (host): F = 32 (64-byte gradient rows), Tout <= 13, Tin <= 17, IPS even.
 // ---------------------------------------------------------------------------------------
-template <int GT>
+template <int GT, bool IN16 = false>
 __global__ __launch_bounds__(256) void conv5_wgrad_wide_bf16_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int z = blockIdx.y;
@@ -2767,8 +2790,13 @@ __global__ __launch_bounds__(256) void conv5_wgrad_wide_bf16_kernel(WgradArgs a)
         glds_copy16(reinterpret_cast<const float*>((const unsigned short*)a.dout +
                                                    ((is + ii) * a.Z + z) * (int64_t)a.Tout * a.F),
                     dst, do_real4, lane);
-        glds_copy16((const float*)a.in + ((is + ii) * a.Ctot + chan0 + c_base) * (int64_t)a.Tx, dst + do_len,
-                    (cw * a.Tin) >> 2, lane);
+        if (IN16)      // bf16 input rows (2 Tin bytes each): cw is a multiple of 8 (host check), whole 16-byte pieces
+          glds_copy16(reinterpret_cast<const float*>((const unsigned short*)a.in +
+                                                     ((is + ii) * a.Ctot + chan0 + c_base) * (int64_t)a.Tx),
+                      dst + do_len, (cw * a.Tin) >> 3, lane);
+        else
+          glds_copy16((const float*)a.in + ((is + ii) * a.Ctot + chan0 + c_base) * (int64_t)a.Tx, dst + do_len,
+                      (cw * a.Tin) >> 2, lane);
       } else {
         // a missing second item of the last pair: its gradient image must read as zero (the x rows may be stale)
         for (int e = lane; e < do_len; e += 64) dst[e] = 0.f;
@@ -2811,15 +2839,27 @@ __global__ __launch_bounds__(256) void conv5_wgrad_wide_bf16_kernel(WgradArgs a)
         af[g] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
       }
       // B: 12 samples of this lane's channel, packed as even pairs (e0e1, e2e3, ...) and odd pairs (e1e2, e3e4, ...)
+      unsigned int pe[6], po[5];
+      if constexpr (IN16) {
+        const unsigned short* xr = reinterpret_cast<const unsigned short*>(smem + item_off + do_len) +
+                                   (wave * 16 + jl) * a.Tin + t0;
+        unsigned int e[12];
+#pragma unroll
+        for (int n = 0; n < 12; ++n) e[n] = xr[n];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) pe[n] = e[2 * n] | (e[2 * n + 1] << 16);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) po[n] = e[2 * n + 1] | (e[2 * n + 2] << 16);
+      } else {
       const float* xr = smem + item_off + b_off;
       float e[12];
 #pragma unroll
       for (int n = 0; n < 12; ++n) e[n] = xr[n];
-      unsigned int pe[6], po[5];
 #pragma unroll
       for (int n = 0; n < 6; ++n) pe[n] = bf16_pack(e[2 * n], e[2 * n + 1]);
 #pragma unroll
       for (int n = 0; n < 5; ++n) po[n] = bf16_pack(e[2 * n + 1], e[2 * n + 2]);
+      }
 #pragma unroll
       for (int k = 0; k < kTaps; ++k) {
         const int h = k >> 1;
@@ -3250,7 +3290,7 @@ static bool bf16_mfma_ok(const isd_conv4_plan* p, const Geo& g, const void* x) {
 
 // cnn1 o cnn2 forward into the A2 buffer; `a` comes back filled with the shared fields for the later layers
 static int first_layer_forward(const isd_conv4_plan* p, const Geo& g, const float* x, int64_t T, float* ws,
-                               hipStream_t st, ConvArgs& a, bool tap16 = false) {
+                               hipStream_t st, ConvArgs& a, bool tap16 = false, bool in16 = false) {
   const int F = p->F;
   int rc;
   a = ConvArgs{};
@@ -3274,13 +3314,14 @@ static int first_layer_forward(const isd_conv4_plan* p, const Geo& g, const floa
     a.IPW = ipw; a.RS = p->W;
     const dim3 grid((unsigned)cdiv(g.items, ipw), p->Z);
     const uint4* w16 = reinterpret_cast<const uint4*>(ws + g.o_eff16);
-#define ISD_BF_LAUNCH(N)                                                                                        \
+#define ISD_BF_LAUNCH(N, I16)                                                                                   \
   do {                                                                                                          \
-    ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_fwd_bf16_kernel<2, N>,                                   \
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)conv5_fwd_bf16_kernel<2, N, I16>,                              \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-    hipLaunchKernelGGL((conv5_fwd_bf16_kernel<2, N>), grid, dim3(256), lds, st, a, w16);                        \
+    hipLaunchKernelGGL((conv5_fwd_bf16_kernel<2, N, I16>), grid, dim3(256), lds, st, a, w16);                   \
   } while (0)
-    if (NT == 4) ISD_BF_LAUNCH(4); else if (NT == 2) ISD_BF_LAUNCH(2); else ISD_BF_LAUNCH(1);
+    if (in16) { if (NT == 4) ISD_BF_LAUNCH(4, true); else if (NT == 2) ISD_BF_LAUNCH(2, true); else ISD_BF_LAUNCH(1, true); }
+    else { if (NT == 4) ISD_BF_LAUNCH(4, false); else if (NT == 2) ISD_BF_LAUNCH(2, false); else ISD_BF_LAUNCH(1, false); }
 #undef ISD_BF_LAUNCH
     ISD_LAUNCH_CHECK();
     a.IPW = g.IPW;
@@ -3470,7 +3511,8 @@ __global__ void scatter_conv_grad_kernel(const float* __restrict__ wg, const isd
 
 // cnn1 o cnn2 backward: dWeff (+ dbeff in the ones channel) from g2 = dL/dA2, then the chain to W1, b1, W2
 static int first_layer_backward(const isd_conv4_plan* p, const Geo& g, const float* x, int64_t T, const float* params,
-                                const float* g2, float* dparams, float* ws, hipStream_t st, bool tap16 = false) {
+                                const float* g2, float* dparams, float* ws, hipStream_t st, bool tap16 = false,
+                                bool in16 = false) {
   const int F = p->F;
   int rc;
   WgradArgs w = {};
@@ -3501,7 +3543,8 @@ static int first_layer_backward(const isd_conv4_plan* p, const Geo& g, const flo
       const size_t lds16 = sizeof(float) * (size_t)(2 * (ips16 * item16 + 32) + 8);
       w.items_per_wg = ipw; w.IPS = ips16;
       const dim3 grid((unsigned)R, p->Z, zg);
-      hipLaunchKernelGGL(conv5_wgrad_wide_bf16_kernel<2>, grid, dim3(256), lds16, st, w);
+      if (in16) hipLaunchKernelGGL((conv5_wgrad_wide_bf16_kernel<2, true>), grid, dim3(256), lds16, st, w);
+      else hipLaunchKernelGGL((conv5_wgrad_wide_bf16_kernel<2, false>), grid, dim3(256), lds16, st, w);
       ISD_LAUNCH_CHECK();
       n_slabs0 = R;
       rc = ISD_OK;
@@ -3545,10 +3588,10 @@ extern "C" int isd_featcnn_supported(const isd_conv4_plan* p, int64_t B, int64_t
   return featcnn_ok(p, g, n_cls) ? 1 : 0;       // (bf16: additionally x must be 16-byte aligned; isd_featcnn_step checks)
 }
 
-extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const float* params, const float* fc_w,
-                                const float* fc_b, const void* labels, int label_bytes, float* dparams, float* dfc,
-                                float* logits, int64_t* pred, float* loss, void* workspace, int64_t B, int64_t T,
-                                int n_cls, float grad_scale, void* stream) {
+static int featcnn_step_impl(const isd_conv4_plan* p, const float* x, const float* params, const float* fc_w,
+                             const float* fc_b, const void* labels, int label_bytes, float* dparams, float* dfc,
+                             float* logits, int64_t* pred, float* loss, void* workspace, int64_t B, int64_t T,
+                             int n_cls, float grad_scale, void* stream, bool x_bf16) {
   ISD_CHECK_ARG(p, "isd_featcnn_step: null plan");
   ISD_CHECK_ARG(B >= 1, "isd_featcnn_step: B=%lld", (long long)B);
   Geo g;
@@ -3560,6 +3603,11 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
     return ISD_ERR_UNSUPPORTED;
   }
   const bool tap16 = p->act_bf16 != 0;
+  if (x_bf16 && !(tap16 && p->max_cz % 8 == 0)) {
+    set_error("isd_featcnn_step_bf16: a bf16 feature map needs a plan with bf16 activations and a multiple of 8 input "
+              "channels (got act_bf16=%d, %d channels)", p->act_bf16, p->max_cz);
+    return ISD_ERR_UNSUPPORTED;
+  }
   ISD_CHECK_ARG(x && params && fc_w && fc_b && logits && pred && workspace, "isd_featcnn_step: null argument");
   ISD_CHECK_ARG(!labels || label_bytes == 1 || label_bytes == 8, "isd_featcnn_step: labels must be uint8 or int64");
   const bool train = labels && dparams && dfc;
@@ -3570,7 +3618,7 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
   rc = launch_prep(p, g, params, ws, st, tap16);
   if (rc) return rc;
   ConvArgs a = {};
-  rc = first_layer_forward(p, g, x, T, ws, st, a, tap16);
+  rc = first_layer_forward(p, g, x, T, ws, st, a, tap16, x_bf16);
   if (rc) return rc;
   TailArgs t = {};
   t.a2 = ws + g.o_a2; t.g2 = ws + g.o_a4;
@@ -3615,7 +3663,24 @@ extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const f
   }
   ISD_LAUNCH_CHECK();
   if (!train) return ISD_OK;
-  return first_layer_backward(p, g, x, T, params, ws + g.o_a4, dparams, ws, st, tap16);
+  return first_layer_backward(p, g, x, T, params, ws + g.o_a4, dparams, ws, st, tap16, x_bf16);
+}
+
+extern "C" int isd_featcnn_step(const isd_conv4_plan* p, const float* x, const float* params, const float* fc_w,
+                                const float* fc_b, const void* labels, int label_bytes, float* dparams, float* dfc,
+                                float* logits, int64_t* pred, float* loss, void* workspace, int64_t B, int64_t T,
+                                int n_cls, float grad_scale, void* stream) {
+  return featcnn_step_impl(p, x, params, fc_w, fc_b, labels, label_bytes, dparams, dfc, logits, pred, loss, workspace, B,
+                           T, n_cls, grad_scale, stream, false);
+}
+
+// The same step on a bf16 feature map x [B][C][T] (isd_features_fused_bf16): the plan must have bf16 activations
+extern "C" int isd_featcnn_step_bf16(const isd_conv4_plan* p, const uint16_t* x, const float* params, const float* fc_w,
+                                     const float* fc_b, const void* labels, int label_bytes, float* dparams, float* dfc,
+                                     float* logits, int64_t* pred, float* loss, void* workspace, int64_t B, int64_t T,
+                                     int n_cls, float grad_scale, void* stream) {
+  return featcnn_step_impl(p, reinterpret_cast<const float*>(x), params, fc_w, fc_b, labels, label_bytes, dparams, dfc,
+                           logits, pred, loss, workspace, B, T, n_cls, grad_scale, stream, true);
 }
 
 static int conv4_backward_impl(const isd_conv4_plan* p, const float* x, const float* params, const float* dfeat,

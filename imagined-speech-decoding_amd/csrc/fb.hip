@@ -648,15 +648,17 @@ template <typename VT, bool PASS_OUTER, bool FULLQ>
 __device__ __forceinline__ void fb_rows4_body(
     const FbSec* __restrict__ secs, const FbBand* __restrict__ bands, const double* __restrict__ Qtab,
     const float* __restrict__ x, float* __restrict__ y, int C, int T, int nb, int ns,
-    const int* __restrict__ bmap, int nb_out, int n_rows) {
+    const int* __restrict__ bmap, int nb_out, int n_rows, int share_n) {
   using O = VOps<VT>;
   __shared__ __attribute__((aligned(16))) float tile[2 * 16 * kPad];        // 32 chunks: two rows of one pass
   __shared__ double carry[kRows4Bands * kMaxSec * 8];                       // [band of this workgroup][section][group][2]
   const int lane = threadIdx.x;
   const int n_iter = T / kSeg;
+  // share_n workgroups share a quad (host: rows4_share(nb) -- the count in [4, 8] that leaves the fewest idle band
+  // slots: 35 bands -> 7 x 5, 5 bands -> 5 x 1; with a fixed 8 the last round of a 35-band set ran 3 of 8 sharers)
   const int id = blockIdx.x;
-  const int quad = (id / (8 * kLongShare)) * 8 + (id & 7);
-  const int share = (id >> 3) % kLongShare;
+  const int quad = (id / (8 * share_n)) * 8 + (id & 7);
+  const int share = (id >> 3) % share_n;
   if (quad * 4 >= n_rows) return;
   const int64_t bstride = (int64_t)C * T;
   const int q = lane >> 4, li = lane & 15;
@@ -718,13 +720,13 @@ __device__ __forceinline__ void fb_rows4_body(
       XArr xs;
       load_x(xs, it);
       int bi = 0;
-      for (int b = share; b < nb; b += kLongShare, ++bi) filter_store(xs, it, b, bi);
+      for (int b = share; b < nb; b += share_n, ++bi) filter_store(xs, it, b, bi);
     }
   } else {
     // fp64: the 16 registers of a pass of x held across the bands cost the instance a wave per SIMD (184 VGPRs, 1.62 ->
     // 1.87 ms per 128 stress trials); it re-reads the pass per band instead
     int bi = 0;
-    for (int b = share; b < nb; b += kLongShare, ++bi) {
+    for (int b = share; b < nb; b += share_n, ++bi) {
       for (int it = 0; it < n_iter; ++it) {
         XArr xs;
         load_x(xs, it);
@@ -737,15 +739,15 @@ template <bool FULLQ>
 __global__ __launch_bounds__(64) void fb_rows4_kernel_f32(
     const FbSec* __restrict__ secs, const FbBand* __restrict__ bands, const double* __restrict__ Qtab,
     const float* __restrict__ x, float* __restrict__ y, int C, int T, int nb, int ns,
-    const int* __restrict__ bmap, int nb_out, int n_rows) {
-  fb_rows4_body<float, true, FULLQ>(secs, bands, Qtab, x, y, C, T, nb, ns, bmap, nb_out, n_rows);
+    const int* __restrict__ bmap, int nb_out, int n_rows, int share_n) {
+  fb_rows4_body<float, true, FULLQ>(secs, bands, Qtab, x, y, C, T, nb, ns, bmap, nb_out, n_rows, share_n);
 }
 template <bool FULLQ>
 __global__ __launch_bounds__(64) void fb_rows4_kernel_f64(
     const FbSec* __restrict__ secs, const FbBand* __restrict__ bands, const double* __restrict__ Qtab,
     const float* __restrict__ x, float* __restrict__ y, int C, int T, int nb, int ns,
-    const int* __restrict__ bmap, int nb_out, int n_rows) {
-  fb_rows4_body<double, false, FULLQ>(secs, bands, Qtab, x, y, C, T, nb, ns, bmap, nb_out, n_rows);
+    const int* __restrict__ bmap, int nb_out, int n_rows, int share_n) {
+  fb_rows4_body<double, false, FULLQ>(secs, bands, Qtab, x, y, C, T, nb, ns, bmap, nb_out, n_rows, share_n);
 }
 
 struct FusedBands {
@@ -757,6 +759,14 @@ struct FusedBands {
 // log(P + eps) on the hardware log2 (v_log_f32, 1 ulp): |error| <= 2e-6 in the log domain for P + eps >= 1e-10,
 // against the 1e-4 feature gate; the libm logf costs ~20 instructions per value and every band needs two.
 __device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.69314718055994531f; }
+
+// fp32 -> bf16 bits, round to nearest even (NaN stays NaN): what torch.bfloat16 conversion and conv.hip's bf16_round do
+__device__ __forceinline__ unsigned short bf16_bits(float x) {
+  unsigned int u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
 
 // Windowed DFT of the band's own bins over the lane's chunk (register pairs) and the reduction to
 // band magnitude / power.  Frame j of the row is chunk j-1 (first window half, table entries 0..31)
@@ -878,7 +888,7 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
                                                    const float2* __restrict__ dft, const float* __restrict__ x,
                                                    float* __restrict__ feat, int R, int C, int T, int nb, int ns,
                                                    int J, float scale2, FusedBands fbnd, int mode, float eps,
-                                                   int vec, const int* __restrict__ bmap, int nb_out) {
+                                                   int vec, const int* __restrict__ bmap, int nb_out, int out16) {
   using O = VOps<VT>;
   static_assert(GPR == 1 || GPR == 2, "rows of at most 1024 samples");
   __shared__ __attribute__((aligned(16))) float tile[4 * 16 * kPad];
@@ -897,7 +907,11 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
   const int row = row0 + lane / LPR;
   const bool row_ok = row < R;
   const int bt = row / C, ch = row - bt * C;
-  float* const orow = feat + ((int64_t)bt * nb_out * C + ch) * (int64_t)J + i;   // band 0, frame i of this lane's row
+  const int64_t oidx = ((int64_t)bt * nb_out * C + ch) * (int64_t)J + i;        // band 0, frame i of this lane's row
+  float* const orow = feat + oidx;
+  // out16 (BASELINE config 3): the feature map leaves as bf16 (RNE) -- the rounding the bf16 first layer (and the
+  // reference's autocast, which casts the convolution's input) applies anyway, half the bytes for the classifier to read
+  unsigned short* const orow16 = reinterpret_cast<unsigned short*>(feat) + oidx;
   const int64_t bstride = (int64_t)C * J;
   const bool st0 = row_ok && i < J, st16 = row_ok && i == LPR - 1 && J == LPR + 1;
   XArr xs;
@@ -931,9 +945,15 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
     o0 *= inv;
     o16 *= inv;
     if (mode == ISD_BP_LOGPOWER) { o0 = fast_log(o0 + eps); o16 = fast_log(o16 + eps); }
-    float* o = orow + (int64_t)bmap[b] * bstride;
-    if (st0) o[0] = o0;
-    if (st16) o[1] = o16;
+    if (out16) {
+      unsigned short* o = orow16 + (int64_t)bmap[b] * bstride;
+      if (st0) o[0] = bf16_bits(o0);
+      if (st16) o[1] = bf16_bits(o16);
+    } else {
+      float* o = orow + (int64_t)bmap[b] * bstride;
+      if (st0) o[0] = o0;
+      if (st16) o[1] = o16;
+    }
   }
 #ifdef ISD_MFMA_PROBE
   {                                                   // keeps the probe's accumulators alive; never true
@@ -1111,7 +1131,7 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
                         const float* __restrict__ x, float* __restrict__ feat, int C,
                         int T, int nb, int ns, int J, int log2_nblk, int n_bins_max,
                         float scale2, FusedBands fbnd, int mode, float eps,
-                        const int* __restrict__ bmap, int nb_out, int n_rows) {
+                        const int* __restrict__ bmap, int nb_out, int n_rows, int share_n) {
   using O = VOps<VT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane0 = threadIdx.x;
@@ -1120,10 +1140,11 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
   float2* tw = ring + 4 * KB * 32;                                         // [64]  e^{-2 pi i u / (2 nblk)}, u < 2 nblk
   double* carry = reinterpret_cast<double*>(tw + 64);                      // [ns][4 groups][2]
   double* Qlds = carry + ns * 8;                                           // [ns][16][4] the band's per-lane M^i
-  // id = 8 kLongShare q + 8 w + c  <->  row quad = 8 q + c, band subset w (the sharers of a quad run on one XCD)
+  // id = 8 share_n q + 8 w + c  <->  row quad = 8 q + c, band subset w (the sharers of a quad run on one XCD);
+  // share_n = rows4_share(nb): 35 bands -> 7 sharers x 5 bands, 5 bands -> 5 x 1 (no idle band slots)
   const int id = blockIdx.x;
-  const int quad = (id / (8 * kLongShare)) * 8 + (id & 7);
-  const int share = (id >> 3) % kLongShare;
+  const int quad = (id / (8 * share_n)) * 8 + (id & 7);
+  const int share = (id >> 3) % share_n;
   if (quad * 4 >= n_rows) return;
   const int nblk = 1 << log2_nblk, nblk2 = 2 * nblk;
   if (lane0 < nblk2) {
@@ -1132,7 +1153,7 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
     tw[lane0] = make_float2(cs, -sn);
   }
   wave_lds_sync();
-  for (int b = share; b < nb; b += kLongShare) {
+  for (int b = share; b < nb; b += share_n) {
     int lane = lane0;                                    // lane-derived addresses are re-formed per band (see above)
     asm volatile("" : "+v"(lane));
     const int q = lane >> 4, li = lane & 15;
@@ -1301,6 +1322,20 @@ using namespace isd;
 
 extern "C" int isd_fb_plan_destroy(isd_fb_plan* p);
 
+// Workgroups that share a quad of rows in the rows4 kernels: the count in [4, 8] (8 preferred) that wastes the fewest
+// band slots -- ceil(nb / s) s / nb -- and keeps a workgroup's bands within its carry slots.
+static int rows4_share(int nb) {
+  int best = kLongShare;
+  double best_w = 1e30;
+  for (int s = kLongShare; s >= 4; --s) {
+    const int per = (nb + s - 1) / s;
+    if (per > kRows4Bands) continue;
+    const double w = (double)per * s / (double)(nb > 0 ? nb : 1);
+    if (w < best_w - 1e-9) { best_w = w; best = s; }
+  }
+  return best;
+}
+
 // ISD_FUSED_ROWS4_OFF=1 sends long rows to the one-row-per-wave kernels (A/B measurements); read once
 static bool rows4_enabled() {
   static const bool on = getenv("ISD_FUSED_ROWS4_OFF") == nullptr;
@@ -1467,9 +1502,10 @@ static int fb_launch_t(const isd_fb_plan* p, const FbSet& fs, const float* x, fl
   const int vec = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
   if (vec && T % kSeg == 0 && fs.nb <= kMaxBands && rows4_enabled()) {   // four rows per wave, group-local carries (carry slots for kMaxBands bands)
-    const dim3 grid4((unsigned)(cdiv(cdiv(R, 4), 8) * 8 * kLongShare));
+    const int share_n = rows4_share(fs.nb);
+    const dim3 grid4((unsigned)(cdiv(cdiv(R, 4), 8) * 8 * share_n));
 #define ISD_R4(K) hipLaunchKernelGGL(K, grid4, dim3(64), 0, st, fs.d_sec, fs.d_band, fs.d_Q, x, y, C, T, fs.nb, \
-                                     p->n_sections, fs.d_map, p->n_bands, (int)R)
+                                     p->n_sections, fs.d_map, p->n_bands, (int)R, share_n)
     const bool fullq = R % 4 == 0;
     if (std::is_same<VT, float>::value) { if (fullq) ISD_R4(fb_rows4_kernel_f32<true>); else ISD_R4(fb_rows4_kernel_f32<false>); }
     else { if (fullq) ISD_R4(fb_rows4_kernel_f64<true>); else ISD_R4(fb_rows4_kernel_f64<false>); }
@@ -1512,7 +1548,7 @@ static void set_band(FusedBands& f, int i, int klo, int khi) {
 
 template <typename VT>
 static int fused_launch(const isd_fb_plan* fb, const FbSet& fs, const isd_stft_plan* st, const float* x, float* feat,
-                        int64_t R, int C, const FusedBands& fbnd, int mode, float eps, hipStream_t stream) {
+                        int64_t R, int C, const FusedBands& fbnd, int mode, float eps, hipStream_t stream, int out16) {
   const bool two = st->T > kSeg;                          // rows of 513..1024 samples: two 16-lane groups per row
   const int64_t items = cdiv(R, two ? 2 : 4);
   const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
@@ -1521,7 +1557,7 @@ static int fused_launch(const isd_fb_plan* fb, const FbSet& fs, const isd_stft_p
 #define ISD_FUSED3(M, G, F)                                                                                          \
   hipLaunchKernelGGL((fused_kernel<VT, M, G, F>), dim3((unsigned)items), dim3(64), 0, stream, fs.d_sec, fs.d_band,   \
                      fs.d_Q, st->d_dft, x, feat, (int)R, C, st->T, fs.nb, fb->n_sections, st->J,                     \
-                     st->scale * st->scale, fbnd, mode, eps, vec, fs.d_map, fb->n_bands)
+                     st->scale * st->scale, fbnd, mode, eps, vec, fs.d_map, fb->n_bands, out16)
 #define ISD_FUSED(M, G) do { if (full) ISD_FUSED3(M, G, true); else ISD_FUSED3(M, G, false); } while (0)
   if (mode == ISD_BP_MAGNITUDE) { if (two) ISD_FUSED(true, 2); else ISD_FUSED(true, 1); }
   else { if (two) ISD_FUSED(false, 2); else ISD_FUSED(false, 1); }
@@ -1531,9 +1567,9 @@ static int fused_launch(const isd_fb_plan* fb, const FbSet& fs, const isd_stft_p
   return ISD_OK;
 }
 
-extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st, const float* x, float* feat,
-                                  int64_t B, int64_t C, const int* klo, const int* khi, int mode, float eps,
-                                  void* stream) {
+static int features_fused_impl(const isd_fb_plan* fb, const isd_stft_plan* st, const float* x, float* feat,
+                               int64_t B, int64_t C, const int* klo, const int* khi, int mode, float eps,
+                               void* stream, int out16) {
   ISD_CHECK_ARG(fb && st, "isd_features_fused: null plan");
   ISD_CHECK_ARG(B == 0 || (x && feat), "isd_features_fused: null argument");
   ISD_CHECK_ARG(B >= 0 && C >= 1 && C <= (1 << 20), "isd_features_fused: bad shape B=%lld C=%lld", (long long)B,
@@ -1552,6 +1588,11 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
   if (B == 0) return ISD_OK;
   ISD_CHECK_ARG(B * C <= kMaxRows, "isd_features_fused: too many rows (%lld)", (long long)(B * C));
   hipStream_t s = (hipStream_t)stream;
+  if (!short_rows && out16) {
+    set_error("isd_features_fused_bf16: bf16 feature maps are written by the short-row extractor only "
+              "(nperseg=64/noverlap=32/T<=1024)");
+    return ISD_ERR_UNSUPPORTED;
+  }
   if (!short_rows) {
     // long rows, heavily overlapped frames: filterbank + block sums in one kernel per band set
     int nbmax = 0;
@@ -1583,14 +1624,15 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
       // rows of whole 512-sample passes covering all 64 blocks: four rows per wave, no cross-group chain
       const bool rows4 = vec && st->T % kSeg == 0 && log2_nblk <= 4 && log2_nblk >= 1 && rows4_enabled();
       const size_t lds4 = sizeof(float2) * ((size_t)4 * KB * 32 + 64) + sizeof(double) * (8 + 64) * (size_t)fb->n_sections;
+      const int share4 = rows4_share(fs.nb);
 #define ISD_FL_LAUNCH4(VT, K)                                                                                         \
   do {                                                                                                                \
     ISD_HIP_TRY(hipFuncSetAttribute((const void*)fused_rows4_kernel<VT, K>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds4));                                                                      \
-    hipLaunchKernelGGL((fused_rows4_kernel<VT, K>), dim3((unsigned)(cdiv(cdiv(rows, 4), 8) * 8 * kLongShare)), dim3(64),  \
+    hipLaunchKernelGGL((fused_rows4_kernel<VT, K>), dim3((unsigned)(cdiv(cdiv(rows, 4), 8) * 8 * share4)), dim3(64),      \
                        lds4, s, fs.d_sec, fs.d_band, fs.d_Q, st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections,  \
                        st->J, log2_nblk, st->n / 2, st->scale * st->scale, fbnd, mode, eps, fs.d_map, fb->n_bands,      \
-                       (int)rows);                                                                                    \
+                       (int)rows, share4);                                                                            \
   } while (0)
 #define ISD_FL_LAUNCH(VT, K)                                        \
   do {                                                              \
@@ -1617,11 +1659,24 @@ extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st
     if (!fs.nb) continue;
     FusedBands fbnd = {};                                  // the set's bands, in the set's order
     for (int i = 0; i < fs.nb; ++i) set_band(fbnd, i, all.klo[fb->host_map[k][i]], all.khi[fb->host_map[k][i]]);
-    rc = k ? fused_launch<double>(fb, fs, st, x, feat, B * C, (int)C, fbnd, mode, eps, s)
-           : fused_launch<float>(fb, fs, st, x, feat, B * C, (int)C, fbnd, mode, eps, s);
+    rc = k ? fused_launch<double>(fb, fs, st, x, feat, B * C, (int)C, fbnd, mode, eps, s, out16)
+           : fused_launch<float>(fb, fs, st, x, feat, B * C, (int)C, fbnd, mode, eps, s, out16);
     if (rc) return rc;
   }
   return ISD_OK;
+}
+
+extern "C" int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st, const float* x, float* feat,
+                                  int64_t B, int64_t C, const int* klo, const int* khi, int mode, float eps,
+                                  void* stream) {
+  return features_fused_impl(fb, st, x, feat, B, C, klo, khi, mode, eps, stream, 0);
+}
+
+// The same extraction with the feature map written as bf16 [B][n_bands][C][J] (round to nearest even)
+extern "C" int isd_features_fused_bf16(const isd_fb_plan* fb, const isd_stft_plan* st, const float* x, uint16_t* feat,
+                                       int64_t B, int64_t C, const int* klo, const int* khi, int mode, float eps,
+                                       void* stream) {
+  return features_fused_impl(fb, st, x, reinterpret_cast<float*>(feat), B, C, klo, khi, mode, eps, stream, 1);
 }
 
 int isd::bandpower_direct(const isd_stft_plan* st, const float* y, float* feat, int64_t R, int C, int nb,

@@ -153,16 +153,32 @@ class FeatureExtractor:
     def n_frames(self):
         return self.stft.n_frames
 
-    def __call__(self, x, fused=None, out=None):
-        """x f32 CUDA [B, C, T] -> f32 CUDA [B, n_bands, C, J]."""
+    def __call__(self, x, fused=None, out=None, out_dtype=None):
+        """x f32 CUDA [B, C, T] -> f32 CUDA [B, n_bands, C, J].  ``out_dtype=torch.bfloat16`` (or a bf16 ``out``): the
+        fused extractor writes the map as bf16, round to nearest even -- BASELINE config 3, what the bf16 classifier
+        (``HotPath`` of a model with ``act_dtype='bf16'``) and the reference's autocast round its input to anyway."""
         _require_cuda(x, "trials")
         B, Cc, T = x.shape
         if T != self.stft.T:
             raise ValueError(f"extractor was planned for T={self.stft.T}, got T={T}")
         if fused is None:
             fused = self.can_fuse
+        if out_dtype is None:
+            out_dtype = torch.float32 if out is None else out.dtype
+        if out_dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f"features are float32 or bfloat16, got {out_dtype}")
         if out is None:
-            out = torch.empty((B, self.n_bands, Cc, self.n_frames), dtype=torch.float32, device=x.device)
+            out = torch.empty((B, self.n_bands, Cc, self.n_frames), dtype=out_dtype, device=x.device)
+        elif out.dtype != out_dtype or tuple(out.shape) != (B, self.n_bands, Cc, self.n_frames) or not out.is_contiguous():
+            raise ValueError("out must be a contiguous [B, n_bands, C, J] tensor of the requested dtype")
+        if out_dtype == torch.bfloat16:
+            if not fused:
+                raise ValueError("bf16 feature maps are written by the fused extractor (fused=True)")
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().isd_features_fused_bf16(self.fb._h, self.stft._h, x.data_ptr(), out.data_ptr(), B,
+                                                              Cc, self._klo, self._khi, _MODE[self.mode], self.eps,
+                                                              _stream_ptr()))
+            return out
         if fused:
             with torch.cuda.device(x.device):
                 _lib.check(_lib.lib().isd_features_fused(self.fb._h, self.stft._h, x.data_ptr(), out.data_ptr(), B, Cc,

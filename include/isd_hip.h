@@ -42,6 +42,11 @@ const char* isd_last_error(void);
  * being timed. */
 int isd_shader_clock_probe(uint64_t* out, int spin_us, void* stream);
 int isd_wall_clock_khz(void);
+/* The exact, order-independent sum of n fp32 values rounded once to fp64: the accumulator the BatchNorm heads keep
+ * their batch sums in (64-bit integer atomics on a fixed-point image of the partials; the same bits on every run --
+ * src/fast/utils.py:104-114 asks for deterministic training).  `workspace`: isd_exact_sum_workspace_bytes() bytes. */
+int64_t isd_exact_sum_workspace_bytes(void);
+int isd_exact_sum(const float* x, int64_t n, double* out, void* workspace, void* stream);
 /* number of visible HIP devices (0 on a CPU-only host; never fails) */
 int isd_device_count(void);
 
@@ -114,6 +119,11 @@ int isd_stft_bandpower(const isd_stft_plan* plan, const float* y, float* feat,
 int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st, const float* x,
                        float* feat, int64_t B, int64_t C, const int* klo, const int* khi,
                        int mode, float eps, void* stream);
+/* The same with the feature map written as bf16 (round to nearest even) -- BASELINE config 3: it is the rounding the
+ * bf16 classifier (isd_featcnn_step_bf16) and the reference's autocast apply to the convolution's input anyway.
+ * Rows of at most 1024 samples (the nperseg 64 / noverlap 32 extractor); ISD_ERR_UNSUPPORTED otherwise. */
+int isd_features_fused_bf16(const isd_fb_plan* fb, const isd_stft_plan* st, const float* x, uint16_t* feat,
+                            int64_t B, int64_t C, const int* klo, const int* khi, int mode, float eps, void* stream);
 
 /* ------------------------------------------------------------------------
  * Zero-phase FIR filter.  Replaces the band-pass of the SVM baseline,
@@ -347,6 +357,14 @@ int isd_featcnn_step(const isd_conv4_plan* plan, const float* x, const float* pa
                      const float* fc_b, const void* labels, int label_bytes, float* dparams, float* dfc,
                      float* logits, int64_t* pred, float* loss, void* workspace, int64_t B, int64_t T, int n_cls,
                      float grad_scale, void* stream);
+/* BASELINE config 3 with the feature map itself in bf16: x [B][c_total][T] bf16 as written by
+ * isd_features_fused_bf16 (the first layer rounds an fp32 map to bf16 as it packs its operands: the results are bit
+ * for bit those of isd_featcnn_step on the same values).  The plan must have bf16 activations and a multiple of 8
+ * input channels; ISD_ERR_UNSUPPORTED otherwise. */
+int isd_featcnn_step_bf16(const isd_conv4_plan* plan, const uint16_t* x, const float* params, const float* fc_w,
+                          const float* fc_b, const void* labels, int label_bytes, float* dparams, float* dfc,
+                          float* logits, int64_t* pred, float* loss, void* workspace, int64_t B, int64_t T,
+                          int n_cls, float grad_scale, void* stream);
 
 /* ----------------------------------------------------------------------
  * HeadConv_Paper_Version  (replaces src/fast/models/fast.py:170-196 behind the head contract :203-210)

@@ -263,6 +263,27 @@ def test_fold_packing_over_worker_processes_equals_serial_run(isd, tmp_path):
             assert rel_err(sb[k].float(), sa[k].float()) < 1e-5, k
 
 
+@pytest.mark.timeout(300)
+def test_fold_worker_failure_reaches_the_parent_instead_of_hanging_it(isd):
+    """a fold that raises inside its worker process (here: a window longer than the trials) must surface
+    as an exception in run_folds, with the worker's traceback, and the other workers must be shut down."""
+    from isd_amd import experiment as E
+    import isd_amd.nn as inn
+    rng = np.random.default_rng(2)
+    electrodes = ["Fp1", "Fp2", "F3", "F4", "C3", "C4", "O1", "O2"]
+    zones = {"Frontal": ["Fp1", "Fp2", "F3", "F4"], "Central": ["C3", "C4"], "Occipital": ["O1", "O2"]}
+    good = inn.fast_config(electrodes, zones, dim_cnn=16, dim_token=16, seq_len=500, n_classes=3, num_layers=1,
+                           num_heads=4, dropout=0.0)
+    bad = inn.fast_config(electrodes, zones, dim_cnn=16, dim_token=16, seq_len=100, window_len=250, n_classes=3,
+                          num_layers=1, num_heads=4, dropout=0.0)            # 250-sample windows of 100-sample trials
+    X = rng.standard_normal((8, 8, 500)).astype(np.float32)
+    y = rng.integers(0, 3, 8).astype(np.uint8)
+    tasks = {("01", 0): (good, X[:6], y[:6], X[6:], y[6:], 1, 4, 1, "default"),
+             ("01", 1): (bad, X[:6, :, :100], y[:6], X[6:, :, :100], y[6:], 1, 4, 1, "default")}
+    with pytest.raises(RuntimeError, match="failed in its worker"):
+        E.run_folds(tasks, workers=2)
+
+
 def test_graphed_training_step_matches_eager_and_advances_dropout(isd):
     """The optimisation step captured as a HIP graph (isd_amd.graph): with dropout off, a fold trained through graph
     replays follows the eager run (same batches, same schedule; AdamW capturable vs foreach arithmetic apart); with

@@ -405,6 +405,41 @@ def test_bf16_matrix_core_step_shapes_vs_fp32_path(inn, B, C, T):
     assert abs(float(ev["loss"]) - float(o16["loss"])) < 1e-6
 
 
+@pytest.mark.parametrize("B,C", [(64, 72), (37, 576), (4096, 576)])
+def test_bf16_feature_map_gives_the_bits_of_the_fp32_map(inn, B, C):
+    """BASELINE config 3, round 3: the extractor can write its feature map as bf16 (isd_features_fused_bf16) and the bf16
+    classifier step reads it directly (isd_featcnn_step_bf16).  The first layer rounds an fp32 map to bf16 (RNE) as it
+    packs its matrix-core operands, so (1) the bf16 map is the RNE rounding of the fp32 map, bit for bit, and (2) the
+    step on the bf16 map returns exactly the logits, loss and gradients of the step on the fp32 map of the same values."""
+    import isd_amd
+    from isd_amd.classifier import _FeatureModel
+    nb = 9
+    fx = isd_amd.FeatureExtractor(512, 256.0, isd_amd.BANDS_9)
+    gen = torch.Generator(device="cuda").manual_seed(B + C)
+    x = torch.randn(B, C // nb, 512, device="cuda", generator=gen)
+    f32 = fx(x)
+    f16 = fx(x, out_dtype=torch.bfloat16)
+    assert f16.dtype == torch.bfloat16 and f16.shape == f32.shape
+    assert torch.equal(f16, f32.to(torch.bfloat16))                     # torch's conversion is round-to-nearest-even
+    out = torch.empty_like(f16)
+    assert fx(x, out=out) is out and torch.equal(out, f16)
+    torch.manual_seed(1)
+    m = _FeatureModel(C, 32, 5, 4, "bf16").cuda()
+    y = torch.randint(0, 5, (B,), device="cuda", generator=gen)
+    hp = isd_amd.HotPath(m)
+    a = hp.forward(f16.float().view(B, C, 17).contiguous(), y, want_grad=True)
+    ga = m.flat_grads().clone()
+    b = hp.forward(f16.view(B, C, 17), y, want_grad=True)
+    gb = m.flat_grads().clone()
+    assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["pred"], b["pred"])
+    assert float(a["loss"]) == float(b["loss"]) and torch.equal(ga, gb)
+    assert torch.equal(hp.forward(f16.view(B, C, 17))["logits"], b["logits"])          # inference call
+    # a model without bf16 activations refuses the bf16 map; so does the layer-wise path
+    m32 = _FeatureModel(C, 32, 5, 4, "f32").cuda()
+    with pytest.raises(TypeError, match="act_dtype"):
+        isd_amd.HotPath(m32).forward(f16.view(B, C, 17), y)
+
+
 def test_bf16_fused_raw_eeg_head_vs_fp32(inn):
     """The reference-native shape (8 zones, windows of 250 samples) with bf16 activations runs the fused forward /
     backward on the bf16 matrix cores (conv4_fused_fwd_bf16_kernel / conv4_fused_bwd_bf16_kernel: [time][channel] bf16
