@@ -760,13 +760,6 @@ struct FusedBands {
 // against the 1e-4 feature gate; the libm logf costs ~20 instructions per value and every band needs two.
 __device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.69314718055994531f; }
 
-// fp32 -> bf16 bits, round to nearest even (NaN stays NaN): what torch.bfloat16 conversion and conv.hip's bf16_round do
-__device__ __forceinline__ unsigned short bf16_bits(float x) {
-  unsigned int u = __float_as_uint(x);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
 
 // Windowed DFT of the band's own bins over the lane's chunk (register pairs) and the reduction to
 // band magnitude / power.  Frame j of the row is chunk j-1 (first window half, table entries 0..31)
@@ -947,8 +940,10 @@ __global__ __launch_bounds__(64) void fused_kernel(const FbSec* __restrict__ sec
     if (mode == ISD_BP_LOGPOWER) { o0 = fast_log(o0 + eps); o16 = fast_log(o16 + eps); }
     if (out16) {
       unsigned short* o = orow16 + (int64_t)bmap[b] * bstride;
-      if (st0) o[0] = bf16_bits(o0);
-      if (st16) o[1] = bf16_bits(o16);
+      unsigned pk;                                      // both values in one gfx950 conversion (RNE)
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(o0), "v"(o16));
+      if (st0) o[0] = (unsigned short)pk;
+      if (st16) o[1] = (unsigned short)(pk >> 16);
     } else {
       float* o = orow + (int64_t)bmap[b] * bstride;
       if (st0) o[0] = o0;
