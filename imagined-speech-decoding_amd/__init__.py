@@ -11,11 +11,12 @@ from .features import FeatureExtractor, Filterbank, Stft, band_bins, extract_fea
 from .bandpass import FirFilter, filter_data  # noqa: F401
 from .filter_design import butter_bandpass_resonators, butter_bandpass_sos, fir_design  # noqa: F401
 from . import data, experiment  # noqa: F401
+from .optim import FusedAdamW  # noqa: F401
 from .classifier import (EEGNetPath, FASTHeadClassifier, FilterbankCNNClassifier,  # noqa: F401
                          FilterbankEEGNetClassifier, GradientBucket, HotPath, NotFittedError, Trainer,
                          cosine_scheduler, lr_multiplier, smoke_classifier)
 
-__all__ = ["FilterbankCNNClassifier", "FilterbankEEGNetClassifier", "FASTHeadClassifier", "EEGNetPath", "NotFittedError", "Trainer", "HotPath", "GradientBucket",
+__all__ = ["FusedAdamW", "FilterbankCNNClassifier", "FilterbankEEGNetClassifier", "FASTHeadClassifier", "EEGNetPath", "NotFittedError", "Trainer", "HotPath", "GradientBucket",
            "cosine_scheduler", "lr_multiplier", "extract_features", "FeatureExtractor", "Filterbank", "Stft", "band_bins", "butter_bandpass_sos",
            "butter_bandpass_resonators", "BANDS_5", "BANDS_9", "BANDS_40", "CLASSES", "ELECTRODES", "ZONES",
            "zone_index_lists", "data", "experiment", "FirFilter", "filter_data", "fir_design"]

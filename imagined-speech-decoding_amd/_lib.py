@@ -37,6 +37,10 @@ SIGNATURES = {
     "isd_exact_sum_workspace_bytes": (_i64, []),
     "isd_exact_sum": (_i, [_p, _i64, _p, _p, _p]),
     "isd_device_count": (_i, []),
+    "isd_adamw_step": (_i, [_p, _p, _p, _p, _i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64,
+                       _p, _p, _p]),
+    "isd_adamw_multi_step": (_i, [_i, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                             _i64, _p, _p, _p]),
     "isd_fb_plan_create": (_i, [C.POINTER(_p), _i, _i, _pd, _pd, _i]),
     "isd_fb_plan_destroy": (_i, [_p]),
     "isd_fb_plan_precision": (_i, [_p]),

@@ -414,24 +414,17 @@ class Trainer:
         flat = model.flat_params()
         gflat = model.flat_grads()
         self.flat, self.flat_grad = flat, gflat
-        # The optimizer sees the flat block as 36 equal views (AdamW is elementwise with uniform hyper-parameters,
-        # so this equals per-tensor AdamW).  torch's fused multi-tensor kernel gives every tensor its own blocks and
-        # takes at most 36 tensors (4 lists deep) per launch; each launch is latency-bound at ~18 us for these sizes.
-        # Measured inside the step (rocprofv3 / bench.py): 8 views = one launch of 96 us (8 blocks), 64 views = two
-        # launches of 18 us, 36 views = one (CNN stage 0.458 -> 0.447 ms).  The host side of opt.step() runs under
-        # the previous kernels (tools/adamw_probe.py).
-        n = flat.numel()
-        step = max(1024, -(-n // 36))
-        self.chunks = []
-        for lo in range(0, n, step):
-            p = nn.Parameter(flat[lo:lo + step])
-            p.grad = gflat[lo:lo + step]
-            self.chunks.append(p)
+        # AdamW runs on the flat block as ONE elementwise HIP kernel (csrc/adamw.hip, isd_adamw_step; torch's
+        # operation order and defaults).  Until round 3 the block went to torch.optim.AdamW(fused=True) as 36 equal
+        # views: its multi-tensor kernel gives every tensor its own few workgroups and took 29 us per step for 0.6 M
+        # parameters (tools/adamw_probe.py); the flat kernel spreads them over the chip.
+        if not flat.is_cuda:
+            raise RuntimeError("Trainer needs the parameters on a HIP device (the AdamW step is a HIP kernel)")
+        self.betas, self.eps, self.weight_decay = (0.9, 0.999), 1e-8, float(weight_decay)
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
         self.base_lr = lr
-        try:
-            self.opt = torch.optim.AdamW(self.chunks, lr=lr, weight_decay=weight_decay, fused=True)
-        except (RuntimeError, TypeError):
-            self.opt = torch.optim.AdamW(self.chunks, lr=lr, weight_decay=weight_decay)
+        self.lr = float(lr)
         self.schedule = schedule
         self.global_step = 0
         self.bucket.broadcast_(flat)
@@ -458,11 +451,21 @@ class Trainer:
         self.bucket.all_reduce_wait(self._pending[0])
         self._pending = None
         if self.schedule is not None:
-            lr = self.base_lr * lr_multiplier(self.schedule, self.global_step)
-            for g in self.opt.param_groups:
-                g["lr"] = lr
-        self.opt.step()
+            self.lr = self.base_lr * lr_multiplier(self.schedule, self.global_step)
         self.global_step += 1
+        _lib.check(_lib.lib().isd_adamw_step(
+            self.flat.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+            self.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.global_step,
+            None, None, _stream()))
+
+    def optimizer_state(self):
+        """The moment estimates and the step count (``load_optimizer_state`` puts them back)."""
+        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.global_step}
+
+    def load_optimizer_state(self, state):
+        self.exp_avg.copy_(state["exp_avg"])
+        self.exp_avg_sq.copy_(state["exp_avg_sq"])
+        self.global_step = int(state["step"])
 
 
 # ----------------------------------------------------------------------------- estimators

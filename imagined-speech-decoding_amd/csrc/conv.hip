@@ -2943,6 +2943,104 @@ static inline void launch_reduce_slabs(float* part, float* out, int64_t n, int n
   launch_reduce_slabs(part, ReduceDst{out, nullptr, nullptr, n, 0}, n, n_slabs, st);
 }
 
+// The three slab sets the fused backward kernels leave (cnn4, cnn3, Weff) summed by ONE launch (two when a set has 64
+// slabs or more), the cnn3 / cnn4 sums written straight to their places in the flat gradient block.  At the
+// reference's batch of 64 a step is ~40 kernels of a few microseconds: as three reductions of two launches each plus
+// two scatter copies these sums were 8 of them (~40 us of a 0.87 ms step).  Same element order as
+// reduce_slabs_kernel: the sums are bit for bit the ones the separate launches produced.
+struct SlabJob {
+  float* part;        // [n_slabs][n]
+  float* out;         // layer < 0: contiguous destination [n]; else the flat gradient block (scattered per zone)
+  int64_t n;
+  int n_slabs, L;     // L: slabs per run of the first level (== n_slabs: one level)
+  int layer;          // 0 / 1: cnn3 / cnn4 block of every zone (n = Z F F 5 in zone order); -1: contiguous
+  unsigned bx0;       // first blockIdx.x of this job
+};
+struct SlabJobs {
+  SlabJob j[3];
+  const ZoneDesc* zones;
+  int F;
+};
+// level 0: every job in one level (runs of L == n_slabs) -> destinations; level 1: run sums over each run's first slab;
+// level 2: the run sums (stride L) -> destinations
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(SlabJobs js, int level) {
+  __shared__ float red[4][64];
+  const int ji = blockIdx.x >= js.j[2].bx0 ? 2 : (blockIdx.x >= js.j[1].bx0 ? 1 : 0);
+  const SlabJob jb = js.j[ji];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t e = (int64_t)(blockIdx.x - jb.bx0) * 64 + lane, n = jb.n;
+  const int two = jb.L < jb.n_slabs;                       // this job needs two levels
+  int k0, k1, stride;
+  if (level == 2) {
+    if (!two) return;                                      // finished by the level-1 launch
+    k0 = 0; k1 = (jb.n_slabs + jb.L - 1) / jb.L; stride = jb.L;
+  } else {
+    k0 = blockIdx.y * jb.L;
+    if (k0 >= jb.n_slabs) return;
+    k1 = k0 + jb.L < jb.n_slabs ? k0 + jb.L : jb.n_slabs; stride = 1;
+  }
+  float s0 = 0.f, s1 = 0.f;
+  if (e < n) {
+    int k = k0 + grp;
+    for (; k + 4 < k1; k += 8) {
+      s0 += jb.part[(int64_t)k * stride * n + e];
+      s1 += jb.part[(int64_t)(k + 4) * stride * n + e];
+    }
+    if (k < k1) s0 += jb.part[(int64_t)k * stride * n + e];
+  }
+  red[grp][lane] = s0 + s1;
+  __syncthreads();
+  if (grp == 0 && e < n) {
+    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (level == 1 && two) {
+      jb.part[(int64_t)k0 * n + e] = v;
+    } else if (jb.layer < 0) {
+      jb.out[e] = v;
+    } else {
+      const int nz = js.F * js.F * kTaps;
+      const int z = (int)(e / nz);
+      const ZoneDesc zd = js.zones[z];
+      jb.out[zd.p_off + js.F * kTaps + js.F + (int64_t)js.F * js.F * zd.cin + (int64_t)jb.layer * nz + (e - (int64_t)z * nz)] = v;
+    }
+  }
+}
+
+// part4 / part3: n34 elements in n_slabs34 slabs -> cnn4 / cnn3 blocks of dparams; part0: n0 elements in n_slabs0
+// slabs -> wg0 (contiguous)
+static inline int launch_reduce_fused_bwd(float* part4, float* part3, float* part0, int64_t n34, int n_slabs34, int64_t n0,
+                                          int n_slabs0, float* dparams, float* wg0, const ZoneDesc* zones, int F,
+                                          hipStream_t st) {
+  SlabJobs js = {};
+  js.zones = zones; js.F = F;
+  const int64_t ns[3] = {n34, n34, n0};
+  const int slabs[3] = {n_slabs34, n_slabs34, n_slabs0};
+  float* parts[3] = {part4, part3, part0};
+  unsigned bx = 0;
+  int s_max = 1;
+  bool two = false;
+  for (int i = 0; i < 3; ++i) {
+    SlabJob& j = js.j[i];
+    j.part = parts[i]; j.n = ns[i]; j.n_slabs = slabs[i]; j.bx0 = bx;
+    j.layer = i == 0 ? 1 : (i == 1 ? 0 : -1);
+    j.out = i == 2 ? wg0 : dparams;
+    const unsigned b = (unsigned)cdiv(ns[i], 64);
+    j.L = slabs[i];
+    if (slabs[i] >= 64 && b < 1024) {                      // few elements, many slabs: two levels (launch_reduce_slabs's rule)
+      int L = 8;
+      while (L * L < slabs[i]) L *= 2;
+      j.L = L;
+      const int S = (int)cdiv(slabs[i], L);
+      if (S > s_max) s_max = S;
+      two = true;
+    }
+    bx += b;
+  }
+  hipLaunchKernelGGL(reduce_jobs_kernel, dim3(bx, s_max), dim3(256), 0, st, js, two ? 1 : 0);
+  if (two) hipLaunchKernelGGL(reduce_jobs_kernel, dim3(bx, 1), dim3(256), 0, st, js, 2);
+  ISD_LAUNCH_CHECK();
+  return ISD_OK;
+}
+
 // Chain dWeff / dbeff back to cnn1.weight, cnn1.bias, cnn2.weight.  grid = (blocks, zones):
 //   blocks [0, nb2)          : dW2[g,f,c] = sum_k dWeff[g,c,k] W1[f,k] + dbeff[g] b1[f]      (one thread per element)
 //   blocks [nb2, nb2 + 5F)   : dW1[f,k]   = sum_{g,c} dWeff[g,c,k] W2[g,f,c]                 (one block per output)
@@ -3723,11 +3821,9 @@ static int conv4_backward_impl(const isd_conv4_plan* p, const float* x, const fl
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((conv4_fused_bwd_bf16_kernel<NW>), dim3(per_zone, p->Z), dim3(NW * 64), lds, st, fb);
     ISD_LAUNCH_CHECK();
-    launch_reduce_slabs(fb.part4, ws + g.o_wg34, g.slab1, per_zone * 4, st);
-    hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 1);
-    launch_reduce_slabs(fb.part3, ws + g.o_wg34, g.slab1, per_zone * 4, st);
-    hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 0);
-    launch_reduce_slabs(fb.part0, ws + g.o_wg, g.slab0, per_zone * NW, st);
+    rc = launch_reduce_fused_bwd(fb.part4, fb.part3, fb.part0, g.slab1, per_zone * 4, g.slab0, per_zone * NW, dparams,
+                                 ws + g.o_wg, p->d_zones, F, st);
+    if (rc) return rc;
     const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
     hipLaunchKernelGGL(fused_bwd_kernel, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,
                        ws + g.o_wg, dparams, F, nb2);
@@ -3762,11 +3858,9 @@ static int conv4_backward_impl(const isd_conv4_plan* p, const float* x, const fl
       ISD_LAUNCH_CHECK();
       // the fp32 kernel leaves two slabs per workgroup for cnn3 / cnn4 and four for Weff (the buffers are sized for the
       // bf16 twin's four and eight)
-      launch_reduce_slabs(fb.part4, ws + g.o_wg34, g.slab1, per_zone * 2, st);
-      hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 1);
-      launch_reduce_slabs(fb.part3, ws + g.o_wg34, g.slab1, per_zone * 2, st);
-      hipLaunchKernelGGL(scatter_conv_grad_kernel, dim3(4, p->Z), dim3(256), 0, st, ws + g.o_wg34, p->d_zones, dparams, F, 0);
-      launch_reduce_slabs(fb.part0, ws + g.o_wg, g.slab0, per_zone * 4, st);
+      rc = launch_reduce_fused_bwd(fb.part4, fb.part3, fb.part0, g.slab1, per_zone * 2, g.slab0, per_zone * 4, dparams,
+                                   ws + g.o_wg, p->d_zones, F, st);
+      if (rc) return rc;
       const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
       hipLaunchKernelGGL(fused_bwd_kernel, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,
                          ws + g.o_wg, dparams, F, nb2);

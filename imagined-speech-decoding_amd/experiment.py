@@ -21,6 +21,7 @@ import torch
 from .classifier import cosine_scheduler, lr_multiplier
 from .data import DeviceStager
 from .graph import GraphedTrainStep, graph_safe
+from .optim import FusedAdamW
 from .nn import FAST, fast_config, reset_dropout_streams, token_mean_cross_entropy
 
 
@@ -100,8 +101,7 @@ def train_one_fold(config, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, for
     Xva = st.get()
     use_graph = graph_safe(model) if graph is None else bool(graph)
     if use_graph:
-        opt = torch.optim.AdamW(model.parameters(), lr=torch.tensor(float(lr), device=Xd.device), capturable=True,
-                                fused=True)
+        opt = FusedAdamW(model.parameters(), lr=torch.tensor(float(lr), device=Xd.device), capturable=True)
         model.train()
         try:
             gstep = GraphedTrainStep(model, opt, Xd, yd, bs, forward_mode)
@@ -116,7 +116,7 @@ def train_one_fold(config, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, for
             reset_dropout_streams()
             model = FAST(config).cuda()
     if not use_graph:
-        opt = torch.optim.AdamW(model.parameters(), lr=lr, fused=True)
+        opt = FusedAdamW(model.parameters(), lr=lr)
     gen = torch.Generator().manual_seed(seed)
     best, best_sd, hist, step = -1.0, None, [], 0
     for ep in range(max_epochs):

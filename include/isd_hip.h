@@ -366,6 +366,25 @@ int isd_featcnn_step_bf16(const isd_conv4_plan* plan, const uint16_t* x, const f
                           float* logits, int64_t* pred, float* loss, void* workspace, int64_t B, int64_t T,
                           int n_cls, float grad_scale, void* stream);
 
+/* One AdamW step on a flat fp32 block (replaces the optimizer of the reference's training loop,
+ * src/fast/train/trainer.py:49 `optim.AdamW(self.parameters(), lr=0.0005)`: decoupled weight decay, torch's
+ * operation order -- p *= 1 - lr wd; m += (g - m)(1 - b1); v = b2 v + (1 - b2) g g;
+ * p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)).  params / grads / exp_avg / exp_avg_sq: n floats each,
+ * 16-byte aligned, device memory; exp_avg and exp_avg_sq start at zero.  `step` = t >= 1 of THIS step.  lr_dev /
+ * step_dev (optional, device memory): learning rate and step count read by the kernel instead of the by-value
+ * arguments, so that a captured HIP graph can replay the step (the caller advances *step_dev before each replay). */
+int isd_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, int64_t step, const float* lr_dev,
+                   const int64_t* step_dev, void* stream);
+/* The same update over a list of tensors in one launch (per 96 tensors): host arrays of n_tensors DEVICE pointers and
+ * element counts; tensors need not be aligned or adjacent.  step_dev (optional): two int64 in device memory, zero before
+ * the first step -- [0] = steps taken so far; the kernel uses t = [0] + 1 and stores it back itself, [1] is its
+ * scratch -- so a captured graph replays the step with nothing to advance on the host. */
+int isd_adamw_multi_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                         float* const* exp_avg_sq, const int64_t* numel, double lr, double beta1, double beta2,
+                         double eps, double weight_decay, int64_t step, const float* lr_dev, int64_t* step_dev,
+                         void* stream);
+
 /* ----------------------------------------------------------------------
  * HeadConv_Paper_Version  (replaces src/fast/models/fast.py:170-196 behind the head contract :203-210)
  *   x [B][C][T] f32 -> out [B][feature_dim];  feature_dim in [3,64] (F1 = F/2, F2 = F3 = F/3, F4 = F), T >= 46.

@@ -1,7 +1,7 @@
 """Throughput of the reference-native paths on raw EEG (fwd+bwd+AdamW, device-resident trials):
 FAST 'train_head' through the autograd-free Trainer, and FAST 'default' -- the mode the reference trains
 (src/fast/train/trainer.py:58: zone CNN -> Linear+GELU -> cls/pos embedding -> 4 pre-LN transformer blocks ->
-classifier) -- through the autograd modules of isd_amd.nn with torch's fused AdamW."""
+classifier) -- through the autograd modules of isd_amd.nn with isd_amd.FusedAdamW (--torch-adamw: torch's fused AdamW)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +9,17 @@ import isd_amd
 import isd_amd.nn as inn
 from isd_amd.classifier import _FastModel
 from isd_amd.nn import fast_config
+
+
+def make_opt(net, capturable):
+    """isd_amd.FusedAdamW (what isd_amd.experiment trains with); --torch-adamw: torch's fused multi-tensor AdamW"""
+    if "--torch-adamw" in sys.argv:
+        if capturable:
+            return torch.optim.AdamW(net.parameters(), lr=torch.tensor(5e-4, device="cuda"), capturable=True, fused=True)
+        return torch.optim.AdamW(net.parameters(), lr=5e-4, fused=True)
+    if capturable:
+        return isd_amd.FusedAdamW(net.parameters(), lr=torch.tensor(5e-4, device="cuda"), capturable=True)
+    return isd_amd.FusedAdamW(net.parameters(), lr=5e-4)
 
 
 def timed(step, n):
@@ -58,14 +69,14 @@ def heads():
                 print(f"FAST default head={head:<22} B={B}: not graph-safe")
                 continue
             if graph:
-                opt = torch.optim.AdamW(net.parameters(), lr=torch.tensor(5e-4, device="cuda"), capturable=True, fused=True)
+                opt = make_opt(net, True)
                 gs = GraphedTrainStep(net, opt, x, y, B)
                 idx = torch.arange(B, device="cuda")
 
                 def step():
                     gs.step(idx, 5e-4)
             else:
-                opt = torch.optim.AdamW(net.parameters(), lr=5e-4, fused=True)
+                opt = make_opt(net, False)
 
                 def step():
                     opt.zero_grad(set_to_none=True)
@@ -76,7 +87,24 @@ def heads():
                   f"{B/dt:.0f} trials/s")
 
 
+def replay_only(act):
+    """--replay f32|bf16: 200 graph replays of the FAST 'default' step at the reference's batch (for rocprofv3)."""
+    from isd_amd.graph import GraphedTrainStep
+    B, T = 64, 800
+    x = torch.randn(B, 64, T, device="cuda")
+    y = torch.randint(0, 5, (B,), device="cuda")
+    torch.manual_seed(0)
+    net = inn.FAST(fast_config(seq_len=T, act_dtype=act)).cuda().train()
+    opt = make_opt(net, True)
+    gs = GraphedTrainStep(net, opt, x, y, B)
+    idx = torch.arange(B, device="cuda")
+    dt, _ = timed(lambda: gs.step(idx, 5e-4), 200)
+    print(f"FAST default {act} B={B} T={T} graph replay: {dt*1e3:.3f} ms/step")
+
+
 def main():
+    if "--replay" in sys.argv:
+        return replay_only(sys.argv[sys.argv.index("--replay") + 1])
     if "--tail" in sys.argv:
         return tail_only()
     if "--heads" in sys.argv:
@@ -99,7 +127,7 @@ def main():
             torch.manual_seed(0)
             net = inn.FAST(fast_config(seq_len=T, act_dtype=act)).cuda().train()
             if graph:                           # the whole step as one HIP graph replay (isd_amd.graph)
-                opt = torch.optim.AdamW(net.parameters(), lr=torch.tensor(5e-4, device="cuda"), capturable=True, fused=True)
+                opt = make_opt(net, True)
                 gs = GraphedTrainStep(net, opt, x, y, B)
                 idx = torch.arange(B, device="cuda")
 
@@ -107,7 +135,7 @@ def main():
                     gs.step(idx, 5e-4)
                     return gs.loss_sum
             else:
-                opt = torch.optim.AdamW(net.parameters(), lr=5e-4, fused=True)
+                opt = make_opt(net, False)
 
                 def step():
                     opt.zero_grad(set_to_none=True)
