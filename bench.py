@@ -360,12 +360,16 @@ def run_workload(config, steps, warmup, batch, bf16, two_kernel, overlap_flag, n
                 "ms_per_launch": round(t_feat, 4),
                 "algorithmic_bytes_per_launch": B * C * 4 * (T + nb * fx.n_frames)}
     elif fused:
-        # cfg5: fused_rows4_kernel<float,5> (24 bands) + fused_rows4_kernel<double,5> (16 bands), one launch each per
-        # extraction; the pair is VALU-bound.  Algorithmic flops per (trial, channel, band): cascade T x (4 x 9 + 1)
-        # + half-block DFT sums of the band's bins and their two Hann neighbours: (bins + 2) x T complex MACs x 4.
+        # cfg5: fused_rows4_kernel<float,5> -- one launch per extraction since the fp32 probe (round 3) keeps all 40
+        # bands of the stress set in fp32; a plan with fp64 bands adds a fused_rows4_kernel<double,5> launch.  VALU-bound.
+        # Algorithmic flops per (trial, channel, band): cascade T x (4 x 9 + 1) + half-block DFT sums of the band's
+        # bins and their two Hann neighbours: (bins + 2) x T complex MACs x 4.
         flops = B * C * sum(T * (n_sec * 9 + 1) + (nbin + 2) * T * 4 for nbin in bins)
-        roof = {"bound": "valu", "kernel": "fused_rows4_kernel<float,5> + fused_rows4_kernel<double,5> (one launch "
-                                           "each per extraction; priced against the fp32 vector peak)",
+        kname = {"f32": "fused_rows4_kernel<float,5> (all bands in fp32; one launch per extraction)",
+                 "f64": "fused_rows4_kernel<double,5> (priced against the fp32 vector peak)",
+                 "mixed": "fused_rows4_kernel<float,5>+<double,5> (one launch each per extraction; priced against "
+                          "the fp32 vector peak)"}[fx.fb.precision]
+        roof = {"bound": "valu", "kernel": kname,
                 "achieved": round(flops / (t_feat * 1e-3) / 1e12, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(flops / (t_feat * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": None,
                 "ms_per_launch": round(t_feat, 4),

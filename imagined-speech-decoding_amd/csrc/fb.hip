@@ -127,6 +127,14 @@ __device__ __forceinline__ const P* later(const P* p) {
   return reinterpret_cast<const P*>(reinterpret_cast<const char*>(p) + zero);
 }
 
+// value of lane 15 of each 16-lane DPP row in every lane of the row (gfx90a+ row_newbcast)
+__device__ __forceinline__ double row_bcast15(double v) {
+  long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x15F, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x15F, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <int D>
 __device__ __forceinline__ void scan_step(double& e1, double& e2, const double* M) {
   double p1 = row_shr<D>(e1), p2 = row_shr<D>(e2);
@@ -1096,6 +1104,21 @@ __device__ __forceinline__ float mul_unpacked(float x, float g) {
   asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(g));
   return r;
 }
+// {hi(p) + lo(q), hi(p) - lo(q)}: the sum and the difference of the two samples that lie symmetrically about the middle
+// of a lane's chunk (pairs hold {sample j, sample j + 16}: sample 16 + m is hi(pair m), sample 16 - m is lo(pair 16 - m))
+__device__ __forceinline__ f2 sym_pair(const f2& p, const f2& q) {
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(p), "v"(q));
+  return r;
+}
+// acc += ad * t elementwise: {sum, difference} x {cos, -sin} of the pair's angle, the table entry in an SGPR pair
+__device__ __forceinline__ void pmac(f2& acc, const f2& ad, const f2& t) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(ad), "s"(t));
+}
+// acc += lo(pr) * conj(t)
+__device__ __forceinline__ void cmac_lo_conj(f2& acc, const f2& pr, const f2& t) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "+v"(acc) : "v"(pr), "s"(t));
+}
 
 // The same extraction with FOUR ROWS PER WAVE (rows of a multiple of 512 samples, at most 16 blocks per frame): every
 // 16-lane group walks its own row in 512-sample passes and carries its section states from pass to pass.  In
@@ -1119,7 +1142,11 @@ __device__ __forceinline__ float mul_unpacked(float x, float g) {
 //    ONE per-lane factor per bin, looked up once per band (it changes sign from pass to pass for odd bins at 16 blocks
 //    per frame: one v_xor per component): a complex multiply instead of two plus an index computation per bin and pass;
 //  * frames are finished every second pass, sixteen at a time (one per lane, no half-window join).
-template <typename VT, int KB>
+//  * NS > 0 (the section count as a template parameter; fp32 instance): the section states a group carries from pass
+//    to pass stay in registers -- lane 15 of the group holds the new state after the scan and one DPP row broadcast
+//    per dword hands it to the group's lanes -- instead of going through LDS (a write, a wait and a read per section
+//    and pass).  NS == 0: any section count, states in LDS (the fp64 instance is at its register cap).
+template <typename VT, int KB, int NS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(std::is_same<VT, float>::value ? 4 : 3)))
 void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict__ bands,
                         const double* __restrict__ Qtab, const float2* __restrict__ blk,
@@ -1132,7 +1159,7 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
   const int lane0 = threadIdx.x;
   const int n_iter = T / kSeg;                                             // 512-sample passes
   float2* ring = reinterpret_cast<float2*>(smem_raw);                      // [4 rows][KB][32]: block m at m & 31
-  float2* tw = ring + 4 * KB * 32;                                         // [64]  e^{-2 pi i u / (2 nblk)}, u < 2 nblk
+  float2* tw = ring + 4 * KB * 32;                                         // [64]  e^{-2 pi i u / (4 nblk)}, u < 4 nblk
   double* carry = reinterpret_cast<double*>(tw + 64);                      // [ns][4 groups][2]
   double* Qlds = carry + ns * 8;                                           // [ns][16][4] the band's per-lane M^i
   // id = 8 share_n q + 8 w + c  <->  row quad = 8 q + c, band subset w (the sharers of a quad run on one XCD);
@@ -1141,10 +1168,10 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
   const int quad = (id / (8 * share_n)) * 8 + (id & 7);
   const int share = (id >> 3) % share_n;
   if (quad * 4 >= n_rows) return;
-  const int nblk = 1 << log2_nblk, nblk2 = 2 * nblk;
-  if (lane0 < nblk2) {
+  const int nblk = 1 << log2_nblk, nblk4 = 4 * nblk;                       // nblk <= 16: the table fits its 64 entries
+  if (lane0 < nblk4) {
     float sn, cs;
-    sincospif(2.f * (float)lane0 / (float)nblk2, &sn, &cs);
+    sincospif(2.f * (float)lane0 / (float)nblk4, &sn, &cs);
     tw[lane0] = make_float2(cs, -sn);
   }
   wave_lds_sync();
@@ -1159,14 +1186,18 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
     float* out = feat + (((int64_t)bt * nb_out + bmap[b]) * C + ch) * (int64_t)J;
     const int klo = fbnd.klo[b], khi = fbnd.khi[b];
     const int k0 = klo - 1, nbin = khi - klo + 1;
-    if (lane < ns * 8) carry[lane] = 0.0;
+    if (NS == 0 && lane < ns * 8) carry[lane] = 0.0;
+    [[maybe_unused]] double creg[NS ? NS : 1][2];
+#pragma unroll
+    for (int e = 0; e < (NS ? NS : 1); ++e) creg[e][0] = creg[e][1] = 0.0;
 #pragma unroll
     for (int e = 0; e < 2 * KB; ++e) ring[e * 64 + lane] = make_float2(0.f, 0.f);      // 4 x KB x 32 slots
     stage_q(Qlds, Qtab, b, ns, lane);
     // this lane's factor per bin: block phase e^{-2 pi i k m / nblk} of its block m = 8 it + (li >> 1) at it = 0, times
-    // the half-block offset e^{-2 pi i k 32 / n} on odd lanes; pass it multiplies by e^{-2 pi i k 8 it / nblk} = +-1
-    // (2 k (li >> 1) + k (li & 1) = k li.)  The fp32 instance keeps the KB factors in registers; the fp64 instance,
-    // which is at its register cap, looks them up per pass.
+    // the half-block offset e^{-2 pi i k 32 / n} on odd lanes, times the rotation e^{-2 pi i k 16 / n} about the middle
+    // of the lane's chunk (the symmetric DFT sums below): k (2 li + 1) steps of 1 / (4 nblk) turns; pass it multiplies by
+    // e^{-2 pi i k 8 it / nblk} = +-1.  The fp32 instance keeps the KB factors in registers; the fp64 instance, which
+    // is at its register cap, looks them up per pass.
     constexpr bool kFacRegs = std::is_same<VT, float>::value;
     f2 fac[kFacRegs ? KB : 1];
     unsigned flip[kFacRegs ? KB : 1];                    // wave-uniform: sign bit when the factor alternates
@@ -1174,9 +1205,9 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
 #pragma unroll
       for (int kk = 0; kk < KB; ++kk) {
         const int kq = k0 + kk;
-        const float2 w = tw[(kq * li) & (nblk2 - 1)];
+        const float2 w = tw[(kq * (2 * li + 1)) & (nblk4 - 1)];
         fac[kk] = (f2){w.x, w.y};
-        flip[kk] = ((16 * kq) & (nblk2 - 1)) ? 0x80000000u : 0u;          // 16 k / (2 nblk) turns per pass: 0 or 1/2
+        flip[kk] = ((32 * kq) & (nblk4 - 1)) ? 0x80000000u : 0u;          // 16 k / (2 nblk) turns per pass: 0 or 1/2
       }
     }
     wave_lds_sync();
@@ -1206,40 +1237,69 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
             }
           }
         }
-        for (int sct = 0; sct < ns; ++sct) {
-          double c1 = carry[(sct * 4 + q) * 2], c2 = carry[(sct * 4 + q) * 2 + 1];
-          section<VT, 1, true>(v, secs[b * ns + sct], Qlds + sct * 64, lane, c1, c2);
-          wave_lds_sync();                              // every lane has read the incoming carry
-          if (li == 15) {
-            carry[(sct * 4 + q) * 2] = c1;
-            carry[(sct * 4 + q) * 2 + 1] = c2;
+        if constexpr (NS > 0) {
+#pragma unroll
+          for (int sct = 0; sct < NS; ++sct) {
+            double c1 = creg[sct][0], c2 = creg[sct][1];
+            section<VT, 1, true>(v, secs[b * NS + sct], Qlds + sct * 64, lane, c1, c2);
+            creg[sct][0] = row_bcast15(c1);             // the state leaving the pass sits on lane 15 of the group
+            creg[sct][1] = row_bcast15(c2);
+          }
+        } else {
+          for (int sct = 0; sct < ns; ++sct) {
+            double c1 = carry[(sct * 4 + q) * 2], c2 = carry[(sct * 4 + q) * 2 + 1];
+            section<VT, 1, true>(v, secs[b * ns + sct], Qlds + sct * 64, lane, c1, c2);
+            wave_lds_sync();                            // every lane has read the incoming carry
+            if (li == 15) {
+              carry[(sct * 4 + q) * 2] = c1;
+              carry[(sct * 4 + q) * 2 + 1] = c2;
+            }
           }
         }
         XArr vf;                                        // fp32 pairs {sample j, sample j + 16} (the chunk itself in fp32)
         O::to_f32(v, vf);
-        // half-block DFT sums with block-local phase (this lane's 32 samples start at offset 32 (lane & 1) in the block)
+        // half-block DFT sums with block-local phase (this lane's 32 samples start at offset 32 (lane & 1) in the block).
+        // The 32 samples are taken in pairs symmetric about sample 16:
+        //   sum_n y[n] e^{-i th n} = e^{-i 16 th} [ y[16] + y[0] e^{+i 16 th} + sum_{m=1..15} (a_m cos(m th) - i d_m sin(m th)) ],
+        //   a_m = y[16 + m] + y[16 - m],  d_m = y[16 + m] - y[16 - m]:
+        // one packed add per pair, shared by the bins, then ONE packed FMA per pair and bin ({a, d} x {cos, -sin}: the
+        // table's own entry m) instead of two -- 17 instead of 32 per bin.  The rotation e^{-i 16 th} rides in the
+        // lane's per-bin factor (tw4 index k (2 li + 1), below).
         const int sl = (it * 8 + (li >> 1)) & 31;
+        f2 ad[15];
+#pragma unroll
+        for (int m = 1; m < 16; ++m) ad[m - 1] = sym_pair(vf[m], vf[16 - m]);
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) {
           const int k = k0 + kk < n_bins_max ? k0 + kk : n_bins_max;
           const f2* __restrict__ tb = reinterpret_cast<const f2*>(blk + (int64_t)k * 64);
-          f2 acc_a = {0.f, 0.f}, acc_b = {0.f, 0.f};     // two chains: samples 0..15 and 16..31
+          f2 acc_a = {0.f, 0.f}, acc_b = {0.f, 0.f};     // two chains
+          {
+            const f2* __restrict__ tq = later(tb);       // entries 1..8: 16 table scalars per batch in the SGPR file
 #pragma unroll
-          for (int j0 = 0; j0 < kL / 2; j0 += 8) {
-            const f2* __restrict__ tq = later(tb);       // 32 table scalars per batch in the SGPR file
-#pragma unroll
-            for (int j = j0; j < j0 + 8; ++j) {
-              cmac_lo(acc_a, vf[j], tq[j]);
-              cmac_hi(acc_b, vf[j], tq[16 + j]);
+            for (int m = 1; m <= 8; m += 2) {
+              pmac(acc_a, ad[m - 1], tq[m]);
+              pmac(acc_b, ad[m], tq[m + 1]);
             }
           }
-          const f2 sum = acc_a + acc_b;
+          {
+            const f2* __restrict__ tq = later(tb);       // entries 9..16
+#pragma unroll
+            for (int m = 9; m <= 13; m += 2) {
+              pmac(acc_a, ad[m - 1], tq[m]);
+              pmac(acc_b, ad[m], tq[m + 1]);
+            }
+            pmac(acc_a, ad[14], tq[15]);
+            cmac_lo_conj(acc_b, vf[0], tq[16]);          // y[0] e^{+i 16 th}
+          }
+          f2 sum = acc_a + acc_b;
+          sum.x += vf[0].y;                              // y[16]
           f2 fk;
           if constexpr (kFacRegs) {
             fk = fac[kk];
             fac[kk] = (f2){__uint_as_float(__float_as_uint(fk.x) ^ flip[kk]), __uint_as_float(__float_as_uint(fk.y) ^ flip[kk])};
           } else {
-            const float2 w = tw[((k0 + kk) * (li + 16 * it)) & (nblk2 - 1)];
+            const float2 w = tw[((k0 + kk) * (2 * (li + 16 * it) + 1)) & (nblk4 - 1)];
             fk = (f2){w.x, w.y};
           }
           float px = sum.x * fk.x - sum.y * fk.y, py = sum.x * fk.y + sum.y * fk.x;
@@ -1283,7 +1343,7 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
             }
           }
         }
-        const float2 wn = tw[(2 * j) & (nblk2 - 1)];                   // e^{-2 pi i j/nblk};  w^j = conj(wn)
+        const float2 wn = tw[(4 * j) & (nblk4 - 1)];                   // e^{-2 pi i j/nblk};  w^j = conj(wn)
         float acc = 0.f;
 #pragma unroll
         for (int bq = 0; bq < KB - 2; ++bq) {
@@ -1337,6 +1397,45 @@ static bool rows4_enabled() {
   return on;
 }
 
+// ISD_ROWS4_LDS_CARRY=1 keeps the carried section states of the fp32 rows4 kernel in LDS (A/B measurements); read once
+static bool rows4_reg_carry() {
+  static const bool on = getenv("ISD_ROWS4_LDS_CARRY") == nullptr;
+  return on;
+}
+
+// The constants of one biquad section (wave-uniform tables of the kernels) and its 16 per-lane matrices M^i
+static void build_section(double a1, double a2, FbSec& sc, double* Qout) {
+  const double A[4] = {-a1, 1.0, -a2, 0.0};
+  double An[4] = {1, 0, 0, 1};
+  for (int k = 0; k < kL; ++k) {              // h[n] = row 0 of A^n ; afterwards An = A^32
+    if (k < kL / 2) {
+      sc.hdq[0][k] = An[0];
+      sc.hdq[1][k] = An[1];
+      sc.hq[0][k] = (float)An[0];
+      sc.hq[1][k] = (float)An[1];
+    }
+    if (k == kL / 2)
+      for (int e = 0; e < 4; ++e) {
+        sc.N16d[e] = An[e];
+        sc.N16f[e] = (float)An[e];
+      }
+    mat2_mul(A, An, An);
+  }
+  double Mk[4];
+  memcpy(Mk, An, sizeof(Mk));
+  double Qi[4] = {1, 0, 0, 1};
+  for (int i = 0; i < 16; ++i) {              // Q_i = M^i
+    memcpy(Qout + i * 4, Qi, sizeof(Qi));
+    mat2_mul(Mk, Qi, Qi);
+  }
+  memcpy(sc.P, Qi, sizeof(Qi));               // M^16
+  for (int k = 0; k < 4; ++k) {               // M^(1,2,4,8)
+    memcpy(sc.Mp[k], Mk, sizeof(Mk));
+    mat2_mul(Mk, Mk, Mk);
+  }
+  sc.a1d = a1; sc.a2d = a2; sc.a1f = (float)a1; sc.a2f = (float)a2;
+}
+
 extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections, const double* a12,
                                   const double* gain, int precision) {
   ISD_CHECK_ARG(out && a12 && gain, "isd_fb_plan_create: null argument");
@@ -1360,36 +1459,7 @@ extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections
       // stability (poles strictly inside the unit circle)
       ISD_CHECK_ARG(a2 < 1.0 && a2 > -1.0 && fabs(a1) < 1.0 + a2,
                     "isd_fb_plan_create: band %d section %d is not stable (a1=%g a2=%g)", b, s, a1, a2);
-      FbSec& sc = secs[bs];
-      const double A[4] = {-a1, 1.0, -a2, 0.0};
-      double An[4] = {1, 0, 0, 1};
-      for (int k = 0; k < kL; ++k) {              // h[n] = row 0 of A^n ; afterwards An = A^32
-        if (k < kL / 2) {
-          sc.hdq[0][k] = An[0];
-          sc.hdq[1][k] = An[1];
-          sc.hq[0][k] = (float)An[0];
-          sc.hq[1][k] = (float)An[1];
-        }
-        if (k == kL / 2)
-          for (int e = 0; e < 4; ++e) {
-            sc.N16d[e] = An[e];
-            sc.N16f[e] = (float)An[e];
-          }
-        mat2_mul(A, An, An);
-      }
-      double Mk[4];
-      memcpy(Mk, An, sizeof(Mk));
-      double Qi[4] = {1, 0, 0, 1};
-      for (int i = 0; i < 16; ++i) {              // Q_i = M^i
-        memcpy(&Q[(size_t)bs * 64 + i * 4], Qi, sizeof(Qi));
-        mat2_mul(Mk, Qi, Qi);
-      }
-      memcpy(sc.P, Qi, sizeof(Qi));               // M^16
-      for (int k = 0; k < 4; ++k) {               // M^(1,2,4,8)
-        memcpy(sc.Mp[k], Mk, sizeof(Mk));
-        mat2_mul(Mk, Mk, Mk);
-      }
-      sc.a1d = a1; sc.a2d = a2; sc.a1f = (float)a1; sc.a2f = (float)a2;
+      build_section(a1, a2, secs[bs], &Q[(size_t)bs * 64]);
       // fp32 round-off amplification of a resonator ~ 1 / ((1-r) sin(theta))
       if (a2 > 0.0) {
         const double r = sqrt(a2);
@@ -1410,8 +1480,13 @@ extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections
   // per-band arithmetic: AUTO sends a band to the fp64 set when one of its poles is too close to z = 1.  The threshold
   // on the round-off amplification estimate was 2000 until round 3; measured at the stress set (tools/
   // auto_limit_probe.py, |feature - scipy fp64| / max(1, |feature|), gate 1e-4): the bands between 2000 and 6000
-  // (2-Hz bands from 14 to 36 Hz at 1024 Hz) stay within 5e-6 in fp32, the five above 6000 (4 - 14 Hz) reach 1.3e-5,
-  // and the 0.5 - 4 Hz band of the 5-band set (20 900) misses the gate by two orders.  ISD_FB_AUTO_LIMIT overrides.
+  // (2-Hz bands from 14 to 36 Hz at 1024 Hz) stay within 5e-6 in fp32, the five above 6000 (4 - 14 Hz) reach 1.3e-5
+  // -- inside that relative gate, but with them in fp32 the 1024-point golden features (g3 "c5") are off by up to
+  // 1.09e-4 in ABSOLUTE log power (a log power near -12: 9e-6 relative), over the 1e-4 the golden-vector tests hold
+  // (tests/test_features_gpu.py), so they stay on the fp64 kernels -- and the 0.5 - 4 Hz band of the 5-band set
+  // (20 900) misses both.  A host replay of the fp32 chunk arithmetic as the criterion was tried and dropped: it
+  // ranks the five like the estimate does (rms error 2.9e-5 / 1.3e-5 / 1.9e-5 / 1.4e-5 / 7e-6 of the signal) and
+  // separates the 5-band set's 0.5 - 4 Hz band (1.4e-4) no better.  ISD_FB_AUTO_LIMIT overrides.
   const char* lim_env = getenv("ISD_FB_AUTO_LIMIT");
   const double auto_limit = lim_env ? atof(lim_env) : 6000.0;
   std::vector<int> idx[2];
@@ -1620,14 +1695,21 @@ static int features_fused_impl(const isd_fb_plan* fb, const isd_stft_plan* st, c
       const bool rows4 = vec && st->T % kSeg == 0 && log2_nblk <= 4 && log2_nblk >= 1 && rows4_enabled();
       const size_t lds4 = sizeof(float2) * ((size_t)4 * KB * 32 + 64) + sizeof(double) * (8 + 64) * (size_t)fb->n_sections;
       const int share4 = rows4_share(fs.nb);
-#define ISD_FL_LAUNCH4(VT, K)                                                                                         \
+#define ISD_FL_LAUNCH4N(VT, K, N)                                                                                     \
   do {                                                                                                                \
-    ISD_HIP_TRY(hipFuncSetAttribute((const void*)fused_rows4_kernel<VT, K>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds4));                                                                      \
-    hipLaunchKernelGGL((fused_rows4_kernel<VT, K>), dim3((unsigned)(cdiv(cdiv(rows, 4), 8) * 8 * share4)), dim3(64),      \
+    ISD_HIP_TRY(hipFuncSetAttribute((const void*)fused_rows4_kernel<VT, K, N>,                                        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));                          \
+    hipLaunchKernelGGL((fused_rows4_kernel<VT, K, N>), dim3((unsigned)(cdiv(cdiv(rows, 4), 8) * 8 * share4)), dim3(64),   \
                        lds4, s, fs.d_sec, fs.d_band, fs.d_Q, st->d_blk, x, feat, (int)C, st->T, fs.nb, fb->n_sections,  \
                        st->J, log2_nblk, st->n / 2, st->scale * st->scale, fbnd, mode, eps, fs.d_map, fb->n_bands,      \
                        (int)rows, share4);                                                                            \
+  } while (0)
+      // fp32 instance with the usual four sections (order-4 Butterworth band-pass): the carried states in registers
+#define ISD_FL_LAUNCH4(VT, K)                                                                           \
+  do {                                                                                                  \
+    if (std::is_same<VT, float>::value && fb->n_sections == 4 && rows4_reg_carry())                     \
+      ISD_FL_LAUNCH4N(VT, K, (std::is_same<VT, float>::value ? 4 : 0));                                 \
+    else ISD_FL_LAUNCH4N(VT, K, 0);                                                                     \
   } while (0)
 #define ISD_FL_LAUNCH(VT, K)                                        \
   do {                                                              \

@@ -53,7 +53,7 @@ def test_filterbank_vs_oracle_shapes(isd, T, precision):
 def test_filterbank_auto_precision_policy(isd):
     assert isd.Filterbank(odsp.BANDS_9, 256.0).precision == "f32"
     assert isd.Filterbank(odsp.BANDS_5, 256.0).precision == "mixed"    # 0.5-4 Hz needs the fp64 recursion, the rest fp32
-    assert isd.Filterbank(odsp.BANDS_40, 1024.0).precision == "mixed"  # the 16 lowest 2-Hz bands
+    assert isd.Filterbank(odsp.BANDS_40, 1024.0).precision == "mixed"  # the five lowest 2-Hz bands (4 - 14 Hz)
     assert isd.Filterbank(odsp.BANDS_5, 256.0, precision="f64").precision == "f64"
     assert isd.Filterbank(odsp.BANDS_5[:1], 256.0).precision == "f64"
 
