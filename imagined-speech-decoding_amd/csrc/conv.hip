@@ -470,16 +470,31 @@ __global__ __launch_bounds__(256) void conv5_fwd_glds_kernel(ConvArgs a) {
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int g = 0; g < GT; ++g) acc[j][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int t_ii[NT], t_t0[NT], boff[NT];
+  // Column tiles.  Rows of more than one tile (TT > 1): tile ct is 16 output steps of item ct / TT.  Rows of ONE tile
+  // (spec-S features: 13 output steps): the workgroup's columns are its items' output steps back to back -- column
+  // 16 ct + jl is step col % Tout of item col / Tout -- so a tile is full instead of 13/16 full (9 items in 8 tiles
+  // instead of 8); every lane keeps its own (item, step).
+  int t_ii[NT], t_t[NT], boff[NT];
   bool t_ok[NT];
+  const bool packed = a.TT == 1;
+  const int n_cols = n_items * a.Tout;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int ct = j * 4 + wave;
-    t_ok[j] = ct < n_ct;
-    const int ctc = t_ok[j] ? ct : 0;
-    t_ii[j] = ctc / a.TT;
-    t_t0[j] = (ctc - t_ii[j] * a.TT) * 16;
-    boff[j] = t_ii[j] * kCK * a.RS + t_t0[j] + jl + q * a.RS;
+    if (packed) {
+      const int col = ct * 16 + jl;
+      t_ok[j] = col < n_cols;
+      const int cc = t_ok[j] ? col : 0;                     // a column past the end computes on column 0, not stored
+      t_ii[j] = cc / a.Tout;
+      t_t[j] = cc - t_ii[j] * a.Tout;
+    } else {
+      const bool tile = ct < n_ct;
+      const int ctc = tile ? ct : 0;
+      t_ii[j] = ctc / a.TT;
+      t_t[j] = (ctc - t_ii[j] * a.TT) * 16 + jl;
+      t_ok[j] = tile && t_t[j] < a.Tout;
+    }
+    boff[j] = t_ii[j] * kCK * a.RS + t_t[j] + q * a.RS;
   }
   struct Frag {
     float af[kTaps][GT];
@@ -528,8 +543,7 @@ __global__ __launch_bounds__(256) void conv5_fwd_glds_kernel(ConvArgs a) {
   for (int j = 0; j < NT; ++j) {
     if (!t_ok[j]) continue;
     const int64_t item = item0 + t_ii[j];
-    const int t = t_t0[j] + jl;
-    if (t >= a.Tout) continue;
+    const int t = t_t[j];
 #pragma unroll
     for (int gt = 0; gt < GT; ++gt) {
 #pragma unroll
@@ -2688,11 +2702,26 @@ __global__ __launch_bounds__(256) void conv5_wgrad_wide_kernel(WgradArgs a) {
     if (!wave_live) continue;
     const float* buf = smem + s * buf_len;
     const int n_it = (int)((i_hi - is) < a.IPS ? (i_hi - is) : a.IPS);
-    const int n_step = n_it * nks;
+    // The reduction runs over (item, output step) pairs four at a time.  With Tout >= 4 the stage's pairs are taken
+    // back to back -- K index 4 st + q is step f % Tout of item f / Tout, kept per lane and advanced by four per load
+    // (the loads are issued in step order) -- so 13 output steps cost 13/4 K steps per item instead of 4.
+    const bool packed = a.Tout >= 4;
+    const int n_step = packed ? (n_it * a.Tout + 3) >> 2 : n_it * nks;
+    int p_ii = 0, p_t = q;                                              // this lane's next (item, step)
     auto load = [&](int st, Frag& f) {
-      const int ii = st / nks, t0 = (st - ii * nks) * 4;
+      int ii, t0;
+      bool ok;
+      if (packed) {
+        ii = p_ii; t0 = p_t - q;                                        // (a_off / b_off carry the + q)
+        ok = p_ii < n_it;
+        if (!ok) { ii = 0; t0 = -q; }                                   // past the stage's last pair: any valid address
+        p_t += 4;
+        if (p_t >= a.Tout) { p_t -= a.Tout; ++p_ii; }
+      } else {
+        ii = st / nks; t0 = (st - ii * nks) * 4;
+        ok = t0 + q < a.Tout;
+      }
       const float* ib = buf + ii * item_len + t0;
-      const bool ok = t0 + q < a.Tout;
 #pragma unroll
       for (int g = 0; g < GT; ++g) {
         const float v = ib[a_off + g * 16 * a.Tout];
@@ -3430,11 +3459,13 @@ static int first_layer_forward(const isd_conv4_plan* p, const Geo& g, const floa
     // when there is enough work (the barrier / DMA wait of one runs under the MFMAs of the other), else one of 16.
     const int GT = F / 16;
     int NT = 2;
-    int ipw = (4 * NT) / g.TT;
-    const int64_t per_slot = cdiv(g.items * p->Z, 512);
-    if (ipw < 1 || per_slot < ipw) {
+    const bool pack = g.TT == 1;                       // one-tile rows: the items' output steps share column tiles
+    int ipw = pack ? (4 * NT * 16) / g.T1 : (4 * NT) / g.TT;
+    // (two workgroups per CU only when there are more workgroups than CUs.  At 4096 items of 13 steps the packed tiles
+    // are 3328 instead of 4096, but both are four per SIMD: the forward pass gains only beyond that batch)
+    if (ipw < 1 || cdiv(g.items * p->Z, ipw) <= 256) {
       NT = 4;
-      ipw = 16 / g.TT;
+      ipw = pack ? (16 * 16) / g.T1 : 16 / g.TT;
       const int64_t per_cu = cdiv(g.items * p->Z, 256);
       if (ipw > per_cu) ipw = (int)per_cu;
     }
