@@ -7,9 +7,11 @@ takes at the reference's batch of 64.  ``FusedAdamW`` hands the pointers to ``is
 one launch, torch's operation order, the learning rate and the step count optionally in device memory so that a
 captured HIP graph (isd_amd.graph) replays the update with nothing to advance on the host.
 
-Only the part of the ``torch.optim.Optimizer`` surface that this package's training loops use is provided:
-``param_groups`` (one group; ``lr`` may be a float or a one-element device tensor), ``step()``, ``zero_grad()``,
-``state`` (the moment blocks and the device step counter, as tensors) and ``state_dict()`` / ``load_state_dict()``.
+``FusedAdamW`` is a ``torch.optim.Optimizer`` (one parameter group): ``param_groups`` / ``zero_grad`` / LR schedulers
+(``LambdaLR`` writes ``param_groups[0]["lr"]``, float or one-element device tensor) work as with torch's class; the
+moment estimates live in two flat blocks, exposed as ``state["flat"]``, and ``state_dict()`` / ``load_state_dict()``
+carry those blocks and the step count.  One step count serves all tensors (torch counts per tensor: the same thing
+whenever a tensor either always or never receives a gradient, as in the reference's modes).
 """
 import ctypes as C
 
@@ -18,21 +20,25 @@ import torch
 from . import _lib
 
 
-class FusedAdamW:
+class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=False):
-        params = [p for p in params if p.requires_grad]
+        if isinstance(lr, torch.Tensor) and not (lr.is_cuda and lr.dtype == torch.float32 and lr.numel() == 1):
+            raise TypeError("FusedAdamW: a tensor lr must be one float32 element on the device")
+        if capturable and not isinstance(lr, torch.Tensor):
+            raise ValueError("FusedAdamW(capturable=True) needs lr as a device tensor (a replayed graph reads it)")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=float(eps), weight_decay=float(weight_decay),
+                                      capturable=bool(capturable)))
+        if len(self.param_groups) != 1:
+            raise ValueError("FusedAdamW takes one parameter group (uniform hyper-parameters: one launch)")
+        g = self.param_groups[0]
+        g["params"] = [p for p in g["params"] if p.requires_grad]
+        params = g["params"]
         if not params:
             raise ValueError("FusedAdamW: no trainable parameters")
         for p in params:
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                 raise TypeError("FusedAdamW needs contiguous float32 parameters on a HIP device (the step is a HIP kernel)")
         dev = params[0].device
-        if isinstance(lr, torch.Tensor) and not (lr.is_cuda and lr.dtype == torch.float32 and lr.numel() == 1):
-            raise TypeError("FusedAdamW: a tensor lr must be one float32 element on the device")
-        if capturable and not isinstance(lr, torch.Tensor):
-            raise ValueError("FusedAdamW(capturable=True) needs lr as a device tensor (a replayed graph reads it)")
-        self.param_groups = [dict(params=params, lr=lr, betas=tuple(betas), eps=float(eps),
-                                  weight_decay=float(weight_decay), capturable=bool(capturable))]
         # both moments of every tensor in one block each; a tensor starts on a 16-byte boundary
         offs, tot = [], 0
         for p in params:
@@ -49,22 +55,16 @@ class FusedAdamW:
         self._p = (C.c_void_p * n)()
         self._g = (C.c_void_p * n)()
         self._n_active = (C.c_int64 * n)()
-        self.state = {"flat": {"exp_avg": self._exp_avg, "exp_avg_sq": self._exp_avg_sq}}
+        self.state["flat"] = {"exp_avg": self._exp_avg, "exp_avg_sq": self._exp_avg_sq}
         if capturable:
-            self.state["flat"]["step"] = self._step_dev
-
-    def zero_grad(self, set_to_none=True):
-        for p in self.param_groups[0]["params"]:
-            if p.grad is None:
-                continue
-            if set_to_none:
-                p.grad = None
-            else:
-                p.grad.detach_()
-                p.grad.zero_()
+            self.state["flat"]["step"] = self._step_dev           # [steps taken, kernel scratch]
 
     @torch.no_grad()
-    def step(self):
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         g = self.param_groups[0]
         for i, p in enumerate(g["params"]):
             gr = p.grad
@@ -82,6 +82,7 @@ class FusedAdamW:
             g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._step, lr_dev,
             self._step_dev.data_ptr() if self._step_dev is not None else None,
             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return loss
 
     def state_dict(self):
         g = {k: v for k, v in self.param_groups[0].items() if k != "params"}

@@ -187,3 +187,33 @@ def test_graphed_step_with_fused_adamw_follows_torch_adamw():
     np.testing.assert_allclose(losses[1], losses[0], rtol=2e-4)
     for k, v in finals[0].items():
         assert float((v - finals[1][k]).abs().max()) < 2e-4 * max(1.0, float(v.abs().max())), k
+
+
+def test_fused_adamw_is_a_torch_optimizer_driven_by_the_reference_schedule():
+    """The reference wraps its optimizer in LambdaLR with the per-step cosine multiplier (trainer.py:48-54): FusedAdamW is
+    a torch.optim.Optimizer, so the same scheduler object drives it, and the run equals torch's AdamW under it."""
+    import isd_amd
+    table = isd_amd.cosine_scheduler(1, 0.1, 4, 5, warmup_epochs=1)
+    init = _param_list(5, [33, 1000])
+    ref = [torch.nn.Parameter(t.clone()) for t in init]
+    dev = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    opts = [torch.optim.AdamW(ref, lr=5e-4, foreach=False), isd_amd.FusedAdamW(dev, lr=5e-4)]
+    assert isinstance(opts[1], torch.optim.Optimizer)
+    scheds = [torch.optim.lr_scheduler.LambdaLR(o, lambda step: float(table[max(step - 1, 0)])) for o in opts]
+    g0 = torch.Generator().manual_seed(6)
+    for _ in range(12):
+        for r, d in zip(ref, dev):
+            g = torch.randn(r.shape, generator=g0)
+            r.grad, d.grad = g.clone(), g.cuda()
+        for o, sc in zip(opts, scheds):
+            o.step()
+            sc.step()
+        assert abs(opts[0].param_groups[0]["lr"] - opts[1].param_groups[0]["lr"]) < 1e-12
+        opts[1].zero_grad()
+        assert all(d.grad is None for d in dev)
+    for r, d in zip(ref, dev):
+        assert (d.detach().cpu() - r.detach()).abs().max().item() < 2e-6 * max(1.0, r.detach().abs().max().item())
+    sd = opts[1].state_dict()
+    fresh = isd_amd.FusedAdamW(dev, lr=5e-4)
+    fresh.load_state_dict(sd)
+    assert fresh.state_dict()["step"] == 12 and torch.equal(fresh.state["flat"]["exp_avg"], opts[1].state["flat"]["exp_avg"])
