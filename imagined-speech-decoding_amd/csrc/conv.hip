@@ -1891,6 +1891,76 @@ __device__ __forceinline__ void tail_store_tile(const f32x4 (&acc)[2], float* __
 constexpr int kTailMaxCls = 16;
 constexpr int kTailNI = 1;        // items a wave carries side by side (measured at cfg 2: 1 -> 107 us, 2 -> 116 us: 512 VGPRs + spills)
 
+// Epilogue of the classifier-tail kernels: the waves' weight-gradient accumulators (cnn3 / cnn4: 40 f32x4 per lane),
+// FC gradients and loss shares are summed across the workgroup and leave as ONE slab in natural order
+// [dW3 [g][c][k] | dW4 | dW_fc [cls][F] | db_fc | loss].
+// Until round 3 the waves took turns: each added its 160 + 10 values into one LDS image of the slab with scalar
+// read-modify-writes at the slab's own (4-way bank-conflicting) addresses, a workgroup barrier per turn -- ~4 us per
+// wave; measured by batch scaling (tools/tail_scaling.py) the bf16 tail spent 50 of its 66 us outside the item loop,
+// the fp32 tail 36 of 104.  Now every copy of the accumulators lives in LDS in REGISTER layout ([value][lane] f32x4:
+// b128 accesses, no conflicts, no index arithmetic), NC copies side by side: in phase p waves p NC .. p NC + NC - 1
+// store (p = 0) or add (p > 0) their registers into their copy, and after ceil(NW / NC) phases every thread sums the
+// copies element by element -- in copy order: the result does not depend on timing -- while it writes the slab, where
+// the one permutation from register layout to natural order happens.
+constexpr int kTailCombV = 43;                            // f32x4 per lane: 20 + 20 accumulators, 2 x FC, {bias, loss}
+constexpr int kTailCombCopy = kTailCombV * 64 * 4;        // floats per copy
+// W(layer, gt, ct, k): the lane's accumulator of (layer 0 = cnn3 / 1 = cnn4, filter tile, channel tile, tap)
+template <int NW, int NC, typename WF>
+__device__ __forceinline__ void tail_combine_store(float* __restrict__ smem, int wave, int lane, WF&& W,
+                                                   const float (&accfc)[kTailMaxCls * 32 / 64], float accb,
+                                                   float loss_acc, float* __restrict__ slab, int slab_len, int n_cls) {
+  constexpr int F = 32;
+  __syncthreads();                                        // the fragment sets and tiles are dead from here on
+  f32x4* mine = reinterpret_cast<f32x4*>(smem + (wave % NC) * kTailCombCopy) + lane;
+  constexpr int n_phase = (NW + NC - 1) / NC;
+#pragma unroll
+  for (int ph = 0; ph < n_phase; ++ph) {
+    if (wave / NC == ph) {
+      auto put = [&](int v, f32x4 x) {
+        if (ph) {
+          const f32x4 o = mine[v * 64];
+          x[0] += o[0]; x[1] += o[1]; x[2] += o[2]; x[3] += o[3];
+        }
+        mine[v * 64] = x;
+      };
+#pragma unroll
+      for (int layer = 0; layer < 2; ++layer)
+#pragma unroll
+        for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int k = 0; k < kTaps; ++k) put(((layer * 2 + gt) * 2 + ct) * kTaps + k, W(layer, gt, ct, k));
+      put(40, (f32x4){accfc[0], accfc[1], accfc[2], accfc[3]});
+      put(41, (f32x4){accfc[4], accfc[5], accfc[6], accfc[7]});
+      put(42, (f32x4){accb, loss_acc, 0.f, 0.f});
+    }
+    __syncthreads();
+  }
+  constexpr int n_copy = NW < NC ? NW : NC;
+  const int n34 = 2 * F * F * kTaps, o_b = n34 + n_cls * F, o_loss = o_b + n_cls;
+  for (int e = threadIdx.x; e < slab_len; e += NW * 64) {
+    int src;                                              // float index inside a copy: (v * 64 + lane) * 4 + r
+    if (e < n34) {
+      const int layer = e >= F * F * kTaps, w = e - layer * F * F * kTaps;
+      const int g = w / (F * kTaps), rem = w - g * (F * kTaps), c = rem / kTaps, k = rem - c * kTaps;
+      const int v = ((layer * 2 + (g >> 4)) * 2 + (c >> 4)) * kTaps + k;
+      src = (v * 64 + ((g & 15) >> 2) * 16 + (c & 15)) * 4 + (g & 3);
+    } else if (e < o_b) {
+      const int f = e - n34, j = f >> 6;                  // flat FC element f = lane + 64 j
+      src = ((40 + (j >> 2)) * 64 + (f & 63)) * 4 + (j & 3);
+    } else if (e < o_loss) {
+      src = (42 * 64 + (e - o_b)) * 4;                    // bias gradient of class e - o_b: lane = class
+    } else {
+      src = (42 * 64) * 4 + 1;                            // loss: lane 0
+    }
+    float v = smem[src];
+#pragma unroll
+    for (int c = 1; c < n_copy; ++c) v += smem[c * kTailCombCopy + src];
+    slab[e] = v;
+  }
+}
+
 // BF (BASELINE config 3): A2 arrives and G2 leaves as bf16 in [item][t][filter] order (the bf16 first-layer kernels),
 // and every activation / activation gradient the tail hands from one layer to the next is rounded to bf16 (the
 // cnn3 / cnn4 fragment copies already are); the products are those of a bf16 MFMA, the accumulation is fp32.
@@ -1918,10 +1988,13 @@ __global__ __launch_bounds__(NW * 64) void featcnn_tail_kernel(TailArgs a) {
     featL[i] = base + 4 * tpad;                               // [32] pooled features, then [16] logits, [16] dlogits
     logL[i] = featL[i] + 32;
   }
-  for (int e = threadIdx.x; e < WF; e += NW * 64) {
-    w3s[e] = a.w3[e];
-    w4s[e] = a.w4[e];
-    if (a.train) { w3ts[e] = a.w3t[e]; w4ts[e] = a.w4t[e]; }
+  for (int e = threadIdx.x; e < WF / 4; e += NW * 64) {      // float4: the sets are 16-byte aligned workspace blocks
+    reinterpret_cast<float4*>(w3s)[e] = reinterpret_cast<const float4*>(a.w3)[e];
+    reinterpret_cast<float4*>(w4s)[e] = reinterpret_cast<const float4*>(a.w4)[e];
+    if (a.train) {
+      reinterpret_cast<float4*>(w3ts)[e] = reinterpret_cast<const float4*>(a.w3t)[e];
+      reinterpret_cast<float4*>(w4ts)[e] = reinterpret_cast<const float4*>(a.w4t)[e];
+    }
   }
   for (int e = threadIdx.x; e < n_cls * F; e += NW * 64) fcs[e] = a.fc_w[e];
   for (int e = threadIdx.x; e < n_cls; e += NW * 64) fcs[n_cls * F + e] = a.fc_b[e];
@@ -2103,36 +2176,10 @@ __global__ __launch_bounds__(NW * 64) void featcnn_tail_kernel(TailArgs a) {
     wave_lds_sync();                                          // tiles are reused by the next items
   }
   if (!a.labels) return;
-  // combine the 4 waves in wave order through LDS (the fragment sets are dead), then one slab per workgroup
-  __syncthreads();
-  float* comb = smem;                                         // [2*F*F*5 + n_cls*(F+1) + 1]
-  const int o_fc = 2 * F * F * kTaps, o_b = o_fc + n_cls * F, o_loss = o_b + n_cls;
-  for (int w = 0; w < NW; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int gt = 0; gt < 2; ++gt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int k = 0; k < kTaps; ++k)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int idx = ((gt * 16 + 4 * q + r) * F + ct * 16 + jl) * kTaps + k;
-              comb[idx] = (w == 0 ? 0.f : comb[idx]) + accW3[gt][ct][k][r];
-              comb[F * F * kTaps + idx] = (w == 0 ? 0.f : comb[F * F * kTaps + idx]) + accW4[gt][ct][k][r];
-            }
-#pragma unroll
-      for (int i = 0; i < kTailMaxCls * F / 64; ++i) {
-        const int e = lane + 64 * i;
-        if (e < n_cls * F) comb[o_fc + e] = (w == 0 ? 0.f : comb[o_fc + e]) + accfc[i];
-      }
-      if (lane < n_cls) comb[o_b + lane] = (w == 0 ? 0.f : comb[o_b + lane]) + accb;
-      if (lane == 0) comb[o_loss] = (w == 0 ? 0.f : comb[o_loss]) + loss_acc;
-    }
-    __syncthreads();
-  }
-  float* slab = a.part + (int64_t)blockIdx.x * a.slab;
-  for (int e = threadIdx.x; e < a.slab; e += NW * 64) slab[e] = comb[e];
+  // the waves' accumulators -> one slab per workgroup (tail_combine_store: two copies, two phases)
+  tail_combine_store<NW, 2>(smem, wave, lane,
+                            [&](int layer, int gt, int ct, int k) -> f32x4 { return layer ? accW4[gt][ct][k] : accW3[gt][ct][k]; },
+                            accfc, accb, loss_acc, a.part + (int64_t)blockIdx.x * a.slab, a.slab, n_cls);
 }
 
 // BASELINE config 3, round 3: the same launch on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16).  The fp32-MFMA
@@ -2302,36 +2349,10 @@ __global__ __launch_bounds__(NW * 64) void featcnn_tail_bf16_kernel(TailArgs a) 
     wave_lds_sync();                                           // tiles are reused by the next item
   }
   if (!a.labels) return;
-  // combine the waves in wave order through LDS (the fragment sets are dead), then one slab per workgroup
-  __syncthreads();
-  float* comb = smem;                                          // [2*F*F*5 + n_cls*(F+1) + 1]
-  const int o_fc = 2 * F * F * kTaps, o_b = o_fc + n_cls * F, o_loss = o_b + n_cls;
-  for (int w = 0; w < NW; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int gt = 0; gt < 2; ++gt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int k = 0; k < kTaps; ++k)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int idx = ((gt * 16 + 4 * q + r) * F + ct * 16 + jl) * kTaps + k;
-              comb[idx] = (w == 0 ? 0.f : comb[idx]) + accW3[ct][gt][k][r];
-              comb[F * F * kTaps + idx] = (w == 0 ? 0.f : comb[F * F * kTaps + idx]) + accW4[ct][gt][k][r];
-            }
-#pragma unroll
-      for (int i = 0; i < kTailMaxCls * F / 64; ++i) {
-        const int e = lane + 64 * i;
-        if (e < n_cls * F) comb[o_fc + e] = (w == 0 ? 0.f : comb[o_fc + e]) + accfc[i];
-      }
-      if (lane < n_cls) comb[o_b + lane] = (w == 0 ? 0.f : comb[o_b + lane]) + accb;
-      if (lane == 0) comb[o_loss] = (w == 0 ? 0.f : comb[o_loss]) + loss_acc;
-    }
-    __syncthreads();
-  }
-  float* slab = a.part + (int64_t)blockIdx.x * a.slab;
-  for (int e = threadIdx.x; e < a.slab; e += NW * 64) slab[e] = comb[e];
+  // the waves' accumulators -> one slab per workgroup (tail_combine_store: three copies, three phases for eight waves)
+  tail_combine_store<NW, 3>(smem, wave, lane,
+                            [&](int layer, int gt, int ct, int k) -> f32x4 { return layer ? accW4[ct][gt][k] : accW3[ct][gt][k]; },
+                            accfc, accb, loss_acc, a.part + (int64_t)blockIdx.x * a.slab, a.slab, n_cls);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -3762,7 +3783,8 @@ static int featcnn_step_impl(const isd_conv4_plan* p, const float* x, const floa
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   const int tile = (F * g.T1 + 3) & ~3;
-  const size_t lds = sizeof(float) * (size_t)(4 * 8 * kTaps * 2 * 64 + kTailMaxCls * (F + 1) + TNW * kTailNI * (4 * tile + 64) + 16);
+  size_t lds = sizeof(float) * (size_t)(4 * 8 * kTaps * 2 * 64 + kTailMaxCls * (F + 1) + TNW * kTailNI * (4 * tile + 64) + 16);
+  if (lds < sizeof(float) * 2 * kTailCombCopy) lds = sizeof(float) * 2 * kTailCombCopy;           // two accumulator copies (epilogue)
   ISD_CHECK_ARG(lds <= 160 * 1024 && (int64_t)blocks * t.slab <= g.total - g.o_part, "isd_featcnn_step: workspace");
   if (tap16) {
     // bf16 matrix cores: eight waves per workgroup, an item per wave and round
@@ -3770,7 +3792,8 @@ static int featcnn_step_impl(const isd_conv4_plan* p, const float* x, const floa
     blocks = (int)cdiv(g.items, BNW * 2);
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-    const size_t lds16 = (size_t)4 * kTaps * 2 * 64 * 16 + sizeof(float) * kTailMaxCls * (F + 1) + (size_t)BNW * (4 * 40 * 64 + 256) + 64;
+    size_t lds16 = (size_t)4 * kTaps * 2 * 64 * 16 + sizeof(float) * kTailMaxCls * (F + 1) + (size_t)BNW * (4 * 40 * 64 + 256) + 64;
+    if (lds16 < sizeof(float) * 3 * kTailCombCopy) lds16 = sizeof(float) * 3 * kTailCombCopy;     // three accumulator copies (epilogue)
     ISD_CHECK_ARG(lds16 <= 160 * 1024 && (int64_t)blocks * t.slab <= g.total - g.o_part, "isd_featcnn_step: workspace");
     ISD_HIP_TRY(hipFuncSetAttribute((const void*)featcnn_tail_bf16_kernel<BNW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
     hipLaunchKernelGGL((featcnn_tail_bf16_kernel<BNW>), dim3(blocks), dim3(BNW * 64), lds16, st, t);
