@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 // nn.Parameter per reference tensor and autograd hands every gradient its own buffer).  The pointers travel in the
 // kernel arguments (4 KiB limit: kAdamMaxTensors per launch), every tensor owns a run of 1024-element blocks, and a
 // workgroup finds its tensor by bisection of the run ends.  With a device-side step counter the kernel advances it
-// itself: every workgroup reads t = counter + 1, and the last one to finish stores t back.
+// itself: every workgroup reads t = counter + 1 and the running powers b1^t, b2^t, and the last one to finish stores
+// them back.
 constexpr int kAdamMaxTensors = 96;
 struct AdamMultiArgs {
   float* p[kAdamMaxTensors];
@@ -94,20 +95,28 @@ struct AdamMultiArgs {
   unsigned bend[kAdamMaxTensors];   // end (exclusive) of the tensor's run of workgroups
   int count, advance;               // advance: this launch is the last of the step (stores the counter)
   float lr, b1, b2, eps, wd, c1, c2, bc1, bc2_sqrt;
+  double b1d, b2d;
   const float* lr_dev;
-  long long* step_dev;              // [0] steps taken so far, [1] workgroups finished (returns to 0)
+  long long* step_dev;              // [0] steps taken so far t, [1] workgroups finished (returns to 0),
+                                    // [2], [3] b1^t, b2^t as doubles (valid when t > 0)
 };
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
   __shared__ float sc[3];
+  __shared__ double pw[2];
   float lr = a.lr, bc1 = a.bc1, bc2s = a.bc2_sqrt;
   if (a.lr_dev || a.step_dev) {
     if (threadIdx.x == 0) {
       if (a.lr_dev) lr = a.lr_dev[0];
       if (a.step_dev) {
-        const double t = (double)(a.step_dev[0] + 1);
-        bc1 = (float)(1.0 - pow((double)a.b1, t));
-        bc2s = (float)sqrt(1.0 - pow((double)a.b2, t));
+        // b^t by recurrence from the powers the previous step left (a double-precision pow() per workgroup was 15 of
+        // this kernel's 20 us); a zeroed counter block (t = 0) starts from b^0 = 1
+        const bool first = a.step_dev[0] == 0;
+        const double p1 = (first ? 1.0 : __longlong_as_double(a.step_dev[2])) * a.b1d;
+        const double p2 = (first ? 1.0 : __longlong_as_double(a.step_dev[3])) * a.b2d;
+        pw[0] = p1; pw[1] = p2;
+        bc1 = (float)(1.0 - p1);
+        bc2s = (float)sqrt(1.0 - p2);
       }
       sc[0] = lr; sc[1] = bc1; sc[2] = bc2s;
     }
@@ -155,6 +164,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
       const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(a.step_dev + 1), 1ull);
       if (done + 1 == gridDim.x) {
         a.step_dev[1] = 0;
+        a.step_dev[2] = __double_as_longlong(pw[0]);
+        a.step_dev[3] = __double_as_longlong(pw[1]);
         a.step_dev[0] = t;
       }
     }
@@ -209,6 +220,7 @@ extern "C" int isd_adamw_multi_step(int n_tensors, float* const* params, const f
   const double t = (double)(step >= 1 ? step : 1);
   a.bc1 = (float)(1.0 - pow(beta1, t));
   a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
+  a.b1d = beta1; a.b2d = beta2;
   a.lr_dev = lr_dev; a.step_dev = (long long*)step_dev;
   int last = -1;                                             // the launch that holds the last non-empty tensor
   for (int i = 0; i < n_tensors; ++i)

@@ -46,8 +46,7 @@ __device__ __forceinline__ void linear_fwd_kernel_body(const float* __restrict__
   // chunk goes out behind clamped addresses, not bounds tests): with the fetch at the top of each chunk a
   // [320 x 256] x [256 x 32] product was four exposed memory latencies long, 34 us on 5 workgroups.
   constexpr int NL = 64 * kKC / 256;
-  float xv[NL], wv[NL];
-  auto fetch = [&](int k0) {
+  auto fetch = [&](int k0, float (&xv)[NL], float (&wv)[NL]) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int e = threadIdx.x + 256 * i;
@@ -60,8 +59,7 @@ __device__ __forceinline__ void linear_fwd_kernel_body(const float* __restrict__
       wv[i] = w[(int64_t)(o < Nout ? o : Nout - 1) * so + kc * si];
     }
   };
-  fetch(0);
-  for (int k0 = 0; k0 < K; k0 += kKC) {
+  auto chunk = [&](int k0, const float (&xv)[NL], const float (&wv)[NL]) {
     __syncthreads();                                    // the previous chunk's readers are done
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -72,7 +70,8 @@ __device__ __forceinline__ void linear_fwd_kernel_body(const float* __restrict__
       wsm[r * kRS + c] = (o0 + r < Nout && kin) ? wv[i] : 0.f;
     }
     __syncthreads();
-    if (k0 + kKC < K) fetch(k0 + kKC);
+  };
+  auto mma = [&]() {
     const float* xr = xs + (wave * 16 + (lane & 15)) * kRS + (lane >> 4);
     const float* wr = wsm + (lane & 15) * kRS + (lane >> 4);
 #pragma unroll 4
@@ -82,6 +81,29 @@ __device__ __forceinline__ void linear_fwd_kernel_body(const float* __restrict__
       for (int t = 0; t < 4; ++t) {
         if (o0 + t * 16 < Nout) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t * 16 * kRS + kk], bf, acc[t], 0, 0, 0);
       }
+    }
+  };
+  if (K <= 4 * kKC) {
+    // Short reductions (the token projection Linear(256, 32) of FAST: [320 x 256] x [256 x 32] at the reference's
+    // batch): ALL chunks are fetched before the first is used -- 128 registers, ONE exposed memory latency instead
+    // of one per chunk (the kernel was 20 us whatever the batch: four latencies with a few MFMAs between them).
+    float xa[4][NL], wa[4][NL];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c * kKC < K) fetch(c * kKC, xa[c], wa[c]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c * kKC < K) {
+        chunk(c * kKC, xa[c], wa[c]);
+        mma();
+      }
+  } else {
+    float xv[NL], wv[NL];
+    fetch(0, xv, wv);
+    for (int k0 = 0; k0 < K; k0 += kKC) {
+      chunk(k0, xv, wv);
+      if (k0 + kKC < K) fetch(k0 + kKC, xv, wv);
+      mma();
     }
   }
   const int64_t m = m0 + wave * 16 + (lane & 15);

@@ -14,6 +14,7 @@ carry those blocks and the step count.  One step count serves all tensors (torch
 whenever a tensor either always or never receives a gradient, as in the reference's modes).
 """
 import ctypes as C
+import struct
 
 import torch
 
@@ -46,7 +47,7 @@ class FusedAdamW(torch.optim.Optimizer):
             tot += (p.numel() + 3) & ~3
         self._exp_avg = torch.zeros(tot, dtype=torch.float32, device=dev)
         self._exp_avg_sq = torch.zeros(tot, dtype=torch.float32, device=dev)
-        self._step_dev = torch.zeros(2, dtype=torch.int64, device=dev) if capturable else None
+        self._step_dev = torch.zeros(4, dtype=torch.int64, device=dev) if capturable else None
         self._step = 0
         n = len(params)
         self._numel = (C.c_int64 * n)(*[p.numel() for p in params])
@@ -57,7 +58,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._n_active = (C.c_int64 * n)()
         self.state["flat"] = {"exp_avg": self._exp_avg, "exp_avg_sq": self._exp_avg_sq}
         if capturable:
-            self.state["flat"]["step"] = self._step_dev           # [steps taken, kernel scratch]
+            self.state["flat"]["step"] = self._step_dev           # [steps taken, kernel scratch, b1^t, b2^t (double bits)]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -96,5 +97,6 @@ class FusedAdamW(torch.optim.Optimizer):
         self._exp_avg_sq.copy_(sd["exp_avg_sq"])
         self._step = int(sd["step"])
         if self._step_dev is not None:
-            self._step_dev[0] = self._step
-            self._step_dev[1] = 0
+            b1, b2 = self.param_groups[0]["betas"]
+            bits = [struct.unpack("q", struct.pack("d", b ** self._step))[0] for b in (b1, b2)]
+            self._step_dev.copy_(torch.tensor([self._step, 0] + bits, dtype=torch.int64))

@@ -377,9 +377,10 @@ int isd_adamw_step(float* params, const float* grads, float* exp_avg, float* exp
                    double beta1, double beta2, double eps, double weight_decay, int64_t step, const float* lr_dev,
                    const int64_t* step_dev, void* stream);
 /* The same update over a list of tensors in one launch (per 96 tensors): host arrays of n_tensors DEVICE pointers and
- * element counts; tensors need not be aligned or adjacent.  step_dev (optional): two int64 in device memory, zero before
- * the first step -- [0] = steps taken so far; the kernel uses t = [0] + 1 and stores it back itself, [1] is its
- * scratch -- so a captured graph replays the step with nothing to advance on the host. */
+ * element counts; tensors need not be aligned or adjacent.  step_dev (optional): FOUR int64 in device memory, zero
+ * before the first step -- [0] = steps taken so far: the kernel uses t = [0] + 1 and stores it back itself; [1] is its
+ * scratch; [2], [3] hold beta1^t, beta2^t as doubles (kept by recurrence; to resume at step t > 0 store the bit
+ * patterns of beta^t there) -- so a captured graph replays the step with nothing to advance on the host. */
 int isd_adamw_multi_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                          float* const* exp_avg_sq, const int64_t* numel, double lr, double beta1, double beta2,
                          double eps, double weight_decay, int64_t step, const float* lr_dev, int64_t* step_dev,

@@ -129,7 +129,7 @@ def test_fused_adamw_list_of_tensors_matches_torch(capturable):
         opt_ref.step()
         opt.step()
     if capturable:
-        assert opt.state["flat"]["step"].tolist() == [25, 0]         # advanced by the kernel itself
+        assert opt.state["flat"]["step"].tolist()[:2] == [25, 0]     # advanced by the kernel itself
     for i, (r, d) in enumerate(zip(ref, dev)):
         err = (d.detach().cpu() - r.detach()).abs().max().item()
         assert err < 2e-6 * max(1.0, r.detach().abs().max().item()), (i, err)
@@ -154,7 +154,7 @@ def test_fused_adamw_more_tensors_than_one_launch_holds():
             r.grad, d.grad = g.clone(), g.cuda()
         opt_ref.step()
         opt.step()
-    assert opt.state["flat"]["step"].tolist() == [5, 0]
+    assert opt.state["flat"]["step"].tolist()[:2] == [5, 0]
     for r, d in zip(ref, dev):
         assert (d.detach().cpu() - r.detach()).abs().max().item() < 2e-6 * max(1.0, r.detach().abs().max().item())
 
@@ -185,8 +185,14 @@ def test_graphed_step_with_fused_adamw_follows_torch_adamw():
         losses.append(ls)
         finals.append({k: v.detach().clone() for k, v in m.named_parameters()})
     np.testing.assert_allclose(losses[1], losses[0], rtol=2e-4)
+    # parameters: 1e-3 = two steps of the learning rate.  The key bias of the attention (a third of in_proj_bias) has
+    # NO gradient mathematically -- softmax is invariant to it -- so its computed gradient is rounding noise, which
+    # AdamW normalises to full-size steps: the two optimizers' last bits decide its walk (observed 1.9e-4 to 2.3e-4
+    # after eight steps); every other tensor agrees to ~1e-5.
     for k, v in finals[0].items():
-        assert float((v - finals[1][k]).abs().max()) < 2e-4 * max(1.0, float(v.abs().max())), k
+        assert float((v - finals[1][k]).abs().max()) < 1e-3 * max(1.0, float(v.abs().max())), k
+    tight = [k for k in finals[0] if "in_proj_bias" not in k]
+    assert max(float((finals[0][k] - finals[1][k]).abs().max()) for k in tight) < 1e-4
 
 
 def test_fused_adamw_is_a_torch_optimizer_driven_by_the_reference_schedule():
@@ -217,3 +223,28 @@ def test_fused_adamw_is_a_torch_optimizer_driven_by_the_reference_schedule():
     fresh = isd_amd.FusedAdamW(dev, lr=5e-4)
     fresh.load_state_dict(sd)
     assert fresh.state_dict()["step"] == 12 and torch.equal(fresh.state["flat"]["exp_avg"], opts[1].state["flat"]["exp_avg"])
+
+
+def test_fused_adamw_capturable_state_round_trip_resumes_the_trajectory():
+    """state_dict() / load_state_dict() with the device-side step block: a run interrupted after 7 steps and resumed in
+    a fresh optimizer ends where the uninterrupted torch run ends (the block's running powers beta^t are restored)."""
+    import isd_amd
+    init = _param_list(8, [257, 4100])
+    ref = [torch.nn.Parameter(t.clone()) for t in init]
+    dev = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+    opt_ref = torch.optim.AdamW(ref, lr=1e-3, foreach=False)
+    opt = isd_amd.FusedAdamW(dev, lr=torch.tensor(1e-3, device="cuda"), capturable=True)
+    g0 = torch.Generator().manual_seed(9)
+    for t in range(15):
+        if t == 7:
+            sd = opt.state_dict()
+            opt = isd_amd.FusedAdamW(dev, lr=torch.tensor(1e-3, device="cuda"), capturable=True)
+            opt.load_state_dict(sd)
+        for r, d in zip(ref, dev):
+            g = torch.randn(r.shape, generator=g0)
+            r.grad, d.grad = g.clone(), g.cuda()
+        opt_ref.step()
+        opt.step()
+    assert opt.state["flat"]["step"].tolist()[:2] == [15, 0]
+    for r, d in zip(ref, dev):
+        assert (d.detach().cpu() - r.detach()).abs().max().item() < 2e-6 * max(1.0, r.detach().abs().max().item())

@@ -88,9 +88,10 @@ def heads():
 
 
 def replay_only(act):
-    """--replay f32|bf16: 200 graph replays of the FAST 'default' step at the reference's batch (for rocprofv3)."""
+    """--replay f32|bf16 [--batch B]: 200 graph replays of the FAST 'default' step (default: the reference's batch of
+    64), for rocprofv3."""
     from isd_amd.graph import GraphedTrainStep
-    B, T = 64, 800
+    B, T = (int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 64), 800
     x = torch.randn(B, 64, T, device="cuda")
     y = torch.randint(0, 5, (B,), device="cuda")
     torch.manual_seed(0)
