@@ -16,6 +16,7 @@ bash tools/pmc_r2.sh cfg2 > $O/pmc_cfg2.txt 2>&1 || true
 cp gpurun_out/pmc_r2_cfg2/summary.txt $O/pmc_cfg2_summary.txt || true
 bash tools/pmc_r2.sh cfg5 > $O/pmc_cfg5.txt 2>&1 || true
 cp gpurun_out/pmc_r2_cfg5/summary.txt $O/pmc_cfg5_summary.txt || true
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/fast_replay -- python3 $R/tools/bench_fast.py --replay f32 > $O/fast_replay.log 2>&1; cp $(ls $O/fast_replay/*/*kernel_stats.csv | tail -1) $O/fast_replay_b64_kernel_stats.csv) || true
 python tools/bench_fast.py > $O/bench_fast.txt 2>&1 || true
 python tools/bench_fast.py --heads > $O/bench_fast_heads.txt 2>&1 || true
 python tools/bench_features.py > $O/bench_features.txt 2>&1 || true
