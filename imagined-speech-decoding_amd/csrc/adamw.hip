@@ -86,31 +86,76 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 // itself: every workgroup reads t = counter + 1 and the running powers b1^t, b2^t, and the last one to finish stores
 // them back.
 constexpr int kAdamMaxTensors = 96;
+// One record per tensor, 40 bytes: a workgroup reads ITS tensor's pointers and length from one cache line of the
+// argument block.  (The argument block of a launch lives in host-visible memory and is not cached across workgroups'
+// CUs: as five parallel arrays -- p[], g[], m[], v[], n[] -- every workgroup paid five of those reads, and the
+// bisection of the one-dimensional grid seven dependent ones: the kernel took 19 us for 0.2 M parameters.)
+struct AdamTensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int n;
+  unsigned bend;                    // end (exclusive) of the tensor's run of workgroups (one-dimensional grid)
+};
 struct AdamMultiArgs {
-  float* p[kAdamMaxTensors];
-  const float* g[kAdamMaxTensors];
-  float* m[kAdamMaxTensors];
-  float* v[kAdamMaxTensors];
-  int n[kAdamMaxTensors];
-  unsigned bend[kAdamMaxTensors];   // end (exclusive) of the tensor's run of workgroups
   int count, advance;               // advance: this launch is the last of the step (stores the counter)
+  int two_d;                        // grid (max runs, count) instead of the runs back to back along x
+  unsigned n_blocks;                // workgroups of this launch that own elements (the counter's target)
   float lr, b1, b2, eps, wd, c1, c2, bc1, bc2_sqrt;
   double b1d, b2d;
   const float* lr_dev;
   long long* step_dev;              // [0] steps taken so far t, [1] workgroups finished (returns to 0),
                                     // [2], [3] b1^t, b2^t as doubles (valid when t > 0)
+  AdamTensor t[kAdamMaxTensors];
 };
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
   __shared__ float sc[3];
   __shared__ double pw[2];
+  // this workgroup's tensor and its run of 1024 elements.  two_d: blockIdx.y IS the tensor (workgroups past the
+  // tensor's end leave at once); otherwise the tensors' runs lie back to back along x and the tensor is found by
+  // bisection of the run ends -- seven dependent scalar loads from the argument block, which is why the two-dimensional
+  // grid is used whenever it is not mostly empty.
+  int lo;
+  unsigned bx;
+  if (a.two_d) {
+    lo = blockIdx.y;
+    bx = blockIdx.x;
+    if ((int64_t)bx * 1024 >= a.t[lo].n) return;
+  } else {
+    lo = 0;
+    int hi = a.count - 1;                                  // first tensor whose run ends past this workgroup
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (blockIdx.x < a.t[mid].bend) hi = mid; else lo = mid + 1;
+    }
+    bx = blockIdx.x - (lo ? a.t[lo - 1].bend : 0u);
+  }
+  const AdamTensor T = a.t[lo];
+  float* __restrict__ P = T.p;
+  const float* __restrict__ G = T.g;
+  float* __restrict__ M = T.m;
+  float* __restrict__ V = T.v;
+  const int n = T.n;
+  const int i4 = ((int)bx * 256 + (int)threadIdx.x) * 4;
+  const bool vec = ((((uintptr_t)P | (uintptr_t)G | (uintptr_t)M | (uintptr_t)V) & 15) == 0);   // wave-uniform
+  const bool full = i4 + 4 <= n && vec;
+  // the data loads go out BEFORE the step scalars are waited for (two memory latencies side by side, not in a row)
+  float4 p = {0.f, 0.f, 0.f, 0.f}, g = p, m = p, v = p;
+  if (full) {
+    p = *reinterpret_cast<float4*>(P + i4);
+    g = *reinterpret_cast<const float4*>(G + i4);
+    m = *reinterpret_cast<float4*>(M + i4);
+    v = *reinterpret_cast<float4*>(V + i4);
+  }
   float lr = a.lr, bc1 = a.bc1, bc2s = a.bc2_sqrt;
   if (a.lr_dev || a.step_dev) {
     if (threadIdx.x == 0) {
       if (a.lr_dev) lr = a.lr_dev[0];
       if (a.step_dev) {
-        // b^t by recurrence from the powers the previous step left (a double-precision pow() per workgroup was 15 of
-        // this kernel's 20 us); a zeroed counter block (t = 0) starts from b^0 = 1
+        // b^t by recurrence from the powers the previous step left (a double-precision pow() per workgroup is
+        // hundreds of instructions); a zeroed counter block (t = 0) starts from b^0 = 1
         const bool first = a.step_dev[0] == 0;
         const double p1 = (first ? 1.0 : __longlong_as_double(a.step_dev[2])) * a.b1d;
         const double p2 = (first ? 1.0 : __longlong_as_double(a.step_dev[3])) * a.b2d;
@@ -124,24 +169,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
     lr = sc[0]; bc1 = sc[1]; bc2s = sc[2];
   }
   const float decay = 1.f - lr * a.wd, step_size = lr / bc1;
-  int lo = 0, hi = a.count - 1;                            // first tensor whose run ends past this workgroup
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (blockIdx.x < a.bend[mid]) hi = mid; else lo = mid + 1;
-  }
-  const unsigned b0 = lo ? a.bend[lo - 1] : 0u;
-  float* __restrict__ P = a.p[lo];
-  const float* __restrict__ G = a.g[lo];
-  float* __restrict__ M = a.m[lo];
-  float* __restrict__ V = a.v[lo];
-  const int n = a.n[lo];
-  const int i4 = ((int)(blockIdx.x - b0) * 256 + (int)threadIdx.x) * 4;
-  const bool vec = ((((uintptr_t)P | (uintptr_t)G | (uintptr_t)M | (uintptr_t)V) & 15) == 0);   // wave-uniform
-  if (i4 + 4 <= n && vec) {
-    float4 p = *reinterpret_cast<float4*>(P + i4);
-    const float4 g = *reinterpret_cast<const float4*>(G + i4);
-    float4 m = *reinterpret_cast<float4*>(M + i4);
-    float4 v = *reinterpret_cast<float4*>(V + i4);
+  if (full) {
     adamw_one(p.x, g.x, m.x, v.x, decay, a.c1, a.b2, a.c2, step_size, bc2s, a.eps);
     adamw_one(p.y, g.y, m.y, v.y, decay, a.c1, a.b2, a.c2, step_size, bc2s, a.eps);
     adamw_one(p.z, g.z, m.z, v.z, decay, a.c1, a.b2, a.c2, step_size, bc2s, a.eps);
@@ -151,9 +179,9 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
     *reinterpret_cast<float4*>(V + i4) = v;
   } else {
     for (int i = i4; i < n && i < i4 + 4; ++i) {
-      float p = P[i], m = M[i], v = V[i];
-      adamw_one(p, G[i], m, v, decay, a.c1, a.b2, a.c2, step_size, bc2s, a.eps);
-      P[i] = p; M[i] = m; V[i] = v;
+      float pp = P[i], mm = M[i], vv = V[i];
+      adamw_one(pp, G[i], mm, vv, decay, a.c1, a.b2, a.c2, step_size, bc2s, a.eps);
+      P[i] = pp; M[i] = mm; V[i] = vv;
     }
   }
   if (a.step_dev && a.advance) {                           // the last workgroup to get here advances the counter
@@ -162,7 +190,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMultiArgs a) {
       const long long t = a.step_dev[0] + 1;
       __threadfence();
       const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(a.step_dev + 1), 1ull);
-      if (done + 1 == gridDim.x) {
+      if (done + 1 == a.n_blocks) {
         a.step_dev[1] = 0;
         a.step_dev[2] = __double_as_longlong(pw[0]);
         a.step_dev[3] = __double_as_longlong(pw[1]);
@@ -233,13 +261,21 @@ extern "C" int isd_adamw_multi_step(int n_tensors, float* const* params, const f
     for (; i <= last && a.count < isd::kAdamMaxTensors; ++i) {
       if (numel[i] == 0) continue;
       const int c = a.count++;
-      a.p[c] = params[i]; a.g[c] = grads[i]; a.m[c] = exp_avg[i]; a.v[c] = exp_avg_sq[i];
-      a.n[c] = (int)numel[i];
+      a.t[c].p = params[i]; a.t[c].g = grads[i]; a.t[c].m = exp_avg[i]; a.t[c].v = exp_avg_sq[i];
+      a.t[c].n = (int)numel[i];
       blocks += (unsigned)isd::cdiv(numel[i], 1024);
-      a.bend[c] = blocks;
+      a.t[c].bend = blocks;
     }
     a.advance = i > last ? 1 : 0;
-    hipLaunchKernelGGL(isd::adamw_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    a.n_blocks = blocks;
+    unsigned gx = 1;
+    for (int c = 0; c < a.count; ++c) {
+      const unsigned b = (unsigned)isd::cdiv(a.t[c].n, 1024);
+      if (b > gx) gx = b;
+    }
+    a.two_d = (uint64_t)gx * a.count <= 16ull * blocks + 1024 ? 1 : 0;   // empty workgroups read one line and leave
+    const dim3 grid = a.two_d ? dim3(gx, (unsigned)a.count) : dim3(blocks);
+    hipLaunchKernelGGL(isd::adamw_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     ISD_LAUNCH_CHECK();
   }
   return ISD_OK;

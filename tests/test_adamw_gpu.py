@@ -139,9 +139,12 @@ def test_fused_adamw_list_of_tensors_matches_torch(capturable):
 
 
 def test_fused_adamw_more_tensors_than_one_launch_holds():
-    """More than 96 tensors: several launches per step, the device step count advanced once."""
+    """More than 96 tensors: several launches per step, the device step count advanced once.  (Equal-sized small
+    tensors take the two-dimensional grid; one 2.1 M-element tensor among them sends its launch to the one-dimensional
+    grid with the bisection.)"""
     import isd_amd
     sizes = [17 + 3 * i for i in range(230)]
+    sizes[40] = 2_100_003
     init = _param_list(2, sizes)
     ref = [torch.nn.Parameter(t.clone()) for t in init]
     dev = [torch.nn.Parameter(t.clone().cuda()) for t in init]
