@@ -167,8 +167,8 @@ __device__ __forceinline__ void linear_wgrad_kernel_body(const float* __restrict
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int64_t ms = m_lo; ms < m_hi; ms += 64) {
     __syncthreads();
-#pragma unroll 8
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {   // clamped addresses + selects: the loads go out together
+#pragma unroll
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {   // clamped addresses + selects: all 32 loads go out together
       const int r = e >> 6, c = e & 63;
       const int64_t m = ms + r;
       const bool ok = m < m_hi;
