@@ -215,3 +215,23 @@ def test_zone_batch_recorder_states_without_a_gpu():
     assert lib.isd_zone_batch_begin() == 0
     assert lib.isd_zone_batch_next() == 0
     assert lib.isd_zone_batch_launch(None) == 0
+
+
+def test_optimizers_reject_what_the_hip_kernels_cannot_take():
+    """isd_amd.FusedAdamW / Trainer are HIP-only (no silent torch fallback): host tensors and inconsistent options are
+    refused with a message, before any launch."""
+    import torch
+    import isd_amd
+    p = torch.nn.Parameter(torch.zeros(8))
+    with pytest.raises(TypeError, match="HIP device"):
+        isd_amd.FusedAdamW([p], lr=1e-3)
+    with pytest.raises(ValueError, match="capturable"):
+        isd_amd.FusedAdamW([p], lr=1e-3, capturable=True)                 # needs lr as a device tensor
+    with pytest.raises(TypeError, match="tensor lr"):
+        isd_amd.FusedAdamW([p], lr=torch.zeros(1))                        # a host tensor is not a device-side rate
+    with pytest.raises(ValueError):
+        isd_amd.FusedAdamW([], lr=1e-3)
+    assert issubclass(isd_amd.FusedAdamW, torch.optim.Optimizer)
+    from isd_amd.classifier import _FeatureModel
+    with pytest.raises((RuntimeError, TypeError, isd_amd._lib.IsdError if hasattr(isd_amd, "_lib") else RuntimeError)):
+        isd_amd.Trainer(_FeatureModel(8, 32, 5, 4))                        # parameters on the host
