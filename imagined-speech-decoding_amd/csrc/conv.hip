@@ -3123,11 +3123,14 @@ static inline int launch_reduce_fused_bwd(float* part4, float* part3, float* par
 //   blocks [0, nb2)          : dW2[g,f,c] = sum_k dWeff[g,c,k] W1[f,k] + dbeff[g] b1[f]      (one thread per element)
 //   blocks [nb2, nb2 + 5F)   : dW1[f,k]   = sum_{g,c} dWeff[g,c,k] W2[g,f,c]                 (one block per output)
 //   blocks [nb2 + 5F, +F)    : db1[f]     = sum_g dbeff[g] sum_c W2[g,f,c]
-__global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict__ params,
-                                                        const ZoneDesc* __restrict__ zones,
-                                                        const float* __restrict__ dweff, float* __restrict__ dparams,
-                                                        int F, int nb2) {
-  __shared__ float red[256];
+// kFbwThreads: 1024 for wide inputs (the spec-S classifier: 576 channels), 256 for the zone shapes (<= 15 channels:
+// 480 terms per output, where the longer reduction tree of a 1024-thread workgroup costs more than it saves)
+template <int kFbwThreads>
+__global__ __launch_bounds__(kFbwThreads) void fused_bwd_kernel(const float* __restrict__ params,
+                                                                const ZoneDesc* __restrict__ zones,
+                                                                const float* __restrict__ dweff,
+                                                                float* __restrict__ dparams, int F, int nb2) {
+  __shared__ float red[kFbwThreads];
   const ZoneDesc zd = zones[blockIdx.y];
   const int cz = zd.cin, cin1 = cz + 1;
   const float* W1 = params + zd.p_off;
@@ -3139,7 +3142,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
   float* dW2 = db1 + F;
   const int blk = blockIdx.x;
   if (blk < nb2) {
-    const int e = blk * 256 + threadIdx.x;
+    const int e = blk * kFbwThreads + threadIdx.x;
     if (e >= F * F * cz) return;
     const int c = e % cz, f = (e / cz) % F, g = e / (cz * F);
     float s = dWe[(g * cin1 + cz) * kTaps] * b1[f];
@@ -3150,23 +3153,29 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
   }
   const int o = blk - nb2;                              // output index: [0, 5F) -> dW1, [5F, 6F) -> db1
   if (o >= F * kTaps + F) return;
+  // one workgroup per output, its F x cz terms spread over ALL 1024 threads as (g, c) pairs (18 terms per thread at
+  // 576 channels, 1 at a 15-channel zone): with 256 threads walking c and looping g, a 576-channel output was 72
+  // dependent-latency-bound terms per thread and a 15-channel zone used 15 of its threads
   float s = 0.f;
+  const int n_pair = F * cz;
   if (o < F * kTaps) {
     const int f = o / kTaps, k = o - f * kTaps;
-    for (int c = threadIdx.x; c < cz; c += 256) {            // independent loads, no division: they pipeline
-#pragma unroll 8
-      for (int g = 0; g < F; ++g) s = fmaf(dWe[(g * cin1 + c) * kTaps + k], W2[((int64_t)g * F + f) * cz + c], s);
+#pragma unroll 4
+    for (int pi = threadIdx.x; pi < n_pair; pi += kFbwThreads) {
+      const int g = pi / cz, c = pi - g * cz;
+      s = fmaf(dWe[(g * cin1 + c) * kTaps + k], W2[((int64_t)g * F + f) * cz + c], s);
     }
   } else {
     const int f = o - F * kTaps;
-    for (int c = threadIdx.x; c < cz; c += 256) {
-#pragma unroll 8
-      for (int g = 0; g < F; ++g) s = fmaf(dWe[(g * cin1 + cz) * kTaps], W2[((int64_t)g * F + f) * cz + c], s);
+#pragma unroll 4
+    for (int pi = threadIdx.x; pi < n_pair; pi += kFbwThreads) {
+      const int g = pi / cz, c = pi - g * cz;
+      s = fmaf(dWe[(g * cin1 + cz) * kTaps], W2[((int64_t)g * F + f) * cz + c], s);
     }
   }
   red[threadIdx.x] = s;
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
+  for (int w = kFbwThreads / 2; w > 0; w >>= 1) {
     if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
@@ -3687,6 +3696,21 @@ __global__ void scatter_conv_grad_kernel(const float* __restrict__ wg, const isd
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) dst[e] = wg[(int64_t)z * n + e];
 }
 
+// the chain dWeff -> (dW1, db1, dW2): 1024-thread workgroups for wide inputs, 256 for the zone shapes
+static inline void launch_fused_bwd(const isd_conv4_plan* p, const float* params, const float* dweff, float* dparams,
+                                    hipStream_t st) {
+  const int F = p->F;
+  if (p->max_cz >= 64) {
+    const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 1024);
+    hipLaunchKernelGGL(fused_bwd_kernel<1024>, dim3(nb2 + F * kTaps + F, p->Z), dim3(1024), 0, st, params, p->d_zones,
+                       dweff, dparams, F, nb2);
+  } else {
+    const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
+    hipLaunchKernelGGL(fused_bwd_kernel<256>, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,
+                       dweff, dparams, F, nb2);
+  }
+}
+
 // cnn1 o cnn2 backward: dWeff (+ dbeff in the ones channel) from g2 = dL/dA2, then the chain to W1, b1, W2
 static int first_layer_backward(const isd_conv4_plan* p, const Geo& g, const float* x, int64_t T, const float* params,
                                 const float* g2, float* dparams, float* ws, hipStream_t st, bool tap16 = false,
@@ -3742,9 +3766,7 @@ static int first_layer_backward(const isd_conv4_plan* p, const Geo& g, const flo
   if (rc) return rc;
   launch_reduce_slabs(ws + g.o_part, ws + g.o_wg, g.slab0, n_slabs0, st);
   {
-    const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
-    hipLaunchKernelGGL(fused_bwd_kernel, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,
-                       ws + g.o_wg, dparams, F, nb2);
+    launch_fused_bwd(p, params, ws + g.o_wg, dparams, st);
   }
   ISD_LAUNCH_CHECK();
   return ISD_OK;
@@ -3906,9 +3928,7 @@ static int conv4_backward_impl(const isd_conv4_plan* p, const float* x, const fl
     rc = launch_reduce_fused_bwd(fb.part4, fb.part3, fb.part0, g.slab1, per_zone * 4, g.slab0, per_zone * NW, dparams,
                                  ws + g.o_wg, p->d_zones, F, st);
     if (rc) return rc;
-    const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
-    hipLaunchKernelGGL(fused_bwd_kernel, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,
-                       ws + g.o_wg, dparams, F, nb2);
+    launch_fused_bwd(p, params, ws + g.o_wg, dparams, st);
     ISD_LAUNCH_CHECK();
     return ISD_OK;
   }
@@ -3943,9 +3963,7 @@ static int conv4_backward_impl(const isd_conv4_plan* p, const float* x, const fl
       rc = launch_reduce_fused_bwd(fb.part4, fb.part3, fb.part0, g.slab1, per_zone * 2, g.slab0, per_zone * 4, dparams,
                                    ws + g.o_wg, p->d_zones, F, st);
       if (rc) return rc;
-      const int nb2 = (int)cdiv((int64_t)F * F * p->max_cz, 256);
-      hipLaunchKernelGGL(fused_bwd_kernel, dim3(nb2 + F * kTaps + F, p->Z), dim3(256), 0, st, params, p->d_zones,
-                         ws + g.o_wg, dparams, F, nb2);
+      launch_fused_bwd(p, params, ws + g.o_wg, dparams, st);
       ISD_LAUNCH_CHECK();
       return ISD_OK;
     }
