@@ -694,6 +694,30 @@ class _Conv4Params(nn.Module):
         return ps
 
 
+class _PackedTheta(torch.autograd.Function):
+    """The packed parameter block as ONE differentiable tensor without copying it: forward hands out the flat block the
+    parameters already alias (``flat_params``), backward hands every parameter its slice of the flat gradient as a
+    view.  (``torch.cat`` of the parameters did the same with a copy kernel per forward pass -- 5 us of a 0.8 ms step
+    at the reference's batch -- and split the gradient the same way.)"""
+
+    @staticmethod
+    def forward(ctx, flat, *params):
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return flat.view_as(flat)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        out, off = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            out.append(g[off:off + n].view(shp))
+            off += n
+        return (None, *out)
+
+
 class _FlatParamMixin:
     """Keeps a list of nn.Parameters packed, in order, in one contiguous flat buffer.
 
@@ -730,6 +754,13 @@ class _FlatParamMixin:
                 p.data = flat[off:off + p.numel()].view(p.shape)
                 off += p.numel()
         return flat
+
+    def packed_theta(self):
+        """The flat block as the differentiable operand of the module's autograd function (see ``_PackedTheta``)."""
+        flat = self.flat_params()
+        if not torch.is_grad_enabled():
+            return flat
+        return _PackedTheta.apply(flat.detach(), *self._ordered_params())
 
     def flat_grads(self):
         """One flat gradient buffer aliased by every ``p.grad`` (allocated when the grads are not packed yet)."""
@@ -771,9 +802,7 @@ class Conv4Layers(_Conv4Params, _FlatParamMixin):
     def forward(self, x):
         if x.dim() != 3:
             raise ValueError("expected [batch, channels, time]")
-        flat = self.flat_params()
-        theta = torch.cat([p.reshape(-1) for p in self.ordered()]) if torch.is_grad_enabled() else flat
-        return _ConvStackFn.apply(x, theta, self._plan(x.shape[-1])).squeeze(1)
+        return _ConvStackFn.apply(x, self.packed_theta(), self._plan(x.shape[-1])).squeeze(1)
 
 
 _dropout_streams = [0]
@@ -841,8 +870,7 @@ class _BNStackMixin(_FlatParamMixin):
         """One forward's bookkeeping (call counter, ``num_batches_tracked``) and the arguments of ``_EEGNetFn`` after
         ``x`` -- also what ``Head`` hands to the zone-batched ``_BNZonesFn``."""
         plan = self._plan_for(T)
-        flat = self.flat_params()
-        theta = torch.cat([p.reshape(-1) for p in self._ordered_params()]) if torch.is_grad_enabled() else flat
+        theta = self.packed_theta()
         bn = self._bns()[0]
         self._calls += 1
         if self.training:
@@ -970,8 +998,7 @@ class HeadConv_Paper_Version(nn.Module, _BNStackMixin):
         plan = self._plans.get(T)
         if plan is None:
             plan = self._plans[T] = PaperHeadPlan(self.in_channels, self.feature_dim, T)
-        flat = self.flat_params()
-        theta = torch.cat([p.reshape(-1) for p in self._ordered_params()]) if torch.is_grad_enabled() else flat
+        theta = self.packed_theta()
         if self.training:
             for b in self._bns():
                 b.num_batches_tracked += 1
@@ -1026,10 +1053,7 @@ class Head(nn.Module, _FlatParamMixin):
         return pl
 
     def _theta(self):
-        flat = self.flat_params()
-        if torch.is_grad_enabled():
-            return torch.cat([p.reshape(-1) for p in self._ordered_params()])
-        return flat
+        return self.packed_theta()
 
     @staticmethod
     def _zone_batchable(encs, xw):
