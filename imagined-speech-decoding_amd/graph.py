@@ -90,7 +90,7 @@ class GraphedTrainStep:
         loss = token_mean_cross_entropy(self.model(xb, forward_mode=self.mode), yb)
         loss.backward()
         self.opt.step()
-        self.loss_sum.add_(loss.detach() * float(idx.numel()))
+        self.loss_sum.add_(loss.detach(), alpha=float(idx.numel()))      # one kernel (a product first would be two)
 
     def step(self, idx, lr):
         self.lr.fill_(float(lr))
