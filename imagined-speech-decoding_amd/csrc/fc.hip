@@ -293,7 +293,9 @@ __device__ __forceinline__ void softmax_ce_kernel_body(const float* __restrict__
     if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && zgx == 1) {                   // one workgroup (B <= 256): nothing to combine, no ticket
+    *loss = red[0] * grad_scale;
+  } else if (threadIdx.x == 0) {
     __hip_atomic_store(&part[blockIdx.x], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -435,7 +437,9 @@ extern "C" int isd_softmax_ce(const float* logits_tok, const void* labels, int l
     return ISD_OK;
   }
   float* scratch = want_loss ? (float*)workspace : nullptr;
-  if (scratch) ISD_HIP_TRY(zone_clear(scratch, sizeof(unsigned int), st));   // arrival ticket
+  // arrival ticket of the cross-workgroup loss sum (a single workgroup needs none: at the reference's batch of 64 the
+  // clear was a 5-us node of the replayed step)
+  if (scratch && cdiv(B, 256) > 1) ISD_HIP_TRY(zone_clear(scratch, sizeof(unsigned int), st));
   ISD_ZLAUNCH(softmax_ce_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, logits_tok, labels, label_bytes,
                      logits_mean, want_loss ? loss : nullptr, labels ? dlogits_tok : nullptr, pred, B, n_tok, n_cls,
                      grad_scale, scratch ? scratch + 64 : nullptr, reinterpret_cast<unsigned int*>(scratch));

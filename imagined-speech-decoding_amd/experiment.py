@@ -22,7 +22,7 @@ from .classifier import cosine_scheduler, lr_multiplier
 from .data import DeviceStager
 from .graph import GraphedTrainStep, graph_safe
 from .optim import FusedAdamW
-from .nn import FAST, fast_config, reset_dropout_streams, token_mean_cross_entropy
+from .nn import FAST, fast_config, reset_dropout_streams, token_mean_cross_entropy, unit_grad
 
 
 def accuracy(y_true, y_pred):
@@ -135,7 +135,7 @@ def train_one_fold(config, Xtr, ytr, Xva, yva, max_epochs, batch_size, seed, for
                 opt.zero_grad(set_to_none=True)
                 logits = model(Xd[idx].contiguous(), forward_mode=forward_mode)
                 loss = token_mean_cross_entropy(logits, yd[idx].contiguous())
-                loss.backward()
+                loss.backward(unit_grad(loss.device))
                 opt.step()
                 tot += loss.detach() * len(idx)          # summed on the device: one host read per epoch
             step += 1

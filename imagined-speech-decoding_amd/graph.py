@@ -9,7 +9,7 @@ the kernels, include/isd_hip.h ``seed_dev``).
 """
 import torch
 
-from .nn import token_mean_cross_entropy
+from .nn import token_mean_cross_entropy, unit_grad
 
 
 def graph_safe(model):
@@ -88,7 +88,7 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         xb, yb = self.X.index_select(0, idx), self.y.index_select(0, idx)
         loss = token_mean_cross_entropy(self.model(xb, forward_mode=self.mode), yb)
-        loss.backward()
+        loss.backward(unit_grad(loss.device))             # (no ones fill, no multiply by it: nn.unit_grad)
         self.opt.step()
         self.loss_sum.add_(loss.detach(), alpha=float(idx.numel()))      # one kernel (a product first would be two)
 

@@ -158,6 +158,21 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+_unit_grads = {}
+
+
+def unit_grad(device):
+    """A cached scalar 1.0 on ``device`` to start backward passes from: ``loss.backward(unit_grad(loss.device))``.
+    ``loss.backward()`` fills a fresh ones tensor every time and ``_SoftmaxCEFn.backward`` multiplied its stored
+    gradient by it -- two 5-us kernels per step to multiply by one; started from THIS tensor (recognised by its
+    address) the backward pass does neither."""
+    key = str(torch.device(device))
+    t = _unit_grads.get(key)
+    if t is None:
+        t = _unit_grads[key] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
 class _SoftmaxCEFn(torch.autograd.Function):
     """loss = CrossEntropyLoss()(logits_tok.mean(1), y) * (B / global_batch)."""
 
@@ -182,6 +197,9 @@ class _SoftmaxCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dlt,) = ctx.saved_tensors
+        u = _unit_grads.get(str(g.device))
+        if u is not None and g.data_ptr() == u.data_ptr():       # the cached unit gradient: nothing to scale
+            return dlt, None, None
         return dlt * g, None, None
 
 
