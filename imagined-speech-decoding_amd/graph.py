@@ -49,7 +49,12 @@ class GraphedTrainStep:
         self.idx = torch.zeros(self.bs, dtype=torch.int64, device=dev)
         self.loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
         self.lr = g0["lr"]
-        model.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        # the dropout step counter: the optimizer's own device-side step count when it keeps one (FusedAdamW advances
+        # it inside its kernel: no launch of ours), else a counter this class advances with a one-element add per step
+        from .optim import FusedAdamW
+        self._own_counter = not (isinstance(opt, FusedAdamW) and "step" in opt.state["flat"])
+        model.seed_dev = (torch.zeros(1, dtype=torch.int64, device=dev) if self._own_counter
+                          else opt.state["flat"]["step"][:1])
         for enc in getattr(model.head, "encoders", {}).values():
             if hasattr(enc, "set_seed_counter"):
                 enc.set_seed_counter(model.seed_dev)
@@ -81,10 +86,12 @@ class GraphedTrainStep:
                     if isinstance(v, torch.Tensor):
                         v.zero_()
             self.loss_sum.zero_()
-            model.seed_dev.zero_()
+            if self._own_counter:
+                model.seed_dev.zero_()
 
     def _body(self, idx):
-        self.model.seed_dev.add_(1)
+        if self._own_counter:
+            self.model.seed_dev.add_(1)
         self.opt.zero_grad(set_to_none=True)
         xb, yb = self.X.index_select(0, idx), self.y.index_select(0, idx)
         loss = token_mean_cross_entropy(self.model(xb, forward_mode=self.mode), yb)
