@@ -15,6 +15,13 @@ Workloads (``--config``):
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (no WORLD_SIZE in the environment: this process starts the N ranks itself as
+                                       CHILD processes through torch.distributed.run, never touches the GPU, and
+                                       exits with their code -- rank 0's JSON line is the only stdout)
+
+Before the W warm-up steps every workload runs a time-based GPU pre-roll of the SAME step (>= ``--preroll-ms``,
+default 100 ms, disclosed in the line as ``preroll_ms`` / ``preroll_steps``): a fresh box's first milliseconds are
+spent at idle clocks and on first-touch page faults, and W = 5 steps of 1.3 ms do not get past them.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
@@ -161,6 +168,35 @@ def shader_clock_mhz(spin_us=300):
     return round(t / r * L.isd_wall_clock_khz() / 1000.0, 1) if r > 0 else None
 
 
+def clock_probe_start(spin_us=300):
+    """Queue the shader-clock probe on its own stream WITHOUT waiting for it (for use inside a timed region: one
+    one-wave launch, no host synchronisation); ``clock_probe_read`` after the region's final synchronize."""
+    global _clock_stream
+    from isd_amd import _lib
+    L = _lib.lib()
+    if _clock_stream is None:
+        _clock_stream = torch.cuda.Stream()
+    with torch.cuda.stream(_clock_stream):
+        out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    _clock_stream.synchronize()                                  # the fill is done before the region starts
+
+    def fire():
+        _lib.check(L.isd_shader_clock_probe(out.data_ptr(), int(spin_us), _clock_stream.cuda_stream))
+    return out, fire
+
+
+def clock_probe_read(out):
+    from isd_amd import _lib
+    t, r = (int(v) for v in out.tolist())
+    return round(t / r * _lib.lib().isd_wall_clock_khz() / 1000.0, 1) if r > 0 else None
+
+
+def spread(v):
+    """min / median / max of a list of per-step milliseconds"""
+    v = [float(a) for a in v]
+    return {"min": round(min(v), 4), "median": round(float(np.median(v)), 4), "max": round(max(v), 4)} if v else None
+
+
 def filterbank_hbm_roofline(fx, x, nb, groups=8, per_group=4):
     """North-star evidence: achieved HBM rate of the MATERIALISING filterbank stage (read x once, write nb filtered
     copies -- what the scipy path does), measured after the timed region on (a slice of) the resident batch.
@@ -212,15 +248,23 @@ def parse_args():
                          "current one, the CNN stream at high priority (measured, round 3: 1.32 ms against 1.26 ms "
                          "per step on one stream -- the fused extractor already fills every wave slot and the "
                          "CNN's short kernels queue behind its waves -- so the default is one stream)")
+    ap.add_argument("--preroll-ms", type=float, default=100.0,
+                    help="time-based GPU pre-roll of the same step ahead of the warm-up steps (0: none)")
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher self-test (tests/test_bench_launch_cpu.py): no HIP, a CPU tensor through the same "
+                         "rank bring-up, GradientBucket all-reduce, barriers, MAX-over-ranks timing and one JSON line")
+    ap.add_argument("--stub-fail-rank", type=int, default=-1, help="--stub only: this rank raises before the timed loop")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N > 1 only: wait for the gradient all-reduce before extracting the next batch's features "
                          "(default: the all-reduce of step k runs under the feature extraction of batch k+1)")
     return ap.parse_args()
 
 
-def run_workload(config, steps, warmup, batch, bf16, two_kernel, overlap_flag, no_pipeline, hbm_roofline, env):
-    """One workload: W untimed warm-up steps, exactly K timed steps between barrier + synchronize pairs, the MAX of the
-    ranks' wall times.  Returns the JSON line's fields on rank 0 (None elsewhere)."""
+def run_workload(config, steps, warmup, batch, bf16, two_kernel, overlap_flag, no_pipeline, hbm_roofline, env,
+                 preroll_ms=100.0):
+    """One workload: a time-based pre-roll of the same step, W untimed warm-up steps, exactly K timed steps between
+    barrier + synchronize pairs, the MAX of the ranks' wall times.  Returns the JSON line's fields on rank 0 (None
+    elsewhere)."""
     import torch.distributed as dist
     import isd_amd
     from isd_amd.classifier import _EEGNetFeatureModel, _FeatureModel
@@ -248,7 +292,7 @@ def run_workload(config, steps, warmup, batch, bf16, two_kernel, overlap_flag, n
     global_batch = B * world
     fused = not two_kernel
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
     overlap = fused and overlap_flag
     # --overlap: the CNN step runs on a HIGH-priority stream (its kernels are short and latency-bound: they take the
     # wave slots that free up first), the extractor on a normal one
@@ -297,7 +341,9 @@ def run_workload(config, steps, warmup, batch, bf16, two_kernel, overlap_flag, n
     def pipelined_step(e=None):
         out = trainer.step_begin(feats.view(B, nb * C, fx.n_frames), y, global_batch=global_batch)
         extract(0, e)                                       # same stream: queued behind the backward pass that read feats
-        trainer.step_finish()
+        # e[1] (end of the extraction) -> e[4] (the stream got past its wait for the collective) = the part of the
+        # all-reduce that did NOT hide under the extraction
+        trainer.step_finish(after_wait=e[4] if e else None)
         if e:
             e[2].record(main_stream)
         return out
@@ -308,44 +354,78 @@ def run_workload(config, steps, warmup, batch, bf16, two_kernel, overlap_flag, n
     freed[0].record(main_stream); freed[1].record(main_stream)
     if overlap or pipelined:
         extract(0)
-    for i in range(warmup):
+    it = 0                                                  # steps issued so far (the overlap mode's buffer parity)
+
+    def one_step(e=None):
+        nonlocal it
         if pipelined:
-            pipelined_step()
+            out = pipelined_step(e)
         elif overlap:
-            extract((i + 1) % 2)
-            train(i % 2)
+            extract((it + 1) % 2, e)
+            out = train(it % 2, e)
         else:
-            extract(0)
-            train(0)
+            extract(0, e)
+            out = train(0, e)
+        it += 1
+        return out
+
+    def over_ranks(v, op):
+        if world == 1:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=op)
+        return float(tt.item())
+
+    # Pre-roll: the same step, untimed, until >= preroll_ms of wall time have passed on EVERY rank (the ranks decide
+    # on the all-reduced minimum, so they run the same number of steps and collectives).
+    pre_steps, pre_ms = 0, 0.0
+    if preroll_ms > 0:
+        chunk = 1 if config == "cfg5" else 8
+        tp = time.perf_counter()
+        while pre_ms < preroll_ms and pre_steps < 4096:
+            for _ in range(chunk):
+                one_step()
+            pre_steps += chunk
+            torch.cuda.synchronize()
+            pre_ms = over_ranks((time.perf_counter() - tp) * 1e3, dist.ReduceOp.MIN)
+    for i in range(warmup):
+        one_step()
+    clk_out, clk_fire = clock_probe_start()
+    host_ms = []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    base = warmup
     for i in range(steps):
-        if pipelined:
-            out = pipelined_step(ev[i])
-        elif overlap:
-            extract((base + i + 1) % 2, ev[i])
-            out = train((base + i) % 2, ev[i])
-        else:
-            extract(0, ev[i])
-            out = train(0, ev[i])
+        h0 = time.perf_counter()
+        out = one_step(ev[i])
+        if i == steps // 2:
+            clk_fire()                                      # shader clock WHILE the timed steps run (no host sync)
+        host_ms.append((time.perf_counter() - h0) * 1e3)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = over_ranks(dt, dist.ReduceOp.MAX)
+    clk_timed = clock_probe_read(clk_out)
     loss = float(out["loss"])
     if rank != 0:
         return None
 
     ms = dt / steps * 1e3
-    t_feat = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    t_train = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if not (overlap or pipelined) else float("nan")
+    feat_i = [e[0].elapsed_time(e[1]) for e in ev]
+    train_i = [e[1].elapsed_time(e[2]) for e in ev] if not (overlap or pipelined) else []
+    t_feat = float(np.mean(feat_i))
+    t_train = float(np.mean(train_i)) if train_i else float("nan")
+    stage_spread = {"extract_features": spread(feat_i), "cnn_fwd_bwd_allreduce_adamw": spread(train_i),
+                    "step": spread([ev[i][0].elapsed_time(ev[i + 1][0]) for i in range(steps - 1)]),
+                    "host_issue": spread(host_ms)}
+    if pipelined:
+        # the exposed part of the all-reduce (0 when it hid under the extraction), the forward/backward between the
+        # AdamW of step i-1 and the extraction of step i, and AdamW behind the wait
+        stage_spread["allreduce_exposed"] = spread([e[1].elapsed_time(e[4]) for e in ev])
+        stage_spread["adamw_after_wait"] = spread([e[4].elapsed_time(e[2]) for e in ev])
+        stage_spread["cnn_fwd_bwd"] = spread([ev[i][2].elapsed_time(ev[i + 1][0]) for i in range(steps - 1)])
     n_sec, bins = 4, [hi - lo + 1 for lo, hi in fx.bins]
     roof_hbm = None
     if fused and config == "cfg2":
@@ -415,12 +495,71 @@ def run_workload(config, steps, warmup, batch, bf16, two_kernel, overlap_flag, n
                               "extraction of batch k+1" if pipelined else "one stream"},
         "stages_ms": {"extract_features": round(t_feat, 4),
                       "cnn_fwd_bwd_allreduce_adamw": None if (overlap or pipelined) else round(t_train, 4)},
+        "stages_ms_spread": stage_spread,
+        "shader_clock_mhz_timed": clk_timed,
+        "preroll_ms": round(pre_ms, 1), "preroll_steps": pre_steps,
         "final_loss": round(loss, 5),
         "roofline": roof,
     }
+    if pipelined:
+        line["allreduce_exposed_ms"] = stage_spread["allreduce_exposed"]["median"]
     if roof_hbm:
         line["roofline_hbm"] = roof_hbm
     return line
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes through
+    torch.distributed.run and exit with their code.  Called before anything in this process touches the GPU (no HIP
+    call, no exec): rank 0's JSON line goes straight to the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ISD_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", "1")                       # what torchrun would set (with a warning) anyway
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def run_stub(args, env):
+    """Launcher self-test: the rank bring-up, GradientBucket's flat all-reduce (start / wait), the barrier-bracketed
+    timed region and the MAX-over-ranks reduction on CPU tensors -- everything of the N > 1 path except the kernels."""
+    import torch.distributed as dist
+    from isd_amd.classifier import GradientBucket
+    rank, world = env["rank"], env["world"]
+    bucket = GradientBucket()
+    grad = torch.empty(157381)                                   # the train_head gradient block's size (SURVEY 8e)
+    if rank == args.stub_fail_rank:
+        raise RuntimeError(f"--stub-fail-rank: rank {rank} fails on purpose")
+    for _ in range(args.warmup):
+        bucket.all_reduce_wait(bucket.all_reduce_start(grad.fill_(rank + 1.0)))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bucket.all_reduce_wait(bucket.all_reduce_start(grad.fill_(rank + 1.0)))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    want = world * (world + 1) / 2.0
+    if float(grad[0]) != want or float(grad[-1]) != want:
+        raise RuntimeError(f"stub all-reduce: got {float(grad[0])}, want {want}")
+    if rank != 0:
+        return None
+    return {"metric": "stub steps/sec (launcher self-test; no GPU work)", "value": round(args.steps / dt, 1),
+            "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "stub: flat-gradient all-reduce of 157381 floats on CPU tensors",
+                       "parallelism": f"dp{world}", "backend": env["backend"],
+                       "self_launched": bool(os.environ.get("ISD_BENCH_SELF_LAUNCHED"))}}
 
 
 def main():
@@ -433,6 +572,12 @@ def main():
     args.batch = cfg["batch"] if args.batch is None else args.batch
     if args.config == "cfg5" and (args.bf16 or args.two_kernel):
         raise SystemExit("--bf16 / --two-kernel apply to cfg2")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it has not touched the GPU)
+        raise SystemExit(self_launch(args.gpus))
 
     import torch.distributed as dist
 
@@ -440,9 +585,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus disagree")
     # ISD_DIST_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (ranks share a card)
-    backend = os.environ.get("ISD_DIST_BACKEND", "nccl")
+    backend = os.environ.get("ISD_DIST_BACKEND", "gloo" if args.stub else "nccl")
+    if args.stub:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        line = run_stub(args, dict(rank=rank, world=world, backend=backend))
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if backend != "nccl":
         local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
@@ -450,33 +605,40 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # RCCL's stream at HIGH priority: its few workgroups take the first wave slots the extractor's 65 536
+            # waves free instead of queueing behind them (the collective runs under the next batch's extraction)
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     env = dict(rank=rank, world=world, dev=dev, backend=backend)
 
     line = run_workload(args.config, args.steps, args.warmup, args.batch, args.bf16, args.two_kernel, args.overlap,
-                        args.no_pipeline, not args.no_hbm_roofline, env)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args.config, cfg)
+                        args.no_pipeline, not args.no_hbm_roofline, env, preroll_ms=args.preroll_ms)
     # The driver's plain `python bench.py` also times BASELINE config 3 (the same workload with bf16 activations and
     # gradients) and config 5 (the stress configuration at its own batch of 2048) after the cfg2 fp32 region: `value`
-    # stays the cfg2 fp32 number, the other two ride along under "also" (VERDICT r2, item 3).
+    # stays the cfg2 fp32 number, the other two ride along under "also" (VERDICT r2, item 3).  Each leg has its own
+    # pre-roll; the host-only CPU baseline (14 s of scipy, the GPU idle) comes LAST so that no leg starts cold.
     if world == 1 and (default_call or os.environ.get("ISD_BENCH_ALSO")) and not args.no_also:
         also = {}
+        keep = ("value", "ms_per_step", "stages_ms", "stages_ms_spread", "shader_clock_mhz_timed", "preroll_ms",
+                "preroll_steps", "dtype", "steps", "warmup", "final_loss")
         torch.cuda.empty_cache()
-        l3 = run_workload("cfg2", 10, 3, CONFIGS["cfg2"]["batch"], True, False, False, False, False, env)
-        also["cfg3"] = {k: l3[k] for k in ("value", "ms_per_step", "stages_ms", "dtype", "steps", "warmup", "final_loss")}
+        l3 = run_workload("cfg2", 10, 3, CONFIGS["cfg2"]["batch"], True, False, False, False, False, env,
+                          preroll_ms=args.preroll_ms)
+        also["cfg3"] = {k: l3[k] for k in keep}
         also["cfg3"]["workload"] = "cfg2's workload with a bf16 feature map and bf16 activations / activation gradients " \
                                    "in the CNN (bf16 MFMA); f32 extraction arithmetic, parameters and accumulation"
         torch.cuda.empty_cache()
-        l5 = run_workload("cfg5", 3, 1, CONFIGS["cfg5"]["batch"], False, False, False, False, True, env)
-        also["cfg5"] = {k: l5[k] for k in ("value", "ms_per_step", "stages_ms", "dtype", "steps", "warmup", "final_loss",
-                                           "roofline", "roofline_hbm") if k in l5}
+        l5 = run_workload("cfg5", 3, 1, CONFIGS["cfg5"]["batch"], False, False, False, False, True, env,
+                          preroll_ms=args.preroll_ms)
+        also["cfg5"] = {k: l5[k] for k in keep + ("roofline", "roofline_hbm") if k in l5}
         also["cfg5"]["workload"] = CONFIGS["cfg5"]["workload"]
         line["also"] = also
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.config, cfg)
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -444,12 +444,16 @@ class Trainer:
         self._pending = (self.bucket.all_reduce_start(self.flat_grad),)
         return out
 
-    def step_finish(self):
-        """Wait for the all-reduce started by ``step_begin`` and apply AdamW."""
+    def step_finish(self, after_wait=None):
+        """Wait for the all-reduce started by ``step_begin`` and apply AdamW.  ``after_wait``: a ``torch.cuda.Event``
+        recorded on the current stream between the wait and AdamW (bench.py: how long the stream stood still for the
+        collective)."""
         if getattr(self, "_pending", None) is None:
             raise RuntimeError("step_finish without step_begin")
         self.bucket.all_reduce_wait(self._pending[0])
         self._pending = None
+        if after_wait is not None:
+            after_wait.record(torch.cuda.current_stream())
         if self.schedule is not None:
             self.lr = self.base_lr * lr_multiplier(self.schedule, self.global_step)
         self.global_step += 1

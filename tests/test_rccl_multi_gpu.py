@@ -21,7 +21,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-MAX_RANKS = 4                      # divides the test batches; keeps the process count small on a shared node
+MAX_RANKS = 8                      # one rank per GPU of a whole node; 2, 4 and 8 all divide the test batches (64, 24)
 # ISD_TEST_DP_REHEARSE=1: run the same workers with two gloo ranks sharing cuda:0 (checks the test's own logic on a
 # one-GPU box; RCCL refuses two ranks on one device)
 REHEARSE = bool(os.environ.get("ISD_TEST_DP_REHEARSE"))
@@ -29,12 +29,14 @@ needs_two = pytest.mark.skipif(torch.cuda.device_count() < 2 and not REHEARSE,
                                reason="needs at least two GPUs (RCCL with more than one rank)")
 
 
+def _ranks_for(n_dev):
+    """2, 4 or 8 ranks: the largest of them the devices allow (all divide the test batches)."""
+    n = min(n_dev, MAX_RANKS)
+    return 8 if n >= 8 else 4 if n >= 4 else 2 if n >= 2 else 1
+
+
 def _n_ranks():
-    if REHEARSE:
-        return 2
-    n = torch.cuda.device_count()
-    n = min(n, MAX_RANKS)
-    return n if n < 3 else (2 if n == 3 else 4)
+    return 2 if REHEARSE else _ranks_for(torch.cuda.device_count())
 
 
 def _free_port():
@@ -198,7 +200,6 @@ def test_rccl_synchronised_batchnorm_equals_single_process(kind):
 
 def test_rank_count_rule():
     """The helper that picks the number of ranks divides the test batches (64 and 24) for every device count."""
-    for n_dev, want in ((1, 1), (2, 2), (3, 2), (4, 4), (8, 4)):
-        n = min(n_dev, MAX_RANKS)
-        n = n if n < 3 else (2 if n == 3 else 4)
+    for n_dev, want in ((1, 1), (2, 2), (3, 2), (4, 4), (6, 4), (8, 8), (16, 8)):
+        n = _ranks_for(n_dev)
         assert n == want and 64 % n == 0 and 24 % n == 0
