@@ -6,7 +6,9 @@ noise), same initial parameters, same batches, same schedule:
   * the CPU reference path: scipy butter / sosfilt / stft features (oracle.dsp) + the functional torch restatement of
     Conv4Layers + Linear + CE (oracle.cnn) + torch AdamW on the host -- run TWICE, with all host threads and with one;
   * the HIP path in fp32;
-  * the HIP path with bf16 activations / gradients (BASELINE config 3).
+  * the HIP path with bf16 activations / gradients (BASELINE config 3);
+  * the CPU reference under ``torch.autocast("cpu", bfloat16)`` -- the reference's own precision='bf16-mixed'
+    (scripts/train_fast.py:277) -- again with all host threads and with one.
 Each is evaluated on 4 096 held-out trials (another seed): one trial is 0.024 % of the set, so the 0.1 % gate is four
 trials wide.
 
@@ -18,6 +20,14 @@ and 99.90 / 99.88 / 99.90 % (0 - 1 of 4 096 predictions differ) at the noise lev
 evaluated where the reference itself is reproducible to 0.1 %, the test checks that precondition on the box it runs
 on, and it also checks the part that does not depend on the trajectory: the HIP-trained parameters evaluated through
 the CPU pipeline give the HIP pipeline's predictions.
+
+bf16: the reference's OWN autocast training does not define its accuracy to 0.1 % at this setting.  Measured in the
+build container (tools/accuracy_autocast_cpu.py, profiles/r04_accuracy_autocast_cpu.txt), same task, same initial
+parameters, only the host thread count (= the summation order inside the bf16 convolutions) changed: 99.88 % /
+last-epoch loss 0.059 (8 threads), 99.78 % / 0.096 (4 threads), 99.19 % / 0.195 (1 thread) -- against 99.90 % /
+0.029 in fp32 at every thread count.  The HIP bf16 path (99.12 % / 0.156 in round 3) sits inside that range: the 0.8 %
+is the arithmetic's, not the kernels'.  So the bf16 gate is: not below the worse of the two autocast references by
+more than 0.3 % (and within 1 % of the fp32 reference), and its last-epoch loss not above 1.5 x the worse autocast one.
 """
 import concurrent.futures as cf
 import multiprocessing as mp
@@ -51,13 +61,16 @@ def _oracle_features(X, workers=8):
         return np.concatenate(list(ex.map(_scipy_features, chunks)))
 
 
-def _oracle_predict(fte, p):
-    with torch.no_grad():
-        return torch.cat([ocnn.predict(ocnn.feature_cnn_logits(fte[i:i + 512], p)) for i in range(0, len(fte), 512)]).numpy()
+def _oracle_predict(fte, p, autocast=False):
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+        return torch.cat([ocnn.predict(ocnn.feature_cnn_logits(fte[i:i + 512], p).float())
+                          for i in range(0, len(fte), 512)]).numpy()
 
 
-def _oracle_fit(ftr, ytr, threads):
-    """The CPU reference training: same initial parameters (seed 1), same schedule, same batch order as the estimator."""
+def _oracle_fit(ftr, ytr, threads, autocast=False):
+    """The CPU reference training: same initial parameters (seed 1), same schedule, same batch order as the estimator.
+    ``autocast``: forward under torch.autocast(bfloat16) with fp32 master parameters and an fp32 loss -- what the
+    reference's precision='bf16-mixed' (scripts/train_fast.py:277) does."""
     from isd_amd.classifier import _FeatureModel
     old = torch.get_num_threads()
     torch.set_num_threads(threads)
@@ -77,7 +90,9 @@ def _oracle_fit(ftr, ytr, threads):
                     gr["lr"] = 5e-4 * ocnn.lr_multiplier(table, step)
                 opt.zero_grad()
                 sl = slice(i * BS, (i + 1) * BS)
-                ls = ocnn.cross_entropy(ocnn.feature_cnn_logits(ftr[sl], p), yt[sl])
+                with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+                    logits = ocnn.feature_cnn_logits(ftr[sl], p)
+                ls = ocnn.cross_entropy(logits.float(), yt[sl])
                 ls.backward()
                 opt.step()
                 tot += float(ls.detach()) * BS
@@ -112,14 +127,25 @@ def test_held_out_accuracy_within_a_tenth_of_a_percent_of_the_cpu_reference():
     p_b, last_b = _oracle_fit(ftr, ytr, 1)
     acc["cpu"] = float((_oracle_predict(fte, p_a) == yte).mean())
     acc["cpu_1thread"] = float((_oracle_predict(fte, p_b) == yte).mean())
+    # (3) the CPU reference under bf16 autocast (the reference's bf16-mixed), the same two thread counts
+    p_c, last_c = _oracle_fit(ftr, ytr, n_thr, autocast=True)
+    p_d, last_d = _oracle_fit(ftr, ytr, 1, autocast=True)
+    acc["cpu_autocast"] = float((_oracle_predict(fte, p_c, autocast=True) == yte).mean())
+    acc["cpu_autocast_1thread"] = float((_oracle_predict(fte, p_d, autocast=True) == yte).mean())
     print(f"held-out accuracy on {N_TEST} trials: cpu reference {acc['cpu']:.4f} ({n_thr} threads) / "
-          f"{acc['cpu_1thread']:.4f} (1 thread), hip fp32 {acc['fp32']:.4f}, hip bf16 {acc['bf16']:.4f}; last-epoch "
-          f"training loss cpu {last_a:.4f} / {last_b:.4f}, fp32 {loss['fp32']:.4f}, bf16 {loss['bf16']:.4f}; "
+          f"{acc['cpu_1thread']:.4f} (1 thread), hip fp32 {acc['fp32']:.4f}; cpu reference under bf16 autocast "
+          f"{acc['cpu_autocast']:.4f} ({n_thr} threads) / {acc['cpu_autocast_1thread']:.4f} (1 thread), hip bf16 "
+          f"{acc['bf16']:.4f}; last-epoch training loss cpu {last_a:.4f} / {last_b:.4f}, hip fp32 {loss['fp32']:.4f}, "
+          f"cpu autocast {last_c:.4f} / {last_d:.4f}, hip bf16 {loss['bf16']:.4f}; "
           f"HIP-trained parameters: {flips} of {N_TEST} predictions differ between the HIP and the CPU pipeline")
     assert flips <= 2, flips                               # inference parity at scale (ties at the 1e-6 level only)
     assert acc["cpu"] > 0.9, acc                           # the task is learnt
     # the precondition of the gate: the reference defines its own accuracy to 0.1 % at this setting
     assert abs(acc["cpu"] - acc["cpu_1thread"]) <= 0.001 + 1e-9, acc
     assert abs(acc["fp32"] - acc["cpu"]) <= 0.001 + 1e-9, acc
-    # bf16 activations: stated, not gated at 0.1 % (its logits differ at the 1e-2 level by construction)
+    # bf16: against the reference's own bf16-mixed arithmetic, whose accuracy moves by several 0.1 % with the summation
+    # order alone (module docstring) -- not below the worse of its two runs by more than 0.3 %, within 1 % of fp32
+    worst_acc = min(acc["cpu_autocast"], acc["cpu_autocast_1thread"])
+    assert acc["bf16"] >= worst_acc - 0.003, acc
+    assert loss["bf16"] <= 1.5 * max(last_c, last_d) + 0.02, (loss, last_c, last_d)
     assert abs(acc["bf16"] - acc["cpu"]) <= 0.01, acc
