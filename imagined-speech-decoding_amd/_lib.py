@@ -53,6 +53,7 @@ SIGNATURES = {
     "isd_stft_bandpower": (_i, [_p, _p, _p, _i64, _i64, _i, _i, _pi, _pi, _i, _f, _p]),
     "isd_features_fused": (_i, [_p, _p, _p, _p, _i64, _i64, _pi, _pi, _i, _f, _p]),
     "isd_features_fused_bf16": (_i, [_p, _p, _p, _p, _i64, _i64, _pi, _pi, _i, _f, _p]),
+    "isd_features_fused_last_path": (_i, []),
     "isd_fir_plan_create": (_i, [C.POINTER(_p), _i, _pd]),
     "isd_fir_plan_destroy": (_i, [_p]),
     "isd_fir_plan_taps": (_i, [_p]),

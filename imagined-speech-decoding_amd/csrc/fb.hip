@@ -47,6 +47,16 @@ struct FbBand {
   float pad;
 };
 
+// The constants of one (band, section) as fused_serial_kernel reads them: three 64-byte lines, every scalar load inside
+// one line, 6.8 KiB for the nine bands of the headline set (FbSec, 624 bytes of which that kernel needs 192 scattered
+// over seven lines, made the tables of a workgroup's step -- 22 KiB -- larger than the 16 KiB scalar cache).
+struct alignas(64) SerSec {
+  double M[4];                  // A^32
+  float a1, a2, N16[4], one, pad;   // recursion coefficients, A^16, 1.0f (see section_serial_f32)
+  float hq[2][kL / 2];          // zero-input response at the output, n < 16
+};
+static_assert(sizeof(SerSec) == 192, "SerSec is three cache lines");
+
 }  // namespace isd
 
 // The bands of a plan are split by arithmetic: set 0 runs the in-chunk recursion in fp32, set 1 in fp64
@@ -58,6 +68,7 @@ struct FbSet {
   isd::FbBand* d_band; // [nb]
   double* d_Q;         // [nb][n_sections][16][4]  per-lane M^i
   int* d_map;          // [nb] output band index
+  isd::SerSec* d_ser;  // [nb][n_sections] compact copy for fused_serial_kernel (fp32 set only)
 };
 struct isd_fb_plan {
   int n_bands, n_sections, precision;   // precision: ISD_FB_F32, ISD_FB_F64 or ISD_FB_MIXED
@@ -1372,6 +1383,232 @@ void fused_rows4_kernel(const FbSec* __restrict__ secs, const FbBand* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the fused spec-S extractor with ONE ROW PER LANE (rows of whole 32-sample chunks, nperseg 64 / hop 32).
+//
+// fused_kernel gives a 16-lane DPP row one (trial, channel) row and a lane one 32-sample chunk, so every biquad section
+// pays for a lane scan of the chunk-end states: 16 v_fma_f64 + 24 DPP moves + the joins = 48 of the section body's 130
+// vector instructions (ISA count, profiles/r04_fused_isa_counts.txt), in a kernel that is vector-issue bound.  Here a
+// lane OWNS a row and walks it chunk by chunk: the state entering chunk c is simply the state that left chunk c - 1,
+// carried in two fp64 registers per section -- S' = M S + e, four v_fma_f64 -- and there is no scan, no DPP and no
+// cross-lane traffic at all.  The arithmetic of every sample is the arithmetic of fused_kernel / fb_kernel, operation
+// for operation (fp32 zero-state recursion over the chunk's two 16-sample halves side by side in one register pair,
+// the A^16 join in fp32, chunk-end states accumulated in fp64, fp32 state fix-up from the same tables), so the
+// materialising path and this one still round alike; only the fp64 summation order of the carried state differs.
+//
+// Workgroup = 64 consecutive rows x NW waves; wave w runs bands w, w + NW, ... (at most BPW of them) and keeps their
+// section states (8 doubles per band) and the previous chunk's half-frame DFT sums in registers.  The row chunks
+// (64 rows x 128 bytes per step) are fetched once per workgroup, coalesced (eight lanes per row), through a
+// double-buffered LDS tile with a 16-byte XOR swizzle (slot = quad ^ ((row >> 1) & 7): the loader's writes are
+// contiguous kilobytes, the readers' ds_read_b128 -- lane = row -- hit every bank once per 16 lanes).
+//
+// Band power: the UNWINDOWED half-frame sums U_c[k] = sum_{n<32} y[32 c + n] e^{-2 pi i k n / 64} over sample pairs
+// symmetric about the middle of the chunk ({y[16+m] + y[16-m], y[16+m] - y[16-m]} x {cos, -sin}: 17 packed FMAs per
+// bin), frame j = U_{j-1} + (-1)^k U_j, and the periodic Hann window applied in the frequency
+// domain, 0.5 X[k] - 0.25 (X[k-1] + X[k+1]).  The rotation e^{-i 16 th_k} = (-i)^k of the symmetric form is never
+// applied: it cancels out of |.|^2 once the neighbours' relative rotations (+-i) are folded into the combination.
+// Scalar tables by hand.  The section's constants (44 dwords: M = A^32 in fp64, A^16 and the 2 x 16 fix-up table in fp32)
+// are fetched by explicit s_loads IN FRONT of the recursion and waited for behind it: the 64 packed instructions of the
+// recursion cover the scalar-cache latency.  Left to the compiler the loads sink to their first use (its scheduler works
+// bottom-up and prices a scalar load at a few cycles), which parked the wave twice per section -- PMC of the first
+// version: 57 % of the wave cycles in s_waitcnt at three waves per SIMD.  The asm statements are volatile (they keep
+// their order) and each carries a vector register of the arithmetic it must stay in front of / behind.
+// 16 bytes per lane, global -> LDS (lds_base + 16 lane; lds_base wave-uniform), issued behind the compiler's back like
+// conv.hip's dma16_async: through the builtin every later LDS access of the kernel would first wait for it.
+__device__ __forceinline__ void ser_dma16(const void* src_lane, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(src_lane) : "memory", "m0");
+}
+
+// One section over the lane's chunk.  All of the section's constants (48 dwords) come in ONE batch of scalar loads at
+// the top -- the lane-scan kernels fetch them in three, each where it is needed, because the scan holds the SGPR file
+// in between -- so a section parks its wave on the scalar cache once instead of three or four times (PMC of the first
+// version of this kernel, three waves per SIMD: 57 % of the wave cycles in s_waitcnt, 34 waits per band and chunk).
+// (Issuing the loads a stage AHEAD by hand does not work with this compiler: an inline-asm output of an SGPR vector
+// type reads back as its first element in every lane of the vector -- hipcc 7.2, "=s" / "+s" on ext_vector_type(2..16)
+// -- and left to itself the scheduler sinks scalar loads to their first use.)
+__device__ __forceinline__ void section_serial_f32(f2 (&v)[kL / 2], const SerSec& sc0, double& c1, double& c2) {
+  const SerSec& sc = *later(&sc0);
+  const float na1 = -sc.a1, na2 = -sc.a2;
+  const float n16[4] = {sc.N16[0], sc.N16[1], sc.N16[2], sc.N16[3]};
+  const double m0 = sc.M[0], m1 = sc.M[1], m2 = sc.M[2], m3 = sc.M[3];
+  float h0[kL / 2], h1[kL / 2];
+#pragma unroll
+  for (int j = 0; j < kL / 2; ++j) { h0[j] = sc.hq[0][j]; h1[j] = sc.hq[1][j]; }
+  // y = x + S1 is issued as the packed FMA one * x + S1 -- the same value, bit for bit -- with `one` = 1.0f from the
+  // section's table: hipcc's gfx940 "destination select" forwarding rule takes the default op_sel_hi bit of a packed
+  // fp32 operation's FIRST source for a 16-bit partial write and puts an s_nop behind every v_pk_add_f32 whose result
+  // the next instruction reads (a packed fp32 result is two whole dwords); a scalar splat as first source clears the bit.
+  // That was 14 s_nop per section in a chain that has nothing else to put there: a tenth of the kernel's issue slots.
+  const float one = sc.one;
+  const f2 NA1 = {na1, na1}, NA2 = {na2, na2}, ONE = {one, one};
+  f2 S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < kL / 2; ++j) {
+    const f2 x = v[j];
+    const f2 y = j == 0 ? x : __builtin_elementwise_fma(ONE, x, S1);
+    S1 = j == 0 ? NA1 * y : __builtin_elementwise_fma(NA1, y, S2);
+    S2 = __builtin_elementwise_fma(NA2, y, -x);
+    v[j] = y;
+  }
+  const float sA1 = S1.x, sA2 = S2.x;
+  const double e1 = (double)fmaf(n16[0], S1.x, fmaf(n16[1], S2.x, S1.y));
+  const double e2 = (double)fmaf(n16[2], S1.x, fmaf(n16[3], S2.x, S2.y));
+  const float t1 = (float)c1, t2 = (float)c2;                      // state entering the chunk
+  const double n1 = fma(m0, c1, fma(m1, c2, e1));                  // state leaving it: M c + e
+  const double n2 = fma(m2, c1, fma(m3, c2, e2));
+  c1 = n1;
+  c2 = n2;
+  const float u1 = fmaf(n16[0], t1, fmaf(n16[1], t2, sA1));
+  const float u2 = fmaf(n16[2], t1, fmaf(n16[3], t2, sA2));
+  const f2 T1 = {t1, u1}, T2 = {t2, u2};
+#pragma unroll
+  for (int j = 0; j < kL / 2; ++j)
+    v[j] = __builtin_elementwise_fma((f2){h0[j], h0[j]}, T1, __builtin_elementwise_fma((f2){h1[j], h1[j]}, T2, v[j]));
+}
+
+constexpr int kSerRows = 64;                 // rows per workgroup = lanes per wave
+constexpr int kSerBins = 4;                  // a band's bins plus its two neighbours (bands of one or two bins)
+
+constexpr int kSerMaxWaves = 12;
+template <int BPW, bool MAG>
+__global__ __launch_bounds__(64 * kSerMaxWaves) __attribute__((amdgpu_waves_per_eu(BPW == 1 ? 5 : BPW == 2 ? 4 : 3)))
+void fused_serial_kernel(const SerSec* __restrict__ secs, const FbBand* __restrict__ bands,
+                         const float2* __restrict__ sym, const float* __restrict__ x, float* __restrict__ feat,
+                         int R, int C, int T, int nb, int J, float scale2, FusedBands fbnd, int mode, float eps,
+                         const int* __restrict__ bmap, int nb_out, int out16, int dbg) {
+  constexpr int NS = 4;                                              // order-4 Butterworth band-pass: four sections
+  const int NW = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));   // waves of the workgroup
+  __shared__ __attribute__((aligned(16))) float ring[2][kSerRows * kL];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int row = blockIdx.x * kSerRows + lane;
+  const bool row_ok = row < R;
+  const int rowc = row_ok ? row : R - 1;                             // a missing row recomputes the last one
+  const int bt = rowc / C, ch = rowc - bt * C;
+  // band 0, frame 0 of this lane's row as a 32-bit BYTE offset (the host sends maps of 2 GiB and more to the other
+  // kernel); opaque, so that it stays in its register instead of being re-derived (a dozen 64-bit multiply steps) in
+  // front of every store.  The band / frame part of the address is wave-uniform and rides in the store's scalar base.
+  unsigned obyte = (unsigned)(((int64_t)bt * nb_out * C + ch) * (int64_t)J) << (out16 ? 1 : 2);
+  asm volatile("" : "+v"(obyte));
+  const int64_t bstride = (int64_t)C * J;
+  const int n_chunks = T / kL;
+
+  // loader (LDS-DMA, 16 bytes per lane straight into the tile: no registers, nothing to spill): instruction i covers
+  // rows 8 i .. 8 i + 7 of the workgroup, eight lanes per row; the instruction's kilobyte of LDS is contiguous, so the
+  // swizzle is applied on the GLOBAL side -- the lane that fills slot p of row r fetches quad p ^ ((r >> 1) & 7)
+  const unsigned ring_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&ring[0][0];
+  auto fetch_tile = [&](int c) {                                     // chunk c of the 64 rows -> ring[c & 1]
+    for (int i = wave; i < 8; i += NW) {
+      const int r = 8 * i + (lane >> 3);
+      int gr = blockIdx.x * kSerRows + r;
+      gr = gr < R ? gr : R - 1;
+      const float* src = x + (int64_t)gr * T + c * kL + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+      ser_dma16(src, ring_base + (unsigned)((c & 1) * kSerRows * kL * 4 + i * 1024));
+    }
+  };
+  const int rbase = lane * kL, rswz = (lane >> 1) & 7;
+
+  double S[BPW][NS][2];
+  f2 prevU[BPW][kSerBins];
+#pragma unroll
+  for (int i = 0; i < BPW; ++i) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) S[i][s][0] = S[i][s][1] = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < kSerBins; ++kk) prevU[i][kk] = (f2){0.f, 0.f};
+  }
+
+  fetch_tile(0);
+  for (int c = 0; c <= n_chunks; ++c) {
+    const bool last = c == n_chunks;                                 // the closing frame: chunk n_chunks - 1 + zeros
+    const float* tile = ring[c & 1];
+    // this wave's share of tile c has landed (vmcnt 0; it was issued a whole step ago) ... everyone's has, and every
+    // wave is done reading tile c - 1, whose buffer the next fetch overwrites
+    if (!(dbg & 4)) __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (!(dbg & 1)) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (c + 1 < n_chunks) fetch_tile(c + 1);
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+      const int b = wave + i * NW;
+      if (b < nb) {
+        const int klo = fbnd.klo[b], khi = fbnd.khi[b];
+        const int k0 = klo - 1, nbin = khi - klo + 1;
+        f2 Xs[kSerBins];
+        if (!last) {
+          f2 v[kL / 2];
+          {
+            const float gain = bands[b].gf;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {                          // quads qd and qd + 4: samples 4 qd .. and 16 + 4 qd ..
+              const float4 a = *reinterpret_cast<const float4*>(&tile[rbase + ((qd ^ rswz) << 2)]);
+              const float4 h = *reinterpret_cast<const float4*>(&tile[rbase + (((qd + 4) ^ rswz) << 2)]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v[4 * qd + e] = (f2){mul_unpacked(f4_get(a, e), gain), mul_unpacked(f4_get(h, e), gain)};
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < NS; ++s) section_serial_f32(v, secs[b * NS + s], S[i][s][0], S[i][s][1]);
+          f2 ad[15];
+#pragma unroll
+          for (int m = 1; m < 16; ++m) ad[m - 1] = sym_pair(v[m], v[16 - m]);
+#pragma unroll
+          for (int kk = 0; kk < kSerBins; ++kk) {
+            const int k = k0 + kk;
+            // the bin's 16 table entries in ONE batch of scalar loads (32 dwords)
+            const f2* __restrict__ tq = later(reinterpret_cast<const f2*>(sym + (int64_t)k * 16));
+            f2 tc[17];
+#pragma unroll
+            for (int m = 1; m <= 16; ++m) tc[m] = tq[m - 1];
+            f2 acc_a = {0.f, 0.f}, acc_b = {0.f, 0.f};
+#pragma unroll
+            for (int m = 1; m <= 13; m += 2) {
+              pmac(acc_a, ad[m - 1], tc[m]);
+              pmac(acc_b, ad[m], tc[m + 1]);
+            }
+            pmac(acc_a, ad[14], tc[15]);
+            cmac_lo_conj(acc_b, v[0], tc[16]);                        // y[0] e^{+i 16 th}
+            f2 U = acc_a + acc_b;
+            U.x += v[0].y;                                            // y[16]
+            const float sg = (k & 1) ? -1.f : 1.f;                    // frame j = U_{j-1} + (-1)^k U_j
+            Xs[kk] = __builtin_elementwise_fma(U, (f2){sg, sg}, prevU[i][kk]);
+            prevU[i][kk] = U;
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < kSerBins; ++kk) Xs[kk] = prevU[i][kk];
+        }
+        // Hann in the frequency domain, in the un-rotated coordinates: Z'[k] = 0.5 X'[k] - 0.25 i (X'[k-1] - X'[k+1])
+        float acc = 0.f;
+#pragma unroll
+        for (int bq = 0; bq < kSerBins - 2; ++bq) {
+          const f2 w = Xs[bq] - Xs[bq + 2], mid = Xs[bq + 1];
+          const float vx = fmaf(0.25f, w.y, 0.5f * mid.x), vy = fmaf(-0.25f, w.x, 0.5f * mid.y);
+          float pw = (vx * vx + vy * vy) * scale2;
+          if (MAG) pw = sqrtf(pw);
+          acc += bq < nbin ? pw : 0.f;
+        }
+        float r = acc * fbnd.inv[b];
+        if (mode == ISD_BP_LOGPOWER) r = fast_log(r + eps);
+        if (row_ok && !(dbg & 2)) {
+          const int64_t ou = (int64_t)bmap[b] * bstride + c;         // wave-uniform
+          if (out16) {
+            unsigned pk;                                              // gfx950 conversion (RNE)
+            asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(pk) : "v"(r));
+            char* fu = reinterpret_cast<char*>(reinterpret_cast<unsigned short*>(feat) + ou);
+            *reinterpret_cast<unsigned short*>(fu + obyte) = (unsigned short)pk;
+          } else {
+            char* fu = reinterpret_cast<char*>(feat + ou);
+            *reinterpret_cast<float*>(fu + obyte) = r;
+          }
+        }
+      }
+    }
+  }
+}
+
 static void mat2_mul(const double* a, const double* b, double* o) {
   double r[4] = {a[0] * b[0] + a[1] * b[2], a[0] * b[1] + a[1] * b[3], a[2] * b[0] + a[3] * b[2],
                  a[2] * b[1] + a[3] * b[3]};
@@ -1481,7 +1718,7 @@ extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections
   isd_fb_plan* p = new isd_fb_plan();
   p->n_bands = n_bands; p->n_sections = n_sections;
   for (int k = 0; k < 2; ++k) {
-    p->set[k] = FbSet{0, nullptr, nullptr, nullptr, nullptr};
+    p->set[k] = FbSet{0, nullptr, nullptr, nullptr, nullptr, nullptr};
     p->host_map[k] = nullptr;
   }
   // per-band arithmetic: AUTO sends a band to the fp64 set when one of its poles is too close to z = 1.  The threshold
@@ -1529,6 +1766,19 @@ extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections
     if (e == hipSuccess) e = hipMemcpy(fs.d_band, bb.data(), sizeof(FbBand) * nb, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(fs.d_Q, qq.data(), sizeof(double) * qq.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(fs.d_map, idx[k].data(), sizeof(int) * nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && k == 0) {
+      std::vector<SerSec> sv(ss.size());
+      for (size_t i = 0; i < ss.size(); ++i) {
+        SerSec& d = sv[i];
+        const FbSec& c = ss[i];
+        memcpy(d.M, c.Mp[0], sizeof(d.M));
+        d.a1 = c.a1f; d.a2 = c.a2f; d.one = 1.f; d.pad = 0.f;
+        memcpy(d.N16, c.N16f, sizeof(d.N16));
+        memcpy(d.hq, c.hq, sizeof(d.hq));
+      }
+      e = hipMalloc(&fs.d_ser, sizeof(SerSec) * sv.size());
+      if (e == hipSuccess) e = hipMemcpy(fs.d_ser, sv.data(), sizeof(SerSec) * sv.size(), hipMemcpyHostToDevice);
+    }
   }
   if (e != hipSuccess) {
     set_error("isd_fb_plan_create: %s", hipGetErrorString(e));
@@ -1547,6 +1797,7 @@ extern "C" int isd_fb_plan_destroy(isd_fb_plan* p) {
     if (fs.d_band) (void)hipFree(fs.d_band);
     if (fs.d_Q) (void)hipFree(fs.d_Q);
     if (fs.d_map) (void)hipFree(fs.d_map);
+    if (fs.d_ser) (void)hipFree(fs.d_ser);
     delete[] p->host_map[k];
   }
   delete p;
@@ -1623,9 +1874,65 @@ static void set_band(FusedBands& f, int i, int klo, int khi) {
   f.inv[i] = khi >= klo ? 1.f / (float)(khi - klo + 1) : 0.f;
 }
 
+// One row per lane (fused_serial_kernel): rows of whole 32-sample chunks, 16-byte aligned, four sections, every band of
+// the set with one or two interior bins.  ISD_FUSED_SERIAL=0 keeps the 16-lanes-per-row kernel (A/B measurements and the
+// test that holds the two against each other); read per call so that a test can switch it.
+static thread_local int g_fused_path = 0;
+extern "C" int isd_features_fused_last_path(void) { return g_fused_path; }
+
+static bool serial_wanted() {
+  const char* e = getenv("ISD_FUSED_SERIAL");
+  return !(e && e[0] == '0');
+}
+
+static bool fused_serial_launch(const isd_fb_plan* fb, const FbSet& fs, const isd_stft_plan* st, const float* x,
+                                float* feat, int64_t R, int C, const FusedBands& fbnd, int mode, float eps,
+                                hipStream_t stream, int out16) {
+  if (!serial_wanted() || !st->d_sym || !fs.d_ser || st->n != 64 || st->hop != 32 || st->T % kL != 0 || st->T < kL) return false;
+  if (st->J != st->T / kL + 1 || fb->n_sections != 4 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return false;
+  if (fs.nb < 1 || fs.nb > 12) return false;
+  if (cdiv(R, C) * (int64_t)fb->n_bands * C * st->J * 4 >= (1LL << 31)) return false;   // 32-bit byte offsets into the map
+  for (int i = 0; i < fs.nb; ++i) {
+    const int nbin = fbnd.khi[i] - fbnd.klo[i] + 1;
+    if (nbin < 1 || nbin > kSerBins - 2 || fbnd.klo[i] < 1 || fbnd.khi[i] > st->n / 2 - 1) return false;
+  }
+  // bands per wave: 1 (five waves per SIMD), 2 (four) or 3 (three); ISD_SERIAL_BPW overrides the choice
+  int bpw = 3;
+  if (const char* e = getenv("ISD_SERIAL_BPW")) { const int v = atoi(e); if (v >= 1 && v <= 3) bpw = v; }
+  while (bpw < 3 && (fs.nb + bpw - 1) / bpw > kSerMaxWaves) ++bpw;
+  const int nw = (fs.nb + bpw - 1) / bpw;
+  bpw = (fs.nb + nw - 1) / nw;
+  const dim3 grid((unsigned)cdiv(R, kSerRows));
+  const bool mag = mode == ISD_BP_MAGNITUDE;
+  const int dbg = getenv("ISD_SER_DBG") ? atoi(getenv("ISD_SER_DBG")) : 0;
+#define ISD_SER(BPW_)                                                                                                   \
+  do {                                                                                                                  \
+    if (mag)                                                                                                            \
+      hipLaunchKernelGGL((fused_serial_kernel<BPW_, true>), grid, dim3(64 * nw), 0, stream, fs.d_ser, fs.d_band,        \
+                         st->d_sym, x, feat, (int)R, C, st->T, fs.nb, st->J, st->scale * st->scale, fbnd, mode, eps,    \
+                         fs.d_map, fb->n_bands, out16, dbg);                                                            \
+    else                                                                                                                \
+      hipLaunchKernelGGL((fused_serial_kernel<BPW_, false>), grid, dim3(64 * nw), 0, stream, fs.d_ser, fs.d_band,       \
+                         st->d_sym, x, feat, (int)R, C, st->T, fs.nb, st->J, st->scale * st->scale, fbnd, mode, eps,    \
+                         fs.d_map, fb->n_bands, out16, dbg);                                                            \
+  } while (0)
+  if (bpw == 1) ISD_SER(1);
+  else if (bpw == 2) ISD_SER(2);
+  else ISD_SER(3);
+#undef ISD_SER
+  return true;
+}
+
 template <typename VT>
 static int fused_launch(const isd_fb_plan* fb, const FbSet& fs, const isd_stft_plan* st, const float* x, float* feat,
                         int64_t R, int C, const FusedBands& fbnd, int mode, float eps, hipStream_t stream, int out16) {
+  if (std::is_same<VT, float>::value &&
+      fused_serial_launch(fb, fs, st, x, feat, R, C, fbnd, mode, eps, stream, out16)) {
+    g_fused_path = 2;
+    ISD_LAUNCH_CHECK();
+    return ISD_OK;
+  }
+  if (std::is_same<VT, float>::value) g_fused_path = 1;
   const bool two = st->T > kSeg;                          // rows of 513..1024 samples: two 16-lane groups per row
   const int64_t items = cdiv(R, two ? 2 : 4);
   const int vec = ((st->T & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
@@ -1671,6 +1978,7 @@ static int features_fused_impl(const isd_fb_plan* fb, const isd_stft_plan* st, c
     return ISD_ERR_UNSUPPORTED;
   }
   if (!short_rows) {
+    g_fused_path = 3;
     // long rows, heavily overlapped frames: filterbank + block sums in one kernel per band set
     int nbmax = 0;
     for (int b = 0; b < fb->n_bands; ++b) {

@@ -238,6 +238,17 @@ extern "C" int isd_stft_plan_create(isd_stft_plan** out, int T, int nperseg, int
           dft[k * 64 + c * 16 + j] = make_float2(t[0], t[1]);
         }
   }
+  // symmetric-pair table of the serial-lane fused extractor (fb.hip): entry m - 1 of bin k = e^{-i m th_k}, m = 1..16
+  // (128 bytes = two cache lines per bin)
+  std::vector<float2> sym;
+  if (nperseg == 64 && p->hop == 32) {
+    sym.assign(33 * 16, make_float2(0.f, 0.f));
+    for (int k = 0; k <= 32; ++k)
+      for (int m = 1; m <= 16; ++m) {
+        const double ph = 2.0 * M_PI * ((k * m) % 64) / 64.0;
+        sym[k * 16 + m - 1] = make_float2((float)cos(ph), (float)(-sin(ph)));
+      }
+  }
   // block-sum table for heavily overlapped frames
   std::vector<float2> blk;
   {
@@ -252,7 +263,7 @@ extern "C" int isd_stft_plan_create(isd_stft_plan** out, int T, int nperseg, int
         }
     }
   }
-  p->d_win = nullptr; p->d_tw = nullptr; p->d_dft = nullptr; p->d_blk = nullptr;
+  p->d_win = nullptr; p->d_tw = nullptr; p->d_dft = nullptr; p->d_blk = nullptr; p->d_sym = nullptr;
   hipError_t e = hipMalloc(&p->d_win, sizeof(float) * nperseg);
   if (e == hipSuccess) e = hipMalloc(&p->d_tw, sizeof(float2) * (nperseg / 2));
   if (e == hipSuccess) e = hipMemcpy(p->d_win, win.data(), sizeof(float) * nperseg, hipMemcpyHostToDevice);
@@ -260,6 +271,10 @@ extern "C" int isd_stft_plan_create(isd_stft_plan** out, int T, int nperseg, int
   if (e == hipSuccess && !dft.empty()) {
     e = hipMalloc(&p->d_dft, sizeof(float2) * dft.size());
     if (e == hipSuccess) e = hipMemcpy(p->d_dft, dft.data(), sizeof(float2) * dft.size(), hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess && !sym.empty()) {
+    e = hipMalloc(&p->d_sym, sizeof(float2) * sym.size());
+    if (e == hipSuccess) e = hipMemcpy(p->d_sym, sym.data(), sizeof(float2) * sym.size(), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess && !blk.empty()) {
     e = hipMalloc(&p->d_blk, sizeof(float2) * blk.size());
@@ -280,6 +295,7 @@ extern "C" int isd_stft_plan_destroy(isd_stft_plan* p) {
   if (p->d_tw) (void)hipFree(p->d_tw);
   if (p->d_dft) (void)hipFree(p->d_dft);
   if (p->d_blk) (void)hipFree(p->d_blk);
+  if (p->d_sym) (void)hipFree(p->d_sym);
   delete p;
   return ISD_OK;
 }

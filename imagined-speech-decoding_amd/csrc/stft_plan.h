@@ -8,6 +8,9 @@ struct isd_stft_plan {
   float* d_win;         // [n] periodic Hann
   float2* d_tw;         // [n/2] exp(-2 pi i k / n)
   float2* d_dft;        // n == 64 only: [33][4][16] w[n] * exp(-2 pi i k n / 64) as sample pairs (stft.hip plan create)
+  float2* d_sym;        // n == 64, hop == 32: [33][16] {cos(m th_k), -sin(m th_k)}, th_k = 2 pi k / 64, m = 1..16 -- the
+                        // UNWINDOWED half-frame DFT over sample pairs symmetric about the middle of a 32-sample chunk
+                        // (fb.hip fused_serial_kernel; the Hann window is applied in the frequency domain)
   float2* d_blk;        // heavily overlapped frames (n = 2^a * hop, hop 32 or 64, T <= 64 * hop): [n/2+1][hop]
                         // exp(-2 pi i k i / n), the per-block DFT table of the block-sum band-power kernel
 };

@@ -125,6 +125,13 @@ int isd_features_fused(const isd_fb_plan* fb, const isd_stft_plan* st, const flo
 int isd_features_fused_bf16(const isd_fb_plan* fb, const isd_stft_plan* st, const float* x, uint16_t* feat,
                             int64_t B, int64_t C, const int* klo, const int* khi, int mode, float eps, void* stream);
 
+/* Which kernel family the calling thread's last isd_features_fused / _bf16 call launched for its fp32 bands
+ * (diagnostic; the tests that hold the two extractors against each other read it):
+ *   0 none yet, 1 sixteen lanes per row (fused_kernel), 2 one row per lane (fused_serial_kernel: rows of whole
+ *   32-sample chunks, bands of one or two bins; ISD_FUSED_SERIAL=0 in the environment selects 1), 3 the long-row
+ *   block-sum kernels. */
+int isd_features_fused_last_path(void);
+
 /* ------------------------------------------------------------------------
  * Zero-phase FIR filter.  Replaces the band-pass of the SVM baseline,
  *   mne.filter.filter_data(X, 250, l_freq=4, h_freq=40)   notebooks/svm_baseline.ipynb:238-239, :968-969
