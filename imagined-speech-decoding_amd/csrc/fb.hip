@@ -1469,6 +1469,8 @@ __device__ __forceinline__ void section_serial_f32(f2 (&v)[kL / 2], const SerSec
 
 constexpr int kSerRows = 64;                 // rows per workgroup = lanes per wave
 constexpr int kSerBins = 4;                  // a band's bins plus its two neighbours (bands of one or two bins)
+constexpr int kSerCPT = 1;                   // chunks per LDS tile = chunk steps per workgroup barrier
+constexpr int kSerMaxGroups = 4;             // row groups (of 64 rows) per workgroup
 
 constexpr int kSerMaxWaves = 12;
 template <int BPW, bool MAG>
@@ -1476,13 +1478,18 @@ __global__ __launch_bounds__(64 * kSerMaxWaves) __attribute__((amdgpu_waves_per_
 void fused_serial_kernel(const SerSec* __restrict__ secs, const FbBand* __restrict__ bands,
                          const float2* __restrict__ sym, const float* __restrict__ x, float* __restrict__ feat,
                          int R, int C, int T, int nb, int J, float scale2, FusedBands fbnd, int mode, float eps,
-                         const int* __restrict__ bmap, int nb_out, int out16, int dbg) {
+                         const int* __restrict__ bmap, int nb_out, int out16, int NW) {
   constexpr int NS = 4;                                              // order-4 Butterworth band-pass: four sections
-  const int NW = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));   // waves of the workgroup
-  __shared__ __attribute__((aligned(16))) float ring[2][kSerRows * kL];
+  // A workgroup = G row groups of 64 rows x NW waves per row group, G NW a multiple of four: the waves of a workgroup
+  // are placed on the CU's SIMDs by their index modulo 4, so workgroups of three waves fill SIMDs 0 - 2 and leave the
+  // fourth empty (measured: 9-wave workgroups at five waves per SIMD fit once per CU, 8-wave ones twice).
+  extern __shared__ __attribute__((aligned(16))) float ring_raw[];   // [G][2][kSerCPT][64 * 32]
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int row = blockIdx.x * kSerRows + lane;
+  const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int grp = wave_all / NW, wave = wave_all - grp * NW;        // row group of this wave, its index in the group
+  float* const ring = ring_raw + grp * (2 * kSerCPT * kSerRows * kL);
+  const int row0 = (blockIdx.x * (int)(blockDim.x >> 6) / NW + grp) * kSerRows;   // first row of the group
+  const int row = row0 + lane;
   const bool row_ok = row < R;
   const int rowc = row_ok ? row : R - 1;                             // a missing row recomputes the last one
   const int bt = rowc / C, ch = rowc - bt * C;
@@ -1497,38 +1504,55 @@ void fused_serial_kernel(const SerSec* __restrict__ secs, const FbBand* __restri
   // loader (LDS-DMA, 16 bytes per lane straight into the tile: no registers, nothing to spill): instruction i covers
   // rows 8 i .. 8 i + 7 of the workgroup, eight lanes per row; the instruction's kilobyte of LDS is contiguous, so the
   // swizzle is applied on the GLOBAL side -- the lane that fills slot p of row r fetches quad p ^ ((r >> 1) & 7)
-  const unsigned ring_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&ring[0][0];
-  auto fetch_tile = [&](int c) {                                     // chunk c of the 64 rows -> ring[c & 1]
-    for (int i = wave; i < 8; i += NW) {
-      const int r = 8 * i + (lane >> 3);
-      int gr = blockIdx.x * kSerRows + r;
-      gr = gr < R ? gr : R - 1;
-      const float* src = x + (int64_t)gr * T + c * kL + 4 * ((lane & 7) ^ ((r >> 1) & 7));
-      ser_dma16(src, ring_base + (unsigned)((c & 1) * kSerRows * kL * 4 + i * 1024));
+  const unsigned ring_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ring;
+  auto fetch_tile = [&](int t) {                                     // chunks t CPT .. t CPT + CPT - 1 -> ring[t & 1]
+    for (int p = wave; p < 8 * kSerCPT; p += NW) {
+      const int h = p >> 3, i = p & 7, c = t * kSerCPT + h;
+      if (c < n_chunks) {
+        const int r = 8 * i + (lane >> 3);
+        int gr = row0 + r;
+        gr = gr < R ? gr : R - 1;
+        const float* src = x + (int64_t)gr * T + c * kL + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+        ser_dma16(src, ring_base + (unsigned)((((t & 1) * kSerCPT + h) * kSerRows * kL) * 4 + i * 1024));
+      }
     }
   };
   const int rbase = lane * kL, rswz = (lane >> 1) & 7;
 
   double S[BPW][NS][2];
   f2 prevU[BPW][kSerBins];
+  float ob[BPW][4];                                                  // the band's last frames, waiting for their store
 #pragma unroll
   for (int i = 0; i < BPW; ++i) {
+    ob[i][0] = ob[i][1] = ob[i][2] = ob[i][3] = 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) S[i][s][0] = S[i][s][1] = 0.0;
 #pragma unroll
     for (int kk = 0; kk < kSerBins; ++kk) prevU[i][kk] = (f2){0.f, 0.f};
   }
 
+  // One workgroup barrier per TILE of kSerCPT chunks (one per chunk cost a tenth of the kernel: the three waves of a
+  // workgroup sit on three SIMDs with other company each, and every barrier waits for the slowest of them).
+  int pend = 0;                                  // stores issued behind the last fetch (wave-uniform)
   fetch_tile(0);
-  for (int c = 0; c <= n_chunks; ++c) {
-    const bool last = c == n_chunks;                                 // the closing frame: chunk n_chunks - 1 + zeros
-    const float* tile = ring[c & 1];
-    // this wave's share of tile c has landed (vmcnt 0; it was issued a whole step ago) ... everyone's has, and every
-    // wave is done reading tile c - 1, whose buffer the next fetch overwrites
-    if (!(dbg & 4)) __builtin_amdgcn_s_waitcnt(0x0F70);
-    if (!(dbg & 1)) __builtin_amdgcn_s_barrier();
+  for (int t = 0; t * kSerCPT <= n_chunks; ++t) {
+    // This wave's share of tile t has landed (it was issued a whole tile ago) ... everyone's has, and every wave is done
+    // reading tile t - 1, whose buffer the next fetch overwrites.  The wait must not cover the feature stores the wave
+    // issued BEHIND that fetch (an acknowledged store is a microsecond away): vmcnt counts in order, so "all but the
+    // youngest `pend`" retires the fetch and leaves the stores in flight.
+    if (pend == 1) __builtin_amdgcn_s_waitcnt(0x0F71);
+    else if (pend == 2) __builtin_amdgcn_s_waitcnt(0x0F72);
+    else if (pend == 3) __builtin_amdgcn_s_waitcnt(0x0F73);
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (c + 1 < n_chunks) fetch_tile(c + 1);
+    fetch_tile(t + 1);
+    pend = 0;
+    for (int hh = 0; hh < kSerCPT; ++hh) {
+    const int c = t * kSerCPT + hh;
+    if (c > n_chunks) break;
+    const bool last = c == n_chunks;                                 // the closing frame: chunk n_chunks - 1 + zeros
+    const float* tile = ring + ((t & 1) * kSerCPT + hh) * (kSerRows * kL);
 #pragma unroll
     for (int i = 0; i < BPW; ++i) {
       const int b = wave + i * NW;
@@ -1592,19 +1616,46 @@ void fused_serial_kernel(const SerSec* __restrict__ secs, const FbBand* __restri
         }
         float r = acc * fbnd.inv[b];
         if (mode == ISD_BP_LOGPOWER) r = fast_log(r + eps);
-        if (row_ok && !(dbg & 2)) {
-          const int64_t ou = (int64_t)bmap[b] * bstride + c;         // wave-uniform
+        // Four frames per store.  A lane's frames of one band are 4 (2) bytes apart, the lanes' rows 4 J bytes: a store
+        // per frame is 64 separate dword requests to the L2 (17 per row and band: the first version spent a seventh of
+        // its time there); the lane keeps four frames and writes them as one 16-byte (8-byte) piece -- dword (half-word)
+        // aligned only, which gfx950's global stores take (tools/ubench/unaligned_x4.hip) -- and the rest one by one.
+        const int cq = c & 3;
+        if (cq == 0) ob[i][0] = r; else if (cq == 1) ob[i][1] = r; else if (cq == 2) ob[i][2] = r; else ob[i][3] = r;
+        if ((cq == 3 || last) && row0 < R) pend += (cq == 3) ? 1 : cq + 1;   // (a group past the end stores nothing)
+        if (row_ok && (cq == 3 || last)) {
+          const int64_t ou = (int64_t)bmap[b] * bstride + (c - cq);  // wave-uniform: first frame of the group
           if (out16) {
-            unsigned pk;                                              // gfx950 conversion (RNE)
-            asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(pk) : "v"(r));
-            char* fu = reinterpret_cast<char*>(reinterpret_cast<unsigned short*>(feat) + ou);
-            *reinterpret_cast<unsigned short*>(fu + obyte) = (unsigned short)pk;
+            char* fu = reinterpret_cast<char*>(reinterpret_cast<unsigned short*>(feat) + ou) + obyte;
+            if (cq == 3) {
+              unsigned p0, p1;                                        // gfx950 conversion (RNE)
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p0) : "v"(ob[i][0]), "v"(ob[i][1]));
+              asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p1) : "v"(ob[i][2]), "v"(ob[i][3]));
+              typedef unsigned u2h __attribute__((ext_vector_type(2), aligned(2)));
+              *reinterpret_cast<u2h*>(fu) = (u2h){p0, p1};
+            } else {
+#pragma unroll
+              for (int k = 0; k < 3; ++k)
+                if (k <= cq) {
+                  unsigned pk;
+                  asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(pk) : "v"(ob[i][k]));
+                  reinterpret_cast<unsigned short*>(fu)[k] = (unsigned short)pk;
+                }
+            }
           } else {
-            char* fu = reinterpret_cast<char*>(feat + ou);
-            *reinterpret_cast<float*>(fu + obyte) = r;
+            char* fu = reinterpret_cast<char*>(feat + ou) + obyte;
+            if (cq == 3) {
+              typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+              *reinterpret_cast<f4u*>(fu) = (f4u){ob[i][0], ob[i][1], ob[i][2], ob[i][3]};
+            } else {
+#pragma unroll
+              for (int k = 0; k < 3; ++k)
+                if (k <= cq) reinterpret_cast<float*>(fu)[k] = ob[i][k];
+            }
           }
         }
       }
+    }
     }
   }
 }
@@ -1900,21 +1951,30 @@ static bool fused_serial_launch(const isd_fb_plan* fb, const FbSet& fs, const is
   int bpw = 3;
   if (const char* e = getenv("ISD_SERIAL_BPW")) { const int v = atoi(e); if (v >= 1 && v <= 3) bpw = v; }
   while (bpw < 3 && (fs.nb + bpw - 1) / bpw > kSerMaxWaves) ++bpw;
-  const int nw = (fs.nb + bpw - 1) / bpw;
+  const int nw = (fs.nb + bpw - 1) / bpw;                             // waves per row group
   bpw = (fs.nb + nw - 1) / nw;
-  const dim3 grid((unsigned)cdiv(R, kSerRows));
+  int groups = nw % 4 == 0 ? 1 : nw % 2 == 0 ? 2 : 4;                 // waves per workgroup: a multiple of four
+  while (groups > 1 && groups * nw > kSerMaxWaves) groups >>= 1;
+  if (const char* e = getenv("ISD_SERIAL_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= kSerMaxGroups && v * nw <= kSerMaxWaves) groups = v; }
+  const dim3 grid((unsigned)cdiv(R, (int64_t)kSerRows * groups));
+  const size_t lds = sizeof(float) * (size_t)groups * 2 * kSerCPT * kSerRows * kL;
   const bool mag = mode == ISD_BP_MAGNITUDE;
-  const int dbg = getenv("ISD_SER_DBG") ? atoi(getenv("ISD_SER_DBG")) : 0;
 #define ISD_SER(BPW_)                                                                                                   \
   do {                                                                                                                  \
+    if (lds > 48 * 1024) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)fused_serial_kernel<BPW_, true>,                                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+      (void)hipFuncSetAttribute((const void*)fused_serial_kernel<BPW_, false>,                                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+    }                                                                                                                   \
     if (mag)                                                                                                            \
-      hipLaunchKernelGGL((fused_serial_kernel<BPW_, true>), grid, dim3(64 * nw), 0, stream, fs.d_ser, fs.d_band,        \
-                         st->d_sym, x, feat, (int)R, C, st->T, fs.nb, st->J, st->scale * st->scale, fbnd, mode, eps,    \
-                         fs.d_map, fb->n_bands, out16, dbg);                                                            \
+      hipLaunchKernelGGL((fused_serial_kernel<BPW_, true>), grid, dim3(64 * nw * groups), lds, stream, fs.d_ser,        \
+                         fs.d_band, st->d_sym, x, feat, (int)R, C, st->T, fs.nb, st->J, st->scale * st->scale, fbnd,    \
+                         mode, eps, fs.d_map, fb->n_bands, out16, nw);                                                  \
     else                                                                                                                \
-      hipLaunchKernelGGL((fused_serial_kernel<BPW_, false>), grid, dim3(64 * nw), 0, stream, fs.d_ser, fs.d_band,       \
-                         st->d_sym, x, feat, (int)R, C, st->T, fs.nb, st->J, st->scale * st->scale, fbnd, mode, eps,    \
-                         fs.d_map, fb->n_bands, out16, dbg);                                                            \
+      hipLaunchKernelGGL((fused_serial_kernel<BPW_, false>), grid, dim3(64 * nw * groups), lds, stream, fs.d_ser,       \
+                         fs.d_band, st->d_sym, x, feat, (int)R, C, st->T, fs.nb, st->J, st->scale * st->scale, fbnd,    \
+                         mode, eps, fs.d_map, fb->n_bands, out16, nw);                                                  \
   } while (0)
   if (bpw == 1) ISD_SER(1);
   else if (bpw == 2) ISD_SER(2);

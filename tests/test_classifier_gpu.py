@@ -97,7 +97,17 @@ def test_filterbank_cnn_classifier_learns_and_matches_cpu_path_accuracy(isd):
             step += 1
     with torch.no_grad():
         acc_ref = float((ocnn.predict(ocnn.feature_cnn_logits(feats, p)).numpy() == y).mean())
-    assert abs(acc - acc_ref) <= 0.001 + 1e-9, (acc, acc_ref)
+        # trajectory-independent: the HIP-trained parameters through the CPU pipeline give the HIP pipeline's predictions
+        p_hip = {k[len("net."):]: v.detach().cpu() for k, v in clf.model_.state_dict().items()}
+        flips = int((ocnn.predict(ocnn.feature_cnn_logits(feats, p_hip)).numpy() != clf.predict(X)).sum())
+    assert flips <= 1, flips
+    # The two TRAININGS are chaotic maps of their rounding errors: HIP trainings of this classifier on inputs scaled by
+    # 1 + 1e-6 k end between 99.80 % and 99.98 % on 4 096 held-out trials (tools/bf16_spread.py, profiles/
+    # r04_training_spread.txt), so on these 256 trials an accuracy is defined to one trial, not to a tenth of one: the
+    # round-3 form of this assertion (|acc - acc_ref| <= 0.1 % = identical predictions) held for one rounding pattern of
+    # the feature kernels and broke for another whose features differ from it by 1e-5.  The 0.1 % gate of the north star
+    # is tests/test_accuracy_gate_gpu.py, at a size that resolves it.
+    assert abs(acc - acc_ref) <= 1.0 / len(y) + 1e-9, (acc, acc_ref)
 
 
 def test_estimator_accepts_device_tensors_and_uint8_labels(isd):

@@ -14,8 +14,14 @@ def t(n=20):
     for _ in range(n): fx(x, fused=True, out=out)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for bpw in ("3", "2"):
-    os.environ["ISD_SERIAL_BPW"] = bpw
-    for dbg in (0, 1, 2, 4, 3, 7, 0):
+t(); t()
+for bpw, groups in (("3", "1"), ("3", "2"), ("3", "4"), ("2", "1"), ("2", "2"), ("1", "1"), ("3", "4")):
+    os.environ["ISD_SERIAL_BPW"] = bpw; os.environ["ISD_SERIAL_GROUPS"] = groups
+    r = []
+    for dbg in (0, 1, 2, 3):
         os.environ["ISD_SER_DBG"] = str(dbg)
-        print(f"bpw {bpw} dbg {dbg} (1 no barrier, 2 no stores, 4 no dma wait): {t():.4f} ms", flush=True)
+        r.append(f"dbg{dbg} {t():.4f}")
+    print(f"bpw {bpw} groups {groups}: " + "  ".join(r) + "   (dbg: 1 no barrier, 2 no stores)", flush=True)
+os.environ["ISD_SER_DBG"] = "0"; os.environ.pop("ISD_SERIAL_GROUPS"); os.environ.pop("ISD_SERIAL_BPW")
+os.environ["ISD_FUSED_SERIAL"] = "0"; a = t(); os.environ["ISD_FUSED_SERIAL"] = "1"; b = t()
+print(f"defaults: lane-scan {a:.4f}  serial {b:.4f}")
