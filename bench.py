@@ -440,8 +440,8 @@ def run_workload(config, steps, warmup, batch, bf16, two_kernel, overlap_flag, n
                 "ms_per_launch": round(t_feat, 4),
                 "algorithmic_bytes_per_launch": B * C * 4 * (T + nb * fx.n_frames)}
     elif fused:
-        # cfg5: fused_rows4_kernel<float,5> -- one launch per extraction since the fp32 probe (round 3) keeps all 40
-        # bands of the stress set in fp32; a plan with fp64 bands adds a fused_rows4_kernel<double,5> launch.  VALU-bound.
+        # cfg5: fused_rows4_kernel<float,5> for the 35 bands the AUTO rule keeps in fp32 + fused_rows4_kernel<double,5>
+        # for the five lowest 2-Hz bands (4 - 14 Hz at 1024 Hz), one launch each per extraction.  VALU-bound.
         # Algorithmic flops per (trial, channel, band): cascade T x (4 x 9 + 1) + half-block DFT sums of the band's
         # bins and their two Hann neighbours: (bins + 2) x T complex MACs x 4.
         flops = B * C * sum(T * (n_sec * 9 + 1) + (nbin + 2) * T * 4 for nbin in bins)

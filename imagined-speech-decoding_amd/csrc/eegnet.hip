@@ -70,6 +70,12 @@ struct EegStats {
   double dWp[kF2][kF2], dWd[kF2][kK2];
 };
 
+// every block isd_eegnet_sync_block hands out holds ONE kind of word (isd_eegnet_sync_block_kind): fp64 sums in front of
+// Sx, exact-accumulator words from u1 up to dWp
+static_assert(offsetof(EegStats, Ts) + sizeof(double) * 33 == offsetof(EegStats, Sx), "fp64 sums end where Sx begins");
+static_assert(offsetof(EegStats, Sx) < offsetof(EegStats, D) && offsetof(EegStats, D) < offsetof(EegStats, u1) &&
+              offsetof(EegStats, T1) < offsetof(EegStats, dWp), "exact accumulators sit between Sx and dWp");
+
 // derived per-step coefficients (floats/doubles) in the workspace
 struct EegCoef {
   double m[kMaxK];              // mean xpad[.+k]
@@ -2355,7 +2361,9 @@ extern "C" int isd_eegnet_sync_block(const isd_eegnet_plan* p, int64_t B, int ba
   const EegWs w = eeg_layout(p, B);
   size_t lo, hi;
   if (!backward) {
-    if (stage == 0) { lo = offsetof(EegStats, A); hi = offsetof(EegStats, D); }                 // A, H, Tl, S, Hs, Ts
+    // A, H, Tl, S, Hs, Ts: fp64 sums only -- the block ends in front of Sx, the first integer accumulator (its words
+    // are the raw material S was derived from before the exchange; summed as doubles they would be garbage)
+    if (stage == 0) { lo = offsetof(EegStats, A); hi = offsetof(EegStats, Sx); }
     else if (stage == 1) { lo = offsetof(EegStats, u1); hi = offsetof(EegStats, a1); }
     else { lo = offsetof(EegStats, a1); hi = offsetof(EegStats, dy3s); }
   } else {

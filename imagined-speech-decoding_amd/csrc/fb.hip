@@ -1783,7 +1783,14 @@ extern "C" int isd_fb_plan_create(isd_fb_plan** out, int n_bands, int n_sections
   // ranks the five like the estimate does (rms error 2.9e-5 / 1.3e-5 / 1.9e-5 / 1.4e-5 / 7e-6 of the signal) and
   // separates the 5-band set's 0.5 - 4 Hz band (1.4e-4) no better.  ISD_FB_AUTO_LIMIT overrides.
   const char* lim_env = getenv("ISD_FB_AUTO_LIMIT");
-  const double auto_limit = lim_env ? atof(lim_env) : 6000.0;
+  double auto_limit = 6000.0;
+  if (lim_env) {                                            // a positive number, or the call fails (atof("") = 0 would
+    char* end = nullptr;                                    // silently send every band to the fp64 kernels)
+    const double v = strtod(lim_env, &end);
+    ISD_CHECK_ARG(end != lim_env && *end == '\0' && v > 0.0 && v < 1e300,
+                  "isd_fb_plan_create: ISD_FB_AUTO_LIMIT='%s' is not a positive number", lim_env);
+    auto_limit = v;
+  }
   std::vector<int> idx[2];
   for (int b = 0; b < n_bands; ++b) {
     const int k = precision == ISD_FB_AUTO ? (worst[b] > auto_limit ? 1 : 0) : (precision == ISD_FB_F64 ? 1 : 0);

@@ -49,8 +49,13 @@ class GraphedTrainStep:
         self.idx = torch.zeros(self.bs, dtype=torch.int64, device=dev)
         self.loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
         self.lr = g0["lr"]
-        # the dropout step counter: the optimizer's own device-side step count when it keeps one (FusedAdamW advances
-        # it inside its kernel: no launch of ours), else a counter this class advances with a one-element add per step
+        # the dropout step counter = the number of optimisation steps COMPLETED so far (0 while the first step runs): the
+        # optimizer's own device-side step count when it keeps one (FusedAdamW advances it inside its kernel, at the end
+        # of the step: no launch of ours), else a counter this class advances with a one-element add behind the step.
+        # Both counters therefore give a step the same masks.  Sharing has consequences that are wanted: restoring the
+        # optimizer (``opt.load_state_dict``) puts the mask stream back where that optimizer state was taken -- a resumed
+        # run draws the masks the uninterrupted one would have drawn; a step without any gradient still advances it
+        # (optim.FusedAdamW.step).
         from .optim import FusedAdamW
         self._own_counter = not (isinstance(opt, FusedAdamW) and "step" in opt.state["flat"])
         model.seed_dev = (torch.zeros(1, dtype=torch.int64, device=dev) if self._own_counter
@@ -90,13 +95,13 @@ class GraphedTrainStep:
                 model.seed_dev.zero_()
 
     def _body(self, idx):
-        if self._own_counter:
-            self.model.seed_dev.add_(1)
         self.opt.zero_grad(set_to_none=True)
         xb, yb = self.X.index_select(0, idx), self.y.index_select(0, idx)
         loss = token_mean_cross_entropy(self.model(xb, forward_mode=self.mode), yb)
         loss.backward(unit_grad(loss.device))             # (no ones fill, no multiply by it: nn.unit_grad)
         self.opt.step()
+        if self._own_counter:
+            self.model.seed_dev.add_(1)
         self.loss_sum.add_(loss.detach(), alpha=float(idx.numel()))      # one kernel (a product first would be two)
 
     def step(self, idx, lr):

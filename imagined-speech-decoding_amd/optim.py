@@ -78,6 +78,11 @@ class FusedAdamW(torch.optim.Optimizer):
         lr = g["lr"]
         lr_dev = lr.data_ptr() if isinstance(lr, torch.Tensor) else None
         self._step += 1
+        if self._step_dev is not None and not any(self._n_active[i] for i in range(len(g["params"]))):
+            # no gradient at all: the kernel has nothing to launch, but the device-side step count (which a captured
+            # training step also reads as its dropout counter, graph.GraphedTrainStep) still counts the step
+            self._step_dev[0:1].add_(1)
+            return loss
         _lib.check(_lib.lib().isd_adamw_multi_step(
             len(g["params"]), self._p, self._g, self._m, self._v, self._n_active, 0.0 if lr_dev else float(lr),
             g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._step, lr_dev,
@@ -93,6 +98,23 @@ class FusedAdamW(torch.optim.Optimizer):
         return {"exp_avg": self._exp_avg.clone(), "exp_avg_sq": self._exp_avg_sq.clone(), "step": step, "group": g}
 
     def load_state_dict(self, sd):
+        """Restores what ``state_dict`` returned: both moment blocks, the step count and the group's hyper-parameters.
+        The layout is this class's own (two flat blocks in the order of the parameters, ONE step count for all tensors --
+        torch keeps one per tensor, so a parameter that only starts to receive gradients later is bias-corrected as if it
+        had been stepped from the start); a ``torch.optim.AdamW`` state dict is refused, not misread."""
+        if not isinstance(sd, dict) or set(sd) != {"exp_avg", "exp_avg_sq", "step", "group"}:
+            raise ValueError("FusedAdamW.load_state_dict: not a FusedAdamW state dict (keys exp_avg, exp_avg_sq, step, "
+                             f"group; got {sorted(sd) if isinstance(sd, dict) else type(sd).__name__})")
+        for k in ("exp_avg", "exp_avg_sq"):
+            if tuple(sd[k].shape) != tuple(self._exp_avg.shape):
+                raise ValueError(f"FusedAdamW.load_state_dict: {k} has {tuple(sd[k].shape)} elements, this optimizer's "
+                                 f"parameters need {tuple(self._exp_avg.shape)} (another model or parameter order)")
+        g = self.param_groups[0]
+        for k, v in sd["group"].items():
+            if k == "lr" and isinstance(g["lr"], torch.Tensor):
+                g["lr"].fill_(float(v))                            # the device tensor a captured graph reads stays in place
+            elif k in ("betas", "eps", "weight_decay", "lr"):
+                g[k] = tuple(v) if k == "betas" else float(v)
         self._exp_avg.copy_(sd["exp_avg"])
         self._exp_avg_sq.copy_(sd["exp_avg_sq"])
         self._step = int(sd["step"])

@@ -198,6 +198,52 @@ def test_graphed_step_with_fused_adamw_follows_torch_adamw():
     assert max(float((finals[0][k] - finals[1][k]).abs().max()) for k in tight) < 1e-4
 
 
+def test_graphed_step_with_fused_adamw_advances_the_dropout_masks():
+    """FusedAdamW(capturable) shares its device-side step count with the captured step as the dropout counter
+    (graph.GraphedTrainStep) -- the production pairing (experiment.train_one_fold).  Replays of one batch at learning
+    rate 0 must draw new masks each time, the counter must read the number of completed steps (as the own-counter path
+    with torch's AdamW does), a ragged eager batch and a step without gradients advance it, and the first step of both
+    pairings draws the same masks."""
+    import isd_amd
+    import isd_amd.nn as inn
+    from isd_amd.graph import GraphedTrainStep
+    rng = np.random.default_rng(1)
+    X = torch.from_numpy(rng.standard_normal((32, 64, 800)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.integers(0, 5, 32).astype(np.uint8)).cuda()
+    idx = torch.arange(16, device="cuda")
+    first = {}
+    for fused in (True, False):
+        torch.manual_seed(0)
+        m = inn.FAST(inn.fast_config(dropout=0.3)).cuda().train()
+        lr = torch.tensor(0.0, device="cuda")
+        opt = (isd_amd.FusedAdamW(m.parameters(), lr=lr, capturable=True) if fused
+               else torch.optim.AdamW(m.parameters(), lr=lr, capturable=True))
+        g = GraphedTrainStep(m, opt, X, y, 16)
+        assert g._own_counter == (not fused) and int(m.seed_dev) == 0
+        losses = []
+        for _ in range(3):
+            g.loss_sum.zero_()
+            g.step(idx, 0.0)
+            losses.append(float(g.loss_sum) / 16)
+        assert len(set(losses)) == 3 and all(np.isfinite(losses)), losses
+        assert int(m.seed_dev) == 3
+        g.step(idx[:5], 0.0)                                       # ragged batch: eager, same code
+        assert int(m.seed_dev) == 4
+        first[fused] = losses[0]
+        if fused:
+            opt.zero_grad(set_to_none=True)
+            opt.step()                                             # no gradient anywhere: the step still counts
+            assert int(m.seed_dev) == 5
+            sd = opt.state_dict()
+            assert sd["step"] == 5
+            opt.step()
+            opt.load_state_dict(sd)                                # the mask stream goes back with the optimizer state
+            assert int(m.seed_dev) == 5
+            with pytest.raises(ValueError):
+                opt.load_state_dict(torch.optim.AdamW(m.parameters(), lr=1e-3).state_dict())
+    assert abs(first[True] - first[False]) < 1e-6 * max(1.0, abs(first[False])), first      # same masks in step one
+
+
 def test_fused_adamw_is_a_torch_optimizer_driven_by_the_reference_schedule():
     """The reference wraps its optimizer in LambdaLR with the per-step cosine multiplier (trainer.py:48-54): FusedAdamW is
     a torch.optim.Optimizer, so the same scheduler object drives it, and the run equals torch's AdamW under it."""
