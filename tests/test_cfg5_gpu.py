@@ -82,9 +82,12 @@ def test_stress_configuration_composed_matches_golden(isd):
     assert abs(float(out["loss"]) - float(g["loss"])) < 1e-5
     assert np.array_equal(out["pred"].cpu().numpy(), g["logits"].argmax(1))
     scale = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("enc.grad."))
-    _check_grads(m.net.enc.named_parameters(), lambda k: g[f"enc.grad.{k}"], scale, rel=1e-3)
-    assert rel_err(m.net.fc.weight.grad.cpu(), g["fc.grad.weight"]) < 1e-3
-    assert rel_err(m.net.fc.bias.grad.cpu(), g["fc.grad.bias"]) < 1e-3
+    # measured (tools/grad_slack_probe.py, profiles/r04_grad_slack.txt): 1.7e-5 worst in this metric (BN1's bias), with
+    # HIP's features and with scipy's alike (they differ by 4.6e-5 in the log domain: not where the error comes from);
+    # fc 1.1e-6.  The bound was 1e-3 until round 4.
+    _check_grads(m.net.enc.named_parameters(), lambda k: g[f"enc.grad.{k}"], scale, rel=1e-4)
+    assert rel_err(m.net.fc.weight.grad.cpu(), g["fc.grad.weight"]) < 1e-5
+    assert rel_err(m.net.fc.bias.grad.cpu(), g["fc.grad.bias"]) < 1e-5
     # the autograd modules run the same kernels: same loss, same gradient block
     g_path = m.flat_grads().clone()
     m.zero_grad(set_to_none=True)

@@ -120,7 +120,9 @@ def test_fast_small_train_head_matches_reference_golden(inn):
     assert abs(float(loss) - float(g["train_head.loss"])) < 1e-5
     for k, p in m.named_parameters():
         if f"train_head.grad.{k}" in g.files:
-            assert rel_err(p.grad.cpu(), g[f"train_head.grad.{k}"]) < 2e-4, k
+            # measured 4.7e-7 worst (tools/grad_slack_probe.py, profiles/r04_grad_slack.txt); the golden's own fp32
+            # error against an fp64 run of the reference is 5e-7.  (2e-4 until round 4: slack nobody had measured.)
+            assert rel_err(p.grad.cpu(), g[f"train_head.grad.{k}"]) < 1e-5, k
     # forward_mode='default': the mode the reference trains (trainer.py:58) -- transformer tail included
     m.zero_grad(set_to_none=True)
     logits = m(x)
@@ -129,7 +131,7 @@ def test_fast_small_train_head_matches_reference_golden(inn):
     assert rel_err(logits.detach().cpu(), g["default.logits"]) < TOL
     assert abs(float(loss.detach()) - float(g["default.loss"])) < 1e-5
     for k, p in m.named_parameters():
-        assert rel_err(p.grad.cpu(), g[f"default.grad.{k}"]) < 5e-4, k
+        assert rel_err(p.grad.cpu(), g[f"default.grad.{k}"]) < 1e-5, k          # measured 6.1e-7 worst (5e-4 until round 4)
     # 'train_transformer': the CNN head is frozen (no gradient reaches it)
     m.zero_grad(set_to_none=True)
     m(x, forward_mode="train_transformer").sum().backward()
