@@ -434,7 +434,11 @@ def run_workload(config, steps, warmup, batch, bf16, two_kernel, overlap_flag, n
         # samples x (4 sections x 9 flop [3-op recursion + two state fix-up FMAs] + 1 gain multiply); band DFT =
         # 64 windowed samples per (frame, in-band bin), one complex MAC by a real sample each (4 flop).
         flops = B * C * (nb * T * (n_sec * 9 + 1) + sum(bins) * fx.n_frames * 64 * 4)
-        roof = {"bound": "valu", "kernel": "fused_kernel<float> (fp32 vector ALU; no MFMA in this kernel)",
+        from isd_amd import _lib as _l
+        serial = int(_l.lib().isd_features_fused_last_path()) == 2      # which extractor family the timed steps launched
+        kname = ("fused_serial_kernel<3,false> (one row per lane; fp32 vector ALU; no MFMA in this kernel)" if serial
+                 else "fused_kernel<float> (fp32 vector ALU; no MFMA in this kernel)")
+        roof = {"bound": "valu", "kernel": kname,
                 "achieved": round(flops / (t_feat * 1e-3) / 1e12, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(flops / (t_feat * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4), "traffic": None,
                 "ms_per_launch": round(t_feat, 4),
