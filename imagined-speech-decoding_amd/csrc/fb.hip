@@ -1469,7 +1469,6 @@ __device__ __forceinline__ void section_serial_f32(f2 (&v)[kL / 2], const SerSec
 
 constexpr int kSerRows = 64;                 // rows per workgroup = lanes per wave
 constexpr int kSerBins = 4;                  // a band's bins plus its two neighbours (bands of one or two bins)
-constexpr int kSerCPT = 1;                   // chunks per LDS tile = chunk steps per workgroup barrier
 constexpr int kSerMaxGroups = 4;             // row groups (of 64 rows) per workgroup
 
 constexpr int kSerMaxWaves = 12;
@@ -1480,14 +1479,15 @@ void fused_serial_kernel(const SerSec* __restrict__ secs, const FbBand* __restri
                          int R, int C, int T, int nb, int J, float scale2, FusedBands fbnd, int mode, float eps,
                          const int* __restrict__ bmap, int nb_out, int out16, int NW) {
   constexpr int NS = 4;                                              // order-4 Butterworth band-pass: four sections
-  // A workgroup = G row groups of 64 rows x NW waves per row group, G NW a multiple of four: the waves of a workgroup
-  // are placed on the CU's SIMDs by their index modulo 4, so workgroups of three waves fill SIMDs 0 - 2 and leave the
-  // fourth empty (measured: 9-wave workgroups at five waves per SIMD fit once per CU, 8-wave ones twice).
-  extern __shared__ __attribute__((aligned(16))) float ring_raw[];   // [G][2][kSerCPT][64 * 32]
+  // A workgroup = G row groups of 64 rows x NW waves per row group; the host makes G NW a multiple of four where it can
+  // (the waves of a workgroup go to the CU's SIMDs by their index modulo 4: 9-wave workgroups at five waves per SIMD fit
+  // once per CU, 8-wave ones twice, 6-wave ones ran a third slower than 3- or 12-wave ones).  Row groups are independent;
+  // they only share the workgroup barrier.
+  extern __shared__ __attribute__((aligned(16))) float ring_raw[];   // [G][2][64 * 32]: two tiles per row group
   const int lane = threadIdx.x & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int grp = wave_all / NW, wave = wave_all - grp * NW;        // row group of this wave, its index in the group
-  float* const ring = ring_raw + grp * (2 * kSerCPT * kSerRows * kL);
+  float* const ring = ring_raw + grp * (2 * kSerRows * kL);
   const int row0 = (blockIdx.x * (int)(blockDim.x >> 6) / NW + grp) * kSerRows;   // first row of the group
   const int row = row0 + lane;
   const bool row_ok = row < R;
@@ -1505,16 +1505,14 @@ void fused_serial_kernel(const SerSec* __restrict__ secs, const FbBand* __restri
   // rows 8 i .. 8 i + 7 of the workgroup, eight lanes per row; the instruction's kilobyte of LDS is contiguous, so the
   // swizzle is applied on the GLOBAL side -- the lane that fills slot p of row r fetches quad p ^ ((r >> 1) & 7)
   const unsigned ring_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ring;
-  auto fetch_tile = [&](int t) {                                     // chunks t CPT .. t CPT + CPT - 1 -> ring[t & 1]
-    for (int p = wave; p < 8 * kSerCPT; p += NW) {
-      const int h = p >> 3, i = p & 7, c = t * kSerCPT + h;
-      if (c < n_chunks) {
-        const int r = 8 * i + (lane >> 3);
-        int gr = row0 + r;
-        gr = gr < R ? gr : R - 1;
-        const float* src = x + (int64_t)gr * T + c * kL + 4 * ((lane & 7) ^ ((r >> 1) & 7));
-        ser_dma16(src, ring_base + (unsigned)((((t & 1) * kSerCPT + h) * kSerRows * kL) * 4 + i * 1024));
-      }
+  auto fetch_tile = [&](int c) {                                     // chunk c of the group's 64 rows -> ring[c & 1]
+    if (c >= n_chunks) return;
+    for (int i = wave; i < 8; i += NW) {
+      const int r = 8 * i + (lane >> 3);
+      int gr = row0 + r;
+      gr = gr < R ? gr : R - 1;
+      const float* src = x + (int64_t)gr * T + c * kL + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+      ser_dma16(src, ring_base + (unsigned)(((c & 1) * kSerRows * kL) * 4 + i * 1024));
     }
   };
   const int rbase = lane * kL, rswz = (lane >> 1) & 7;
@@ -1531,13 +1529,16 @@ void fused_serial_kernel(const SerSec* __restrict__ secs, const FbBand* __restri
     for (int kk = 0; kk < kSerBins; ++kk) prevU[i][kk] = (f2){0.f, 0.f};
   }
 
-  // One workgroup barrier per TILE of kSerCPT chunks (one per chunk cost a tenth of the kernel: the three waves of a
-  // workgroup sit on three SIMDs with other company each, and every barrier waits for the slowest of them).
+  // One workgroup barrier per chunk step (0.03 of the kernel's 0.77 ms at the headline shape: the waves of a workgroup sit
+  // on different SIMDs with other company each, and every barrier waits for the slowest; one barrier per TWO chunks, with
+  // tiles of two chunks, measured the same -- the skew is persistent, not per-step noise).
   int pend = 0;                                  // stores issued behind the last fetch (wave-uniform)
   fetch_tile(0);
-  for (int t = 0; t * kSerCPT <= n_chunks; ++t) {
-    // This wave's share of tile t has landed (it was issued a whole tile ago) ... everyone's has, and every wave is done
-    // reading tile t - 1, whose buffer the next fetch overwrites.  The wait must not cover the feature stores the wave
+  for (int c = 0; c <= n_chunks; ++c) {
+    const bool last = c == n_chunks;             // the closing frame: chunk n_chunks - 1 + zeros
+    const float* tile = ring + (c & 1) * (kSerRows * kL);
+    // This wave's share of tile c has landed (it was issued a whole step ago) ... everyone's has, and every wave is done
+    // reading tile c - 1, whose buffer the next fetch overwrites.  The wait must not cover the feature stores the wave
     // issued BEHIND that fetch (an acknowledged store is a microsecond away): vmcnt counts in order, so "all but the
     // youngest `pend`" retires the fetch and leaves the stores in flight.
     if (pend == 1) __builtin_amdgcn_s_waitcnt(0x0F71);
@@ -1546,13 +1547,8 @@ void fused_serial_kernel(const SerSec* __restrict__ secs, const FbBand* __restri
     else __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    fetch_tile(t + 1);
+    fetch_tile(c + 1);
     pend = 0;
-    for (int hh = 0; hh < kSerCPT; ++hh) {
-    const int c = t * kSerCPT + hh;
-    if (c > n_chunks) break;
-    const bool last = c == n_chunks;                                 // the closing frame: chunk n_chunks - 1 + zeros
-    const float* tile = ring + ((t & 1) * kSerCPT + hh) * (kSerRows * kL);
 #pragma unroll
     for (int i = 0; i < BPW; ++i) {
       const int b = wave + i * NW;
@@ -1655,7 +1651,6 @@ void fused_serial_kernel(const SerSec* __restrict__ secs, const FbBand* __restri
           }
         }
       }
-    }
     }
   }
 }
@@ -1964,7 +1959,7 @@ static bool fused_serial_launch(const isd_fb_plan* fb, const FbSet& fs, const is
   while (groups > 1 && groups * nw > kSerMaxWaves) groups >>= 1;
   if (const char* e = getenv("ISD_SERIAL_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= kSerMaxGroups && v * nw <= kSerMaxWaves) groups = v; }
   const dim3 grid((unsigned)cdiv(R, (int64_t)kSerRows * groups));
-  const size_t lds = sizeof(float) * (size_t)groups * 2 * kSerCPT * kSerRows * kL;
+  const size_t lds = sizeof(float) * (size_t)groups * 2 * kSerRows * kL;
   const bool mag = mode == ISD_BP_MAGNITUDE;
 #define ISD_SER(BPW_)                                                                                                   \
   do {                                                                                                                  \
