@@ -112,3 +112,53 @@ def test_shapes_the_serial_kernel_does_not_take_fall_back(isd):
         fx = isd.FeatureExtractor(T, 256.0, bands)
         _, p = _run(fx, x, True)
         assert p == 1, (T, p)
+
+
+def test_serial_kernel_random_shapes_against_the_lane_scan_kernel(isd):
+    """Seeded sweep over batch, channel count (row groups that start and end inside a trial, one-channel trials, a
+    single row), row length (1 .. 32 chunks) and band subsets (1 .. 12 bands: every wave / bands-per-wave split the
+    launcher can choose): the two extractors agree to 5e-5 everywhere and both stay inside the north-star gate."""
+    rng = np.random.default_rng(2024)
+    extra = (("x1", 10.0, 14.0), ("x2", 18.0, 22.0), ("x3", 26.0, 30.0))
+    pool = tuple(odsp.BANDS_9) + extra
+    for trial in range(14):
+        B = int(rng.integers(1, 6))
+        C = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 65]))
+        T = 32 * int(rng.integers(1, 33))
+        nb = int(rng.integers(1, 13))
+        idx = np.sort(rng.choice(len(pool), nb, replace=False))
+        bands = tuple(pool[i] for i in idx)
+        X = rng.standard_normal((B, C, T)).astype(np.float32)
+        x = torch.from_numpy(X).cuda()
+        fx = isd.FeatureExtractor(T, 256.0, bands)
+        a, pa = _run(fx, x, True)
+        b, pb = _run(fx, x, False)
+        assert (pa, pb) == (2, 1), (trial, pa, pb)
+        assert bool(torch.isfinite(a).all())
+        assert float((a - b).abs().max()) < 5e-5, (trial, B, C, T, nb, float((a - b).abs().max()))
+        if T >= 64 and trial % 3 == 0:
+            ref = odsp.extract_features_scipy(X, fs=256.0, bands=bands).astype(np.float64)
+            got = a.cpu().numpy().astype(np.float64)
+            assert (np.abs(got - ref) <= 1e-4 * np.maximum(1.0, np.abs(ref))).all(), (trial, B, C, T, nb)
+
+
+def test_serial_kernel_empty_batch_and_bands_per_wave_overrides(isd):
+    fx = isd.FeatureExtractor(512, 256.0, odsp.BANDS_9)
+    out, _ = _run(fx, torch.empty(0, 64, 512, device="cuda"), True)
+    assert out.shape == (0, 9, 64, 17)
+    X, _ = odsp.synth_trials(3, 64, 512, 256.0, seed=5)
+    x = torch.from_numpy(X).cuda()
+    base, p = _run(fx, x, True)
+    assert p == 2
+    old = {k: os.environ.get(k) for k in ("ISD_SERIAL_BPW", "ISD_SERIAL_GROUPS")}
+    try:
+        for bpw, groups in (("1", "1"), ("2", "2"), ("3", "1"), ("3", "4")):      # every launch geometry: the same values
+            os.environ["ISD_SERIAL_BPW"], os.environ["ISD_SERIAL_GROUPS"] = bpw, groups
+            alt, p = _run(fx, x, True)
+            assert p == 2 and torch.equal(alt, base), (bpw, groups)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
